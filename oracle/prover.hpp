@@ -1,0 +1,360 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/gl.hpp header). Never linked into libaero_stark.so.
+//
+// CPU restatement of the prover side of the hot path for the built-in FibAir(W).
+// Stage order and split points follow the reference's driver:
+//   aero-sdk/miden-wasm/src/proving_worker.rs:238-278  stage 1: channel, domain, interpolate_columns, evaluate_columns_over
+//   proving_worker.rs:280-310 + hashing_worker.rs:12-26  row hashing
+//   proving_worker.rs:161-162                            MerkleTree::new
+//   proving_worker.rs:323-332                            commit_to_trace_and_validate (reseed with root)
+//   proving_worker.rs:355-439 + constraints_worker.rs:14-79  constraint evaluation (numerators per divisor)
+//   proving_worker.rs:344-352                            prove_after_constraint_eval: composition poly -> commit ->
+//                                                        OOD -> DEEP -> FRI -> grind -> queries -> StarkProof
+// The bodies of those winter-prover 0.4 functions are not in the mount (empty submodule); the published
+// algorithms are restated (see oracle/stark.hpp header for how they are pinned).
+// Threading: OpenMP loops give the "all host cores" variant (per-column/per-coset NTTs, per-row hashing,
+// per-row constraint evaluation — the same split as winter's `concurrent` feature); OMP_NUM_THREADS=1 or
+// orc_set_threads(1) gives the single-threaded run the reference binary actually performs.
+#pragma once
+#include <chrono>
+#include "stark.hpp"
+
+namespace orc {
+
+struct StageTimes {   // seconds, stage names after proving_worker.rs:125-172 console labels
+    double interpolate = 0, lde = 0, trace_commit = 0, constraints = 0, composition = 0, comp_commit = 0,
+           ood = 0, deep = 0, fri = 0, grind = 0, queries = 0, total = 0;
+};
+static inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Captured intermediates for per-stage parity tests against the HIP path.
+template <class F> struct ProverArtifacts {
+    std::vector<Col> trace_polys, trace_lde;          // W x n, W x N
+    std::vector<Digest> trace_leaves;                 // N
+    std::vector<std::vector<typename F::T>> ce_cols;  // 3 x (C*n) numerators
+    std::vector<Col> comp_polys;                      // (C*DEG) x n  component columns
+    std::vector<Col> comp_lde;                        // (C*DEG) x N
+    std::vector<typename F::T> deep;                  // N
+    std::vector<std::vector<typename F::T>> fri_layers;   // transposed evaluations per layer (incl. remainder layer)
+    std::vector<typename F::T> ood_cur, ood_next, ood_h;
+};
+
+// hash every row of a column-major matrix: leaf_j = hash_elements(row j)   [a5]
+static std::vector<Digest> hash_rows(const std::vector<Col>& cols, size_t rows) {
+    std::vector<Digest> out(rows);
+    size_t w = cols.size();
+#pragma omp parallel for schedule(static)
+    for (size_t j = 0; j < rows; j++) {
+        uint64_t buf[512];
+        for (size_t c = 0; c < w; c++) buf[c] = cols[c][j];
+        out[j] = hash_elements(buf, w);
+    }
+    return out;
+}
+
+template <class F>
+static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& opt, Col* pub_out,
+                       StageTimes* times = nullptr, ProverArtifacts<F>* art = nullptr) {
+    typedef typename F::T T;
+    const uint32_t W = (uint32_t)trace.size();
+    const size_t n = (size_t)1 << log_n, B = opt.blowup, N = n * B, Fd = opt.fri_fold;
+    const size_t C = FibAir::ce_blowup(), ceN = C * n, ce_step = B / C;
+    if (W < 2 || (W & 1) || W > 254) throw Err("prove: FibAir needs an even column count in [2, 254]");
+    if (B < C || (B & (B - 1))) throw Err("prove: blowup must be a power of two >= 2");
+    if (Fd != 2 && Fd != 4 && Fd != 8 && Fd != 16) throw Err("prove: unsupported FRI folding factor");
+    if (opt.hash_fn != HASH_BLAKE2S_256) throw Err("prove: only Blake2s_256 is supported");
+    if (ilog2(N) > TWO_ADICITY) throw Err("prove: LDE domain exceeds field two-adicity");
+    for (auto& c : trace) if (c.size() != n) throw Err("prove: ragged trace");
+    StageTimes tm; double t0 = now_s(), t1;
+
+    // 0. AIR + channel [proving_worker.rs:248-268]
+    FibAir air; air.W = W; air.log_n = log_n;
+    for (uint32_t k = 0; k < W / 2; k++) air.results.push_back(trace[2 * k + 1][n - 1]);
+    if (pub_out) *pub_out = air.results;
+    Coin coin = Coin::from_pub_elements(air.results.data(), air.results.size());
+    const uint64_t g = gl_root_of_unity(log_n), gN = gl_root_of_unity(ilog2(N));
+    Proof pr;
+    pr.main_width = (uint8_t)W; pr.aux_width = 0; pr.aux_rands = 0; pr.log_n = (uint8_t)log_n;
+    pr.modulus.resize(8); for (int i = 0; i < 8; i++) pr.modulus[i] = (uint8_t)(P >> (8 * i));
+    pr.opt = opt;
+
+    // 1. interpolate_columns [a3, proving_worker.rs:273]
+    std::vector<Col> polys = trace;
+    for (uint32_t c = 0; c < W; c++) intt(polys[c].data(), n, true);
+    t1 = now_s(); tm.interpolate = t1 - t0; t0 = t1;
+    // 2. evaluate_columns_over [a4, proving_worker.rs:274]
+    std::vector<Col> tlde(W);
+    for (uint32_t c = 0; c < W; c++) tlde[c] = lde(polys[c].data(), n, B, GEN);
+    t1 = now_s(); tm.lde = t1 - t0; t0 = t1;
+    // 3. row hashes + Merkle tree, commit [a5, a6, a8]
+    std::vector<Digest> tleaves = hash_rows(tlde, N);
+    MerkleTree ttree(tleaves);
+    wbytes(pr.commitments, Bytes(ttree.root().b, ttree.root().b + 32));
+    coin.reseed(ttree.root());
+    t1 = now_s(); tm.trace_commit = t1 - t0; t0 = t1;
+
+    // 4. constraint evaluation over the ce domain [a9, a10]
+    auto cc = draw_constraint_coeffs<F>(coin, air.num_transition(), air.num_assertions());
+    FibCombine cb(air);
+    std::vector<std::vector<T>> ce(3, std::vector<T>(ceN));
+    const uint64_t gce = gl_root_of_unity(ilog2(ceN));
+#pragma omp parallel
+    {
+        std::vector<uint64_t> cur(W), nxt(W);
+#pragma omp for schedule(static)
+        for (size_t s = 0; s < ceN; s++) {
+            size_t r = s * ce_step, rn = (r + B) % N;     // frame = (row j, row j + blowup mod N)
+            for (uint32_t c = 0; c < W; c++) { cur[c] = tlde[c][r]; nxt[c] = tlde[c][rn]; }
+            uint64_t x = gl_mul(GEN, gl_pow(gce, s));
+            T o[3];
+            fib_eval_point<F, FB>(air, cb, cc, cur.data(), nxt.data(), x, o);
+            ce[0][s] = o[0]; ce[1][s] = o[1]; ce[2][s] = o[2];
+        }
+    }
+    t1 = now_s(); tm.constraints = t1 - t0; t0 = t1;
+
+    // 5. composition polynomial [a11]: divide by divisors, sum, interpolate over the coset, split into C columns
+    std::vector<Col> hcomp(F::DEG, Col(ceN));
+    {
+        const uint64_t wl = gl_pow(g, n - 1);
+        // x^n takes only C distinct values on the ce domain: (7 w_ce^s)^n = 7^n * w_C^(s mod C)
+        Col zinv(C);
+        for (size_t k = 0; k < C; k++) zinv[k] = gl_inv(gl_sub(gl_mul(gl_pow(GEN, n), gl_pow(gl_root_of_unity(ilog2(C)), k)), 1));
+        const size_t CH = 1024;
+#pragma omp parallel for schedule(static)
+        for (size_t c0 = 0; c0 < ceN; c0 += CH) {
+            size_t m = std::min(CH, ceN - c0);
+            // batch-invert (x - 1) and (x - w^(n-1)) for the chunk
+            Col d(2 * m), pre(2 * m);
+            uint64_t x = gl_mul(GEN, gl_pow(gce, c0));
+            Col xs(m);
+            for (size_t i = 0; i < m; i++) { xs[i] = x; d[2 * i] = gl_sub(x, 1); d[2 * i + 1] = gl_sub(x, wl); x = gl_mul(x, gce); }
+            uint64_t acc = 1;
+            for (size_t i = 0; i < 2 * m; i++) { pre[i] = acc; acc = gl_mul(acc, d[i]); }
+            uint64_t ia = gl_inv(acc);
+            for (size_t i = 2 * m; i-- > 0;) { uint64_t inv = gl_mul(ia, pre[i]); ia = gl_mul(ia, d[i]); d[i] = inv; }
+            for (size_t i = 0; i < m; i++) {
+                size_t s = c0 + i;
+                uint64_t tdiv = gl_mul(gl_sub(xs[i], wl), zinv[s % C]);    // 1 / ((x^n - 1)/(x - w^(n-1)))
+                T h = F::mulb(ce[0][s], tdiv);
+                h = F::add(h, F::mulb(ce[1][s], d[2 * i]));
+                h = F::add(h, F::mulb(ce[2][s], d[2 * i + 1]));
+                for (int k = 0; k < F::DEG; k++) hcomp[k][s] = F::comp(h, k);
+            }
+        }
+    }
+    for (int k = 0; k < F::DEG; k++) intt_coset(hcomp[k].data(), ceN, GEN, true);
+    // split: coefficient i -> column i mod C (H(x) = sum_c x^c H_c(x^C); stark_verifier.cairo:166-176)
+    std::vector<Col> cpolys(C * F::DEG, Col(n));   // index c*DEG + k
+    for (size_t c = 0; c < C; c++) for (int k = 0; k < F::DEG; k++) for (size_t i = 0; i < n; i++) cpolys[c * F::DEG + k][i] = hcomp[k][i * C + c];
+    t1 = now_s(); tm.composition = t1 - t0; t0 = t1;
+    // 6. composition commitment [a12]
+    std::vector<Col> clde(C * F::DEG);
+    for (size_t c = 0; c < C * F::DEG; c++) clde[c] = lde(cpolys[c].data(), n, B, GEN);
+    std::vector<Digest> cleaves = hash_rows(clde, N);
+    MerkleTree ctree(cleaves);
+    wbytes(pr.commitments, Bytes(ctree.root().b, ctree.root().b + 32));
+    coin.reseed(ctree.root());
+    t1 = now_s(); tm.comp_commit = t1 - t0; t0 = t1;
+
+    // 7. OOD frame [a13]
+    T z = coin.draw<F>();
+    T z_next = F::mulb(z, g), zC = f_pow<F>(z, C);
+    std::vector<T> ood_cur(W), ood_next(W), ood_h(C);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (uint32_t c = 0; c < W; c++) { ood_cur[c] = horner<F>(polys[c].data(), n, z); ood_next[c] = horner<F>(polys[c].data(), n, z_next); }
+    for (size_t c = 0; c < C; c++) {
+        // H_c has E-valued coefficients: evaluate component polynomials and recombine (a0 + a1*phi)
+        T acc = F::zero();
+        for (int k = 0; k < F::DEG; k++) {
+            T e = horner<F>(cpolys[c * F::DEG + k].data(), n, zC);
+            uint64_t basis[2] = {k == 0 ? 1ULL : 0ULL, k == 1 ? 1ULL : 0ULL};
+            acc = F::add(acc, F::mul(e, F::make(basis)));
+        }
+        ood_h[c] = acc;
+    }
+    {
+        Col flat; f_flatten<F>(ood_cur.data(), W, flat); f_flatten<F>(ood_next.data(), W, flat);
+        for (uint64_t v : flat) w64(pr.ood_trace_states, v);
+        Col fh; f_flatten<F>(ood_h.data(), C, fh);
+        for (uint64_t v : fh) w64(pr.ood_evaluations, v);
+    }
+    coin.reseed(f_hash<F>(ood_cur.data(), W));
+    coin.reseed(f_hash<F>(ood_next.data(), W));
+    coin.reseed(f_hash<F>(ood_h.data(), C));
+    t1 = now_s(); tm.ood = t1 - t0; t0 = t1;
+
+    // 8. DEEP composition over the LDE domain [a14]
+    std::vector<T> da(W), db(W), dg(W), dc(C);
+    for (uint32_t i = 0; i < W; i++) { da[i] = coin.draw<F>(); db[i] = coin.draw<F>(); dg[i] = coin.draw<F>(); }
+    for (size_t i = 0; i < C; i++) dc[i] = coin.draw<F>();
+    T lambda = coin.draw<F>(), mu = coin.draw<F>();
+    T z_conj = F::conj(z);
+    std::vector<T> deep(N);
+    {
+        const size_t CH = 1024;
+        const int ND = F::DEG > 1 ? 4 : 3;
+#pragma omp parallel for schedule(static)
+        for (size_t c0 = 0; c0 < N; c0 += CH) {
+            size_t m = std::min(CH, N - c0);
+            std::vector<T> d(ND * m), pre(ND * m);
+            Col xs(m);
+            uint64_t x = gl_mul(GEN, gl_pow(gN, c0));
+            for (size_t i = 0; i < m; i++) {
+                xs[i] = x; T xe = F::from(x);
+                d[ND * i] = F::sub(xe, z); d[ND * i + 1] = F::sub(xe, z_next); d[ND * i + 2] = F::sub(xe, zC);
+                if (ND == 4) d[ND * i + 3] = F::sub(xe, z_conj);
+                x = gl_mul(x, gN);
+            }
+            T acc = F::one();
+            for (size_t i = 0; i < ND * m; i++) { pre[i] = acc; acc = F::mul(acc, d[i]); }
+            T ia = F::inv(acc);
+            for (size_t i = ND * m; i-- > 0;) { T inv = F::mul(ia, pre[i]); ia = F::mul(ia, d[i]); d[i] = inv; }
+            for (size_t i = 0; i < m; i++) {
+                size_t r = c0 + i;
+                T s1 = F::zero(), s2 = F::zero(), s3 = F::zero();
+                for (uint32_t c = 0; c < W; c++) {
+                    T v = F::from(tlde[c][r]);
+                    s1 = F::add(s1, F::mul(F::sub(v, ood_cur[c]), da[c]));
+                    s2 = F::add(s2, F::mul(F::sub(v, ood_next[c]), db[c]));
+                    if (F::DEG > 1) s3 = F::add(s3, F::mul(F::sub(v, F::conj(ood_cur[c])), dg[c]));
+                }
+                T t = F::add(F::mul(s1, d[ND * i]), F::mul(s2, d[ND * i + 1]));
+                if (F::DEG > 1) t = F::add(t, F::mul(s3, d[ND * i + 3]));
+                T sc = F::zero();
+                for (size_t c = 0; c < C; c++) {
+                    uint64_t comp[2] = {clde[c * F::DEG][r], F::DEG > 1 ? clde[c * F::DEG + F::DEG - 1][r] : 0};
+                    sc = F::add(sc, F::mul(F::sub(F::make(comp), ood_h[c]), dc[c]));
+                }
+                t = F::add(t, F::mul(sc, d[ND * i + 2]));
+                deep[r] = F::mul(t, F::add(lambda, F::mulb(mu, xs[i])));
+            }
+        }
+    }
+    t1 = now_s(); tm.deep = t1 - t0; t0 = t1;
+
+    // 9. FRI commit phase [a15]: num_fri_layers + 1 rounds (the last one commits the remainder)
+    const int layers = num_fri_layers(N, Fd, (uint64_t)1 << opt.log_max_remainder);
+    { uint64_t rem = N; for (int l = 0; l < layers; l++) rem /= Fd; if (rem < Fd) throw Err("prove: FRI remainder smaller than the folding factor"); }
+    struct Layer { MerkleTree tree; std::vector<T> rows; size_t nrows; bool has_tree; Digest root; };
+    std::vector<Layer> fl(layers + 1);
+    {
+        std::vector<T> ev = deep;
+        uint64_t dom = N, omega = gN;
+        // inverse DFT matrix of size Fd: winv[j*k] = w_F^(-jk)
+        for (int l = 0; l <= layers; l++) {
+            size_t rows = dom / Fd;
+            Layer& L = fl[l];
+            L.nrows = rows;
+            L.rows.resize(dom);
+            std::vector<Digest> leaves(rows);
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < rows; i++) {
+                T row[16];
+                for (size_t j = 0; j < Fd; j++) { row[j] = ev[i + j * rows]; L.rows[i * Fd + j] = row[j]; }
+                leaves[i] = f_hash<F>(row, Fd);
+            }
+            if (rows >= 2) { L.tree = MerkleTree(leaves); L.root = L.tree.root(); L.has_tree = true; }
+            else { L.root = leaves[0]; L.has_tree = false; }
+            wbytes(pr.commitments, Bytes(L.root.b, L.root.b + 32));
+            coin.reseed(L.root);
+            T alpha = coin.draw<F>();
+            if (l == layers) break;   // the alpha drawn after the remainder commitment is unused
+            // fold: p_i = interpolant through (7 w^i w_F^j, row_i[j]); next[i] = p_i(alpha); offset stays 7
+            const uint64_t wF = gl_pow(omega, rows), wFi = gl_inv(wF), Finv = gl_inv(Fd), oinv = gl_inv(omega);
+            Col tw(Fd * Fd);
+            for (size_t j = 0; j < Fd; j++) for (size_t k = 0; k < Fd; k++) tw[j * Fd + k] = gl_pow(wFi, j * k);
+            std::vector<T> nxt(rows);
+            const size_t CH = 1024;
+#pragma omp parallel for schedule(static)
+            for (size_t c0 = 0; c0 < rows; c0 += CH) {
+                size_t m = std::min(CH, rows - c0);
+                uint64_t xinv = gl_mul(gl_inv(GEN), gl_pow(oinv, c0));
+                for (size_t i = 0; i < m; i++) {
+                    const T* row = &L.rows[(c0 + i) * Fd];
+                    T r = F::mulb(alpha, xinv), rp = F::one(), acc = F::zero();
+                    for (size_t k = 0; k < Fd; k++) {
+                        T ck = F::zero();
+                        for (size_t j = 0; j < Fd; j++) ck = F::add(ck, F::mulb(row[j], tw[j * Fd + k]));
+                        acc = F::add(acc, F::mul(ck, rp));
+                        rp = F::mul(rp, r);
+                    }
+                    nxt[c0 + i] = F::mulb(acc, Finv);
+                    xinv = gl_mul(xinv, oinv);
+                }
+            }
+            ev.swap(nxt); dom = rows; omega = gl_pow(omega, Fd);
+        }
+    }
+    t1 = now_s(); tm.fri = t1 - t0; t0 = t1;
+
+    // 10. grinding [a16]: smallest nonce >= 1 with enough leading zeros (winter-prover 0.4 scans 1..u64::MAX)
+    {
+        uint64_t nonce = 0;
+        const uint64_t CH = 1 << 14;
+        for (uint64_t base = 1; nonce == 0; base += CH) {
+            uint64_t best = UINT64_MAX;
+#pragma omp parallel for schedule(static) reduction(min : best)
+            for (uint64_t v = base; v < base + CH; v++)
+                if (coin.check_leading_zeros(v) >= opt.grinding && v < best) best = v;
+            if (best != UINT64_MAX) nonce = best;
+        }
+        pr.pow_nonce = nonce;
+        coin.reseed_int(nonce);
+    }
+    t1 = now_s(); tm.grind = t1 - t0; t0 = t1;
+
+    // 11. queries [a17]
+    std::vector<uint64_t> pos = coin.draw_integers(opt.num_queries, N);
+    {
+        Proof::Q q;
+        for (uint64_t p : pos) for (uint32_t c = 0; c < W; c++) w64(q.values, tlde[c][p]);
+        q.paths = batch_serialize(batch_prove(ttree, pos));
+        pr.trace_queries.push_back(q);
+    }
+    {
+        Proof::Q& q = pr.constraint_queries;
+        for (uint64_t p : pos) for (size_t c = 0; c < C * F::DEG; c++) w64(q.values, clde[c][p]);
+        q.paths = batch_serialize(batch_prove(ctree, pos));
+    }
+    {
+        std::vector<uint64_t> fp = pos;
+        uint64_t dom = N;
+        for (int l = 0; l < layers; l++) {
+            fp = fold_positions(fp, dom, Fd);
+            Proof::Q q;
+            for (uint64_t p : fp) { Col flat; f_flatten<F>(&fl[l].rows[p * Fd], Fd, flat); for (uint64_t v : flat) w64(q.values, v); }
+            q.paths = batch_serialize(batch_prove(fl[l].tree, fp));
+            pr.fri_layers.push_back(q);
+            dom /= Fd;
+        }
+        // remainder: un-transpose the last layer (winter-fri 0.4 build_proof)
+        const Layer& L = fl[layers];
+        size_t rows = L.nrows;
+        std::vector<T> rem(rows * Fd);
+        for (size_t i = 0; i < rows; i++) for (size_t j = 0; j < Fd; j++) rem[i + rows * j] = L.rows[i * Fd + j];
+        Col flat; f_flatten<F>(rem.data(), rem.size(), flat);
+        for (uint64_t v : flat) w64(pr.fri_remainder, v);
+        pr.fri_log_partitions = 0;
+    }
+    t1 = now_s(); tm.queries = t1 - t0;
+    tm.total = tm.interpolate + tm.lde + tm.trace_commit + tm.constraints + tm.composition + tm.comp_commit + tm.ood +
+               tm.deep + tm.fri + tm.grind + tm.queries;
+    if (times) *times = tm;
+    if (art) {
+        art->trace_polys = polys; art->trace_lde = tlde; art->trace_leaves = tleaves; art->ce_cols = ce;
+        art->comp_polys = cpolys; art->comp_lde = clde; art->deep = deep;
+        for (auto& L : fl) art->fri_layers.push_back(L.rows);
+        art->ood_cur = ood_cur; art->ood_next = ood_next; art->ood_h = ood_h;
+    }
+    return pr.to_bytes();
+}
+
+static Bytes prove_fib_any(const std::vector<Col>& trace, int log_n, const Options& opt, Col* pub_out, StageTimes* times = nullptr) {
+    if (opt.field_ext == EXT_NONE) return prove_fib<FB>(trace, log_n, opt, pub_out, times);
+    if (opt.field_ext == EXT_QUADRATIC) return prove_fib<FQ>(trace, log_n, opt, pub_out, times);
+    throw Err("prove: unsupported field extension");
+}
+
+}  // namespace orc
