@@ -1,0 +1,326 @@
+"""aero_amd — Python harness binding of libaero_stark.so (the MI355X-native Winterfell proving backend).
+
+This module is plumbing for tests, bench.py and the multi-GPU launcher: it loads the C-ABI library
+(include/aero_stark.h) with ctypes and mirrors the reference's operator surface by name
+(ProofOptions, Matrix, MerkleTree, Prover.prove ... — see aero_amd/csrc/prover.hpp for the file:line map).
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, construction fails loudly.
+Nothing here imports oracle/ or tests/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaero_stark.so")
+CSRC = os.path.join(_HERE, "csrc")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "aero_stark.h")
+
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+
+P = 0xFFFFFFFF00000001
+
+STAGE_NAMES = ["interpolate", "lde", "trace_commit", "constraints", "composition", "comp_commit", "ood", "deep", "fri",
+               "grind", "queries", "total"]
+
+
+class AeroError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"aero_stark error {code}: {msg}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile every HIP translation unit for gfx950 into aero_amd/libaero_stark.so (hipcc cross-compiles
+    without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"])
+    return LIB_PATH
+
+
+class ProofOptions(C.Structure):
+    """Mirror of winter_air::ProofOptions (convert_inputs.rs:54-66); byte order = proof-context order."""
+    _fields_ = [("num_queries", C.c_uint8), ("blowup_factor", C.c_uint8), ("grinding_factor", C.c_uint8),
+                ("hash_fn", C.c_uint8), ("field_extension", C.c_uint8), ("fri_folding_factor", C.c_uint8),
+                ("fri_log_max_remainder", C.c_uint8)]
+
+    @classmethod
+    def with_96_bit_security(cls):
+        return cls(27, 8, 16, 4, 1, 8, 8)
+
+    def to_list(self):
+        return [self.num_queries, self.blowup_factor, self.grinding_factor, self.hash_fn, self.field_extension,
+                self.fri_folding_factor, self.fri_log_max_remainder]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP library is required; there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.aero_last_error.restype = C.c_char_p
+        L.aero_last_error.argtypes = [C.c_void_p]
+        L.aero_device_count.restype = C.c_int32
+        _lib = L
+    return _lib
+
+
+def _p8(a):
+    return a.ctypes.data_as(u8p)
+
+
+def _p64(a):
+    return a.ctypes.data_as(u64p)
+
+
+def fib_trace(width, log_n):
+    """Synthetic Fibonacci trace, column-major (width, 2^log_n) uint64 (host)."""
+    out = np.zeros((width, 1 << log_n), np.uint64)
+    rc = lib().aero_fib_trace(C.c_uint32(width), C.c_uint32(log_n), _p64(out))
+    if rc != 0:
+        raise AeroError(rc, "fib_trace: width must be even and >= 2")
+    return out
+
+
+def proof_container(inputs: bytes, proof: bytes) -> bytes:
+    """bincode ProofData{input_bytes, proof_bytes} (miden-proof-generator/src/lib.rs:1-6)."""
+    out = u8p()
+    n = C.c_size_t(0)
+    a = np.frombuffer(inputs, np.uint8) if inputs else np.zeros(1, np.uint8)
+    b = np.frombuffer(proof, np.uint8) if proof else np.zeros(1, np.uint8)
+    rc = lib().aero_proof_container(_p8(a), C.c_size_t(len(inputs)), _p8(b), C.c_size_t(len(proof)), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise AeroError(rc, "proof_container")
+    data = C.string_at(out, n.value)
+    lib().aero_free(out)
+    return data
+
+
+class Matrix:
+    """Device column-major matrix handle (winter Matrix<Felt>)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    @property
+    def shape(self):
+        c = C.c_uint32(0)
+        r = C.c_uint64(0)
+        lib().aero_matrix_shape(self.h, C.byref(c), C.byref(r))
+        return (c.value, r.value)
+
+    def download(self):
+        cols, rows = self.shape
+        out = np.zeros((cols, rows), np.uint64)
+        self.ctx._ck(lib().aero_matrix_download(self.ctx.h, self.h, _p64(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib().aero_matrix_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MerkleTree:
+    def __init__(self, ctx, handle, root, n):
+        self.ctx = ctx
+        self.h = handle
+        self.root = root
+        self.n = n
+
+    def prove_batch(self, positions) -> bytes:
+        """MerkleTree::prove_batch + BatchMerkleProof::serialize_nodes."""
+        pos = np.ascontiguousarray(positions, np.uint64)
+        cap = 1 + len(pos) * (1 + 32 * 40)
+        out = np.zeros(cap, np.uint8)
+        n = C.c_size_t(0)
+        self.ctx._ck(lib().aero_merkle_open_batch(self.ctx.h, self.h, _p64(pos), C.c_uint32(len(pos)), _p8(out), C.c_size_t(cap), C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def nodes(self):
+        out = np.zeros((2 * self.n, 32), np.uint8)
+        self.ctx._ck(lib().aero_merkle_nodes(self.ctx.h, self.h, _p8(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            lib().aero_tree_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU + one HIP stream + a device memory pool."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib().aero_ctx_create(C.c_int32(device), C.byref(self.h))
+        if rc != 0:
+            raise AeroError(rc, lib().aero_last_error(None).decode())
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise AeroError(rc, lib().aero_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            lib().aero_ctx_destroy(self.h)
+            self.h = None
+
+    # ---- matrices / stage 1
+    def trace_upload(self, trace: np.ndarray) -> Matrix:
+        t = np.ascontiguousarray(trace, np.uint64)
+        w, n = t.shape
+        log_n = int(n).bit_length() - 1
+        if (1 << log_n) != n:
+            raise AeroError(-1, "trace length must be a power of two")
+        h = C.c_void_p()
+        self._ck(lib().aero_trace_upload(self.h, _p64(t), C.c_uint32(w), C.c_uint32(log_n), C.byref(h)))
+        return Matrix(self, h)
+
+    def interpolate_columns(self, trace: Matrix) -> Matrix:
+        h = C.c_void_p()
+        self._ck(lib().aero_interpolate_columns(self.h, trace.h, C.byref(h)))
+        return Matrix(self, h)
+
+    def evaluate_columns_over(self, polys: Matrix, log_blowup: int) -> Matrix:
+        h = C.c_void_p()
+        self._ck(lib().aero_evaluate_columns_over(self.h, polys.h, C.c_uint32(log_blowup), C.byref(h)))
+        return Matrix(self, h)
+
+    def poly_eval(self, polys: Matrix, z: int):
+        cols, _ = polys.shape
+        out = np.zeros(cols, np.uint64)
+        self._ck(lib().aero_poly_eval(self.h, polys.h, C.c_uint64(z), _p64(out)))
+        return out.tolist()
+
+    # ---- hashing / Merkle
+    def hash_rows(self, rows: np.ndarray) -> np.ndarray:
+        """HashingWorkItem.data (n_rows, width) -> HashingResult.hashes (n_rows, 32)."""
+        r = np.ascontiguousarray(rows, np.uint64)
+        n, w = r.shape
+        out = np.zeros((n, 32), np.uint8)
+        self._ck(lib().aero_hash_rows(self.h, _p64(r) if n else None, C.c_uint32(w), C.c_uint64(n), _p8(out) if n else _p8(np.zeros(1, np.uint8))))
+        return out
+
+    def hash_matrix_rows(self, m: Matrix) -> np.ndarray:
+        _, rows = m.shape
+        out = np.zeros((rows, 32), np.uint8)
+        self._ck(lib().aero_hash_matrix_rows(self.h, m.h, _p8(out)))
+        return out
+
+    def merkle_from_leaves(self, leaves: np.ndarray) -> MerkleTree:
+        l = np.ascontiguousarray(leaves, np.uint8)
+        h = C.c_void_p()
+        root = np.zeros(32, np.uint8)
+        self._ck(lib().aero_merkle_from_leaves(self.h, _p8(l), C.c_uint64(l.shape[0]), C.byref(h), _p8(root)))
+        return MerkleTree(self, h, root.tobytes(), l.shape[0])
+
+    def merkle_commit_rows(self, m: Matrix) -> MerkleTree:
+        h = C.c_void_p()
+        root = np.zeros(32, np.uint8)
+        self._ck(lib().aero_merkle_commit_rows(self.h, m.h, C.byref(h), _p8(root)))
+        return MerkleTree(self, h, root.tobytes(), m.shape[1])
+
+    # ---- constraints / FRI / grinding
+    def eval_constraints_fib(self, lde: Matrix, log_blowup, results, coeffs, field_extension=1, fragment_offset=0, num_fragments=1):
+        """ConstraintComputeWorkItem -> ConstraintComputeResult for FibAir. Returns (frag_index, cols (3*deg, rows))."""
+        w, N = lde.shape
+        deg = 2 if field_extension == 2 else 1
+        n = N >> log_blowup
+        rows = 2 * n // num_fragments
+        res = np.ascontiguousarray(results, np.uint64)
+        co = np.ascontiguousarray(coeffs, np.uint64)
+        assert co.size == 2 * deg * (w + w + w // 2), "coeffs: (alpha, beta) per transition constraint then per assertion"
+        out = np.zeros((3 * deg, rows), np.uint64)
+        fi = C.c_uint64(0)
+        self._ck(lib().aero_eval_constraints_fib(self.h, lde.h, C.c_uint32(log_blowup), _p64(res), _p64(co), C.c_uint8(field_extension),
+                                                 C.c_uint32(fragment_offset), C.c_uint32(num_fragments), _p64(out), C.byref(fi)))
+        return fi.value, out
+
+    def fri_fold(self, values: np.ndarray, fold: int, alpha: int) -> np.ndarray:
+        v = np.ascontiguousarray(values, np.uint64)
+        out = np.zeros(max(v.size // fold, 1), np.uint64)
+        self._ck(lib().aero_fri_fold(self.h, _p64(v), C.c_uint64(v.size), C.c_uint32(fold), C.c_uint64(alpha), _p64(out)))
+        return out
+
+    def grind(self, seed: bytes, bits: int) -> int:
+        s = np.frombuffer(seed, np.uint8).copy()
+        n = C.c_uint64(0)
+        self._ck(lib().aero_grind(self.h, _p8(s), C.c_uint32(bits), C.byref(n)))
+        return n.value
+
+    # ---- whole proof
+    def prove_fib(self, trace, options: ProofOptions):
+        """Prover::prove for FibAir. `trace` is a device Matrix (resident) or a host ndarray (copied in).
+        Returns (proof_bytes, public_inputs)."""
+        proof = u8p()
+        plen = C.c_size_t(0)
+        if isinstance(trace, Matrix):
+            w, _ = trace.shape
+            pub = np.zeros(w // 2, np.uint64)
+            rc = lib().aero_prove_fib(self.h, trace.h, C.byref(options), C.byref(proof), C.byref(plen), _p64(pub))
+        else:
+            t = np.ascontiguousarray(trace, np.uint64)
+            w, n = t.shape
+            pub = np.zeros(w // 2, np.uint64)
+            rc = lib().aero_prove_fib_host(self.h, _p64(t), C.c_uint32(w), C.c_uint32(int(n).bit_length() - 1), C.byref(options),
+                                           C.byref(proof), C.byref(plen), _p64(pub))
+        self._ck(rc)
+        data = C.string_at(proof, plen.value)
+        lib().aero_free(proof)
+        return data, pub.tolist()
+
+    # ---- instrumentation
+    def set_stage_timing(self, on):
+        self._ck(lib().aero_set_stage_timing(self.h, C.c_int32(1 if on else 0)))
+
+    def last_stage_ms(self):
+        out = np.zeros(12, np.float64)
+        self._ck(lib().aero_last_stage_ms(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return dict(zip(STAGE_NAMES, out.tolist()))
+
+    def set_kernel_timing(self, on, only_kernel=None):
+        self._ck(lib().aero_set_kernel_timing(self.h, C.c_int32(1 if on else 0), only_kernel.encode() if only_kernel else None))
+
+    def kernel_timing_report(self):
+        """{kernel_name: (calls, total_ms, algorithmic_bytes)} measured with HIP events on the launch stream; resets
+        the counters."""
+        buf = C.create_string_buffer(1 << 16)
+        self._ck(lib().aero_kernel_timing_report(self.h, buf, C.c_size_t(1 << 16)))
+        out = {}
+        for line in buf.value.decode().strip().split("\n"):
+            if line:
+                name, calls, ms, nbytes = line.split()
+                out[name] = (int(calls), float(ms), float(nbytes))
+        return out
+
+    def memory_stats(self):
+        a = C.c_uint64(0)
+        b = C.c_uint64(0)
+        lib().aero_memory_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+
+def device_count():
+    return lib().aero_device_count()

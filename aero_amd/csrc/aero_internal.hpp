@@ -1,0 +1,134 @@
+// Internal declarations shared by the HIP translation units of libaero_stark.so.
+// Nothing here is part of the public boundary (see include/aero_stark.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "blake2s.cuh"
+#include "gl.cuh"
+
+namespace aero {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& s) : std::runtime_error(s), code(c) {}
+};
+// status codes of the C ABI (include/aero_stark.h)
+enum { ST_OK = 0, ST_BAD_ARG = -1, ST_OOM = -2, ST_HIP = -3, ST_COMM = -4, ST_UNSUPPORTED = -5, ST_INTERNAL = -6 };
+
+[[noreturn]] inline void fail(const std::string& s, int code = ST_BAD_ARG) { throw Error(code, s); }
+
+#define AERO_HIP(expr)                                                                                       \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            throw ::aero::Error(e_ == hipErrorOutOfMemory ? ::aero::ST_OOM : ::aero::ST_HIP,                  \
+                                std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+    } while (0)
+
+// Every kernel launch goes through this macro so that it can be bracketed by HIP events on the launch stream.
+// `abytes` = algorithmic HBM bytes of the launch (every input read once + every output written once).
+#define AERO_LAUNCH(ctxp, name, abytes, kern, grid, block, shm, ...)                 \
+    do {                                                                             \
+        ::aero::Context* c_ = (ctxp);                                                \
+        const bool t_ = c_->kernel_timing && c_->kt_match(name);                     \
+        if (t_) c_->kt_begin(name, (size_t)(abytes));                                \
+        hipLaunchKernelGGL(kern, grid, block, shm, c_->stream, __VA_ARGS__);         \
+        if (t_) c_->kt_end();                                                        \
+    } while (0)
+
+struct NttTables {
+    int log_n = 0, h = 0;
+    uint64_t *lo_fwd = nullptr, *hi_fwd = nullptr, *lo_inv = nullptr, *hi_inv = nullptr;
+};
+struct NttPass {
+    int log_s, log_r, log_tl;
+};
+std::vector<NttPass> plan_passes(int log_n);
+
+typedef b2s::Digest Digest;   // 8 x u32, byte order = digest byte order (little-endian words)
+
+// One context = one device + one stream. Not thread-safe: one host thread drives it (SURVEY 8b "Threading").
+class Context {
+public:
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    explicit Context(int dev);
+    ~Context();
+
+    // ---- memory: size-keyed free lists so steady-state proving performs no hipMalloc/hipFree ----
+    void* pool_alloc(size_t bytes);
+    void pool_free(void* p);
+    void* dev_alloc(size_t bytes);       // lives until the context dies (tables)
+    void* scratch_alloc(size_t bytes);   // released by scratch_reset() (stream-ordered reuse)
+    void scratch_reset();
+    size_t bytes_in_use = 0, bytes_peak = 0;
+
+    void check_launch(const char* what);
+    void sync();
+
+    // ---- per-kernel HIP-event timing on this context's stream (off by default) ----
+    bool kernel_timing = false;
+    std::string kt_filter;       // empty = every kernel, otherwise only launches of this kernel are bracketed
+    bool kt_match(const char* name) const { return kt_filter.empty() || kt_filter == name; }
+    void kt_begin(const char* name, size_t abytes);
+    void kt_end();
+    std::string kt_report();   // "name calls total_ms algorithmic_bytes" lines sorted by total; resets the counters
+
+    // ---- NTT (ntt.hip) ----
+    NttTables* ntt_tables(int log_n);
+    void ensure_small_twiddles();
+    void ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad);
+    void ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift);
+
+    // ---- hashing (hash.hip) ----
+    // leaf j = hash_elements(row j) of a column-major matrix (ncols columns, `rows` rows, column stride in elements)
+    void hash_rows(const uint64_t* cols, size_t col_stride, int ncols, size_t rows, Digest* leaves);
+    // FRI layer rows: row i = (v[i + j*rows] for j < fold), each value having `deg` base components stored as
+    // component columns comp[k] (k < deg): leaf i = hash_elements(flattened row)
+    void hash_fri_rows(const uint64_t* const comp[2], int deg, size_t rows, int fold, Digest* leaves);
+    // nodes[n + i] already hold the leaves; fills nodes[1 .. n-1]
+    void merkle_build(Digest* nodes, size_t n);
+
+    // internal state
+    std::map<int, NttTables> ntt_tabs;
+    uint64_t *tw4096_fwd = nullptr, *tw4096_inv = nullptr;
+
+private:
+    struct KtRec { const char* name; size_t abytes; hipEvent_t start, stop; };
+    std::vector<KtRec> kt_recs;
+    std::vector<hipEvent_t> kt_pool;
+    hipEvent_t kt_event();
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live_blocks;
+    std::vector<void*> persistent, scratch;
+};
+
+// RAII device buffer from the context pool
+template <class T> struct DevBuf {
+    Context* ctx = nullptr;
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(Context* c, size_t count) : ctx(c), n(count) { p = (T*)c->pool_alloc(count * sizeof(T)); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : ctx(o.ctx), p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); ctx = o.ctx; p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() { if (p) { ctx->pool_free(p); p = nullptr; n = 0; } }
+    T* get() const { return p; }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+}  // namespace aero

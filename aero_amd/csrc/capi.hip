@@ -1,0 +1,441 @@
+// extern "C" boundary of libaero_stark.so (declarations + reference citations: include/aero_stark.h).
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/aero_stark.h"
+#include "prover.hpp"
+#include "stark_kernels.hpp"
+
+using namespace aero;
+
+struct aero_ctx {
+    Context* c = nullptr;
+    std::string err;
+    StageMs last_ms;
+    bool stage_timing = false;
+};
+struct aero_matrix {
+    Matrix m;
+};
+struct aero_tree {
+    MerkleTree t;
+};
+
+static thread_local std::string g_create_err;
+
+template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
+    try {
+        if (!ctx || !ctx->c) { g_create_err = "null context"; return AERO_E_BAD_ARG; }
+        AERO_HIP(hipSetDevice(ctx->c->device));
+        fn();
+        return AERO_OK;
+    } catch (const Error& e) {
+        if (ctx) { ctx->err = e.what(); if (ctx->c) ctx->c->scratch_reset(); }
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        if (ctx) ctx->err = "host allocation failed";
+        return AERO_E_OOM;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->err = e.what();
+        return AERO_E_INTERNAL;
+    }
+}
+#define REQUIRE(cond, msg) do { if (!(cond)) fail(msg); } while (0)
+
+static int ilog2u(uint64_t x) { int r = 0; while ((1ull << r) < x) r++; return r; }
+
+extern "C" {
+
+int32_t aero_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int32_t aero_ctx_create(int32_t device_id, aero_ctx** out) {
+    if (!out) return AERO_E_BAD_ARG;
+    *out = nullptr;
+    try {
+        aero_ctx* h = new aero_ctx();
+        try { h->c = new Context(device_id); } catch (...) { delete h; throw; }
+        *out = h;
+        return AERO_OK;
+    } catch (const Error& e) { g_create_err = e.what(); return e.code; }
+    catch (const std::exception& e) { g_create_err = e.what(); return AERO_E_INTERNAL; }
+}
+void aero_ctx_destroy(aero_ctx* ctx) {
+    if (!ctx) return;
+    delete ctx->c;
+    delete ctx;
+}
+const char* aero_last_error(const aero_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+void aero_free(void* p) { free(p); }
+
+// ---- matrices ----------------------------------------------------------------------------------
+int32_t aero_trace_upload(aero_ctx* ctx, const uint64_t* col_major, uint32_t width, uint32_t log_n, aero_matrix** out) {
+    return guard(ctx, [&] {
+        REQUIRE(col_major && out, "trace_upload: null argument");
+        REQUIRE(width >= 1 && width <= 255 && log_n >= 3 && log_n <= 29, "trace_upload: width must be in [1,255] and log_n in [3,29]");
+        size_t n = (size_t)1 << log_n;
+        aero_matrix* h = new aero_matrix();
+        try {
+            h->m = Matrix(ctx->c, (int)width, n);
+            AERO_HIP(hipMemcpyAsync(h->m.data.get(), col_major, (size_t)width * n * 8, hipMemcpyHostToDevice, ctx->c->stream));
+            ctx->c->sync();
+        } catch (...) { delete h; throw; }
+        *out = h;
+    });
+}
+int32_t aero_matrix_shape(const aero_matrix* m, uint32_t* cols, uint64_t* rows) {
+    if (!m) return AERO_E_BAD_ARG;
+    if (cols) *cols = (uint32_t)m->m.cols;
+    if (rows) *rows = m->m.rows;
+    return AERO_OK;
+}
+int32_t aero_matrix_download(aero_ctx* ctx, const aero_matrix* m, uint64_t* out) {
+    return guard(ctx, [&] {
+        REQUIRE(m && out, "matrix_download: null argument");
+        AERO_HIP(hipMemcpyAsync(out, m->m.data.get(), (size_t)m->m.cols * m->m.rows * 8, hipMemcpyDeviceToHost, ctx->c->stream));
+        ctx->c->sync();
+    });
+}
+void aero_matrix_free(aero_ctx* ctx, aero_matrix* m) {
+    (void)ctx;
+    delete m;
+}
+int32_t aero_fib_trace(uint32_t width, uint32_t log_n, uint64_t* out) {
+    if (!out || width < 2 || (width & 1) || log_n > 29) return AERO_E_BAD_ARG;
+    size_t n = (size_t)1 << log_n;
+    for (uint32_t k = 0; k < width / 2; k++) {
+        uint64_t a = 1 + 2 * (uint64_t)k, b = 2 + 2 * (uint64_t)k;
+        uint64_t* ca = out + (size_t)(2 * k) * n;
+        uint64_t* cb = out + (size_t)(2 * k + 1) * n;
+        for (size_t i = 0; i < n; i++) {
+            ca[i] = a; cb[i] = b;
+            uint64_t na = gl::add(a, b), nb = gl::add(b, na);
+            a = na; b = nb;
+        }
+    }
+    return AERO_OK;
+}
+
+// ---- stage 1 -----------------------------------------------------------------------------------
+int32_t aero_interpolate_columns(aero_ctx* ctx, const aero_matrix* trace, aero_matrix** polys) {
+    return guard(ctx, [&] {
+        REQUIRE(trace && polys, "interpolate_columns: null argument");
+        REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0 && trace->m.rows >= 8, "interpolate_columns: row count must be a power of two >= 8");
+        Prover p(ctx->c, ProofOptions::with_96_bit_security());
+        aero_matrix* h = new aero_matrix();
+        try { h->m = p.interpolate_columns(trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows)); ctx->c->sync(); ctx->c->scratch_reset(); }
+        catch (...) { delete h; throw; }
+        *polys = h;
+    });
+}
+int32_t aero_evaluate_columns_over(aero_ctx* ctx, const aero_matrix* polys, uint32_t log_blowup, aero_matrix** lde) {
+    return guard(ctx, [&] {
+        REQUIRE(polys && lde, "evaluate_columns_over: null argument");
+        REQUIRE(log_blowup >= 1 && log_blowup <= 7, "evaluate_columns_over: log_blowup must be in [1,7]");
+        REQUIRE(ilog2u(polys->m.rows) + (int)log_blowup <= gl::TWO_ADICITY, "evaluate_columns_over: domain exceeds two-adicity");
+        Prover p(ctx->c, ProofOptions::with_96_bit_security());
+        aero_matrix* h = new aero_matrix();
+        try { h->m = p.evaluate_columns_over(polys->m, (int)log_blowup); ctx->c->sync(); }
+        catch (...) { delete h; throw; }
+        *lde = h;
+    });
+}
+int32_t aero_poly_eval(aero_ctx* ctx, const aero_matrix* polys, uint64_t z, uint64_t* out) {
+    return guard(ctx, [&] {
+        REQUIRE(polys && out, "poly_eval: null argument");
+        REQUIRE(z < gl::P, "poly_eval: non-canonical field element");
+        DevBuf<uint64_t> d(ctx->c, polys->m.cols);
+        launch_eval_bitrev<gl::FB>(ctx->c, polys->m.data.get(), polys->m.rows, 0, polys->m.cols, 1, ilog2u(polys->m.rows),
+                                   gl::mul(z, gl::inv(gl::GEN)), 0, 1, d.get());
+        AERO_HIP(hipMemcpyAsync(out, d.get(), polys->m.cols * 8, hipMemcpyDeviceToHost, ctx->c->stream));
+        ctx->c->sync();
+        ctx->c->scratch_reset();
+    });
+}
+
+// ---- hashing / Merkle ----------------------------------------------------------------------------
+int32_t aero_hash_rows(aero_ctx* ctx, const uint64_t* rows_row_major, uint32_t width, uint64_t n_rows, uint8_t* digests_out) {
+    return guard(ctx, [&] {
+        REQUIRE(digests_out && (rows_row_major || n_rows == 0), "hash_rows: null argument");
+        REQUIRE(width >= 1, "hash_rows: rows must have at least one element");
+        if (n_rows == 0) return;
+        // row-major host rows -> column-major device matrix (strided copy), then the coalesced row-hash kernel
+        Matrix m(ctx->c, (int)width, n_rows);
+        std::vector<uint64_t> cm((size_t)width * n_rows);
+        for (uint64_t r = 0; r < n_rows; r++)
+            for (uint32_t c = 0; c < width; c++) cm[(size_t)c * n_rows + r] = rows_row_major[r * width + c];
+        AERO_HIP(hipMemcpyAsync(m.data.get(), cm.data(), cm.size() * 8, hipMemcpyHostToDevice, ctx->c->stream));
+        DevBuf<Digest> d(ctx->c, n_rows);
+        ctx->c->hash_rows(m.data.get(), n_rows, (int)width, n_rows, d.get());
+        AERO_HIP(hipMemcpyAsync(digests_out, d.get(), n_rows * 32, hipMemcpyDeviceToHost, ctx->c->stream));
+        ctx->c->sync();
+    });
+}
+int32_t aero_hash_matrix_rows(aero_ctx* ctx, const aero_matrix* m, uint8_t* digests_out) {
+    return guard(ctx, [&] {
+        REQUIRE(m, "hash_matrix_rows: null argument");
+        DevBuf<Digest> d(ctx->c, m->m.rows);
+        ctx->c->hash_rows(m->m.data.get(), m->m.rows, m->m.cols, m->m.rows, d.get());
+        if (digests_out) AERO_HIP(hipMemcpyAsync(digests_out, d.get(), m->m.rows * 32, hipMemcpyDeviceToHost, ctx->c->stream));
+        ctx->c->sync();
+    });
+}
+int32_t aero_merkle_from_leaves(aero_ctx* ctx, const uint8_t* leaves, uint64_t n, aero_tree** out, uint8_t root_out[32]) {
+    return guard(ctx, [&] {
+        REQUIRE(leaves && out, "merkle_from_leaves: null argument");
+        REQUIRE(n >= 2 && (n & (n - 1)) == 0, "merkle_from_leaves: leaf count must be a power of two >= 2");
+        aero_tree* h = new aero_tree();
+        try {
+            h->t = MerkleTree(ctx->c, n);
+            AERO_HIP(hipMemcpyAsync(h->t.leaves(), leaves, n * 32, hipMemcpyHostToDevice, ctx->c->stream));
+            ctx->c->merkle_build(h->t.nodes.get(), n);
+            AERO_HIP(hipMemcpyAsync(&h->t.root_host, h->t.nodes.get() + 1, 32, hipMemcpyDeviceToHost, ctx->c->stream));
+            ctx->c->sync();
+        } catch (...) { delete h; throw; }
+        if (root_out) memcpy(root_out, h->t.root_host.w, 32);
+        *out = h;
+    });
+}
+int32_t aero_merkle_commit_rows(aero_ctx* ctx, const aero_matrix* m, aero_tree** out, uint8_t root_out[32]) {
+    return guard(ctx, [&] {
+        REQUIRE(m && out, "merkle_commit_rows: null argument");
+        REQUIRE(m->m.rows >= 2 && (m->m.rows & (m->m.rows - 1)) == 0, "merkle_commit_rows: row count must be a power of two >= 2");
+        Prover p(ctx->c, ProofOptions::with_96_bit_security());
+        aero_tree* h = new aero_tree();
+        try { h->t = p.commit_to_rows(m->m); } catch (...) { delete h; throw; }
+        if (root_out) memcpy(root_out, h->t.root_host.w, 32);
+        *out = h;
+    });
+}
+int32_t aero_merkle_open_batch(aero_ctx* ctx, const aero_tree* tree, const uint64_t* positions, uint32_t k, uint8_t* out, size_t cap,
+                               size_t* out_len) {
+    return guard(ctx, [&] {
+        REQUIRE(tree && positions && out_len && k >= 1, "merkle_open_batch: null or empty argument");
+        std::vector<uint64_t> pos(positions, positions + k);
+        auto idx = batch_proof_indices(tree->t.n, pos);
+        std::vector<uint64_t> flat;
+        for (auto& v : idx) flat.insert(flat.end(), v.begin(), v.end());
+        size_t need = 1 + idx.size() + flat.size() * 32;
+        *out_len = need;
+        REQUIRE(out && cap >= need, "merkle_open_batch: output buffer too small");
+        REQUIRE(idx.size() <= 255, "merkle_open_batch: too many paths");
+        std::vector<Digest> got(flat.size());
+        if (!flat.empty()) {
+            DevBuf<uint64_t> d_idx(ctx->c, flat.size());
+            DevBuf<Digest> d_out(ctx->c, flat.size());
+            AERO_HIP(hipMemcpyAsync(d_idx.get(), flat.data(), flat.size() * 8, hipMemcpyHostToDevice, ctx->c->stream));
+            launch_gather_digests(ctx->c, tree->t.nodes.get(), d_idx.get(), (int)flat.size(), d_out.get());
+            AERO_HIP(hipMemcpyAsync(got.data(), d_out.get(), flat.size() * 32, hipMemcpyDeviceToHost, ctx->c->stream));
+            ctx->c->sync();
+        }
+        size_t o = 0, g = 0;
+        out[o++] = (uint8_t)idx.size();
+        for (auto& v : idx) {
+            REQUIRE(v.size() <= 255, "merkle_open_batch: too many nodes");
+            out[o++] = (uint8_t)v.size();
+            for (size_t i = 0; i < v.size(); i++) { memcpy(out + o, got[g++].w, 32); o += 32; }
+        }
+    });
+}
+int32_t aero_merkle_nodes(aero_ctx* ctx, const aero_tree* tree, uint8_t* out) {
+    return guard(ctx, [&] {
+        REQUIRE(tree && out, "merkle_nodes: null argument");
+        AERO_HIP(hipMemcpyAsync(out, tree->t.nodes.get(), 2 * tree->t.n * 32, hipMemcpyDeviceToHost, ctx->c->stream));
+        ctx->c->sync();
+        memset(out, 0, 32);
+    });
+}
+void aero_tree_free(aero_ctx* ctx, aero_tree* tree) {
+    (void)ctx;
+    delete tree;
+}
+
+}  // extern "C"
+
+// ---- constraint evaluation -----------------------------------------------------------------------
+template <class F>
+static void eval_constraints_fib(Context* c, const Matrix& lde, uint32_t log_blowup, const uint64_t* results, const uint64_t* coeffs,
+                                 uint32_t frag, uint32_t nfrags, uint64_t* out_cols, uint64_t* frag_index_out) {
+    typedef typename F::T T;
+    const uint32_t W = (uint32_t)lde.cols;
+    const size_t N = lde.rows, B = (size_t)1 << log_blowup, n = N / B, C = FibAir::ce_blowup_factor(), ceN = C * n;
+    REQUIRE(W >= 2 && !(W & 1), "eval_constraints_fib: FibAir needs an even width");
+    REQUIRE(B >= C && n >= 8, "eval_constraints_fib: bad blowup / trace length");
+    REQUIRE(nfrags >= 1 && (nfrags & (nfrags - 1)) == 0 && ceN / nfrags >= 1 && frag < nfrags, "eval_constraints_fib: bad fragment spec");
+    const size_t rows = ceN / nfrags, first = (size_t)frag * rows;
+    const size_t nt = W, na = W + W / 2;
+    std::vector<T> ta(nt), tb(nt), ba(na), bb(na);
+    const uint64_t* p = coeffs;
+    auto rd = [&]() { uint64_t c0 = *p++; uint64_t c1 = F::DEG > 1 ? *p++ : 0; REQUIRE(c0 < gl::P && c1 < gl::P, "eval_constraints_fib: non-canonical coefficient"); return F::make(c0, c1); };
+    for (size_t i = 0; i < nt; i++) { ta[i] = rd(); tb[i] = rd(); }
+    for (size_t i = 0; i < na; i++) { ba[i] = rd(); bb[i] = rd(); }
+    std::vector<uint64_t> res(results, results + W / 2);
+    auto up = [&](const void* src, size_t bytes) { void* d = c->scratch_alloc(bytes + 8); AERO_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, c->stream)); return d; };
+    const int log_ce = ilog2u(ceN);
+    NttTables* tce = c->ntt_tables(log_ce);
+    FibConsArgs<F> a{};
+    a.lde = lde.data.get(); a.N = N; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)B; a.ce_step = (uint32_t)(B / C);
+    a.first = first; a.count = rows;
+    a.ta = (const T*)up(ta.data(), nt * sizeof(T)); a.tb = (const T*)up(tb.data(), nt * sizeof(T));
+    a.ba = (const T*)up(ba.data(), na * sizeof(T)); a.bb = (const T*)up(bb.data(), na * sizeof(T));
+    a.results = (const uint64_t*)up(res.data(), res.size() * 8);
+    a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.twi_lo = tce->lo_inv; a.twi_hi = tce->hi_inv; a.tw_h = tce->h;
+    a.gen_inv = gl::inv(gl::GEN); a.k7 = gl::pow(gl::GEN, ceN);
+    std::vector<uint64_t> xn(C), zn(C);
+    uint64_t g7n = gl::pow(gl::GEN, n), wC = gl::root_of_unity(ilog2u(C));
+    for (size_t k = 0; k < C; k++) { uint64_t xnk = gl::mul(g7n, gl::pow(wC, k)); xn[k] = gl::inv(xnk); zn[k] = gl::inv(gl::sub(xnk, 1)); }
+    a.xn_inv = (const uint64_t*)up(xn.data(), C * 8); a.zn_inv = (const uint64_t*)up(zn.data(), C * 8);
+    a.w_last = gl::pow(gl::root_of_unity(ilog2u(n)), n - 1);
+    DevBuf<uint64_t> d_out(c, 3 * F::DEG * rows);
+    a.out_cols = d_out.get();
+    launch_fib_constraints<F>(c, a, 0);
+    AERO_HIP(hipMemcpyAsync(out_cols, d_out.get(), 3 * F::DEG * rows * 8, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    c->scratch_reset();
+    if (frag_index_out) *frag_index_out = first;
+}
+extern "C" {
+
+int32_t aero_eval_constraints_fib(aero_ctx* ctx, const aero_matrix* trace_lde, uint32_t log_blowup, const uint64_t* results,
+                                  const uint64_t* coeffs, uint8_t field_extension, uint32_t fragment_offset, uint32_t num_fragments,
+                                  uint64_t* out_cols, uint64_t* frag_index_out) {
+    return guard(ctx, [&] {
+        REQUIRE(trace_lde && results && coeffs && out_cols, "eval_constraints_fib: null argument");
+        REQUIRE(log_blowup >= 1 && log_blowup <= 7, "eval_constraints_fib: log_blowup must be in [1,7]");
+        if (field_extension == EXT_NONE) eval_constraints_fib<gl::FB>(ctx->c, trace_lde->m, log_blowup, results, coeffs, fragment_offset, num_fragments, out_cols, frag_index_out);
+        else if (field_extension == EXT_QUADRATIC) eval_constraints_fib<gl::FQ>(ctx->c, trace_lde->m, log_blowup, results, coeffs, fragment_offset, num_fragments, out_cols, frag_index_out);
+        else fail("eval_constraints_fib: field extension must be 1 (None) or 2 (Quadratic)", ST_UNSUPPORTED);
+    });
+}
+
+// ---- FRI / grinding ---------------------------------------------------------------------------------
+int32_t aero_fri_fold(aero_ctx* ctx, const uint64_t* values, uint64_t dom, uint32_t fold, uint64_t alpha, uint64_t* out) {
+    return guard(ctx, [&] {
+        REQUIRE(values && out, "fri_fold: null argument");
+        REQUIRE(fold == 2 || fold == 4 || fold == 8 || fold == 16, "fri_fold: folding factor must be 2, 4, 8 or 16");
+        REQUIRE(dom >= fold && (dom & (dom - 1)) == 0 && ilog2u(dom) <= gl::TWO_ADICITY, "fri_fold: domain must be a power of two >= fold");
+        REQUIRE(alpha < gl::P, "fri_fold: non-canonical alpha");
+        Context* c = ctx->c;
+        const size_t rows = dom / fold;
+        DevBuf<uint64_t> d_in(c, dom), d_out(c, rows);
+        AERO_HIP(hipMemcpyAsync(d_in.get(), values, dom * 8, hipMemcpyHostToDevice, c->stream));
+        NttTables* td = c->ntt_tables(ilog2u(dom));
+        FoldArgs<gl::FB> a{};
+        a.in[0] = a.in[1] = d_in.get(); a.out[0] = a.out[1] = d_out.get();
+        a.rows = rows; a.fold = (int)fold; a.alpha = alpha;
+        a.twi_lo = td->lo_inv; a.twi_hi = td->hi_inv; a.tw_h = td->h;
+        a.gen_inv = gl::inv(gl::GEN); a.fold_inv = gl::inv(fold);
+        uint64_t wFi = gl::inv(gl::root_of_unity(ilog2u(fold)));
+        for (uint32_t m = 0; m < fold; m++) a.dft[m] = gl::pow(wFi, m);
+        launch_fri_fold<gl::FB>(c, a);
+        AERO_HIP(hipMemcpyAsync(out, d_out.get(), rows * 8, hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+    });
+}
+int32_t aero_grind(aero_ctx* ctx, const uint8_t seed[32], uint32_t bits, uint64_t* nonce_out) {
+    return guard(ctx, [&] {
+        REQUIRE(seed && nonce_out, "grind: null argument");
+        REQUIRE(bits <= 32, "grind: more than 32 bits of grinding is not supported");
+        Digest s;
+        memcpy(s.w, seed, 32);
+        DevBuf<unsigned long long> d(ctx->c, 1);
+        launch_grind(ctx->c, s, bits, d.get());
+        unsigned long long best = 0;
+        AERO_HIP(hipMemcpyAsync(&best, d.get(), 8, hipMemcpyDeviceToHost, ctx->c->stream));
+        ctx->c->sync();
+        *nonce_out = best;
+    });
+}
+
+}  // extern "C"
+
+// ---- whole proof ----------------------------------------------------------------------------------------
+static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, int log_n, const aero_proof_options* o, uint8_t** proof,
+                     size_t* proof_len, uint64_t* pub_out) {
+    REQUIRE(o && proof && proof_len, "prove: null argument");
+    ProofOptions po{o->num_queries, o->blowup_factor, o->grinding_factor, o->hash_fn, o->field_extension, o->fri_folding_factor, o->fri_log_max_remainder};
+    Prover p(ctx->c, po);
+    p.collect_stage_times = ctx->stage_timing;
+    std::vector<uint64_t> pub;
+    Bytes b = p.prove(trace_dev, width, log_n, &pub);
+    ctx->last_ms = p.last_stage_ms;
+    uint8_t* buf = (uint8_t*)malloc(b.size());
+    if (!buf) throw std::bad_alloc();
+    memcpy(buf, b.data(), b.size());
+    *proof = buf; *proof_len = b.size();
+    if (pub_out) memcpy(pub_out, pub.data(), pub.size() * 8);
+}
+extern "C" {
+
+int32_t aero_prove_fib(aero_ctx* ctx, const aero_matrix* trace, const aero_proof_options* options, uint8_t** proof, size_t* proof_len,
+                       uint64_t* pub_out) {
+    return guard(ctx, [&] {
+        REQUIRE(trace, "prove_fib: null trace");
+        REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0, "prove_fib: trace length must be a power of two");
+        do_prove(ctx, trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows), options, proof, proof_len, pub_out);
+    });
+}
+int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n, const aero_proof_options* options,
+                            uint8_t** proof, size_t* proof_len, uint64_t* pub_out) {
+    return guard(ctx, [&] {
+        REQUIRE(trace_col_major, "prove_fib_host: null trace");
+        REQUIRE(width >= 2 && width <= 254 && log_n >= 3 && log_n <= 29, "prove_fib_host: bad shape");
+        size_t n = (size_t)1 << log_n;
+        DevBuf<uint64_t> d(ctx->c, (size_t)width * n);
+        AERO_HIP(hipMemcpyAsync(d.get(), trace_col_major, (size_t)width * n * 8, hipMemcpyHostToDevice, ctx->c->stream));
+        do_prove(ctx, d.get(), width, (int)log_n, options, proof, proof_len, pub_out);
+    });
+}
+int32_t aero_proof_container(const uint8_t* inputs, size_t inputs_len, const uint8_t* proof, size_t proof_len, uint8_t** out, size_t* out_len) {
+    if (!out || !out_len || (!inputs && inputs_len) || (!proof && proof_len)) return AERO_E_BAD_ARG;
+    size_t total = 16 + inputs_len + proof_len;
+    uint8_t* b = (uint8_t*)malloc(total);
+    if (!b) return AERO_E_OOM;
+    uint64_t l = inputs_len;
+    memcpy(b, &l, 8);
+    if (inputs_len) memcpy(b + 8, inputs, inputs_len);
+    l = proof_len;
+    memcpy(b + 8 + inputs_len, &l, 8);
+    if (proof_len) memcpy(b + 16 + inputs_len, proof, proof_len);
+    *out = b; *out_len = total;
+    return AERO_OK;
+}
+
+// ---- instrumentation ------------------------------------------------------------------------------------
+int32_t aero_set_stage_timing(aero_ctx* ctx, int32_t enable) {
+    if (!ctx) return AERO_E_BAD_ARG;
+    ctx->stage_timing = enable != 0;
+    return AERO_OK;
+}
+int32_t aero_last_stage_ms(const aero_ctx* ctx, double out[12]) {
+    if (!ctx || !out) return AERO_E_BAD_ARG;
+    const StageMs& m = ctx->last_ms;
+    double v[12] = {m.interpolate, m.lde, m.trace_commit, m.constraints, m.composition, m.comp_commit, m.ood, m.deep, m.fri, m.grind, m.queries, m.total};
+    memcpy(out, v, sizeof v);
+    return AERO_OK;
+}
+int32_t aero_set_kernel_timing(aero_ctx* ctx, int32_t enable, const char* only_kernel) {
+    return guard(ctx, [&] {
+        if (!enable && ctx->c->kernel_timing) ctx->c->kt_report();
+        ctx->c->kernel_timing = enable != 0;
+        ctx->c->kt_filter = (enable && only_kernel) ? only_kernel : "";
+    });
+}
+int32_t aero_kernel_timing_report(aero_ctx* ctx, char* buf, size_t cap) {
+    return guard(ctx, [&] {
+        REQUIRE(buf && cap > 0, "kernel_timing_report: null buffer");
+        std::string s = ctx->c->kt_report();
+        REQUIRE(s.size() + 1 <= cap, "kernel_timing_report: buffer too small");
+        memcpy(buf, s.c_str(), s.size() + 1);
+    });
+}
+int32_t aero_memory_stats(const aero_ctx* ctx, uint64_t* in_use, uint64_t* peak) {
+    if (!ctx || !ctx->c) return AERO_E_BAD_ARG;
+    if (in_use) *in_use = ctx->c->bytes_in_use;
+    if (peak) *peak = ctx->c->bytes_peak;
+    return AERO_OK;
+}
+
+}  // extern "C"

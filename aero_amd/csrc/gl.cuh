@@ -1,0 +1,158 @@
+// Goldilocks field arithmetic for gfx950 (and the same code for the host side of the prover).
+//
+// Replaces winter-math 0.4 `fields::f64::BaseElement` / `QuadExtension<BaseElement>` as used by the reference
+// through `miden_core::Felt` (/root/reference/miden-proof-generator/src/main.rs:3,
+// aero-sdk/miden-wasm/src/utils.rs:365-409 canonical `as_int()` <-> `new()`); constants from
+// /root/reference/src/utils/math_goldilocks.cairo:4 and src/stark_verifier/fri/fri_verifier.cairo:154-155.
+//
+// gfx950 has no 64x64 multiplier: a field multiply is four 32x32->64 multiply-adds (v_mad_u64_u32) plus the
+// 2^64 = 2^32 - 1 (mod p) fold. MFMA is deliberately not used: 64-bit modular mul-add is not a dense fp
+// contraction. All values are kept canonical (< p) between operations so results are bit-exact by construction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GL_HD __host__ __device__ __forceinline__
+
+namespace gl {
+
+constexpr uint64_t P = 0xFFFFFFFF00000001ULL;
+constexpr uint64_t EPS = 0xFFFFFFFFULL;           // 2^64 mod p
+constexpr uint64_t GEN = 7;                       // multiplicative generator = LDE / FRI domain offset
+constexpr uint64_t ROOT_2_32 = 1753635133440165772ULL;
+constexpr int TWO_ADICITY = 32;
+
+GL_HD uint64_t add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    uint64_t c = (s < a) ? EPS : 0;               // wrapped past 2^64: + (2^64 mod p)
+    s += c;
+    return s >= P ? s - P : s;
+}
+GL_HD uint64_t sub(uint64_t a, uint64_t b) {
+    uint64_t d = a - b;
+    return a < b ? d + P : d;                     // a - b + p, computed mod 2^64
+}
+GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
+GL_HD uint64_t dbl(uint64_t a) { return add(a, a); }
+
+GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    lo = a * b;
+    hi = __umul64hi(a, b);
+#else
+    unsigned __int128 x = (unsigned __int128)a * b;
+    lo = (uint64_t)x;
+    hi = (uint64_t)(x >> 64);
+#endif
+}
+// hi*2^64 + lo  ->  canonical residue. Uses 2^64 = 2^32 - 1, 2^96 = -1 (mod p).
+GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
+    uint64_t hh = hi >> 32, hl = hi & EPS;
+    uint64_t t0 = lo - hh;
+    if (lo < hh) t0 -= EPS;                       // borrow: adding p back == subtracting 2^32 - 1 (mod 2^64)
+    uint64_t t1 = hl * EPS;                       // < 2^64
+    uint64_t r = t0 + t1;
+    if (r < t1) r += EPS;
+    return r >= P ? r - P : r;
+}
+GL_HD uint64_t mul(uint64_t a, uint64_t b) {
+    uint64_t lo, hi;
+    mul_wide(a, b, lo, hi);
+    return reduce128(lo, hi);
+}
+GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
+GL_HD uint64_t pow(uint64_t b, uint64_t e) {
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = sqr(b);
+        e >>= 1;
+    }
+    return r;
+}
+// a^(p-2), p - 2 = 2^64 - 2^32 - 1 = (2^32 - 2) * 2^32 + (2^32 - 1). inv(0) = 0 (winter-math convention).
+GL_HD uint64_t inv(uint64_t a) {
+    uint64_t x31 = a;                              // a^(2^1 - 1)
+#pragma unroll 1
+    for (int i = 1; i < 31; i++) x31 = mul(sqr(x31), a);   // a^(2^31 - 1)
+    uint64_t y = sqr(x31);                         // a^(2^32 - 2)
+    uint64_t t = mul(y, a);                        // a^(2^32 - 1)
+#pragma unroll 1
+    for (int i = 0; i < 32; i++) y = sqr(y);       // a^((2^32 - 2) * 2^32)
+    return mul(y, t);
+}
+GL_HD uint64_t root_of_unity(int log_n) { return pow(ROOT_2_32, 1ULL << (TWO_ADICITY - log_n)); }
+
+// ---- quadratic extension F_p[phi]/(phi^2 - phi + 2) ------------------------------------------------
+struct E2 {
+    uint64_t a0, a1;
+};
+GL_HD E2 e2(uint64_t a) { return E2{a, 0}; }
+GL_HD E2 add(E2 a, E2 b) { return E2{add(a.a0, b.a0), add(a.a1, b.a1)}; }
+GL_HD E2 sub(E2 a, E2 b) { return E2{sub(a.a0, b.a0), sub(a.a1, b.a1)}; }
+GL_HD E2 mul(E2 a, E2 b) {
+    uint64_t a0b0 = mul(a.a0, b.a0), a1b1 = mul(a.a1, b.a1);
+    uint64_t s = mul(add(a.a0, a.a1), add(b.a0, b.a1));
+    return E2{sub(a0b0, dbl(a1b1)), sub(s, a0b0)};
+}
+GL_HD E2 mulb(E2 a, uint64_t b) { return E2{mul(a.a0, b), mul(a.a1, b)}; }
+GL_HD E2 conj(E2 a) { return E2{add(a.a0, a.a1), neg(a.a1)}; }
+GL_HD E2 inv(E2 a) {
+    uint64_t n = add(add(sqr(a.a0), mul(a.a0, a.a1)), dbl(sqr(a.a1)));
+    uint64_t ni = inv(n);
+    E2 c = conj(a);
+    return E2{mul(c.a0, ni), mul(c.a1, ni)};
+}
+
+// ---- uniform interface over E = F_p and E = F_p^2 (kernels are templated on one of these) ----------
+struct FB {
+    typedef uint64_t T;
+    static constexpr int DEG = 1;
+    GL_HD static T zero() { return 0; }
+    GL_HD static T one() { return 1; }
+    GL_HD static T from(uint64_t b) { return b; }
+    GL_HD static T add(T a, T b) { return gl::add(a, b); }
+    GL_HD static T sub(T a, T b) { return gl::sub(a, b); }
+    GL_HD static T mul(T a, T b) { return gl::mul(a, b); }
+    GL_HD static T mulb(T a, uint64_t b) { return gl::mul(a, b); }
+    GL_HD static T inv(T a) { return gl::inv(a); }
+    GL_HD static T conj(T a) { return a; }
+    GL_HD static uint64_t comp(T a, int) { return a; }
+    GL_HD static T make(uint64_t c0, uint64_t) { return c0; }
+};
+struct FQ {
+    typedef E2 T;
+    static constexpr int DEG = 2;
+    GL_HD static T zero() { return E2{0, 0}; }
+    GL_HD static T one() { return E2{1, 0}; }
+    GL_HD static T from(uint64_t b) { return E2{b, 0}; }
+    GL_HD static T add(T a, T b) { return gl::add(a, b); }
+    GL_HD static T sub(T a, T b) { return gl::sub(a, b); }
+    GL_HD static T mul(T a, T b) { return gl::mul(a, b); }
+    GL_HD static T mulb(T a, uint64_t b) { return gl::mulb(a, b); }
+    GL_HD static T inv(T a) { return gl::inv(a); }
+    GL_HD static T conj(T a) { return gl::conj(a); }
+    GL_HD static uint64_t comp(T a, int i) { return i ? a.a1 : a.a0; }
+    GL_HD static T make(uint64_t c0, uint64_t c1) { return E2{c0, c1}; }
+};
+template <class F> GL_HD typename F::T fpow(typename F::T b, uint64_t e) {
+    typename F::T r = F::one();
+    while (e) {
+        if (e & 1) r = F::mul(r, b);
+        b = F::mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+
+GL_HD uint32_t bitrev(uint32_t x, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+}  // namespace gl

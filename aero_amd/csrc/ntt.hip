@@ -1,0 +1,285 @@
+// Radix-2 Goldilocks NTT for gfx950: batched column transforms staged through LDS.
+//
+// Replaces, for the reference's stage 1 (/root/reference/aero-sdk/miden-wasm/src/proving_worker.rs:271-274):
+//   main_trace.interpolate_columns()            -> interpolate (evaluations on <w_n>  -> coefficients)
+//   trace_polys.evaluate_columns_over(&domain)  -> lde         (coefficients -> evaluations on 7*<w_N>, natural row order)
+// whose bodies live in winter-math 0.4 `fft` (submodule absent from the mount).
+//
+// Layout decisions (MI355X-first, not a translation of winter's in-place serial FFT):
+//  * Column-major matrices, one transform per column, all columns of a pass in one launch (grid.y = column).
+//  * Coefficients are kept in BIT-REVERSED order and PRE-SCALED by offset^i, so neither direction ever runs a
+//    bit-reversal permutation pass and the LDE needs no separate coset-shift pass:
+//        interpolate = decimation-in-frequency (natural in -> bit-reversed out),
+//        lde         = decimation-in-time      (bit-reversed in -> natural out).
+//  * A transform of size 2^L is split "four-step" style into passes: the first pass covers the low 12 index bits
+//    (4096 contiguous elements = 32 KiB of LDS per workgroup, perfectly coalesced), the remaining bits are covered by
+//    strided passes over tiles of R x TL elements (TL consecutive addresses per row, R*TL = 4096), so every HBM
+//    access is a segment of at least TL*8 bytes and each pass reads and writes every element exactly once.
+//    Between passes elements are multiplied by w_n^(S * rev(block) * k) (two-level twiddle table, L1-resident).
+//  * The LDE is ONE transform of size N = blowup*n on the zero-padded coefficient vector: in bit-reversed order the
+//    non-zero inputs sit at positions = 0 mod blowup, so the first log2(blowup) butterfly stages are a broadcast and
+//    are skipped; the first pass reads n/... coefficients and writes `blowup` times as many values.
+// Algorithmic HBM bytes per element and pass: 16 (8 read + 8 written); interpolate(2^20) = 2 passes, lde(2^20 -> 2^23)
+// = 3 passes of which the first reads 1/8 of what it writes.
+#include "aero_internal.hpp"
+
+namespace aero {
+
+using gl::add;
+using gl::mul;
+using gl::sub;
+
+// twiddle exponent e on w_n -> value, via two-level table: w^e = lo[e & (2^h - 1)] * hi[e >> h]
+__device__ __forceinline__ uint64_t tw_lookup(const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, uint32_t e, int h) {
+    uint64_t a = lo[e & ((1u << h) - 1)];
+    uint64_t b = hi[e >> h];
+    return mul(a, b);
+}
+
+struct PassArgs {
+    const uint64_t* in;
+    uint64_t* out;
+    size_t in_col_stride, out_col_stride;   // elements
+    int log_n;        // transform size
+    int log_s;        // stride of this pass (0 for the contiguous pass)
+    int log_r;        // radix of this pass
+    int log_tl;       // tile width (consecutive addresses per row)
+    int log_pad;      // forward first pass only: input holds n >> log_pad coefficients (zero-padded transform)
+    int first;        // forward: this is the pass with the largest stride? (no twiddle after it) / inverse: no twiddle before
+    const uint64_t* tw_r;     // w_4096^j (j < 2048), forward or inverse roots
+    const uint64_t* tw_lo;    // two-level table of w_n (or its inverse)
+    const uint64_t* tw_hi;
+    int tw_h;
+    // inverse contiguous pass only: out[p] *= ktab[k] * blockfac(block)
+    const uint64_t* ktab;     // R entries: c0 * (a^(2^(L-r)) * b^(2^(L-r-shift)))^rev_r(k)
+    uint64_t sc_a, sc_b;      // per-block factor = a^rev(block) * b^(rev(block) >> shift)
+    int sc_shift;
+};
+
+// Forward: decimation in time, bit-reversed input -> natural output (within the pass' index bits).
+__global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    const int R = 1 << a.log_r, TL = 1 << a.log_tl, E = R << a.log_tl;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tiles_per_b = 1u << (a.log_s - a.log_tl);       // S / TL
+    const uint32_t b = tile >> (a.log_s - a.log_tl);
+    const uint32_t lo0 = (tile & (tiles_per_b - 1)) << a.log_tl;
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    const size_t base = (size_t)lo0 + (((size_t)b << a.log_r) << a.log_s);
+
+    if (a.log_pad == 0) {
+        for (int e = threadIdx.x; e < E; e += 256) {
+            int tl = e & (TL - 1), k = e >> a.log_tl;
+            lds[e] = in[base + tl + ((size_t)k << a.log_s)];
+        }
+    } else {
+        // contiguous pass of a zero-padded transform: position k of the block holds coefficient (b*R + k) >> log_pad
+        // when k = 0 mod 2^log_pad, zero otherwise; the first log_pad butterfly stages therefore broadcast it.
+        const size_t cbase = ((size_t)b << a.log_r) >> a.log_pad;
+        for (int e = threadIdx.x; e < E; e += 256) lds[e] = in[cbase + (e >> a.log_pad)];
+    }
+    __syncthreads();
+    const int tw_shift = 12 - a.log_r;
+    for (int u = a.log_pad; u < a.log_r; u++) {
+        const int half = 1 << u;
+        for (int bf = threadIdx.x; bf < E / 2; bf += 256) {
+            int tl = bf & (TL - 1), j = bf >> a.log_tl;
+            int jl = j & (half - 1);
+            int k0 = ((j >> u) << (u + 1)) | jl;
+            int i0 = (k0 << a.log_tl) | tl, i1 = i0 + (half << a.log_tl);
+            uint64_t x = lds[i0], y = lds[i1];
+            if (u) y = mul(y, a.tw_r[(jl << (a.log_r - 1 - u)) << tw_shift]);
+            lds[i0] = add(x, y);
+            lds[i1] = sub(x, y);
+        }
+        __syncthreads();
+    }
+    const int bbits = a.log_n - a.log_s - a.log_r;
+    const uint32_t rb = gl::bitrev(b, bbits);
+    for (int e = threadIdx.x; e < E; e += 256) {
+        int tl = e & (TL - 1), k = e >> a.log_tl;
+        uint64_t v = lds[e];
+        if (!a.first && rb && k) {
+            uint32_t ex = (uint32_t)((((uint64_t)rb * (uint32_t)k) << a.log_s) & ((1ull << a.log_n) - 1));
+            v = mul(v, tw_lookup(a.tw_lo, a.tw_hi, ex, a.tw_h));
+        }
+        out[base + tl + ((size_t)k << a.log_s)] = v;
+    }
+}
+
+// Inverse: exact mirror (decimation in frequency with inverse roots), natural input -> bit-reversed output.
+__global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    const int R = 1 << a.log_r, TL = 1 << a.log_tl, E = R << a.log_tl;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tiles_per_b = 1u << (a.log_s - a.log_tl);
+    const uint32_t b = tile >> (a.log_s - a.log_tl);
+    const uint32_t lo0 = (tile & (tiles_per_b - 1)) << a.log_tl;
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    const size_t base = (size_t)lo0 + (((size_t)b << a.log_r) << a.log_s);
+    const int bbits = a.log_n - a.log_s - a.log_r;
+    const uint32_t rb = gl::bitrev(b, bbits);
+
+    for (int e = threadIdx.x; e < E; e += 256) {
+        int tl = e & (TL - 1), k = e >> a.log_tl;
+        uint64_t v = in[base + tl + ((size_t)k << a.log_s)];
+        if (!a.first && rb && k) {
+            uint32_t ex = (uint32_t)((((uint64_t)rb * (uint32_t)k) << a.log_s) & ((1ull << a.log_n) - 1));
+            v = mul(v, tw_lookup(a.tw_lo, a.tw_hi, ex, a.tw_h));
+        }
+        lds[e] = v;
+    }
+    __syncthreads();
+    const int tw_shift = 12 - a.log_r;
+    for (int u = a.log_r - 1; u >= 0; u--) {
+        const int half = 1 << u;
+        for (int bf = threadIdx.x; bf < E / 2; bf += 256) {
+            int tl = bf & (TL - 1), j = bf >> a.log_tl;
+            int jl = j & (half - 1);
+            int k0 = ((j >> u) << (u + 1)) | jl;
+            int i0 = (k0 << a.log_tl) | tl, i1 = i0 + (half << a.log_tl);
+            uint64_t x = lds[i0], y = lds[i1];
+            uint64_t d = sub(x, y);
+            if (u) d = mul(d, a.tw_r[(jl << (a.log_r - 1 - u)) << tw_shift]);
+            lds[i0] = add(x, y);
+            lds[i1] = d;
+        }
+        __syncthreads();
+    }
+    uint64_t bf = 1;
+    if (a.ktab) {
+        // every thread derives the (uniform) block factor itself: <= 2*bbits multiplies, cheaper than a broadcast
+        bf = mul(gl::pow(a.sc_a, rb), gl::pow(a.sc_b, rb >> a.sc_shift));
+    }
+    for (int e = threadIdx.x; e < E; e += 256) {
+        int tl = e & (TL - 1), k = e >> a.log_tl;
+        uint64_t v = lds[e];
+        if (a.ktab) v = mul(v, mul(a.ktab[k], bf));
+        out[base + tl + ((size_t)k << a.log_s)] = v;
+    }
+}
+
+// tab[k] = c0 * abase^rev(k) * bbase^(rev(k) >> bshift), rev over `bits` bits, k < 2^bits
+__global__ void fill_pow_bitrev(uint64_t* tab, int bits, uint64_t abase, uint64_t bbase, int bshift, uint64_t c0) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1u << bits)) return;
+    uint32_t r = gl::bitrev(k, bits);
+    tab[k] = mul(mul(c0, gl::pow(abase, r)), gl::pow(bbase, r >> bshift));
+}
+// tab[j] = root^(j * step)
+__global__ void fill_pow_linear(uint64_t* tab, uint32_t count, uint64_t root, uint64_t step) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    tab[k] = gl::pow(root, (uint64_t)k * step);
+}
+
+// ------------------------------------------------------------------------------------------------
+NttTables* Context::ntt_tables(int log_n) {
+    auto it = ntt_tabs.find(log_n);
+    if (it != ntt_tabs.end()) return &it->second;
+    NttTables t;
+    t.log_n = log_n;
+    t.h = (log_n + 1) / 2;
+    uint32_t nlo = 1u << t.h, nhi = 1u << (log_n - t.h);
+    uint64_t w = gl::root_of_unity(log_n), wi = gl::inv(w);
+    t.lo_fwd = (uint64_t*)dev_alloc((size_t)nlo * 8);
+    t.hi_fwd = (uint64_t*)dev_alloc((size_t)nhi * 8);
+    t.lo_inv = (uint64_t*)dev_alloc((size_t)nlo * 8);
+    t.hi_inv = (uint64_t*)dev_alloc((size_t)nhi * 8);
+    AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3((nlo + 255) / 256), dim3(256), 0, t.lo_fwd, nlo, w, 1ull);
+    AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3((nhi + 255) / 256), dim3(256), 0, t.hi_fwd, nhi, w, (uint64_t)nlo);
+    AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3((nlo + 255) / 256), dim3(256), 0, t.lo_inv, nlo, wi, 1ull);
+    AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3((nhi + 255) / 256), dim3(256), 0, t.hi_inv, nhi, wi, (uint64_t)nlo);
+    check_launch("ntt tables");
+    ntt_tabs[log_n] = t;
+    return &ntt_tabs[log_n];
+}
+
+void Context::ensure_small_twiddles() {
+    if (tw4096_fwd) return;
+    tw4096_fwd = (uint64_t*)dev_alloc(2048 * 8);
+    tw4096_inv = (uint64_t*)dev_alloc(2048 * 8);
+    uint64_t w = gl::root_of_unity(12);
+    AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3(8), dim3(256), 0, tw4096_fwd, 2048u, w, 1ull);
+    AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3(8), dim3(256), 0, tw4096_inv, 2048u, gl::inv(w), 1ull);
+    check_launch("small twiddles");
+}
+
+// Pass plan for a transform of 2^L points: first the contiguous pass (<= 12 bits), then strided passes.
+std::vector<NttPass> plan_passes(int L) {
+    std::vector<NttPass> p;
+    int r1 = L < 12 ? L : 12;
+    p.push_back(NttPass{0, r1, 0});
+    int rem = L - r1, s = r1;
+    if (rem == 0) return p;
+    int npass = (rem + 7) / 8;
+    for (int i = 0; i < npass; i++) {
+        int r = (rem + (npass - 1 - i)) / (npass - i);   // split as evenly as possible, larger radices first
+        p.push_back(NttPass{s, r, 12 - r});               // tile = R x TL = 4096 elements, TL = 4096 / R <= S
+        s += r;
+        rem -= r;
+    }
+    return p;
+}
+
+// coefficients (bit-reversed, pre-scaled by offset^i), n_in = 2^(log_out - log_pad) per column
+//   -> evaluations in natural order over offset * <w_(2^log_out)>
+void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad) {
+    ensure_small_twiddles();
+    NttTables* t = ntt_tables(log_out);
+    std::vector<NttPass> plan = plan_passes(log_out);
+    if (plan[0].log_r < log_pad) fail("ntt_forward: transform too small for the requested padding");
+    for (size_t q = 0; q < plan.size(); q++) {
+        PassArgs a{};
+        a.in = q == 0 ? in : out;
+        a.in_col_stride = q == 0 ? in_stride : out_stride;
+        a.out = out;
+        a.out_col_stride = out_stride;
+        a.log_n = log_out; a.log_s = plan[q].log_s; a.log_r = plan[q].log_r; a.log_tl = plan[q].log_tl;
+        a.log_pad = q == 0 ? log_pad : 0;
+        a.first = (q + 1 == plan.size());
+        a.tw_r = tw4096_fwd; a.tw_lo = t->lo_fwd; a.tw_hi = t->hi_fwd; a.tw_h = t->h;
+        size_t E = (size_t)1 << (a.log_r + a.log_tl);
+        dim3 grid((unsigned)(((size_t)1 << log_out) / E), ncols);
+        AERO_LAUNCH(this, "ntt_fwd_pass", (size_t)ncols * 8 * ((((size_t)1 << log_out) >> a.log_pad) + ((size_t)1 << log_out)), ntt_fwd_pass, grid, dim3(256), E * 8, a);
+    }
+    check_launch("ntt_forward");
+}
+
+// evaluations in natural order over <w_n> (n = 2^log_n) -> coefficients in bit-reversed order, where coefficient
+// with natural index I is multiplied by c0 * sa^I * sb^(I >> shift). In place.
+void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift) {
+    ensure_small_twiddles();
+    NttTables* t = ntt_tables(log_n);
+    std::vector<NttPass> plan = plan_passes(log_n);
+    const int r1 = plan[0].log_r;
+    // per-k table for the final (contiguous) pass
+    uint64_t ninv = gl::inv((uint64_t)1 << log_n);
+    // natural index I = rev_r1(k) * 2^(L-r1) + rev(block): the k-dependent part of sa^I * sb^(I >> shift)
+    uint64_t abase, bbase = 1;
+    int bshift = 0;
+    if (log_n - r1 >= shift) {
+        abase = gl::mul(gl::pow(sa, 1ull << (log_n - r1)), gl::pow(sb, 1ull << (log_n - r1 - shift)));
+    } else {
+        if (log_n != r1) fail("ntt_inverse: unsupported scale shift for this size", ST_INTERNAL);
+        abase = sa; bbase = sb; bshift = shift;       // single block: I = rev(k)
+    }
+    uint64_t* ktab = (uint64_t*)scratch_alloc(((size_t)1 << r1) * 8);
+    AERO_LAUNCH(this, "fill_pow_bitrev", 0, fill_pow_bitrev, dim3(((1u << r1) + 255) / 256), dim3(256), 0, ktab, r1, abase, bbase, bshift, gl::mul(c0, ninv));
+    for (size_t qi = plan.size(); qi-- > 0;) {
+        PassArgs a{};
+        a.in = data; a.out = data; a.in_col_stride = stride; a.out_col_stride = stride;
+        a.log_n = log_n; a.log_s = plan[qi].log_s; a.log_r = plan[qi].log_r; a.log_tl = plan[qi].log_tl;
+        a.first = (qi + 1 == plan.size());
+        a.tw_r = tw4096_inv; a.tw_lo = t->lo_inv; a.tw_hi = t->hi_inv; a.tw_h = t->h;
+        if (qi == 0) { a.ktab = ktab; a.sc_a = sa; a.sc_b = sb; a.sc_shift = shift; }
+        size_t E = (size_t)1 << (a.log_r + a.log_tl);
+        dim3 grid((unsigned)(((size_t)1 << log_n) / E), ncols);
+        AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass, grid, dim3(256), E * 8, a);
+    }
+    check_launch("ntt_inverse");
+}
+
+}  // namespace aero

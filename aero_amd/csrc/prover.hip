@@ -1,0 +1,596 @@
+// Host pipeline of the MI355X STARK prover (see prover.hpp for the reference interface it mirrors).
+#include "prover.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <set>
+
+#include "stark_kernels.hpp"
+
+namespace aero {
+
+using gl::FB;
+using gl::FQ;
+
+// ================================================================================================
+// Context
+Context::Context(int dev) : device(dev) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) throw Error(ST_HIP, "no HIP device available: libaero_stark requires an MI355X (there is no CPU fallback)");
+    if (dev < 0 || dev >= count) throw Error(ST_BAD_ARG, "device id out of range");
+    AERO_HIP(hipSetDevice(dev));
+    AERO_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+}
+Context::~Context() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto& kv : free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : live_blocks) (void)hipFree(kv.first);
+    for (void* p : persistent) (void)hipFree(p);
+    for (auto& r : kt_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    for (hipEvent_t e : kt_pool) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+void* Context::pool_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    void* p = nullptr;
+    auto it = free_blocks.find(bytes);
+    if (it != free_blocks.end()) {
+        p = it->second;
+        free_blocks.erase(it);
+    } else {
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            // release cached blocks and retry once
+            (void)hipStreamSynchronize(stream);
+            for (auto& kv : free_blocks) (void)hipFree(kv.second);
+            free_blocks.clear();
+            e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) throw Error(ST_OOM, "device allocation of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+        }
+    }
+    live_blocks[p] = bytes;
+    bytes_in_use += bytes;
+    if (bytes_in_use > bytes_peak) bytes_peak = bytes_in_use;
+    return p;
+}
+void Context::pool_free(void* p) {
+    auto it = live_blocks.find(p);
+    if (it == live_blocks.end()) return;
+    bytes_in_use -= it->second;
+    free_blocks.insert({it->second, p});   // single stream: reuse is stream-ordered
+    live_blocks.erase(it);
+}
+void* Context::dev_alloc(size_t bytes) {
+    void* p = nullptr;
+    AERO_HIP(hipMalloc(&p, bytes ? bytes : 256));
+    persistent.push_back(p);
+    return p;
+}
+void* Context::scratch_alloc(size_t bytes) {
+    void* p = pool_alloc(bytes);
+    scratch.push_back(p);
+    return p;
+}
+void Context::scratch_reset() {
+    for (void* p : scratch) pool_free(p);
+    scratch.clear();
+}
+void Context::check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw Error(ST_HIP, std::string(what) + ": kernel launch failed: " + hipGetErrorString(e));
+}
+void Context::sync() {
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) throw Error(ST_HIP, std::string("stream synchronize: ") + hipGetErrorString(e));
+}
+
+hipEvent_t Context::kt_event() {
+    if (!kt_pool.empty()) { hipEvent_t e = kt_pool.back(); kt_pool.pop_back(); return e; }
+    hipEvent_t e;
+    AERO_HIP(hipEventCreate(&e));
+    return e;
+}
+void Context::kt_begin(const char* name, size_t abytes) {
+    KtRec r{name, abytes, kt_event(), kt_event()};
+    AERO_HIP(hipEventRecord(r.start, stream));
+    kt_recs.push_back(r);
+}
+void Context::kt_end() { AERO_HIP(hipEventRecord(kt_recs.back().stop, stream)); }
+std::string Context::kt_report() {
+    sync();
+    struct Agg { int calls = 0; double ms = 0; double bytes = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto& r : kt_recs) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, r.start, r.stop);
+        auto& a = agg[r.name];
+        a.calls += 1; a.ms += ms; a.bytes += (double)r.abytes;
+        kt_pool.push_back(r.start); kt_pool.push_back(r.stop);
+    }
+    kt_recs.clear();
+    std::vector<std::pair<double, std::string>> rows;
+    for (auto& kv : agg) {
+        char line[256];
+        snprintf(line, sizeof line, "%s %d %.6f %.0f", kv.first.c_str(), kv.second.calls, kv.second.ms, kv.second.bytes);
+        rows.push_back({kv.second.ms, line});
+    }
+    std::sort(rows.begin(), rows.end(), [](auto& a, auto& b) { return a.first > b.first; });
+    std::string out;
+    for (auto& r : rows) out += r.second + "\n";
+    return out;
+}
+
+// ================================================================================================
+// options, coin, proof bytes
+void ProofOptions::validate() const {
+    if (hash_fn != HASH_BLAKE2S_256) fail("ProofOptions: only Blake2s_256 (id 4) is implemented on this path", ST_UNSUPPORTED);
+    if (field_extension != EXT_NONE && field_extension != EXT_QUADRATIC) fail("ProofOptions: field extension must be None (1) or Quadratic (2)", ST_UNSUPPORTED);
+    if (blowup_factor < 2 || (blowup_factor & (blowup_factor - 1)) || blowup_factor > 128) fail("ProofOptions: blowup factor must be a power of two in [2, 128]");
+    if (fri_folding_factor != 2 && fri_folding_factor != 4 && fri_folding_factor != 8 && fri_folding_factor != 16) fail("ProofOptions: FRI folding factor must be 2, 4, 8 or 16");
+    if (num_queries == 0) fail("ProofOptions: at least one query is required");
+    if (grinding_factor > 32) fail("ProofOptions: grinding factor above 32 is not supported");
+    if (fri_log_max_remainder > 16) fail("ProofOptions: FRI max remainder too large");
+}
+
+HostCoin HostCoin::from_elements(const uint64_t* e, uint32_t n) {
+    HostCoin c;
+    c.seed = b2s::hash32(b2s::hash_elements(e, n));   // random.cairo:254-280 then :31-37
+    c.counter = 0;
+    return c;
+}
+static inline uint64_t le64(const Digest& d, int word) { return (uint64_t)d.w[word] | ((uint64_t)d.w[word + 1] << 32); }
+uint64_t HostCoin::draw_base() {
+    for (int i = 0; i < 1000; i++) {
+        Digest d = next();
+        uint64_t v = le64(d, 0);
+        if (v < gl::P) return v;
+    }
+    fail("random coin: failed to draw a field element", ST_INTERNAL);
+}
+gl::E2 HostCoin::draw_quad() {
+    for (int i = 0; i < 1000; i++) {
+        Digest d = next();
+        uint64_t a = le64(d, 0), b = le64(d, 2);
+        if (a < gl::P && b < gl::P) return gl::E2{a, b};
+    }
+    fail("random coin: failed to draw a field element", ST_INTERNAL);
+}
+std::vector<uint64_t> HostCoin::draw_integers(size_t k, uint64_t domain) {
+    std::vector<uint64_t> out;
+    for (int i = 0; i < 1000 && out.size() < k; i++) {
+        uint64_t v = le64(next(), 0) & (domain - 1);
+        if (std::find(out.begin(), out.end(), v) == out.end()) out.push_back(v);
+    }
+    if (out.size() != k) fail("random coin: failed to draw query positions", ST_INTERNAL);
+    return out;
+}
+
+static void w8(Bytes& b, uint8_t v) { b.push_back(v); }
+static void w16(Bytes& b, size_t v) {
+    if (v > 0xffff) fail("proof section exceeds its u16 length prefix", ST_UNSUPPORTED);
+    b.push_back(v & 0xff); b.push_back((v >> 8) & 0xff);
+}
+static void w32(Bytes& b, size_t v) { for (int i = 0; i < 4; i++) b.push_back((v >> (8 * i)) & 0xff); }
+static void w64(Bytes& b, uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((v >> (8 * i)) & 0xff); }
+static void wb(Bytes& b, const Bytes& s) { b.insert(b.end(), s.begin(), s.end()); }
+static void wdigest(Bytes& b, const Digest& d) { const uint8_t* p = reinterpret_cast<const uint8_t*>(d.w); b.insert(b.end(), p, p + 32); }
+
+Bytes StarkProof::to_bytes() const {
+    Bytes b;
+    w8(b, main_width); w8(b, aux_width); w8(b, aux_rands); w8(b, log_n);
+    w16(b, 0);                                   // trace meta
+    w8(b, 8); w64(b, gl::P);                     // field modulus
+    w8(b, options.num_queries); w8(b, options.blowup_factor); w8(b, options.grinding_factor); w8(b, options.hash_fn);
+    w8(b, options.field_extension); w8(b, options.fri_folding_factor); w8(b, options.fri_log_max_remainder);
+    w16(b, commitments.size()); wb(b, commitments);
+    for (auto& q : trace_queries) { w32(b, q.values.size()); wb(b, q.values); w32(b, q.paths.size()); wb(b, q.paths); }
+    w32(b, constraint_queries.values.size()); wb(b, constraint_queries.values);
+    w32(b, constraint_queries.paths.size()); wb(b, constraint_queries.paths);
+    w16(b, ood_trace_states.size()); wb(b, ood_trace_states);
+    w16(b, ood_evaluations.size()); wb(b, ood_evaluations);
+    w8(b, (uint8_t)fri_layers.size());
+    for (auto& q : fri_layers) { w32(b, q.values.size()); wb(b, q.values); w32(b, q.paths.size()); wb(b, q.paths); }
+    w16(b, fri_remainder.size()); wb(b, fri_remainder);
+    w8(b, 0);                                    // log2(num_partitions)
+    w64(b, pow_nonce);
+    return b;
+}
+
+std::vector<uint64_t> fold_positions(const std::vector<uint64_t>& positions, uint64_t source_domain, uint64_t folding_factor) {
+    uint64_t target = source_domain / folding_factor;
+    std::vector<uint64_t> out;
+    for (uint64_t p : positions) {
+        uint64_t q = p % target;
+        if (std::find(out.begin(), out.end(), q) == out.end()) out.push_back(q);
+    }
+    return out;
+}
+int num_fri_layers(uint64_t domain, uint64_t fold, uint64_t max_remainder) {
+    int r = 0;
+    while (domain > max_remainder) { domain /= fold; r++; }
+    return r;
+}
+
+std::vector<std::vector<uint64_t>> batch_proof_indices(size_t n, const std::vector<uint64_t>& positions) {
+    std::set<uint64_t> qs(positions.begin(), positions.end());
+    if (qs.size() != positions.size()) fail("batch opening: duplicate positions");
+    std::set<uint64_t> norm;
+    for (uint64_t p : positions) {
+        if (p >= n) fail("batch opening: position out of range");
+        norm.insert(p - (p & 1));
+    }
+    int depth = 0;
+    while (((size_t)1 << depth) < n) depth++;
+    std::vector<std::vector<uint64_t>> nodes;
+    std::vector<uint64_t> next;
+    for (uint64_t e : norm) {
+        std::vector<uint64_t> miss;
+        for (uint64_t i = e; i < e + 2; i++) if (!qs.count(i)) miss.push_back(n + i);
+        nodes.push_back(miss);
+        next.push_back((e + n) >> 1);
+    }
+    for (int lvl = 1; lvl < depth; lvl++) {
+        std::vector<uint64_t> idx = next;
+        next.clear();
+        size_t i = 0;
+        while (i < idx.size()) {
+            uint64_t sib = idx[i] ^ 1;
+            if (i + 1 < idx.size() && idx[i + 1] == sib) i += 1;
+            else nodes[i].push_back(sib);
+            next.push_back(sib >> 1);
+            i += 1;
+        }
+    }
+    return nodes;
+}
+
+// digests for a batch opening gathered from the device tree -> serialised BatchMerkleProof nodes
+static Bytes open_batch(Context* ctx, const MerkleTree& tree, const std::vector<uint64_t>& positions) {
+    auto idx = batch_proof_indices(tree.n, positions);
+    std::vector<uint64_t> flat;
+    for (auto& v : idx) flat.insert(flat.end(), v.begin(), v.end());
+    std::vector<Digest> got(flat.size());
+    if (!flat.empty()) {
+        DevBuf<uint64_t> d_idx(ctx, flat.size());
+        DevBuf<Digest> d_out(ctx, flat.size());
+        AERO_HIP(hipMemcpyAsync(d_idx.get(), flat.data(), flat.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        launch_gather_digests(ctx, tree.nodes.get(), d_idx.get(), (int)flat.size(), d_out.get());
+        AERO_HIP(hipMemcpyAsync(got.data(), d_out.get(), flat.size() * sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+    }
+    Bytes out;
+    if (idx.size() > 255) fail("batch opening: too many paths", ST_UNSUPPORTED);
+    out.push_back((uint8_t)idx.size());
+    size_t k = 0;
+    for (auto& v : idx) {
+        if (v.size() > 255) fail("batch opening: too many nodes", ST_UNSUPPORTED);
+        out.push_back((uint8_t)v.size());
+        for (size_t i = 0; i < v.size(); i++) wdigest(out, got[k++]);
+    }
+    return out;
+}
+
+// ================================================================================================
+// stage-level API
+static int ilog2(uint64_t x) { int r = 0; while ((1ull << r) < x) r++; return r; }
+
+Matrix Prover::interpolate_columns(const uint64_t* trace_dev, uint32_t width, int log_n) {
+    size_t n = (size_t)1 << log_n;
+    Matrix polys(ctx_, (int)width, n);
+    AERO_HIP(hipMemcpyAsync(polys.data.get(), trace_dev, (size_t)width * n * 8, hipMemcpyDeviceToDevice, ctx_->stream));
+    // coefficient i scaled by 7^i so the LDE needs no coset-shift pass (see ntt.hip)
+    ctx_->ntt_inverse(polys.data.get(), n, (int)width, log_n, 1, gl::GEN, 1, 0);
+    return polys;
+}
+Matrix Prover::evaluate_columns_over(const Matrix& polys, int log_blowup) {
+    int log_n = ilog2(polys.rows);
+    size_t N = polys.rows << log_blowup;
+    Matrix lde(ctx_, polys.cols, N);
+    ctx_->ntt_forward(polys.data.get(), polys.rows, lde.data.get(), N, polys.cols, log_n + log_blowup, log_blowup);
+    return lde;
+}
+MerkleTree Prover::commit_to_rows(const Matrix& lde) {
+    MerkleTree t(ctx_, lde.rows);
+    ctx_->hash_rows(lde.data.get(), lde.rows, lde.cols, lde.rows, t.leaves());
+    ctx_->merkle_build(t.nodes.get(), t.n);
+    AERO_HIP(hipMemcpyAsync(&t.root_host, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx_->stream));
+    ctx_->sync();
+    return t;
+}
+
+// ================================================================================================
+template <class F> static void flatten(const typename F::T* v, size_t n, std::vector<uint64_t>& out) {
+    for (size_t i = 0; i < n; i++) for (int d = 0; d < F::DEG; d++) out.push_back(F::comp(v[i], d));
+}
+template <class F> static Digest hash_e(const typename F::T* v, size_t n) {
+    std::vector<uint64_t> f;
+    flatten<F>(v, n, f);
+    return b2s::hash_elements(f.data(), (uint32_t)f.size());
+}
+template <class T> static T* upload(Context* ctx, const std::vector<T>& v) {
+    T* d = (T*)ctx->scratch_alloc(v.size() * sizeof(T) + 8);
+    if (!v.empty()) AERO_HIP(hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return d;
+}
+
+struct StageClock {
+    Context* ctx; bool on; std::chrono::steady_clock::time_point t0;
+    StageClock(Context* c, bool enable) : ctx(c), on(enable) { if (on) { ctx->sync(); } t0 = std::chrono::steady_clock::now(); }
+    double lap() {
+        if (on) ctx->sync();
+        auto t1 = std::chrono::steady_clock::now();
+        double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        t0 = t1;
+        return ms;
+    }
+};
+
+template <class F>
+Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::vector<uint64_t>* pub_out) {
+    typedef typename F::T T;
+    Context* ctx = ctx_;
+    AERO_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << log_n, B = opt_.blowup_factor, Fd = opt_.fri_folding_factor;
+    const int log_B = ilog2(B);
+    const size_t N = n * B, C = FibAir::ce_blowup_factor(), ceN = C * n;
+    const int log_N = log_n + log_B, log_ce = ilog2(ceN);
+    if (W < 2 || (W & 1) || W > 254) fail("prove: FibAir needs an even column count in [2, 254]");
+    if (B < C) fail("prove: blowup factor smaller than the constraint evaluation blowup");
+    if (log_N > gl::TWO_ADICITY) fail("prove: LDE domain exceeds the field's two-adicity (2^32)");
+    if (log_n < 3) fail("prove: trace must have at least 8 rows");
+    const int layers = num_fri_layers(N, Fd, 1ull << opt_.fri_log_max_remainder);
+    {
+        uint64_t rem = N;
+        for (int l = 0; l < layers; l++) rem /= Fd;
+        if (rem < Fd) fail("prove: FRI remainder smaller than the folding factor");
+        if (rem * 8 * F::DEG > 0xffff) fail("prove: FRI remainder does not fit the proof's u16 length prefix", ST_UNSUPPORTED);
+    }
+    StageMs ms;
+    StageClock clk(ctx, collect_stage_times);
+    auto t_start = std::chrono::steady_clock::now();
+
+    // 0. AIR, public inputs, channel [proving_worker.rs:248-268]
+    FibAir air;
+    air.width = W; air.log_n = log_n; air.results.resize(W / 2);
+    {
+        // results[k] = trace[2k+1][n-1]
+        DevBuf<uint64_t> d_pos(ctx, 1), d_row(ctx, W);
+        uint64_t last = n - 1;
+        AERO_HIP(hipMemcpyAsync(d_pos.get(), &last, 8, hipMemcpyHostToDevice, ctx->stream));
+        launch_gather_rows(ctx, trace_dev, n, (int)W, d_pos.get(), 1, d_row.get());
+        std::vector<uint64_t> row(W);
+        AERO_HIP(hipMemcpyAsync(row.data(), d_row.get(), W * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        for (uint32_t k = 0; k < W / 2; k++) air.results[k] = row[2 * k + 1];
+    }
+    if (pub_out) *pub_out = air.results;
+    HostCoin coin = HostCoin::from_elements(air.results.data(), (uint32_t)air.results.size());
+    StarkProof proof;
+    proof.main_width = (uint8_t)W; proof.log_n = (uint8_t)log_n; proof.options = opt_;
+    const uint64_t g = gl::root_of_unity(log_n);
+    const uint64_t gen_inv = gl::inv(gl::GEN);
+
+    // 1. interpolate_columns [a3]
+    Matrix polys = interpolate_columns(trace_dev, W, log_n);
+    ms.interpolate = clk.lap();
+    // 2. evaluate_columns_over [a4]
+    Matrix tlde = evaluate_columns_over(polys, log_B);
+    ms.lde = clk.lap();
+    // 3. row hashes, Merkle tree, commit [a5, a6, a8]
+    MerkleTree ttree = commit_to_rows(tlde);
+    wdigest(proof.commitments, ttree.root());
+    coin.reseed(ttree.root());
+    ms.trace_commit = clk.lap();
+
+    // 4. constraint composition coefficients + evaluation + division (fused) [a9, a10, a11]
+    std::vector<T> ta, tb, ba, bb;
+    for (size_t i = 0; i < air.num_transition_constraints(); i++) { ta.push_back(coin.draw<F>()); tb.push_back(coin.draw<F>()); }
+    for (size_t i = 0; i < air.num_assertions(); i++) { ba.push_back(coin.draw<F>()); bb.push_back(coin.draw<F>()); }
+    DevBuf<uint64_t> hbuf(ctx, (size_t)F::DEG * ceN);   // H evaluations, then coefficients: [DEG][ceN]
+    {
+        NttTables* tce = ctx->ntt_tables(log_ce);
+        FibConsArgs<F> a{};
+        a.lde = tlde.data.get(); a.N = N; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)B; a.ce_step = (uint32_t)(B / C);
+        a.first = 0; a.count = ceN;
+        a.ta = upload(ctx, ta); a.tb = upload(ctx, tb); a.ba = upload(ctx, ba); a.bb = upload(ctx, bb);
+        a.results = upload(ctx, air.results);
+        a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.twi_lo = tce->lo_inv; a.twi_hi = tce->hi_inv; a.tw_h = tce->h;
+        a.gen_inv = gen_inv; a.k7 = gl::pow(gl::GEN, ceN);
+        std::vector<uint64_t> xn(C), zn(C);
+        uint64_t g7n = gl::pow(gl::GEN, n), wC = gl::root_of_unity(ilog2(C));
+        for (size_t k = 0; k < C; k++) {
+            uint64_t xnk = gl::mul(g7n, gl::pow(wC, k));
+            xn[k] = gl::inv(xnk);
+            zn[k] = gl::inv(gl::sub(xnk, 1));
+        }
+        a.xn_inv = upload(ctx, xn); a.zn_inv = upload(ctx, zn);
+        a.w_last = gl::pow(g, n - 1);
+        a.out_cols = nullptr;
+        for (int d = 0; d < F::DEG; d++) a.out_h[d] = hbuf.get() + (size_t)d * ceN;
+        launch_fib_constraints<F>(ctx, a, 1);
+    }
+    ms.constraints = clk.lap();
+    // 5. composition polynomial: interpolate over the coset; coefficient I gets 7^-I (coset) * 7^(I >> log C)
+    //    (pre-scaling of column coefficient i = I >> log C for the column LDE). In bit-reversed order the C column
+    //    polynomials are the C contiguous chunks of the buffer: no split pass (H(x) = sum_c x^c H_c(x^C)).
+    ctx->ntt_inverse(hbuf.get(), ceN, F::DEG, log_ce, 1, gen_inv, gl::GEN, ilog2(C));
+    ms.composition = clk.lap();
+    // 6. composition commitment [a12]: column c*DEG + d <- chunk c of component d
+    Matrix clde(ctx, (int)(C * F::DEG), N);
+    for (int d = 0; d < F::DEG; d++)
+        ctx->ntt_forward(hbuf.get() + (size_t)d * ceN, n, clde.data.get() + (size_t)d * N, (size_t)F::DEG * N, (int)C, log_N, log_B);
+    MerkleTree ctree = commit_to_rows(clde);
+    wdigest(proof.commitments, ctree.root());
+    coin.reseed(ctree.root());
+    ms.comp_commit = clk.lap();
+
+    // 7. OOD frame [a13]. Coefficients are pre-scaled by 7^i, so evaluate at point / 7.
+    const T z = coin.draw<F>();
+    const T z_next = F::mulb(z, g), z_c = gl::fpow<F>(z, C);
+    std::vector<T> ood(2 * W + C);
+    {
+        DevBuf<T> d_out(ctx, 2 * W + C);
+        launch_eval_bitrev<F>(ctx, polys.data.get(), n, 0, (int)W, 1, log_n, F::mulb(z, gen_inv), F::mulb(z_next, gen_inv), 2, d_out.get());
+        launch_eval_bitrev<F>(ctx, hbuf.get(), n, ceN, (int)C, F::DEG, log_n, F::mulb(z_c, gen_inv), F::zero(), 1, d_out.get() + 2 * W);
+        AERO_HIP(hipMemcpyAsync(ood.data(), d_out.get(), ood.size() * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+    }
+    std::vector<T> ood_cur(W), ood_next(W), ood_h(C);
+    for (uint32_t c = 0; c < W; c++) { ood_cur[c] = ood[2 * c]; ood_next[c] = ood[2 * c + 1]; }
+    for (size_t c = 0; c < C; c++) ood_h[c] = ood[2 * W + c];
+    {
+        std::vector<uint64_t> f;
+        flatten<F>(ood_cur.data(), W, f); flatten<F>(ood_next.data(), W, f);
+        for (uint64_t v : f) w64(proof.ood_trace_states, v);
+        f.clear();
+        flatten<F>(ood_h.data(), C, f);
+        for (uint64_t v : f) w64(proof.ood_evaluations, v);
+    }
+    coin.reseed(hash_e<F>(ood_cur.data(), W));
+    coin.reseed(hash_e<F>(ood_next.data(), W));
+    coin.reseed(hash_e<F>(ood_h.data(), C));
+    ms.ood = clk.lap();
+
+    // 8. DEEP composition [a14]
+    std::vector<T> da(W), db(W), dg(W), dc(C);
+    for (uint32_t i = 0; i < W; i++) { da[i] = coin.draw<F>(); db[i] = coin.draw<F>(); dg[i] = coin.draw<F>(); }
+    for (size_t i = 0; i < C; i++) dc[i] = coin.draw<F>();
+    const T lambda = coin.draw<F>(), mu = coin.draw<F>();
+    // FRI evaluations per layer: [DEG][dom] component arrays, natural order
+    std::vector<DevBuf<uint64_t>> fri_vals;
+    fri_vals.emplace_back(ctx, (size_t)F::DEG * N);
+    {
+        NttTables* tN = ctx->ntt_tables(log_N);
+        DeepArgs<F> a{};
+        a.tlde = tlde.data.get(); a.clde = clde.data.get(); a.N = N; a.W = W; a.C = (uint32_t)C;
+        a.tw_lo = tN->lo_fwd; a.tw_hi = tN->hi_fwd; a.tw_h = tN->h;
+        a.z = z; a.z_next = z_next; a.z_c = z_c; a.z_conj = F::conj(z); a.lambda = lambda; a.mu = mu;
+        a.ood_cur = upload(ctx, ood_cur); a.ood_next = upload(ctx, ood_next); a.ood_h = upload(ctx, ood_h);
+        a.da = upload(ctx, da); a.db = upload(ctx, db); a.dg = upload(ctx, dg); a.dc = upload(ctx, dc);
+        for (int d = 0; d < F::DEG; d++) a.out[d] = fri_vals[0].get() + (size_t)d * N;
+        launch_deep<F>(ctx, a);
+    }
+    ms.deep = clk.lap();
+
+    // 9. FRI commit phase [a15]: layers + 1 rounds (the last commits the remainder)
+    std::vector<MerkleTree> fri_trees;
+    {
+        uint64_t dom = N;
+        for (int l = 0; l <= layers; l++) {
+            const size_t rows = dom / Fd;
+            const uint64_t* comp[2] = {fri_vals[l].get(), fri_vals[l].get() + (F::DEG > 1 ? dom : 0)};
+            fri_trees.emplace_back(ctx, rows >= 2 ? rows : 1);
+            MerkleTree& t = fri_trees.back();
+            if (rows >= 2) {
+                ctx->hash_fri_rows(comp, F::DEG, rows, (int)Fd, t.leaves());
+                ctx->merkle_build(t.nodes.get(), rows);
+                AERO_HIP(hipMemcpyAsync(&t.root_host, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
+            } else {
+                ctx->hash_fri_rows(comp, F::DEG, 1, (int)Fd, t.nodes.get() + 1);
+                AERO_HIP(hipMemcpyAsync(&t.root_host, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            ctx->sync();
+            wdigest(proof.commitments, t.root());
+            coin.reseed(t.root());
+            const T alpha = coin.draw<F>();
+            if (l == layers) break;   // alpha drawn after the remainder commitment is unused
+            fri_vals.emplace_back(ctx, (size_t)F::DEG * rows);
+            NttTables* td = ctx->ntt_tables(ilog2(dom));
+            FoldArgs<F> a{};
+            for (int d = 0; d < F::DEG; d++) { a.in[d] = fri_vals[l].get() + (size_t)d * dom; a.out[d] = fri_vals[l + 1].get() + (size_t)d * rows; }
+            if (F::DEG == 1) { a.in[1] = a.in[0]; a.out[1] = a.out[0]; }
+            a.rows = rows; a.fold = (int)Fd; a.alpha = alpha;
+            a.twi_lo = td->lo_inv; a.twi_hi = td->hi_inv; a.tw_h = td->h;
+            a.gen_inv = gen_inv; a.fold_inv = gl::inv(Fd);
+            uint64_t wFi = gl::inv(gl::root_of_unity(ilog2(Fd)));
+            for (size_t m = 0; m < Fd; m++) a.dft[m] = gl::pow(wFi, m);
+            launch_fri_fold<F>(ctx, a);
+            dom = rows;
+        }
+    }
+    ms.fri = clk.lap();
+
+    // 10. grinding [a16]
+    {
+        uint64_t nonce = 0;
+        if (opt_.grinding_factor == 0) nonce = 1;
+        else {
+            DevBuf<unsigned long long> d_best(ctx, 1);
+            launch_grind(ctx, coin.seed, opt_.grinding_factor, d_best.get());
+            unsigned long long best = 0;
+            AERO_HIP(hipMemcpyAsync(&best, d_best.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->sync();
+            nonce = best;
+        }
+        proof.pow_nonce = nonce;
+        coin.reseed_with_int(nonce);
+    }
+    ms.grind = clk.lap();
+
+    // 11. queries [a17]
+    std::vector<uint64_t> pos = coin.draw_integers(opt_.num_queries, N);
+    {
+        const int Q = (int)pos.size();
+        DevBuf<uint64_t> d_pos(ctx, Q);
+        AERO_HIP(hipMemcpyAsync(d_pos.get(), pos.data(), Q * 8, hipMemcpyHostToDevice, ctx->stream));
+        const size_t tw = W, cw = C * F::DEG;
+        DevBuf<uint64_t> d_rows(ctx, Q * (tw + cw));
+        launch_gather_rows(ctx, tlde.data.get(), N, (int)tw, d_pos.get(), Q, d_rows.get());
+        launch_gather_rows(ctx, clde.data.get(), N, (int)cw, d_pos.get(), Q, d_rows.get() + Q * tw);
+        std::vector<uint64_t> rows(Q * (tw + cw));
+        AERO_HIP(hipMemcpyAsync(rows.data(), d_rows.get(), rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        QueriesBytes tq;
+        for (size_t i = 0; i < (size_t)Q * tw; i++) w64(tq.values, rows[i]);
+        tq.paths = open_batch(ctx, ttree, pos);
+        proof.trace_queries.push_back(tq);
+        for (size_t i = 0; i < (size_t)Q * cw; i++) w64(proof.constraint_queries.values, rows[Q * tw + i]);
+        proof.constraint_queries.paths = open_batch(ctx, ctree, pos);
+    }
+    {
+        std::vector<uint64_t> fp = pos;
+        uint64_t dom = N;
+        for (int l = 0; l < layers; l++) {
+            fp = fold_positions(fp, dom, Fd);
+            const size_t rows = dom / Fd;
+            const int Q = (int)fp.size();
+            DevBuf<uint64_t> d_pos(ctx, Q), d_vals(ctx, Q * Fd * F::DEG);
+            AERO_HIP(hipMemcpyAsync(d_pos.get(), fp.data(), Q * 8, hipMemcpyHostToDevice, ctx->stream));
+            launch_gather_fri_rows(ctx, fri_vals[l].get(), fri_vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd, d_pos.get(), Q, d_vals.get());
+            std::vector<uint64_t> vals(Q * Fd * F::DEG);
+            AERO_HIP(hipMemcpyAsync(vals.data(), d_vals.get(), vals.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->sync();
+            QueriesBytes q;
+            for (uint64_t v : vals) w64(q.values, v);
+            q.paths = open_batch(ctx, fri_trees[l], fp);
+            proof.fri_layers.push_back(q);
+            dom = rows;
+        }
+        // remainder = last layer's evaluations in natural order
+        std::vector<uint64_t> rem((size_t)F::DEG * dom);
+        AERO_HIP(hipMemcpyAsync(rem.data(), fri_vals[layers].get(), rem.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        for (size_t i = 0; i < dom; i++) for (int d = 0; d < F::DEG; d++) w64(proof.fri_remainder, rem[(size_t)d * dom + i]);
+    }
+    ms.queries = clk.lap();
+    ctx->scratch_reset();
+    ms.total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    last_stage_ms = ms;
+    return proof.to_bytes();
+}
+
+Bytes Prover::prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_out) {
+    try {
+        if (opt_.field_extension == EXT_NONE) return prove_impl<FB>(trace_dev, width, log_n, pub_out);
+        return prove_impl<FQ>(trace_dev, width, log_n, pub_out);
+    } catch (...) {
+        ctx_->scratch_reset();
+        throw;
+    }
+}
+
+}  // namespace aero

@@ -1,0 +1,137 @@
+// Host side of the MI355X STARK prover: the C++ mirror of the Winterfell `Prover` surface that Aero drives.
+//
+// Names, argument meaning and stage boundaries follow the reference's call sites (the trait bodies are in the
+// absent winterfell submodule):
+//   ProofOptions .................. miden-proof-generator/src/main.rs:23 (`with_96_bit_security`),
+//                                   aero-sdk/miden-wasm/src/convert/convert_inputs.rs:54-66 (7-field ctor)
+//   ProverChannel ................. aero-sdk/miden-wasm/src/proving_worker.rs:264-268
+//   Matrix / interpolate_columns / evaluate_columns_over ... proving_worker.rs:271-274, utils.rs:235-236
+//   MerkleTree::new ............... proving_worker.rs:161-162
+//   commit_to_trace_and_validate .. proving_worker.rs:323-332   (fork-only split of Prover::prove)
+//   evaluate_constraints .......... proving_worker.rs:355-439, constraints_worker.rs:14-79
+//   prove_after_constraint_eval ... proving_worker.rs:344-352   (fork-only)
+//   Prover::prove ................. proving_worker.rs:465-467, miden-proof-generator/src/main.rs:31
+//   StarkProof::to_bytes .......... miden-proof-generator/src/main.rs:38 (layout: SURVEY a18)
+// The transcript (random coin) lives on the host and is the only serialisation point between device stages.
+#pragma once
+#include <memory>
+
+#include "aero_internal.hpp"
+
+namespace aero {
+
+typedef std::vector<uint8_t> Bytes;
+
+enum HashFn : uint8_t { HASH_BLAKE2S_256 = 4 };
+enum FieldExtension : uint8_t { EXT_NONE = 1, EXT_QUADRATIC = 2 };
+
+struct ProofOptions {
+    uint8_t num_queries, blowup_factor, grinding_factor, hash_fn, field_extension, fri_folding_factor, fri_log_max_remainder;
+    static ProofOptions with_96_bit_security() { return ProofOptions{27, 8, 16, HASH_BLAKE2S_256, EXT_NONE, 8, 8}; }
+    static ProofOptions from_bytes(const uint8_t b[7]) { return ProofOptions{b[0], b[1], b[2], b[3], b[4], b[5], b[6]}; }
+    void validate() const;
+};
+
+// Random coin + proof accumulation (host). Mirror: src/stark_verifier/crypto/random.cairo.
+struct HostCoin {
+    Digest seed;
+    uint64_t counter = 0;
+    static HostCoin from_elements(const uint64_t* e, uint32_t n);
+    void reseed(const Digest& d) { seed = b2s::merge(seed, d); counter = 0; }
+    void reseed_with_int(uint64_t v) { seed = b2s::merge_with_int(seed, v); counter = 0; }
+    Digest next() { counter += 1; return b2s::merge_with_int(seed, counter); }
+    uint64_t draw_base();
+    gl::E2 draw_quad();
+    template <class F> typename F::T draw();
+    std::vector<uint64_t> draw_integers(size_t k, uint64_t domain);
+};
+template <> inline uint64_t HostCoin::draw<gl::FB>() { return draw_base(); }
+template <> inline gl::E2 HostCoin::draw<gl::FQ>() { return draw_quad(); }
+
+struct QueriesBytes { Bytes values, paths; };
+
+// StarkProof container (byte layout: SURVEY a18).
+struct StarkProof {
+    uint8_t main_width = 0, aux_width = 0, aux_rands = 0, log_n = 0;
+    ProofOptions options{};
+    Bytes commitments;
+    std::vector<QueriesBytes> trace_queries;
+    QueriesBytes constraint_queries;
+    Bytes ood_trace_states, ood_evaluations;
+    std::vector<QueriesBytes> fri_layers;
+    Bytes fri_remainder;
+    uint64_t pow_nonce = 0;
+    Bytes to_bytes() const;
+};
+
+// Column-major device matrix (winter `Matrix<Felt>`: num_rows/num_cols/columns, utils.rs:235-236).
+struct Matrix {
+    DevBuf<uint64_t> data;
+    size_t rows = 0;
+    int cols = 0;
+    Matrix() {}
+    Matrix(Context* ctx, int ncols, size_t nrows) : data(ctx, (size_t)ncols * nrows), rows(nrows), cols(ncols) {}
+    uint64_t* col(int c) const { return data.get() + (size_t)c * rows; }
+    size_t num_rows() const { return rows; }
+    int num_cols() const { return cols; }
+};
+
+// Device Merkle tree: nodes[1] = root, leaves at nodes[n + j].
+struct MerkleTree {
+    DevBuf<Digest> nodes;
+    size_t n = 0;
+    Digest root_host{};
+    MerkleTree() {}
+    MerkleTree(Context* ctx, size_t leaves) : nodes(ctx, 2 * leaves), n(leaves) {}
+    Digest* leaves() const { return nodes.get() + n; }
+    const Digest& root() const { return root_host; }
+    int depth() const { int d = 0; while (((size_t)1 << d) < n) d++; return d; }
+};
+
+// Built-in AIR: FibAir(W). Pair k = columns (2k, 2k+1) = (a, b); a' = a + b, b' = b + a';
+// seeds (1+2k, 2+2k); assertions a(0), b(0), b(n-1) = results[k]; public inputs = results.
+struct FibAir {
+    uint32_t width = 0;
+    int log_n = 0;
+    std::vector<uint64_t> results;
+    size_t trace_length() const { return (size_t)1 << log_n; }
+    size_t num_transition_constraints() const { return width; }
+    size_t num_assertions() const { return width + width / 2; }
+    static size_t ce_blowup_factor() { return 2; }
+};
+
+struct StageMs {   // per-stage wall time (ms) of the last prove(), names after proving_worker.rs console labels
+    double interpolate = 0, lde = 0, trace_commit = 0, constraints = 0, composition = 0, comp_commit = 0, ood = 0, deep = 0,
+           fri = 0, grind = 0, queries = 0, total = 0;
+};
+
+class Prover {
+public:
+    Prover(Context* ctx, const ProofOptions& opt) : ctx_(ctx), opt_(opt) { opt_.validate(); }
+    const ProofOptions& options() const { return opt_; }
+    // trace: device, column-major W x 2^log_n (not modified). Returns StarkProof::to_bytes().
+    Bytes prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_inputs_out);
+    StageMs last_stage_ms;
+    bool collect_stage_times = false;   // adds a stream sync per stage
+
+    // ---- stage-level entry points (the reference's split API; also what the C ABI exposes) ----
+    // interpolate_columns: evaluations on <w_n> -> polys (bit-reversed coefficients pre-scaled by 7^i)
+    Matrix interpolate_columns(const uint64_t* trace_dev, uint32_t width, int log_n);
+    // evaluate_columns_over: polys -> LDE over 7<w_N>, natural row order
+    Matrix evaluate_columns_over(const Matrix& polys, int log_blowup);
+    // row hashes + MerkleTree::new
+    MerkleTree commit_to_rows(const Matrix& lde);
+
+private:
+    template <class F> Bytes prove_impl(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_out);
+    Context* ctx_;
+    ProofOptions opt_;
+};
+
+// BatchMerkleProof node selection (winter-crypto 0.4 MerkleTree::prove_batch restated):
+// returns, per vector, the node indices (into the 2n-slot node array) whose digests are serialised.
+std::vector<std::vector<uint64_t>> batch_proof_indices(size_t n_leaves, const std::vector<uint64_t>& positions);
+std::vector<uint64_t> fold_positions(const std::vector<uint64_t>& positions, uint64_t source_domain, uint64_t folding_factor);
+int num_fri_layers(uint64_t domain, uint64_t fold, uint64_t max_remainder);
+
+}  // namespace aero

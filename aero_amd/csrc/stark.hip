@@ -1,0 +1,351 @@
+// Per-row STARK kernels for gfx950: constraint evaluation, composition division, out-of-domain evaluation,
+// DEEP composition, FRI folding, proof-of-work grinding and query gathers.
+//
+// Reference seams replaced (the bodies are winter-prover / winter-fri 0.4, absent from the mount; call sites):
+//   constraint evaluation ... /root/reference/aero-sdk/miden-wasm/src/constraints_worker.rs:32-76
+//                             (ConstraintEvaluator::evaluate_fragment -> per-divisor numerator columns),
+//                             proving_worker.rs:374-437 (divisor list, fragment stitching)
+//   composition / OOD / DEEP / FRI / grind / queries ... proving_worker.rs:344-352 (prove_after_constraint_eval);
+//                             formulas mirrored by the verifier: src/stark_verifier/composer.cairo:48-316,
+//                             fri/fri_verifier.cairo:243-340, crypto/random.cairo:282-316
+// All kernels are one-thread-per-row(-group), column-major coalesced reads, no inter-workgroup communication.
+// Field inversions are batched per thread (Montgomery trick over the thread's K rows).
+#include "aero_internal.hpp"
+#include "stark_kernels.hpp"
+
+namespace aero {
+
+using gl::FB;
+using gl::FQ;
+
+__device__ __forceinline__ uint64_t tw2(const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, uint32_t e, int h) {
+    return gl::mul(lo[e & ((1u << h) - 1)], hi[e >> h]);
+}
+template <class F> __device__ __forceinline__ typename F::T ld(const uint64_t* const* comp, size_t i) {
+    return F::make(comp[0][i], F::DEG > 1 ? comp[1][i] : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FibAir constraint evaluation over the constraint-evaluation domain (ce_n = C*n points, row s <-> LDE row
+// s*ce_step, x = 7 w_ce^s). Frame = (LDE row r, LDE row r + blowup mod N).
+//   MODE 0: write the three per-divisor numerator columns (the reference's ConstraintEvaluationTable seam)
+//   MODE 1: additionally divide by the divisors and write H(x) = sum_i col_i / div_i (fused; columns not stored)
+template <class F, int MODE, int K>
+__global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) {
+    typedef typename F::T T;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t nthreads = a.count / K;       // a.count rows handled by this launch (fragment)
+    if (t >= nthreads) return;
+    T num[K][3];
+    uint64_t xs[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        const size_t s = a.first + t + (size_t)q * nthreads;   // ce step
+        const size_t r = s * a.ce_step;
+        const size_t rn = (r + a.blowup) & (a.N - 1);
+        const uint64_t w = tw2(a.tw_lo, a.tw_hi, (uint32_t)s, a.tw_h);       // w_ce^s
+        const uint64_t wi = tw2(a.twi_lo, a.twi_hi, (uint32_t)s, a.tw_h);    // w_ce^-s
+        const uint64_t x = gl::mul(gl::GEN, w);
+        xs[q] = x;
+        // degree adjustments without exponentiation: x^ce_n = 7^ce_n is constant on the coset
+        //   x^adj_t = x^(ce_n - 1)     = K7 * x^-1
+        //   x^adj_b = x^(ce_n - n + 1) = K7 * x * (x^n)^-1,   x^n = 7^n * w_C^(s mod C)
+        const uint64_t xinv = gl::mul(a.gen_inv, wi);
+        const uint64_t xt = gl::mul(a.k7, xinv);
+        const uint64_t xb = gl::mul(gl::mul(a.k7, x), a.xn_inv[s & (a.C - 1)]);
+        T acc = F::zero(), g0 = F::zero(), g1 = F::zero();
+        for (uint32_t k = 0; k < a.W / 2; k++) {
+            const uint64_t ca = a.lde[(size_t)(2 * k) * a.N + r], cb = a.lde[(size_t)(2 * k + 1) * a.N + r];
+            const uint64_t na = a.lde[(size_t)(2 * k) * a.N + rn], nb = a.lde[(size_t)(2 * k + 1) * a.N + rn];
+            const uint64_t t0 = gl::sub(na, gl::add(ca, cb));
+            const uint64_t t1 = gl::sub(nb, gl::add(cb, na));
+            acc = F::add(acc, F::mulb(F::add(a.ta[2 * k], F::mulb(a.tb[2 * k], xt)), t0));
+            acc = F::add(acc, F::mulb(F::add(a.ta[2 * k + 1], F::mulb(a.tb[2 * k + 1], xt)), t1));
+            g0 = F::add(g0, F::mulb(F::add(a.ba[2 * k], F::mulb(a.bb[2 * k], xb)), gl::sub(ca, 1 + 2 * (uint64_t)k)));
+            g0 = F::add(g0, F::mulb(F::add(a.ba[2 * k + 1], F::mulb(a.bb[2 * k + 1], xb)), gl::sub(cb, 2 + 2 * (uint64_t)k)));
+            g1 = F::add(g1, F::mulb(F::add(a.ba[a.W + k], F::mulb(a.bb[a.W + k], xb)), gl::sub(cb, a.results[k])));
+        }
+        num[q][0] = acc; num[q][1] = g0; num[q][2] = g1;
+        if (MODE == 0) {
+            const size_t o = s - a.first;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                for (int d = 0; d < F::DEG; d++) a.out_cols[(size_t)(c * F::DEG + d) * a.count + o] = F::comp(num[q][c], d);
+        }
+    }
+    if (MODE == 1) {
+        // batch-invert (x - 1), (x - w_n^(n-1)) for the K points
+        uint64_t den[2 * K], pre[2 * K];
+        uint64_t run = 1;
+#pragma unroll
+        for (int q = 0; q < K; q++) {
+            den[2 * q] = gl::sub(xs[q], 1);
+            den[2 * q + 1] = gl::sub(xs[q], a.w_last);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * K; i++) { pre[i] = run; run = gl::mul(run, den[i]); }
+        uint64_t ia = gl::inv(run);
+#pragma unroll
+        for (int i = 2 * K - 1; i >= 0; i--) { uint64_t v = gl::mul(ia, pre[i]); ia = gl::mul(ia, den[i]); den[i] = v; }
+#pragma unroll
+        for (int q = 0; q < K; q++) {
+            const size_t s = a.first + t + (size_t)q * nthreads;
+            // 1 / ((x^n - 1) / (x - w^(n-1))) = (x - w^(n-1)) * zinv[s mod C]
+            const uint64_t tdiv = gl::mul(gl::sub(xs[q], a.w_last), a.zn_inv[s & (a.C - 1)]);
+            T h = F::mulb(num[q][0], tdiv);
+            h = F::add(h, F::mulb(num[q][1], den[2 * q]));
+            h = F::add(h, F::mulb(num[q][2], den[2 * q + 1]));
+            for (int d = 0; d < F::DEG; d++) a.out_h[d][s] = F::comp(h, d);
+        }
+    }
+}
+
+template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F>& a, int mode) {
+    size_t cnt = a.count;
+    if (mode == 0) {
+        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * ((size_t)a.W + 3 * F::DEG), (fib_constraints_kernel<F, 0, 1>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, a);
+    } else if (cnt % 4 == 0) {
+        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * ((size_t)a.W + F::DEG), (fib_constraints_kernel<F, 1, 4>), dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, a);
+    } else {
+        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * ((size_t)a.W + F::DEG), (fib_constraints_kernel<F, 1, 1>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, a);
+    }
+    ctx->check_launch("fib_constraints");
+}
+template void launch_fib_constraints<FB>(Context*, const FibConsArgs<FB>&, int);
+template void launch_fib_constraints<FQ>(Context*, const FibConsArgs<FQ>&, int);
+
+// ------------------------------------------------------------------------------------------------
+// Evaluate polynomials stored as bit-reversed coefficient vectors at up to 2 points:
+//   out[col][pt] = sum_p coeff[col][p] * y_pt^(rev_L(p)).
+// Position p = blk * 2^r + k  ->  rev_L(p) = rev_r(k) * 2^(L-r) + rev_(L-r)(blk), so
+//   y^rev(p) = ktab_pt[k] * y^rev(blk),  ktab_pt[k] = (y^(2^(L-r)))^rev_r(k)   (table built by eval_ktab_kernel).
+// grid = (blocks, columns); each workgroup reduces one block; a second tiny kernel adds the block partials.
+template <class F> __global__ void eval_ktab_kernel(typename F::T* tab, int r, typename F::T y0, typename F::T y1, int npts) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1u << r)) return;
+    uint32_t e = gl::bitrev(k, r);
+    tab[k] = gl::fpow<F>(y0, e);
+    if (npts > 1) tab[(1u << r) + k] = gl::fpow<F>(y1, e);
+}
+template <class F> __global__ __launch_bounds__(256) void eval_bitrev_kernel(EvalArgs<F> a) {
+    typedef typename F::T T;
+    __shared__ T red[2][256];
+    const uint32_t blk = blockIdx.x, col = blockIdx.y;
+    const int R = 1 << a.r;
+    // E-valued polynomial: second component lives comp_stride elements after the first
+    const uint64_t* c0 = a.coeffs + (size_t)col * a.col_stride + ((size_t)blk << a.r);
+    const uint64_t* c1 = a.comps > 1 ? c0 + a.comp_stride : c0;
+    T acc0 = F::zero(), acc1 = F::zero();
+    for (int k = threadIdx.x; k < R; k += 256) {
+        if (a.comps == 1) {
+            uint64_t c = c0[k];
+            acc0 = F::add(acc0, F::mulb(a.ktab[k], c));
+            if (a.npts > 1) acc1 = F::add(acc1, F::mulb(a.ktab[R + k], c));
+        } else {
+            T c = F::make(c0[k], c1[k]);
+            acc0 = F::add(acc0, F::mul(a.ktab[k], c));
+            if (a.npts > 1) acc1 = F::add(acc1, F::mul(a.ktab[R + k], c));
+        }
+    }
+    red[0][threadIdx.x] = acc0; red[1][threadIdx.x] = acc1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] = F::add(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+            red[1][threadIdx.x] = F::add(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < (unsigned)a.npts) {
+        uint32_t rb = gl::bitrev(blk, a.L - a.r);
+        T y = threadIdx.x == 0 ? a.y0 : a.y1;
+        T v = F::mul(red[threadIdx.x][0], gl::fpow<F>(y, rb));
+        a.partials[((size_t)col * a.npts + threadIdx.x) * gridDim.x + blk] = v;
+    }
+}
+template <class F> __global__ __launch_bounds__(256) void eval_reduce_kernel(const typename F::T* partials, uint32_t nblk, typename F::T* out) {
+    typedef typename F::T T;
+    __shared__ T red[256];
+    const typename F::T* p = partials + (size_t)blockIdx.x * nblk;
+    T acc = F::zero();
+    for (uint32_t i = threadIdx.x; i < nblk; i += 256) acc = F::add(acc, p[i]);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = F::add(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+// out (device, ncols*npts values, index col*npts + pt)
+template <class F>
+void launch_eval_bitrev(Context* ctx, const uint64_t* coeffs, size_t col_stride, size_t comp_stride, int ncols, int comps, int L,
+                        typename F::T y0, typename F::T y1, int npts, typename F::T* out) {
+    typedef typename F::T T;
+    int r = L < 10 ? L : 10;
+    uint32_t nblk = 1u << (L - r);
+    T* ktab = (T*)ctx->scratch_alloc(sizeof(T) * 2 * ((size_t)1 << r));
+    T* partials = (T*)ctx->scratch_alloc(sizeof(T) * (size_t)ncols * npts * nblk);
+    T b0 = gl::fpow<F>(y0, 1ull << (L - r)), b1 = gl::fpow<F>(y1, 1ull << (L - r));
+    AERO_LAUNCH(ctx, "eval_ktab_kernel", 0, (eval_ktab_kernel<F>), dim3(((1u << r) + 255) / 256), dim3(256), 0, ktab, r, b0, b1, npts);
+    EvalArgs<F> a;
+    a.coeffs = coeffs; a.col_stride = col_stride; a.comp_stride = comp_stride; a.comps = comps; a.L = L; a.r = r; a.npts = npts; a.y0 = y0; a.y1 = y1;
+    a.ktab = ktab; a.partials = partials;
+    AERO_LAUNCH(ctx, "eval_bitrev_kernel", ((size_t)ncols * comps * 8) << L, (eval_bitrev_kernel<F>), dim3(nblk, ncols), dim3(256), 0, a);
+    AERO_LAUNCH(ctx, "eval_reduce_kernel", 0, (eval_reduce_kernel<F>), dim3(ncols * npts), dim3(256), 0, partials, nblk, out);
+    ctx->check_launch("eval_bitrev");
+}
+template void launch_eval_bitrev<FB>(Context*, const uint64_t*, size_t, size_t, int, int, int, uint64_t, uint64_t, int, uint64_t*);
+template void launch_eval_bitrev<FQ>(Context*, const uint64_t*, size_t, size_t, int, int, int, gl::E2, gl::E2, int, gl::E2*);
+
+// ------------------------------------------------------------------------------------------------
+// DEEP composition over the LDE domain (composer.cairo:48-316 is the verifier-side mirror):
+//   deep(x) = [ sum_i a_i (T_i(x) - T_i(z)) / (x - z) + sum_i b_i (T_i(x) - T_i(z g)) / (x - z g)
+//             (+ sum_i c_i (T_i(x) - conj T_i(z)) / (x - conj z)  when E = F_p^2)
+//             + sum_c d_c (H_c(x) - H_c(z^C)) / (x - z^C) ] * (lambda + mu x)
+template <class F, int K> __global__ __launch_bounds__(256) void deep_kernel(DeepArgs<F> a) {
+    typedef typename F::T T;
+    constexpr int ND = F::DEG > 1 ? 4 : 3;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t nthreads = a.N / K;
+    if (t >= nthreads) return;
+    T den[ND * K], pre[ND * K];
+    uint64_t xs[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        const size_t r = t + (size_t)q * nthreads;
+        const uint64_t x = gl::mul(gl::GEN, tw2(a.tw_lo, a.tw_hi, (uint32_t)r, a.tw_h));
+        xs[q] = x;
+        const T xe = F::from(x);
+        den[ND * q] = F::sub(xe, a.z); den[ND * q + 1] = F::sub(xe, a.z_next); den[ND * q + 2] = F::sub(xe, a.z_c);
+        if (ND == 4) den[ND * q + 3] = F::sub(xe, a.z_conj);
+    }
+    T run = F::one();
+#pragma unroll
+    for (int i = 0; i < ND * K; i++) { pre[i] = run; run = F::mul(run, den[i]); }
+    T ia = F::inv(run);
+#pragma unroll
+    for (int i = ND * K - 1; i >= 0; i--) { T v = F::mul(ia, pre[i]); ia = F::mul(ia, den[i]); den[i] = v; }
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        const size_t r = t + (size_t)q * nthreads;
+        T s1 = F::zero(), s2 = F::zero(), s3 = F::zero();
+        for (uint32_t c = 0; c < a.W; c++) {
+            const T v = F::from(a.tlde[(size_t)c * a.N + r]);
+            s1 = F::add(s1, F::mul(F::sub(v, a.ood_cur[c]), a.da[c]));
+            s2 = F::add(s2, F::mul(F::sub(v, a.ood_next[c]), a.db[c]));
+            if (F::DEG > 1) s3 = F::add(s3, F::mul(F::sub(v, F::conj(a.ood_cur[c])), a.dg[c]));
+        }
+        T acc = F::add(F::mul(s1, den[ND * q]), F::mul(s2, den[ND * q + 1]));
+        if (F::DEG > 1) acc = F::add(acc, F::mul(s3, den[ND * q + 3]));
+        T sc = F::zero();
+        for (uint32_t c = 0; c < a.C; c++) {
+            const T v = F::make(a.clde[(size_t)(c * F::DEG) * a.N + r], F::DEG > 1 ? a.clde[(size_t)(c * F::DEG + F::DEG - 1) * a.N + r] : 0);
+            sc = F::add(sc, F::mul(F::sub(v, a.ood_h[c]), a.dc[c]));
+        }
+        acc = F::add(acc, F::mul(sc, den[ND * q + 2]));
+        acc = F::mul(acc, F::add(a.lambda, F::mulb(a.mu, xs[q])));
+        for (int d = 0; d < F::DEG; d++) a.out[d][r] = F::comp(acc, d);
+    }
+}
+template <class F> void launch_deep(Context* ctx, const DeepArgs<F>& a) {
+    if (a.N % 4 == 0 && a.N >= 4096)
+        AERO_LAUNCH(ctx, "deep_kernel", a.N * 8 * ((size_t)a.W + (size_t)a.C * F::DEG + F::DEG), (deep_kernel<F, 4>), dim3((unsigned)((a.N / 4 + 255) / 256)), dim3(256), 0, a);
+    else
+        AERO_LAUNCH(ctx, "deep_kernel", a.N * 8 * ((size_t)a.W + (size_t)a.C * F::DEG + F::DEG), (deep_kernel<F, 1>), dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, a);
+    ctx->check_launch("deep");
+}
+template void launch_deep<FB>(Context*, const DeepArgs<FB>&);
+template void launch_deep<FQ>(Context*, const DeepArgs<FQ>&);
+
+// ------------------------------------------------------------------------------------------------
+// FRI fold by `fold` (fri_verifier.cairo:305-315 mirror; winter-fri apply_drp): row i = (v[i + j*rows])_j lies on
+// x_i * <w_F>, x_i = 7 * w_dom^i (the offset stays 7 at every layer: fri_verifier.cairo:23,308). With c_k = inverse
+// DFT of the row, the interpolant evaluated at alpha is (1/F) * sum_k (alpha / x_i)^k * sum_j v_j w_F^(-jk).
+template <class F> __global__ __launch_bounds__(256) void fri_fold_kernel(FoldArgs<F> a) {
+    typedef typename F::T T;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.rows) return;
+    T v[16];
+    for (int j = 0; j < a.fold; j++) v[j] = F::make(a.in[0][i + (size_t)j * a.rows], F::DEG > 1 ? a.in[1][i + (size_t)j * a.rows] : 0);
+    const uint64_t xinv = gl::mul(a.gen_inv, tw2(a.twi_lo, a.twi_hi, (uint32_t)i, a.tw_h));
+    const T r = F::mulb(a.alpha, xinv);
+    T rp = F::one(), acc = F::zero();
+    for (int k = 0; k < a.fold; k++) {
+        T ck = F::zero();
+        for (int j = 0; j < a.fold; j++) ck = F::add(ck, F::mulb(v[j], a.dft[(j * k) & (a.fold - 1)]));
+        acc = F::add(acc, F::mul(ck, rp));
+        rp = F::mul(rp, r);
+    }
+    acc = F::mulb(acc, a.fold_inv);
+    for (int d = 0; d < F::DEG; d++) a.out[d][i] = F::comp(acc, d);
+}
+template <class F> void launch_fri_fold(Context* ctx, const FoldArgs<F>& a) {
+    AERO_LAUNCH(ctx, "fri_fold_kernel", a.rows * 8 * F::DEG * ((size_t)a.fold + 1), (fri_fold_kernel<F>), dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, a);
+    ctx->check_launch("fri_fold");
+}
+template void launch_fri_fold<FB>(Context*, const FoldArgs<FB>&);
+template void launch_fri_fold<FQ>(Context*, const FoldArgs<FQ>&);
+
+// ------------------------------------------------------------------------------------------------
+// Grinding (random.cairo:282-316 mirror): smallest nonce >= 1 whose BLAKE2s(seed || LE64(nonce)) has at least
+// `bits` leading zero bits (MSB-first from digest byte 0). Threads scan upward in sweeps; a thread stops once its
+// next candidate exceeds the best hit so far, so every smaller nonce has been tested: the minimum is exact.
+__device__ __forceinline__ uint32_t leading_zeros_be(const Digest& d) {
+    uint32_t w0 = __builtin_bswap32(d.w[0]), w1 = __builtin_bswap32(d.w[1]);
+    if (w0) return __clz(w0);
+    if (w1) return 32 + __clz(w1);
+    return 64;
+}
+__global__ __launch_bounds__(256) void grind_kernel(Digest seed, uint32_t bits, unsigned long long* best) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t nonce = 1 + (uint64_t)blockIdx.x * 256 + threadIdx.x;; nonce += stride) {
+        unsigned long long cur = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nonce >= cur) return;
+        Digest d = b2s::merge_with_int(seed, nonce);
+        if (leading_zeros_be(d) >= bits) { atomicMin(best, (unsigned long long)nonce); return; }
+    }
+}
+void launch_grind(Context* ctx, const Digest& seed, uint32_t bits, unsigned long long* best_dev) {
+    AERO_HIP(hipMemsetAsync(best_dev, 0xff, 8, ctx->stream));
+    AERO_LAUNCH(ctx, "grind_kernel", 0, grind_kernel, dim3(256), dim3(256), 0, seed, bits, best_dev);
+    ctx->check_launch("grind");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Query gathers: rows of a column-major matrix at given positions; digests at given node indices.
+__global__ void gather_rows_kernel(const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npos * ncols) return;
+    int q = t / ncols, c = t % ncols;
+    out[t] = cols[(size_t)c * col_stride + pos[q]];
+}
+// FRI rows: out[q][j][d] = comp[d][pos[q] + j*rows]
+__global__ void gather_fri_rows_kernel(const uint64_t* c0, const uint64_t* c1, int deg, size_t rows, int fold, const uint64_t* pos, int npos, uint64_t* out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npos * fold * deg) return;
+    int d = t % deg, j = (t / deg) % fold, q = t / (deg * fold);
+    const uint64_t* c = d ? c1 : c0;
+    out[t] = c[pos[q] + (size_t)j * rows];
+}
+__global__ void gather_digests_kernel(const Digest* nodes, const uint64_t* idx, int n, Digest* out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    out[t] = nodes[idx[t]];
+}
+void launch_gather_rows(Context* ctx, const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out) {
+    int n = npos * ncols;
+    AERO_LAUNCH(ctx, "gather_rows_kernel", 0, gather_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, cols, col_stride, ncols, pos, npos, out);
+    ctx->check_launch("gather_rows");
+}
+void launch_gather_fri_rows(Context* ctx, const uint64_t* c0, const uint64_t* c1, int deg, size_t rows, int fold, const uint64_t* pos, int npos, uint64_t* out) {
+    int n = npos * fold * deg;
+    AERO_LAUNCH(ctx, "gather_fri_rows_kernel", 0, gather_fri_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, c0, c1, deg, rows, fold, pos, npos, out);
+    ctx->check_launch("gather_fri_rows");
+}
+void launch_gather_digests(Context* ctx, const Digest* nodes, const uint64_t* idx, int n, Digest* out) {
+    AERO_LAUNCH(ctx, "gather_digests_kernel", 0, gather_digests_kernel, dim3((n + 255) / 256), dim3(256), 0, nodes, idx, n, out);
+    ctx->check_launch("gather_digests");
+}
+
+}  // namespace aero

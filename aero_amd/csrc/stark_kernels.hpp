@@ -1,0 +1,72 @@
+// Argument blocks and launchers of the per-row STARK kernels (stark.hip).
+#pragma once
+#include "aero_internal.hpp"
+
+namespace aero {
+
+template <class F> struct FibConsArgs {
+    typedef typename F::T T;
+    const uint64_t* lde;       // trace LDE, column-major W x N
+    size_t N;
+    uint32_t W, C, blowup, ce_step;
+    size_t first, count;       // ce rows [first, first + count)
+    const T *ta, *tb, *ba, *bb;   // composition coefficient pairs (device): transition[W], boundary[W + W/2]
+    const uint64_t* results;      // W/2 public results (device)
+    const uint64_t *tw_lo, *tw_hi, *twi_lo, *twi_hi;   // two-level tables of w_ce and its inverse
+    int tw_h;
+    uint64_t gen_inv, k7;         // 7^-1, 7^ce_n
+    const uint64_t* xn_inv;       // C entries: (7^n w_C^k)^-1
+    const uint64_t* zn_inv;       // C entries: (7^n w_C^k - 1)^-1
+    uint64_t w_last;              // w_n^(n-1)
+    uint64_t* out_cols;           // MODE 0: (3*DEG) x count, column-major
+    uint64_t* out_h[2];           // MODE 1: DEG component arrays of ce_n values
+};
+template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F>& a, int mode);
+
+template <class F> struct EvalArgs {
+    typedef typename F::T T;
+    const uint64_t* coeffs;
+    size_t col_stride, comp_stride;
+    int comps, L, r, npts;
+    T y0, y1;
+    const T* ktab;
+    T* partials;
+};
+template <class F>
+void launch_eval_bitrev(Context* ctx, const uint64_t* coeffs, size_t col_stride, size_t comp_stride, int ncols, int comps, int L,
+                        typename F::T y0, typename F::T y1, int npts, typename F::T* out);
+
+template <class F> struct DeepArgs {
+    typedef typename F::T T;
+    const uint64_t* tlde;   // W x N
+    const uint64_t* clde;   // (C*DEG) x N
+    size_t N;
+    uint32_t W, C;
+    const uint64_t *tw_lo, *tw_hi;   // two-level table of w_N
+    int tw_h;
+    T z, z_next, z_c, z_conj, lambda, mu;
+    const T *ood_cur, *ood_next, *ood_h, *da, *db, *dg, *dc;   // device
+    uint64_t* out[2];
+};
+template <class F> void launch_deep(Context* ctx, const DeepArgs<F>& a);
+
+template <class F> struct FoldArgs {
+    typedef typename F::T T;
+    const uint64_t* in[2];
+    uint64_t* out[2];
+    size_t rows;
+    int fold;
+    T alpha;
+    const uint64_t *twi_lo, *twi_hi;   // two-level table of w_dom^-1
+    int tw_h;
+    uint64_t gen_inv, fold_inv;
+    uint64_t dft[16];                  // w_F^-m, m < fold
+};
+template <class F> void launch_fri_fold(Context* ctx, const FoldArgs<F>& a);
+
+void launch_grind(Context* ctx, const Digest& seed, uint32_t bits, unsigned long long* best_dev);
+void launch_gather_rows(Context* ctx, const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out);
+void launch_gather_fri_rows(Context* ctx, const uint64_t* c0, const uint64_t* c1, int deg, size_t rows, int fold, const uint64_t* pos, int npos, uint64_t* out);
+void launch_gather_digests(Context* ctx, const Digest* nodes, const uint64_t* idx, int n, Digest* out);
+
+}  // namespace aero

@@ -1,0 +1,160 @@
+/*
+ * aero_stark.h — C ABI of libaero_stark.so, the MI355X-native backend for the Winterfell proving hot path that
+ * Aero's miden-proof-generator drives (Goldilocks NTT/LDE, constraint evaluation, BLAKE2s Merkle commitment,
+ * DEEP, FRI, proof bytes).
+ *
+ * This is the drop-in boundary: what a Rust `impl winter_prover::Prover` (or the browser worker protocol) would bind
+ * through FFI. Every entry point cites the reference interface it replaces (paths relative to the reference repo
+ * starkoracles/Aero @ v1). Conventions:
+ *   - plain C types only; opaque handles for device-resident objects; caller owns every host buffer it passes in;
+ *   - every function returns an int32 status: 0 = ok, negative = error (AERO_E_*); aero_last_error() gives the text;
+ *   - no exceptions cross the boundary; a context is NOT thread-safe (one host thread drives it);
+ *   - all integers little-endian, field elements canonical u64 < p = 2^64 - 2^32 + 1, digests 32 bytes;
+ *   - matrices are COLUMN-MAJOR (column c occupies elements [c*rows, (c+1)*rows)), like winter's Matrix<Felt>;
+ *   - there is no CPU fallback: without a HIP device aero_ctx_create fails with AERO_E_HIP.
+ */
+#ifndef AERO_STARK_H
+#define AERO_STARK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AERO_OK 0
+#define AERO_E_BAD_ARG (-1)
+#define AERO_E_OOM (-2)
+#define AERO_E_HIP (-3)
+#define AERO_E_COMM (-4)
+#define AERO_E_UNSUPPORTED (-5)
+#define AERO_E_INTERNAL (-6)
+
+typedef struct aero_ctx aero_ctx;
+typedef struct aero_matrix aero_matrix; /* device, column-major u64 matrix */
+typedef struct aero_tree aero_tree;     /* device Merkle tree: node 1 = root, children 2i / 2i+1, leaves at n + j */
+
+/* The 7 option bytes of the proof context, in serialisation order.
+ * Replaces winter_air::ProofOptions::new(num_queries, blowup_factor, grinding_factor, hash_fn, field_extension,
+ * fri_folding_factor, fri_max_remainder_size): aero-sdk/miden-wasm/src/convert/convert_inputs.rs:54-66,
+ * aero-sdk/proto/context.proto:24-33; `ProofOptions::with_96_bit_security()` (miden-proof-generator/src/main.rs:23)
+ * = {27, 8, 16, 4, 1, 8, 8}. hash_fn: 4 = Blake2s_256 (only one implemented). field_extension: 1 = None,
+ * 2 = Quadratic. fri_log_max_remainder = log2 of the max remainder size (256 -> 8). */
+typedef struct aero_proof_options {
+    uint8_t num_queries;
+    uint8_t blowup_factor;
+    uint8_t grinding_factor;
+    uint8_t hash_fn;
+    uint8_t field_extension;
+    uint8_t fri_folding_factor;
+    uint8_t fri_log_max_remainder;
+} aero_proof_options;
+
+/* ---- context --------------------------------------------------------------------------------------------------- */
+/* One context = one GPU + one HIP stream + a device memory pool. (Reference has no analogue: its workers are
+ * web workers, aero-sdk/miden-wasm/src/pool.rs:28-45.) */
+int32_t aero_device_count(void);
+int32_t aero_ctx_create(int32_t device_id, aero_ctx** out);
+void aero_ctx_destroy(aero_ctx* ctx);
+/* Text of the last error on this context; ctx may be NULL for errors of aero_ctx_create itself. */
+const char* aero_last_error(const aero_ctx* ctx);
+void aero_free(void* p); /* releases buffers returned through uint8_t** out-parameters */
+
+/* ---- matrices -------------------------------------------------------------------------------------------------- */
+/* Trace hand-over. Replaces `trace.main_segment()` handed to the prover: proving_worker.rs:272. */
+int32_t aero_trace_upload(aero_ctx* ctx, const uint64_t* col_major, uint32_t width, uint32_t log_n, aero_matrix** out);
+int32_t aero_matrix_shape(const aero_matrix* m, uint32_t* cols, uint64_t* rows);
+int32_t aero_matrix_download(aero_ctx* ctx, const aero_matrix* m, uint64_t* col_major_out);
+void aero_matrix_free(aero_ctx* ctx, aero_matrix* m);
+/* Synthetic Fibonacci trace (host buffer, column-major width x 2^log_n): pair k = columns (2k, 2k+1) = (a, b),
+ * a' = a + b, b' = b + a', seeds (1 + 2k, 2 + 2k). Pure function of (width, log_n). */
+int32_t aero_fib_trace(uint32_t width, uint32_t log_n, uint64_t* col_major_out);
+
+/* ---- stage 1: interpolation and low-degree extension ----------------------------------------------------------------- */
+/* Replaces `main_trace.interpolate_columns()` (proving_worker.rs:273). Output polynomials are kept in the backend's
+ * internal form (bit-reversed coefficient order, coefficient i pre-multiplied by 7^i); they are only meaningful as
+ * input to aero_evaluate_columns_over / aero_poly_eval. */
+int32_t aero_interpolate_columns(aero_ctx* ctx, const aero_matrix* trace, aero_matrix** polys);
+/* Replaces `trace_polys.evaluate_columns_over(&domain)` (proving_worker.rs:274): evaluations over 7 * <w_N>,
+ * N = rows * 2^log_blowup, natural order (row j <-> x_j = 7 * w_N^j). */
+int32_t aero_evaluate_columns_over(aero_ctx* ctx, const aero_matrix* polys, uint32_t log_blowup, aero_matrix** lde);
+/* Evaluate every column polynomial at a base-field point z (out: cols values). Replaces `trace_polys.get_ood_frame(z)`
+ * inside prove_after_constraint_eval (proving_worker.rs:344-352). */
+int32_t aero_poly_eval(aero_ctx* ctx, const aero_matrix* polys, uint64_t z, uint64_t* out);
+
+/* ---- row hashing and Merkle commitment ---------------------------------------------------------------------------- */
+/* The reference's hashing seam: HashingWorkItem{data: Vec<Vec<u64>> rows, batch_idx} -> HashingResult{hashes:
+ * Vec<[u8;32]>} (aero-sdk/miden-wasm/src/utils.rs:358-362,411-415; hashing_worker.rs:12-26). rows_row_major holds
+ * n_rows rows of `width` elements each; digests_out receives n_rows * 32 bytes. digest = BLAKE2s-256 over the elements,
+ * each serialised as 32 little-endian bytes (src/stark_verifier/crypto/random.cairo:93-104). */
+int32_t aero_hash_rows(aero_ctx* ctx, const uint64_t* rows_row_major, uint32_t width, uint64_t n_rows, uint8_t* digests_out);
+/* Same, for the rows of a device matrix (the `read_row_into` gather of proving_worker.rs:293-296 is the coalesced
+ * column-major read on the device). digests_out may be NULL. */
+int32_t aero_hash_matrix_rows(aero_ctx* ctx, const aero_matrix* m, uint8_t* digests_out);
+/* Replaces `MerkleTree::new(trace_row_hashes)` (proving_worker.rs:161-162). n_leaves must be a power of two >= 2. */
+int32_t aero_merkle_from_leaves(aero_ctx* ctx, const uint8_t* leaves, uint64_t n_leaves, aero_tree** out, uint8_t root_out[32]);
+/* Row hashing + tree in one call (winter `commit_to_rows`). */
+int32_t aero_merkle_commit_rows(aero_ctx* ctx, const aero_matrix* m, aero_tree** out, uint8_t root_out[32]);
+/* Replaces `MerkleTree::prove_batch(positions)` + `BatchMerkleProof::serialize_nodes()`: u8 #vectors, then per vector
+ * u8 len + len * 32 bytes (layout: SURVEY.md App. A.2; consumer: miden-to-cairo-parser/src/lib.rs:363-388). */
+int32_t aero_merkle_open_batch(aero_ctx* ctx, const aero_tree* tree, const uint64_t* positions, uint32_t k, uint8_t* out,
+                               size_t cap, size_t* out_len);
+/* All 2n node slots (slot 0 zeroed, slot 1 = root, slots n.. = leaves); for tests. */
+int32_t aero_merkle_nodes(aero_ctx* ctx, const aero_tree* tree, uint8_t* out);
+void aero_tree_free(aero_ctx* ctx, aero_tree* tree);
+
+/* ---- constraint evaluation ------------------------------------------------------------------------------------------ */
+/* The reference's constraint seam for the built-in FibAir: ConstraintComputeWorkItem{.., constraint_coeffs,
+ * trace_lde, ComputationFragment{fragment_offset, num_fragments}} -> ConstraintComputeResult{frag_index, frag_num,
+ * constraint_evaluations: Vec<Vec<u64>> column-major} (utils.rs:302-347,417-422; constraints_worker.rs:14-79:
+ * `evaluation_table.fragments(n)[k]`, `evaluator.evaluate_fragment`). Columns = one per divisor: [transition,
+ * boundary(step 0), boundary(step n-1)], numerators only. coeffs = (alpha, beta) pairs, first one per transition
+ * constraint (width of them) then one per assertion (width + width/2), each element `deg` u64 (deg = 1, or 2 for the
+ * quadratic extension). out_cols receives 3*deg columns of frag_rows = (2 * trace_len / num_fragments) values each;
+ * *frag_index_out = first constraint-domain row of the fragment (`frag.offset()`). */
+int32_t aero_eval_constraints_fib(aero_ctx* ctx, const aero_matrix* trace_lde, uint32_t log_blowup, const uint64_t* results,
+                                  const uint64_t* coeffs, uint8_t field_extension, uint32_t fragment_offset,
+                                  uint32_t num_fragments, uint64_t* out_cols, uint64_t* frag_index_out);
+
+/* ---- FRI and grinding ------------------------------------------------------------------------------------------------- */
+/* One FRI layer fold over the base field (winter-fri `apply_drp`, mirrored by src/stark_verifier/fri/
+ * fri_verifier.cairo:305-315): values = dom evaluations in natural order over 7 * <w_dom>; out = dom/fold values. */
+int32_t aero_fri_fold(aero_ctx* ctx, const uint64_t* values, uint64_t dom, uint32_t fold, uint64_t alpha, uint64_t* out);
+/* Replaces `channel.grind_query_seed()`: smallest nonce >= 1 such that BLAKE2s(seed || LE64(nonce)) has at least `bits`
+ * leading zero bits counted MSB-first from byte 0 (src/stark_verifier/crypto/random.cairo:282-316). */
+int32_t aero_grind(aero_ctx* ctx, const uint8_t seed[32], uint32_t bits, uint64_t* nonce_out);
+
+/* ---- whole proof ---------------------------------------------------------------------------------------------------------- */
+/* Replaces `Prover::prove(trace)` for the built-in FibAir (proving_worker.rs:465-467; miden-proof-generator/src/
+ * main.rs:31) followed by `proof.to_bytes()` (main.rs:38). `trace` is already resident on the device. *proof is
+ * malloc'd (aero_free). pub_out receives the width/2 public inputs (the asserted results). */
+int32_t aero_prove_fib(aero_ctx* ctx, const aero_matrix* trace, const aero_proof_options* options, uint8_t** proof,
+                       size_t* proof_len, uint64_t* pub_out);
+/* Same with the trace in host memory (includes the host-to-device copy). */
+int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n,
+                            const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
+/* bincode ProofData{input_bytes, proof_bytes} = u64 len || inputs || u64 len || proof
+ * (miden-proof-generator/src/lib.rs:1-6, main.rs:49-51). */
+int32_t aero_proof_container(const uint8_t* inputs, size_t inputs_len, const uint8_t* proof, size_t proof_len, uint8_t** out,
+                             size_t* out_len);
+
+/* ---- instrumentation --------------------------------------------------------------------------------------------------------- */
+/* Per-stage wall-clock of the last aero_prove_* (ms; adds one stream sync per stage when enabled). Order:
+ * interpolate, lde, trace_commit, constraints, composition, comp_commit, ood, deep, fri, grind, queries, total
+ * (stage names after the console labels of proving_worker.rs:125-172). */
+int32_t aero_set_stage_timing(aero_ctx* ctx, int32_t enable);
+int32_t aero_last_stage_ms(const aero_ctx* ctx, double out[12]);
+/* Per-kernel HIP-event timing on the context's own stream. When enabled, kernel launches (all of them, or only the
+ * kernel named `only_kernel` when that is non-NULL) are bracketed by events; aero_kernel_timing_report writes
+ * "name calls total_ms algorithmic_bytes\n" lines (sorted by total time) and resets the counters. algorithmic_bytes =
+ * every input element read once + every output element written once, summed over the bracketed launches. */
+int32_t aero_set_kernel_timing(aero_ctx* ctx, int32_t enable, const char* only_kernel);
+int32_t aero_kernel_timing_report(aero_ctx* ctx, char* buf, size_t cap);
+/* Device memory currently held / peak (bytes). */
+int32_t aero_memory_stats(const aero_ctx* ctx, uint64_t* in_use, uint64_t* peak);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AERO_STARK_H */
