@@ -9,16 +9,21 @@
 using namespace aero;
 
 struct aero_ctx {
-    Context* c = nullptr;
+    std::shared_ptr<Context> keep;   // device objects created from this context share ownership, so destroying the
+    Context* c = nullptr;            // context handle before its matrices / trees is safe
     std::string err;
     StageMs last_ms;
     bool stage_timing = false;
 };
 struct aero_matrix {
+    std::shared_ptr<Context> keep;   // declared first: destroyed after `m`, whose buffers return to the context pool
     Matrix m;
+    explicit aero_matrix(aero_ctx* ctx) : keep(ctx->keep) {}
 };
 struct aero_tree {
+    std::shared_ptr<Context> keep;
     MerkleTree t;
+    explicit aero_tree(aero_ctx* ctx) : keep(ctx->keep) {}
 };
 
 static thread_local std::string g_create_err;
@@ -56,7 +61,7 @@ int32_t aero_ctx_create(int32_t device_id, aero_ctx** out) {
     *out = nullptr;
     try {
         aero_ctx* h = new aero_ctx();
-        try { h->c = new Context(device_id); } catch (...) { delete h; throw; }
+        try { h->keep = std::make_shared<Context>(device_id); h->c = h->keep.get(); } catch (...) { delete h; throw; }
         *out = h;
         return AERO_OK;
     } catch (const Error& e) { g_create_err = e.what(); return e.code; }
@@ -64,8 +69,7 @@ int32_t aero_ctx_create(int32_t device_id, aero_ctx** out) {
 }
 void aero_ctx_destroy(aero_ctx* ctx) {
     if (!ctx) return;
-    delete ctx->c;
-    delete ctx;
+    delete ctx;   // the Context itself dies with the last matrix / tree that still references it
 }
 const char* aero_last_error(const aero_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 void aero_free(void* p) { free(p); }
@@ -76,7 +80,7 @@ int32_t aero_trace_upload(aero_ctx* ctx, const uint64_t* col_major, uint32_t wid
         REQUIRE(col_major && out, "trace_upload: null argument");
         REQUIRE(width >= 1 && width <= 255 && log_n >= 3 && log_n <= 29, "trace_upload: width must be in [1,255] and log_n in [3,29]");
         size_t n = (size_t)1 << log_n;
-        aero_matrix* h = new aero_matrix();
+        aero_matrix* h = new aero_matrix(ctx);
         try {
             h->m = Matrix(ctx->c, (int)width, n);
             AERO_HIP(hipMemcpyAsync(h->m.data.get(), col_major, (size_t)width * n * 8, hipMemcpyHostToDevice, ctx->c->stream));
@@ -124,7 +128,7 @@ int32_t aero_interpolate_columns(aero_ctx* ctx, const aero_matrix* trace, aero_m
         REQUIRE(trace && polys, "interpolate_columns: null argument");
         REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0 && trace->m.rows >= 8, "interpolate_columns: row count must be a power of two >= 8");
         Prover p(ctx->c, ProofOptions::with_96_bit_security());
-        aero_matrix* h = new aero_matrix();
+        aero_matrix* h = new aero_matrix(ctx);
         try { h->m = p.interpolate_columns(trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows)); ctx->c->sync(); ctx->c->scratch_reset(); }
         catch (...) { delete h; throw; }
         *polys = h;
@@ -136,7 +140,7 @@ int32_t aero_evaluate_columns_over(aero_ctx* ctx, const aero_matrix* polys, uint
         REQUIRE(log_blowup >= 1 && log_blowup <= 7, "evaluate_columns_over: log_blowup must be in [1,7]");
         REQUIRE(ilog2u(polys->m.rows) + (int)log_blowup <= gl::TWO_ADICITY, "evaluate_columns_over: domain exceeds two-adicity");
         Prover p(ctx->c, ProofOptions::with_96_bit_security());
-        aero_matrix* h = new aero_matrix();
+        aero_matrix* h = new aero_matrix(ctx);
         try { h->m = p.evaluate_columns_over(polys->m, (int)log_blowup); ctx->c->sync(); }
         catch (...) { delete h; throw; }
         *lde = h;
@@ -186,7 +190,7 @@ int32_t aero_merkle_from_leaves(aero_ctx* ctx, const uint8_t* leaves, uint64_t n
     return guard(ctx, [&] {
         REQUIRE(leaves && out, "merkle_from_leaves: null argument");
         REQUIRE(n >= 2 && (n & (n - 1)) == 0, "merkle_from_leaves: leaf count must be a power of two >= 2");
-        aero_tree* h = new aero_tree();
+        aero_tree* h = new aero_tree(ctx);
         try {
             h->t = MerkleTree(ctx->c, n);
             AERO_HIP(hipMemcpyAsync(h->t.leaves(), leaves, n * 32, hipMemcpyHostToDevice, ctx->c->stream));
@@ -203,7 +207,7 @@ int32_t aero_merkle_commit_rows(aero_ctx* ctx, const aero_matrix* m, aero_tree**
         REQUIRE(m && out, "merkle_commit_rows: null argument");
         REQUIRE(m->m.rows >= 2 && (m->m.rows & (m->m.rows - 1)) == 0, "merkle_commit_rows: row count must be a power of two >= 2");
         Prover p(ctx->c, ProofOptions::with_96_bit_security());
-        aero_tree* h = new aero_tree();
+        aero_tree* h = new aero_tree(ctx);
         try { h->t = p.commit_to_rows(m->m); } catch (...) { delete h; throw; }
         if (root_out) memcpy(root_out, h->t.root_host.w, 32);
         *out = h;
@@ -340,12 +344,7 @@ int32_t aero_grind(aero_ctx* ctx, const uint8_t seed[32], uint32_t bits, uint64_
         REQUIRE(bits <= 32, "grind: more than 32 bits of grinding is not supported");
         Digest s;
         memcpy(s.w, seed, 32);
-        DevBuf<unsigned long long> d(ctx->c, 1);
-        launch_grind(ctx->c, s, bits, d.get());
-        unsigned long long best = 0;
-        AERO_HIP(hipMemcpyAsync(&best, d.get(), 8, hipMemcpyDeviceToHost, ctx->c->stream));
-        ctx->c->sync();
-        *nonce_out = best;
+        *nonce_out = run_grind(ctx->c, s, bits);
     });
 }
 

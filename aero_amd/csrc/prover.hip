@@ -516,16 +516,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
 
     // 10. grinding [a16]
     {
-        uint64_t nonce = 0;
-        if (opt_.grinding_factor == 0) nonce = 1;
-        else {
-            DevBuf<unsigned long long> d_best(ctx, 1);
-            launch_grind(ctx, coin.seed, opt_.grinding_factor, d_best.get());
-            unsigned long long best = 0;
-            AERO_HIP(hipMemcpyAsync(&best, d_best.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
-            ctx->sync();
-            nonce = best;
-        }
+        const uint64_t nonce = run_grind(ctx, coin.seed, opt_.grinding_factor);
         proof.pow_nonce = nonce;
         coin.reseed_with_int(nonce);
     }

@@ -289,27 +289,38 @@ template void launch_fri_fold<FQ>(Context*, const FoldArgs<FQ>&);
 
 // ------------------------------------------------------------------------------------------------
 // Grinding (random.cairo:282-316 mirror): smallest nonce >= 1 whose BLAKE2s(seed || LE64(nonce)) has at least
-// `bits` leading zero bits (MSB-first from digest byte 0). Threads scan upward in sweeps; a thread stops once its
-// next candidate exceeds the best hit so far, so every smaller nonce has been tested: the minimum is exact.
+// `bits` leading zero bits (MSB-first from digest byte 0). One launch tests a contiguous batch of nonces, every
+// hit does an atomicMin; the host reads the result and launches the next batch only if the batch had no hit, so the
+// minimum is exact and no workgroup ever polls another workgroup's result (per-XCD L2s are not coherent: a polled
+// word can stay stale for the whole kernel).
 __device__ __forceinline__ uint32_t leading_zeros_be(const Digest& d) {
     uint32_t w0 = __builtin_bswap32(d.w[0]), w1 = __builtin_bswap32(d.w[1]);
     if (w0) return __clz(w0);
     if (w1) return 32 + __clz(w1);
     return 64;
 }
-__global__ __launch_bounds__(256) void grind_kernel(Digest seed, uint32_t bits, unsigned long long* best) {
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t nonce = 1 + (uint64_t)blockIdx.x * 256 + threadIdx.x;; nonce += stride) {
-        unsigned long long cur = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nonce >= cur) return;
-        Digest d = b2s::merge_with_int(seed, nonce);
-        if (leading_zeros_be(d) >= bits) { atomicMin(best, (unsigned long long)nonce); return; }
-    }
+__global__ __launch_bounds__(256) void grind_kernel(Digest seed, uint32_t bits, uint64_t first, unsigned long long* best) {
+    const uint64_t nonce = first + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    Digest d = b2s::merge_with_int(seed, nonce);
+    if (leading_zeros_be(d) >= bits) atomicMin(best, (unsigned long long)nonce);
 }
-void launch_grind(Context* ctx, const Digest& seed, uint32_t bits, unsigned long long* best_dev) {
-    AERO_HIP(hipMemsetAsync(best_dev, 0xff, 8, ctx->stream));
-    AERO_LAUNCH(ctx, "grind_kernel", 0, grind_kernel, dim3(256), dim3(256), 0, seed, bits, best_dev);
-    ctx->check_launch("grind");
+// Returns the smallest nonce >= 1 with the required leading zeros (synchronises the stream once per batch).
+uint64_t run_grind(Context* ctx, const Digest& seed, uint32_t bits) {
+    if (bits == 0) return 1;
+    DevBuf<unsigned long long> d_best(ctx, 1);
+    AERO_HIP(hipMemsetAsync(d_best.get(), 0xff, 8, ctx->stream));
+    // batch = 4x the expected number of trials (a batch without a hit has probability e^-4), at least 2^16
+    uint64_t batch = 1ull << (bits + 2 < 16 ? 16 : bits + 2);
+    if (batch > (1ull << 30)) batch = 1ull << 30;
+    for (uint64_t first = 1;; first += batch) {
+        AERO_LAUNCH(ctx, "grind_kernel", 0, grind_kernel, dim3((unsigned)(batch / 256)), dim3(256), 0, seed, bits, first, d_best.get());
+        ctx->check_launch("grind");
+        unsigned long long best = 0;
+        AERO_HIP(hipMemcpyAsync(&best, d_best.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        if (best != ~0ull) return best;
+        if (first > (1ull << 40)) fail("grind: no nonce found", ST_INTERNAL);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

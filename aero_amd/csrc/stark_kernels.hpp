@@ -64,7 +64,7 @@ template <class F> struct FoldArgs {
 };
 template <class F> void launch_fri_fold(Context* ctx, const FoldArgs<F>& a);
 
-void launch_grind(Context* ctx, const Digest& seed, uint32_t bits, unsigned long long* best_dev);
+uint64_t run_grind(Context* ctx, const Digest& seed, uint32_t bits);
 void launch_gather_rows(Context* ctx, const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out);
 void launch_gather_fri_rows(Context* ctx, const uint64_t* c0, const uint64_t* c1, int deg, size_t rows, int fold, const uint64_t* pos, int npos, uint64_t* out);
 void launch_gather_digests(Context* ctx, const Digest* nodes, const uint64_t* idx, int n, Digest* out);
