@@ -53,6 +53,20 @@ std::vector<NttPass> plan_passes(int log_n);
 
 typedef b2s::Digest Digest;   // 8 x u32, byte order = digest byte order (little-endian words)
 
+// Leaf sources of a Merkle commitment: leaf j = hash_elements(row j)
+struct RowSrc {   // rows of a column-major matrix
+    const uint64_t* cols;
+    size_t stride;   // column stride in elements
+    int ncols;
+};
+struct FriSrc {   // FRI layer rows: row i = (v[i + j*rows])_{j < fold}, each value = deg base components (c0, c1)
+    const uint64_t* c0;
+    const uint64_t* c1;
+    int deg;
+    size_t rows;
+    int fold;
+};
+
 // One context = one device + one stream. Not thread-safe: one host thread drives it (SURVEY 8b "Threading").
 class Context {
 public:
@@ -93,9 +107,15 @@ public:
     void hash_rows(const uint64_t* cols, size_t col_stride, int ncols, size_t rows, Digest* leaves);
     // FRI layer rows: row i = (v[i + j*rows] for j < fold), each value having `deg` base components stored as
     // component columns comp[k] (k < deg): leaf i = hash_elements(flattened row)
-    void hash_fri_rows(const uint64_t* const comp[2], int deg, size_t rows, int fold, Digest* leaves);
+    void hash_fri_rows(const FriSrc& src, Digest* leaves);
     // nodes[n + i] already hold the leaves; fills nodes[1 .. n-1]
     void merkle_build(Digest* nodes, size_t n);
+    // levels above a stored level of c nodes (heap indices [c, 2c)) up to the root
+    void merkle_upper(Digest* nodes, size_t c);
+    // fused leaf hashing + whole tree; the lowest `skip` (0 or 3) levels are not stored (nodes holds 2n >> skip slots)
+    template <class Src> void merkle_commit(const Src& src, size_t n, Digest* nodes, int skip);
+    // digests of unstored low nodes (heap indices >= 2n >> skip), recomputed from the leaf source
+    template <class Src> void merkle_recompute(const Src& src, size_t n, const uint64_t* idx_dev, int count, Digest* out_dev);
 
     // internal state
     std::map<int, NttTables> ntt_tabs;

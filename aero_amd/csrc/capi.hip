@@ -218,29 +218,10 @@ int32_t aero_merkle_open_batch(aero_ctx* ctx, const aero_tree* tree, const uint6
     return guard(ctx, [&] {
         REQUIRE(tree && positions && out_len && k >= 1, "merkle_open_batch: null or empty argument");
         std::vector<uint64_t> pos(positions, positions + k);
-        auto idx = batch_proof_indices(tree->t.n, pos);
-        std::vector<uint64_t> flat;
-        for (auto& v : idx) flat.insert(flat.end(), v.begin(), v.end());
-        size_t need = 1 + idx.size() + flat.size() * 32;
-        *out_len = need;
-        REQUIRE(out && cap >= need, "merkle_open_batch: output buffer too small");
-        REQUIRE(idx.size() <= 255, "merkle_open_batch: too many paths");
-        std::vector<Digest> got(flat.size());
-        if (!flat.empty()) {
-            DevBuf<uint64_t> d_idx(ctx->c, flat.size());
-            DevBuf<Digest> d_out(ctx->c, flat.size());
-            AERO_HIP(hipMemcpyAsync(d_idx.get(), flat.data(), flat.size() * 8, hipMemcpyHostToDevice, ctx->c->stream));
-            launch_gather_digests(ctx->c, tree->t.nodes.get(), d_idx.get(), (int)flat.size(), d_out.get());
-            AERO_HIP(hipMemcpyAsync(got.data(), d_out.get(), flat.size() * 32, hipMemcpyDeviceToHost, ctx->c->stream));
-            ctx->c->sync();
-        }
-        size_t o = 0, g = 0;
-        out[o++] = (uint8_t)idx.size();
-        for (auto& v : idx) {
-            REQUIRE(v.size() <= 255, "merkle_open_batch: too many nodes");
-            out[o++] = (uint8_t)v.size();
-            for (size_t i = 0; i < v.size(); i++) { memcpy(out + o, got[g++].w, 32); o += 32; }
-        }
+        Bytes b = open_batch(ctx->c, tree->t, pos);
+        *out_len = b.size();
+        REQUIRE(out && cap >= b.size(), "merkle_open_batch: output buffer too small");
+        memcpy(out, b.data(), b.size());
     });
 }
 int32_t aero_merkle_nodes(aero_ctx* ctx, const aero_tree* tree, uint8_t* out) {

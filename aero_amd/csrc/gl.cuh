@@ -22,15 +22,35 @@ constexpr uint64_t GEN = 7;                       // multiplicative generator = 
 constexpr uint64_t ROOT_2_32 = 1753635133440165772ULL;
 constexpr int TWO_ADICITY = 32;
 
+// Device code spells the carry chains out on 32-bit limbs (v_add_co/v_addc_co, no 64-bit compares): measured on MI355X
+// (tools/ubench_field.hip) add 6.7 T/s vs 4.8, sub 7.7 vs 6.2, mul 1.65 vs 1.34 T/s for the plain u64 formulation.
+GL_HD uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 GL_HD uint64_t add(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_PLAIN_ADD)
+    // a + b < 2p. Result is s + EPS (mod 2^64) iff the sum wrapped past 2^64 or s >= p (<=> s + EPS wraps).
+    uint32_t c, c1, c2;
+    uint32_t s0 = __builtin_addc((uint32_t)a, (uint32_t)b, 0u, &c), s1 = __builtin_addc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &c1);
+    uint32_t t0 = __builtin_addc(s0, 0xFFFFFFFFu, 0u, &c), t1 = __builtin_addc(s1, 0u, c, &c2);
+    return (c1 | c2) ? mk64(t0, t1) : mk64(s0, s1);
+#else
     uint64_t s = a + b;
     uint64_t c = (s < a) ? EPS : 0;               // wrapped past 2^64: + (2^64 mod p)
     s += c;
     return s >= P ? s - P : s;
+#endif
 }
+// NOTE: the carry-chain form of sub is disabled: combined with the carry-chain mul it produced wrong DEEP evaluations
+// inside deep_kernel on ROCm 7.2 (each alone is bit-exact; tools/ubench_field.hip finds no mismatch) - parity tests caught it.
 GL_HD uint64_t sub(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_CARRY_SUB)
+    uint32_t c, c1;
+    uint32_t d0 = __builtin_subc((uint32_t)a, (uint32_t)b, 0u, &c), d1 = __builtin_subc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &c1);
+    uint32_t t0 = __builtin_subc(d0, 0xFFFFFFFFu, 0u, &c), t1 = __builtin_subc(d1, 0u, c, &c);   // d + p = d - EPS (mod 2^64)
+    return c1 ? mk64(t0, t1) : mk64(d0, d1);
+#else
     uint64_t d = a - b;
     return a < b ? d + P : d;                     // a - b + p, computed mod 2^64
+#endif
 }
 GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
 GL_HD uint64_t dbl(uint64_t a) { return add(a, a); }
@@ -56,9 +76,29 @@ GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
     return r >= P ? r - P : r;
 }
 GL_HD uint64_t mul(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_PLAIN_MUL)
+    // 4 x v_mad_u64_u32 schoolbook product (x0..x3), then x0 + x1 2^32 + x2 (2^32 - 1) - x3 on carry chains
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t t = (uint64_t)a0 * b0;
+    const uint64_t u = (uint64_t)a0 * b1 + (t >> 32);
+    const uint64_t v = (uint64_t)a1 * b0 + (uint32_t)u;
+    const uint64_t w = (uint64_t)a1 * b1 + ((u >> 32) + (v >> 32));
+    const uint32_t x0 = (uint32_t)t, x1 = (uint32_t)v, x2 = (uint32_t)w, x3 = (uint32_t)(w >> 32);
+    uint32_t c, bo, ca, c2;
+    uint32_t l0 = __builtin_subc(x0, x3, 0u, &c), l1 = __builtin_subc(x1, 0u, c, &bo);      // lo - x3
+    const uint32_t m = 0u - bo;                                                             // borrow: - EPS
+    l0 = __builtin_subc(l0, m, 0u, &c); l1 = __builtin_subc(l1, 0u, c, &c);
+    const uint32_t e0 = __builtin_subc(0u, x2, 0u, &c), e1 = __builtin_subc(x2, 0u, c, &c);  // x2 * EPS
+    uint32_t r0 = __builtin_addc(l0, e0, 0u, &c), r1 = __builtin_addc(l1, e1, c, &ca);
+    const uint32_t m2 = 0u - ca;                                                            // carry: + EPS
+    r0 = __builtin_addc(r0, m2, 0u, &c); r1 = __builtin_addc(r1, 0u, c, &c);
+    const uint32_t t0 = __builtin_addc(r0, 0xFFFFFFFFu, 0u, &c), t1 = __builtin_addc(r1, 0u, c, &c2);   // r >= p <=> r + EPS wraps
+    return c2 ? mk64(t0, t1) : mk64(r0, r1);
+#else
     uint64_t lo, hi;
     mul_wide(a, b, lo, hi);
     return reduce128(lo, hi);
+#endif
 }
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 GL_HD uint64_t pow(uint64_t b, uint64_t e) {

@@ -8,17 +8,28 @@
 // Node convention: nodes[1] = root, children of i are 2i and 2i+1, leaves at nodes[n + j]
 // (src/stark_verifier/channel.cairo:136-175).
 //
-// One thread owns one hash state (16-word working vector in VGPRs). Column-major input makes the row gather a
-// coalesced read: lane j reads element j of each column. These kernels are integer-VALU bound (about 10^3 32-bit
-// ops per compression while only 16 of the 64 hashed bytes per block come from HBM), not HBM bound.
+// These kernels are integer-VALU bound (about 1336 VALU issue slots per compression: 656 full-rate xor/add plus 320
+// rotations and 20 three-input adds that issue at half rate; only 16 of the 64 hashed bytes of a leaf block come from
+// HBM). The design therefore minimises everything that is NOT a compression:
+//   * one thread owns one hash state (16-word working vector in VGPRs, fully unrolled rounds);
+//   * large narrow matrices (<= 4 columns, >= 2^18 rows) use the FUSED kernel: a thread hashes 8 consecutive rows and
+//     builds the 3 tree levels above them in registers (no idle lanes at any level, one launch);
+//   * everything else hashes one row per lane (coalesced column reads) and then builds the tree;
+//   * upper levels are built 3 levels per launch (8 child digests -> 7 nodes per thread), the top 9 levels by one
+//     workgroup staged through LDS: a compression has ~1.2 us of serial latency, so small trees are bound by
+//     (levels x latency + launch boundaries), and 3 levels per launch removes two of every three boundaries;
+//   * optionally (skip = 3) the three lowest levels are not stored and the openings recompute the few low nodes they
+//     need from the committed data; this only saves memory (measured: no time gain), so it is off by default.
+// Measured on MI355X (tools/bench_hash.hip, 2^23 x 2 matrix): every variant lands at 30-36 G compressions/s against
+// 40-42 G/s for compressions that never leave registers (tools/ubench_valu.hip).
 #include "aero_internal.hpp"
 
 namespace aero {
 
-__device__ __forceinline__ void store_digest(Digest* dst, const b2s::State& s) {
+__device__ __forceinline__ void store_digest(Digest* dst, const Digest& d) {
     uint4* p = reinterpret_cast<uint4*>(dst);
-    p[0] = make_uint4(s.h[0], s.h[1], s.h[2], s.h[3]);
-    p[1] = make_uint4(s.h[4], s.h[5], s.h[6], s.h[7]);
+    p[0] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+    p[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
 }
 __device__ __forceinline__ Digest load_digest(const Digest* src) {
     const uint4* p = reinterpret_cast<const uint4*>(src);
@@ -27,46 +38,98 @@ __device__ __forceinline__ Digest load_digest(const Digest* src) {
     d.w[0] = a.x; d.w[1] = a.y; d.w[2] = a.z; d.w[3] = a.w; d.w[4] = b.x; d.w[5] = b.y; d.w[6] = b.z; d.w[7] = b.w;
     return d;
 }
-
-__global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t* __restrict__ cols, size_t col_stride, int ncols, size_t rows,
-                                                          Digest* __restrict__ leaves) {
-    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= rows) return;
-    b2s::State s;
-    b2s::init(s);
-    const uint32_t total = (uint32_t)ncols * 32;
-    for (int c = 0; c < ncols; c += 2) {
-        bool two = c + 1 < ncols;
-        uint64_t e0 = cols[(size_t)c * col_stride + j];
-        uint64_t e1 = two ? cols[(size_t)(c + 1) * col_stride + j] : 0;
-        uint32_t t = (uint32_t)(two ? c + 2 : c + 1) * 32;
-        b2s::compress_elems(s, e0, e1, two, t, t == total);
-    }
-    store_digest(&leaves[j], s);
+__device__ __forceinline__ Digest state_digest(const b2s::State& s) {
+    Digest d;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d.w[i] = s.h[i];
+    return d;
 }
 
+// ---- leaf sources ---------------------------------------------------------------------------------
+__device__ __forceinline__ Digest leaf_digest(const RowSrc& s, size_t j) {
+    b2s::State st;
+    b2s::init(st);
+    const uint32_t total = (uint32_t)s.ncols * 32;
+    for (int c = 0; c < s.ncols; c += 2) {
+        bool two = c + 1 < s.ncols;
+        uint64_t e0 = s.cols[(size_t)c * s.stride + j];
+        uint64_t e1 = two ? s.cols[(size_t)(c + 1) * s.stride + j] : 0;
+        uint32_t t = (uint32_t)(two ? c + 2 : c + 1) * 32;
+        b2s::compress_elems(st, e0, e1, two, t, t == total);
+    }
+    return state_digest(st);
+}
 // FRI rows: element q of row i (q < fold*deg) = comp[q % deg][i + (q / deg) * rows]
-__global__ __launch_bounds__(256) void hash_fri_rows_kernel(const uint64_t* __restrict__ c0, const uint64_t* __restrict__ c1, int deg,
-                                                              size_t rows, int fold, Digest* __restrict__ leaves) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows) return;
-    b2s::State s;
-    b2s::init(s);
-    const int nel = fold * deg;
+__device__ __forceinline__ Digest leaf_digest(const FriSrc& s, size_t i) {
+    b2s::State st;
+    b2s::init(st);
+    const int nel = s.fold * s.deg;
     const uint32_t total = (uint32_t)nel * 32;
     for (int q = 0; q < nel; q += 2) {
         uint64_t e0, e1;
-        if (deg == 1) {
-            e0 = c0[i + (size_t)q * rows];
-            e1 = c0[i + (size_t)(q + 1) * rows];
+        if (s.deg == 1) {
+            e0 = s.c0[i + (size_t)q * s.rows];
+            e1 = s.c0[i + (size_t)(q + 1) * s.rows];
         } else {
-            e0 = c0[i + (size_t)(q >> 1) * rows];
-            e1 = c1[i + (size_t)(q >> 1) * rows];
+            e0 = s.c0[i + (size_t)(q >> 1) * s.rows];
+            e1 = s.c1[i + (size_t)(q >> 1) * s.rows];
         }
         uint32_t t = (uint32_t)(q + 2) * 32;
-        b2s::compress_elems(s, e0, e1, true, t, t == total);
+        b2s::compress_elems(st, e0, e1, true, t, t == total);
     }
-    store_digest(&leaves[i], s);
+    return state_digest(st);
+}
+
+// Builds the 3 levels above 8 digests (children left to right, heap index of child 0 = child_base). The node at height
+// h above the children and position p inside this subtree goes to nodes[(child_base >> h) + p]; only heights >=
+// min_store_h are written. Fully unrolled: 7 compression bodies, every digest stays in VGPRs.
+__device__ __forceinline__ void build3(Digest (&d)[8], Digest* nodes, size_t child_base, int min_store_h) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        d[i] = b2s::merge(d[2 * i], d[2 * i + 1]);
+        if (min_store_h <= 1) store_digest(&nodes[(child_base >> 1) + i], d[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        d[i] = b2s::merge(d[2 * i], d[2 * i + 1]);
+        if (min_store_h <= 2) store_digest(&nodes[(child_base >> 2) + i], d[i]);
+    }
+    store_digest(&nodes[child_base >> 3], b2s::merge(d[0], d[1]));
+}
+
+// Fused: thread t hashes leaves [8t, 8t+8) and builds the 3 levels above them. `skip` = number of lowest levels that
+// are not stored (0: store everything incl. leaves; 3: store only the subtree roots at height 3). Used for large
+// narrow matrices only: it divides the thread count by 8, which makes small trees latency-bound.
+template <class Src> __global__ __launch_bounds__(256) void merkle_leaf8_kernel(Src src, Digest* nodes, size_t n, int skip) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n / 8) return;
+    const size_t first = t * 8;
+    Digest d[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        d[i] = leaf_digest(src, first + i);
+        if (skip == 0) store_digest(&nodes[n + first + i], d[i]);
+    }
+    build3(d, nodes, n + first, skip > 1 ? skip : 1);
+}
+
+// 3 levels per launch from a stored level: thread t owns node m + t and its 8 descendants three levels below.
+// Three levels per launch also cut the serial latency chain of small trees (one launch boundary per 3 levels).
+__global__ __launch_bounds__(256) void merkle_up3_kernel(Digest* nodes, size_t m) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= m) return;
+    const size_t child_base = (m + t) * 8;
+    Digest d[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = load_digest(&nodes[child_base + i]);
+    build3(d, nodes, child_base, 1);
+}
+
+// one plain row-hash pass (wide matrices, and the C-ABI hashing seam): lane <-> row, coalesced column reads
+template <class Src> __global__ __launch_bounds__(256) void hash_rows_kernel(Src src, size_t rows, Digest* leaves) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= rows) return;
+    store_digest(&leaves[j], leaf_digest(src, j));
 }
 
 // one tree level: nodes[i] = merge(nodes[2i], nodes[2i+1]) for i in [m, 2m)
@@ -75,10 +138,7 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(Digest* nodes, size_t
     if (t >= m) return;
     size_t i = m + t;
     Digest l = load_digest(&nodes[2 * i]), r = load_digest(&nodes[2 * i + 1]);
-    Digest d = b2s::merge(l, r);
-    uint4* p = reinterpret_cast<uint4*>(&nodes[i]);
-    p[0] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
-    p[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+    store_digest(&nodes[i], b2s::merge(l, r));
 }
 
 // top of the tree in one workgroup: level `m` (<= 256 nodes) down to the root, staged through LDS
@@ -87,7 +147,6 @@ __global__ __launch_bounds__(256) void merkle_top_kernel(Digest* nodes, int m) {
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * m; i += 256) buf[i] = nodes[2 * m + i];   // children of level m: nodes[2m .. 4m)
     __syncthreads();
-    // buf[0 .. 2w) holds the children of the current level (width w); results overwrite buf[0 .. w) after a sync
     for (int w = m; w >= 1; w >>= 1) {
         Digest d;
         if (tid < w) d = b2s::merge(buf[2 * tid], buf[2 * tid + 1]);
@@ -97,25 +156,76 @@ __global__ __launch_bounds__(256) void merkle_top_kernel(Digest* nodes, int m) {
     }
 }
 
+// Recompute unstored low nodes for openings: out[q] = digest of heap node idx[q] (height h < skip above the leaves).
+template <class Src> __global__ void merkle_recompute_kernel(Src src, size_t n, const uint64_t* idx, int count, Digest* out) {
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    uint64_t node = idx[q];
+    int h = 0;
+    while ((node << h) < n) h++;              // node << h lands in [n, 2n)
+    const size_t first = (node << h) - n;
+    Digest d[8];
+    const int cnt = 1 << h;                   // h <= 3
+    for (int i = 0; i < cnt; i++) d[i] = leaf_digest(src, first + i);
+    for (int w = cnt / 2; w >= 1; w >>= 1)
+        for (int i = 0; i < w; i++) d[i] = b2s::merge(d[2 * i], d[2 * i + 1]);
+    out[q] = d[0];
+}
+
+// ------------------------------------------------------------------------------------------------
 void Context::hash_rows(const uint64_t* cols, size_t col_stride, int ncols, size_t rows, Digest* leaves) {
     if (ncols < 1) fail("hash_rows: empty rows");
-    AERO_LAUNCH(this, "hash_rows_kernel", rows * ((size_t)ncols * 8 + 32), hash_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, cols, col_stride, ncols, rows, leaves);
+    RowSrc src{cols, col_stride, ncols};
+    AERO_LAUNCH(this, "hash_rows_kernel", rows * ((size_t)ncols * 8 + 32), (hash_rows_kernel<RowSrc>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                src, rows, leaves);
     check_launch("hash_rows");
 }
 
-void Context::hash_fri_rows(const uint64_t* const comp[2], int deg, size_t rows, int fold, Digest* leaves) {
-    if ((fold * deg) & 1) fail("hash_fri_rows: odd element count");
-    AERO_LAUNCH(this, "hash_fri_rows_kernel", rows * ((size_t)fold * deg * 8 + 32), hash_fri_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, comp[0], comp[1], deg, rows, fold, leaves);
+void Context::hash_fri_rows(const FriSrc& src, Digest* leaves) {
+    if ((src.fold * src.deg) & 1) fail("hash_fri_rows: odd element count");
+    AERO_LAUNCH(this, "hash_fri_rows_kernel", src.rows * ((size_t)src.fold * src.deg * 8 + 32), (hash_rows_kernel<FriSrc>),
+                dim3((unsigned)((src.rows + 255) / 256)), dim3(256), 0, src, src.rows, leaves);
     check_launch("hash_fri_rows");
+}
+
+// levels above a stored level of `c` nodes (heap indices [c, 2c)) up to the root
+void Context::merkle_upper(Digest* nodes, size_t c) {
+    while (c > 512) {   // c is a power of two >= 1024
+        size_t m = c / 8;
+        AERO_LAUNCH(this, "merkle_up3_kernel", c * 32 + (c - m) * 32, merkle_up3_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, nodes, m);
+        c = m;
+    }
+    if (c >= 2) AERO_LAUNCH(this, "merkle_top_kernel", c * 64, merkle_top_kernel, dim3(1), dim3(256), 0, nodes, (int)(c / 2));
+    check_launch("merkle_upper");
 }
 
 void Context::merkle_build(Digest* nodes, size_t n) {
     if (n < 2 || (n & (n - 1))) fail("merkle_build: leaf count must be a power of two >= 2");
-    size_t m = n / 2;
-    for (; m > 256; m >>= 1)
-        AERO_LAUNCH(this, "merkle_level_kernel", m * 96, merkle_level_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, nodes, m);
-    AERO_LAUNCH(this, "merkle_top_kernel", m * 128, merkle_top_kernel, dim3(1), dim3(256), 0, nodes, (int)m);
-    check_launch("merkle_build");
+    merkle_upper(nodes, n);
 }
+
+template <class Src> static size_t src_leaf_bytes(const Src&);
+template <> size_t src_leaf_bytes<RowSrc>(const RowSrc& s) { return (size_t)s.ncols * 8; }
+template <> size_t src_leaf_bytes<FriSrc>(const FriSrc& s) { return (size_t)s.fold * s.deg * 8; }
+
+// leaves + whole tree from a leaf source; the lowest `skip` levels (0 or 3) are not stored.
+template <class Src> void Context::merkle_commit(const Src& src, size_t n, Digest* nodes, int skip) {
+    if (n < 8 || (n & (n - 1))) fail("merkle_commit: leaf count must be a power of two >= 8");
+    if (skip != 0 && skip != 3) fail("merkle_commit: skip must be 0 or 3", ST_INTERNAL);
+    const size_t stored = skip ? (n / 8) * 32 : (n + n / 2 + n / 4 + n / 8) * 32;
+    AERO_LAUNCH(this, "merkle_leaf8_kernel", n * src_leaf_bytes(src) + stored, (merkle_leaf8_kernel<Src>), dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0,
+                src, nodes, n, skip);
+    merkle_upper(nodes, n / 8);
+}
+template void Context::merkle_commit<RowSrc>(const RowSrc&, size_t, Digest*, int);
+template void Context::merkle_commit<FriSrc>(const FriSrc&, size_t, Digest*, int);
+
+template <class Src> void Context::merkle_recompute(const Src& src, size_t n, const uint64_t* idx_dev, int count, Digest* out_dev) {
+    if (count <= 0) return;
+    AERO_LAUNCH(this, "merkle_recompute_kernel", 0, (merkle_recompute_kernel<Src>), dim3((count + 63) / 64), dim3(64), 0, src, n, idx_dev, count, out_dev);
+    check_launch("merkle_recompute");
+}
+template void Context::merkle_recompute<RowSrc>(const RowSrc&, size_t, const uint64_t*, int, Digest*);
+template void Context::merkle_recompute<FriSrc>(const FriSrc&, size_t, const uint64_t*, int, Digest*);
 
 }  // namespace aero

@@ -56,10 +56,101 @@ struct PassArgs {
     int sc_shift;
 };
 
+// LDS index skew: one extra slot per 32 elements breaks the power-of-two strides of the radix-8 gathers
+// (stride-8 element reads would otherwise put 8 lanes on one bank).
+__device__ __forceinline__ int skew(int e) { return e + (e >> 5); }
+constexpr int LDS_ELEMS = 4096 + 128;
+
+// Small-root constants of this field: w_4 = 2^48, w_8 = 2^120 = -2^24, w_8^3 = 2^168 = -2^72 (2 has order 192).
+// Products with them are written as multiplications by the constants; the rest of a radix-8 butterfly is adds.
+__device__ __forceinline__ uint64_t mul_w4(uint64_t x) { return mul(x, 1ull << 48); }
+__device__ __forceinline__ uint64_t mul_2_24(uint64_t x) { return mul(x, 1ull << 24); }
+__device__ __forceinline__ uint64_t mul_2_72(uint64_t x) { return mul(x, 0xFFFFFFFF00ull); }   // 2^72 = 2^8 * (2^32 - 1)
+
+// Plain DFT of 2^RB points held in registers: decimation in time, bit-reversed input -> natural output,
+// root w_(2^RB) = w_4096^(4096 >> RB). The butterflies below ARE the radix-2 stages, with the constant twiddles folded:
+//   x * w_8 = -(x * 2^24), x * w_4 = x * 2^48, x * w_8^3 = -(x * 2^72)  (negations swap the add and the sub).
+template <int RB> __device__ __forceinline__ void dft_dit(uint64_t (&y)[1 << RB]) {
+    if constexpr (RB >= 1) {
+#pragma unroll
+        for (int i = 0; i < (1 << RB); i += 2) { uint64_t u = y[i], v = y[i + 1]; y[i] = add(u, v); y[i + 1] = sub(u, v); }
+    }
+    if constexpr (RB >= 2) {
+#pragma unroll
+        for (int i = 0; i < (1 << RB); i += 4) {
+            uint64_t u = y[i], v = y[i + 2]; y[i] = add(u, v); y[i + 2] = sub(u, v);
+            u = y[i + 1]; v = mul_w4(y[i + 3]); y[i + 1] = add(u, v); y[i + 3] = sub(u, v);
+        }
+    }
+    if constexpr (RB >= 3) {
+        uint64_t u, v;
+        u = y[0]; v = y[4];            y[0] = add(u, v); y[4] = sub(u, v);
+        u = y[1]; v = mul_2_24(y[5]);  y[1] = sub(u, v); y[5] = add(u, v);      // * w_8   = -2^24
+        u = y[2]; v = mul_w4(y[6]);    y[2] = add(u, v); y[6] = sub(u, v);      // * w_8^2 =  2^48
+        u = y[3]; v = mul_2_72(y[7]);  y[3] = sub(u, v); y[7] = add(u, v);      // * w_8^3 = -2^72
+    }
+}
+// Exact inverse up to the factor 2^RB: decimation in frequency with inverse roots, natural input -> bit-reversed output.
+//   w_8^-1 = 2^72, w_4^-1 = -2^48, w_8^-3 = 2^24.
+template <int RB> __device__ __forceinline__ void dft_dif_inv(uint64_t (&y)[1 << RB]) {
+    if constexpr (RB >= 3) {
+        uint64_t u, v;
+        u = y[0]; v = y[4]; y[0] = add(u, v); y[4] = sub(u, v);
+        u = y[1]; v = y[5]; y[1] = add(u, v); y[5] = mul_2_72(sub(u, v));       // * w_8^-1
+        u = y[2]; v = y[6]; y[2] = add(u, v); y[6] = mul_w4(sub(v, u));         // * w_8^-2 = -2^48
+        u = y[3]; v = y[7]; y[3] = add(u, v); y[7] = mul_2_24(sub(u, v));       // * w_8^-3
+    }
+    if constexpr (RB >= 2) {
+#pragma unroll
+        for (int i = 0; i < (1 << RB); i += 4) {
+            uint64_t u = y[i], v = y[i + 2]; y[i] = add(u, v); y[i + 2] = sub(u, v);
+            u = y[i + 1]; v = y[i + 3]; y[i + 1] = add(u, v); y[i + 3] = mul_w4(sub(v, u));   // * w_4^-1 = -2^48
+        }
+    }
+    if constexpr (RB >= 1) {
+#pragma unroll
+        for (int i = 0; i < (1 << RB); i += 2) { uint64_t u = y[i], v = y[i + 1]; y[i] = add(u, v); y[i + 1] = sub(u, v); }
+    }
+}
+
+// One register round over bits [s, s+RB) of the pass-local index k (tile element e = (k << log_tl) | tl, data in LDS).
+// Cooley-Tukey step: the 2^RB sub-transform values of a group (bit-reversed order) are multiplied by T^rev(i),
+// T = w_(2^(s+RB))^(k mod 2^s), then combined by the plain 2^RB-point DFT above. tw = w_4096^e (forward) or w_4096^-e.
+template <int RB, bool INV>
+__device__ __forceinline__ void ntt_round(uint64_t* lds, int log_e, int log_tl, int s, const uint64_t* __restrict__ tw) {
+    constexpr int G = 1 << RB;
+    const int shift = s + log_tl;
+    const int ngroups = 1 << (log_e - RB);
+    const int tsh = 12 - s - RB;
+    for (int g = threadIdx.x; g < ngroups; g += 256) {
+        const int base = (g & ((1 << shift) - 1)) | ((g >> shift) << (shift + RB));
+        const int klow = (base >> log_tl) & ((1 << s) - 1);
+        uint64_t y[G];
+#pragma unroll
+        for (int i = 0; i < G; i++) y[i] = lds[skew(base + (i << shift))];
+        if (!INV) {
+            if (klow) {
+#pragma unroll
+                for (int i = 1; i < G; i++) y[i] = mul(y[i], tw[(klow * (int)gl::bitrev((uint32_t)i, RB)) << tsh]);
+            }
+            dft_dit<RB>(y);
+        } else {
+            dft_dif_inv<RB>(y);
+            if (klow) {
+#pragma unroll
+                for (int i = 1; i < G; i++) y[i] = mul(y[i], tw[(klow * (int)gl::bitrev((uint32_t)i, RB)) << tsh]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G; i++) lds[skew(base + (i << shift))] = y[i];
+    }
+    __syncthreads();
+}
+
 // Forward: decimation in time, bit-reversed input -> natural output (within the pass' index bits).
 __global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-    const int R = 1 << a.log_r, TL = 1 << a.log_tl, E = R << a.log_tl;
+    __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
+    const int TL = 1 << a.log_tl, log_e = a.log_r + a.log_tl, E = 1 << log_e;
     const uint32_t tile = blockIdx.x;
     const uint32_t tiles_per_b = 1u << (a.log_s - a.log_tl);       // S / TL
     const uint32_t b = tile >> (a.log_s - a.log_tl);
@@ -71,35 +162,27 @@ __global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
     if (a.log_pad == 0) {
         for (int e = threadIdx.x; e < E; e += 256) {
             int tl = e & (TL - 1), k = e >> a.log_tl;
-            lds[e] = in[base + tl + ((size_t)k << a.log_s)];
+            lds[skew(e)] = in[base + tl + ((size_t)k << a.log_s)];
         }
     } else {
         // contiguous pass of a zero-padded transform: position k of the block holds coefficient (b*R + k) >> log_pad
         // when k = 0 mod 2^log_pad, zero otherwise; the first log_pad butterfly stages therefore broadcast it.
         const size_t cbase = ((size_t)b << a.log_r) >> a.log_pad;
-        for (int e = threadIdx.x; e < E; e += 256) lds[e] = in[cbase + (e >> a.log_pad)];
+        for (int e = threadIdx.x; e < E; e += 256) lds[skew(e)] = in[cbase + (e >> a.log_pad)];
     }
     __syncthreads();
-    const int tw_shift = 12 - a.log_r;
-    for (int u = a.log_pad; u < a.log_r; u++) {
-        const int half = 1 << u;
-        for (int bf = threadIdx.x; bf < E / 2; bf += 256) {
-            int tl = bf & (TL - 1), j = bf >> a.log_tl;
-            int jl = j & (half - 1);
-            int k0 = ((j >> u) << (u + 1)) | jl;
-            int i0 = (k0 << a.log_tl) | tl, i1 = i0 + (half << a.log_tl);
-            uint64_t x = lds[i0], y = lds[i1];
-            if (u) y = mul(y, a.tw_r[(jl << (a.log_r - 1 - u)) << tw_shift]);
-            lds[i0] = add(x, y);
-            lds[i1] = sub(x, y);
-        }
-        __syncthreads();
+    for (int s = a.log_pad; s < a.log_r;) {
+        const int rb = a.log_r - s >= 3 ? 3 : a.log_r - s;
+        if (rb == 3) ntt_round<3, false>(lds, log_e, a.log_tl, s, a.tw_r);
+        else if (rb == 2) ntt_round<2, false>(lds, log_e, a.log_tl, s, a.tw_r);
+        else ntt_round<1, false>(lds, log_e, a.log_tl, s, a.tw_r);
+        s += rb;
     }
     const int bbits = a.log_n - a.log_s - a.log_r;
     const uint32_t rb = gl::bitrev(b, bbits);
     for (int e = threadIdx.x; e < E; e += 256) {
         int tl = e & (TL - 1), k = e >> a.log_tl;
-        uint64_t v = lds[e];
+        uint64_t v = lds[skew(e)];
         if (!a.first && rb && k) {
             uint32_t ex = (uint32_t)((((uint64_t)rb * (uint32_t)k) << a.log_s) & ((1ull << a.log_n) - 1));
             v = mul(v, tw_lookup(a.tw_lo, a.tw_hi, ex, a.tw_h));
@@ -110,8 +193,8 @@ __global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
 
 // Inverse: exact mirror (decimation in frequency with inverse roots), natural input -> bit-reversed output.
 __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
-    const int R = 1 << a.log_r, TL = 1 << a.log_tl, E = R << a.log_tl;
+    __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
+    const int TL = 1 << a.log_tl, log_e = a.log_r + a.log_tl, E = 1 << log_e;
     const uint32_t tile = blockIdx.x;
     const uint32_t tiles_per_b = 1u << (a.log_s - a.log_tl);
     const uint32_t b = tile >> (a.log_s - a.log_tl);
@@ -129,25 +212,15 @@ __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
             uint32_t ex = (uint32_t)((((uint64_t)rb * (uint32_t)k) << a.log_s) & ((1ull << a.log_n) - 1));
             v = mul(v, tw_lookup(a.tw_lo, a.tw_hi, ex, a.tw_h));
         }
-        lds[e] = v;
+        lds[skew(e)] = v;
     }
     __syncthreads();
-    const int tw_shift = 12 - a.log_r;
-    for (int u = a.log_r - 1; u >= 0; u--) {
-        const int half = 1 << u;
-        for (int bf = threadIdx.x; bf < E / 2; bf += 256) {
-            int tl = bf & (TL - 1), j = bf >> a.log_tl;
-            int jl = j & (half - 1);
-            int k0 = ((j >> u) << (u + 1)) | jl;
-            int i0 = (k0 << a.log_tl) | tl, i1 = i0 + (half << a.log_tl);
-            uint64_t x = lds[i0], y = lds[i1];
-            uint64_t d = sub(x, y);
-            if (u) d = mul(d, a.tw_r[(jl << (a.log_r - 1 - u)) << tw_shift]);
-            lds[i0] = add(x, y);
-            lds[i1] = d;
-        }
-        __syncthreads();
-    }
+    // mirror of the forward rounds: same bit groups, highest first
+    const int nfull = a.log_r / 3, rem = a.log_r % 3;     // forward rounds: nfull x 3 bits from bit 0, then `rem` bits
+    if (rem == 2) ntt_round<2, true>(lds, log_e, a.log_tl, 3 * nfull, a.tw_r);
+    else if (rem == 1) ntt_round<1, true>(lds, log_e, a.log_tl, 3 * nfull, a.tw_r);
+    for (int q = nfull - 1; q >= 0; q--) ntt_round<3, true>(lds, log_e, a.log_tl, 3 * q, a.tw_r);
+
     uint64_t bf = 1;
     if (a.ktab) {
         // every thread derives the (uniform) block factor itself: <= 2*bbits multiplies, cheaper than a broadcast
@@ -155,7 +228,7 @@ __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
     }
     for (int e = threadIdx.x; e < E; e += 256) {
         int tl = e & (TL - 1), k = e >> a.log_tl;
-        uint64_t v = lds[e];
+        uint64_t v = lds[skew(e)];
         if (a.ktab) v = mul(v, mul(a.ktab[k], bf));
         out[base + tl + ((size_t)k << a.log_s)] = v;
     }
@@ -199,11 +272,11 @@ NttTables* Context::ntt_tables(int log_n) {
 
 void Context::ensure_small_twiddles() {
     if (tw4096_fwd) return;
-    tw4096_fwd = (uint64_t*)dev_alloc(2048 * 8);
-    tw4096_inv = (uint64_t*)dev_alloc(2048 * 8);
+    tw4096_fwd = (uint64_t*)dev_alloc(4096 * 8);
+    tw4096_inv = (uint64_t*)dev_alloc(4096 * 8);
     uint64_t w = gl::root_of_unity(12);
-    AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3(8), dim3(256), 0, tw4096_fwd, 2048u, w, 1ull);
-    AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3(8), dim3(256), 0, tw4096_inv, 2048u, gl::inv(w), 1ull);
+    AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3(16), dim3(256), 0, tw4096_fwd, 4096u, w, 1ull);
+    AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3(16), dim3(256), 0, tw4096_inv, 4096u, gl::inv(w), 1ull);
     check_launch("small twiddles");
 }
 
@@ -243,7 +316,7 @@ void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         a.tw_r = tw4096_fwd; a.tw_lo = t->lo_fwd; a.tw_hi = t->hi_fwd; a.tw_h = t->h;
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
         dim3 grid((unsigned)(((size_t)1 << log_out) / E), ncols);
-        AERO_LAUNCH(this, "ntt_fwd_pass", (size_t)ncols * 8 * ((((size_t)1 << log_out) >> a.log_pad) + ((size_t)1 << log_out)), ntt_fwd_pass, grid, dim3(256), E * 8, a);
+        AERO_LAUNCH(this, "ntt_fwd_pass", (size_t)ncols * 8 * ((((size_t)1 << log_out) >> a.log_pad) + ((size_t)1 << log_out)), ntt_fwd_pass, grid, dim3(256), 0, a);
     }
     check_launch("ntt_forward");
 }
@@ -277,7 +350,7 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
         if (qi == 0) { a.ktab = ktab; a.sc_a = sa; a.sc_b = sb; a.sc_shift = shift; }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
         dim3 grid((unsigned)(((size_t)1 << log_n) / E), ncols);
-        AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass, grid, dim3(256), E * 8, a);
+        AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass, grid, dim3(256), 0, a);
     }
     check_launch("ntt_inverse");
 }

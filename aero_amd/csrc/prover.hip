@@ -249,18 +249,32 @@ std::vector<std::vector<uint64_t>> batch_proof_indices(size_t n, const std::vect
 }
 
 // digests for a batch opening gathered from the device tree -> serialised BatchMerkleProof nodes
-static Bytes open_batch(Context* ctx, const MerkleTree& tree, const std::vector<uint64_t>& positions) {
+Bytes open_batch(Context* ctx, const MerkleTree& tree, const std::vector<uint64_t>& positions) {
     auto idx = batch_proof_indices(tree.n, positions);
-    std::vector<uint64_t> flat;
-    for (auto& v : idx) flat.insert(flat.end(), v.begin(), v.end());
-    std::vector<Digest> got(flat.size());
+    // stored nodes are gathered, unstored low nodes are recomputed from the leaf source; both land in one buffer
+    std::vector<uint64_t> flat, order;          // flat = [stored indices..., low indices...]; order[k] = slot of item k
+    std::vector<uint64_t> hi, lo;
+    for (auto& v : idx) for (uint64_t i : v) (i < tree.stored_limit() ? hi : lo).push_back(i);
+    {
+        size_t nh = 0, nl = 0;
+        for (auto& v : idx) for (uint64_t i : v) order.push_back(i < tree.stored_limit() ? nh++ : hi.size() + nl++);
+    }
+    flat = hi;
+    flat.insert(flat.end(), lo.begin(), lo.end());
+    std::vector<Digest> raw(flat.size()), got(flat.size());
     if (!flat.empty()) {
+        if (!lo.empty() && tree.src_kind == 0) fail("batch opening: tree has unstored levels but no leaf source", ST_INTERNAL);
         DevBuf<uint64_t> d_idx(ctx, flat.size());
         DevBuf<Digest> d_out(ctx, flat.size());
         AERO_HIP(hipMemcpyAsync(d_idx.get(), flat.data(), flat.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        launch_gather_digests(ctx, tree.nodes.get(), d_idx.get(), (int)flat.size(), d_out.get());
-        AERO_HIP(hipMemcpyAsync(got.data(), d_out.get(), flat.size() * sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
+        if (!hi.empty()) launch_gather_digests(ctx, tree.nodes.get(), d_idx.get(), (int)hi.size(), d_out.get());
+        if (!lo.empty()) {
+            if (tree.src_kind == 1) ctx->merkle_recompute(tree.row_src, tree.n, d_idx.get() + hi.size(), (int)lo.size(), d_out.get() + hi.size());
+            else ctx->merkle_recompute(tree.fri_src, tree.n, d_idx.get() + hi.size(), (int)lo.size(), d_out.get() + hi.size());
+        }
+        AERO_HIP(hipMemcpyAsync(raw.data(), d_out.get(), flat.size() * sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
+        for (size_t k = 0; k < order.size(); k++) got[k] = raw[order[k]];
     }
     Bytes out;
     if (idx.size() > 255) fail("batch opening: too many paths", ST_UNSUPPORTED);
@@ -293,10 +307,43 @@ Matrix Prover::evaluate_columns_over(const Matrix& polys, int log_blowup) {
     ctx_->ntt_forward(polys.data.get(), polys.rows, lde.data.get(), N, polys.cols, log_n + log_blowup, log_blowup);
     return lde;
 }
-MerkleTree Prover::commit_to_rows(const Matrix& lde) {
-    MerkleTree t(ctx_, lde.rows);
-    ctx_->hash_rows(lde.data.get(), lde.rows, lde.cols, lde.rows, t.leaves());
-    ctx_->merkle_build(t.nodes.get(), t.n);
+MerkleTree Prover::commit_to_rows(const Matrix& lde, bool keep_low_levels) {
+    const RowSrc src{lde.data.get(), lde.rows, lde.cols};
+    // narrow rows: fused leaf hashing + 3 levels per thread; wide rows: coalesced row-hash pass, then the tree
+    const bool fused = lde.cols <= 4 && lde.rows >= ((size_t)1 << 18);
+    const int skip = (fused && !keep_low_levels && low_level_skip) ? 3 : 0;
+    MerkleTree t(ctx_, lde.rows, skip);
+    if (skip) { t.src_kind = 1; t.row_src = src; }
+    if (fused) {
+        ctx_->merkle_commit(src, lde.rows, t.nodes.get(), skip);
+    } else {
+        ctx_->hash_rows(lde.data.get(), lde.rows, lde.cols, lde.rows, t.leaves());
+        ctx_->merkle_build(t.nodes.get(), t.n);
+    }
+    AERO_HIP(hipMemcpyAsync(&t.root_host, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx_->stream));
+    ctx_->sync();
+    return t;
+}
+MerkleTree Prover::commit_fri_layer(const FriSrc& src, bool keep_low_levels) {
+    const size_t rows = src.rows;
+    if (rows < 2) {   // a single leaf is its own root
+        MerkleTree t(ctx_, 1);
+        ctx_->hash_fri_rows(src, t.nodes.get() + 1);
+        AERO_HIP(hipMemcpyAsync(&t.root_host, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx_->stream));
+        ctx_->sync();
+        return t;
+    }
+    const bool fused = false;   // FRI layers are at most N/8 rows of 4+ compressions: one row per lane keeps the chip busy
+    const int skip = 0;
+    (void)keep_low_levels;
+    MerkleTree t(ctx_, rows, skip);
+    if (skip) { t.src_kind = 2; t.fri_src = src; }
+    if (fused) {
+        ctx_->merkle_commit(src, rows, t.nodes.get(), skip);
+    } else {
+        ctx_->hash_fri_rows(src, t.leaves());
+        ctx_->merkle_build(t.nodes.get(), rows);
+    }
     AERO_HIP(hipMemcpyAsync(&t.root_host, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx_->stream));
     ctx_->sync();
     return t;
@@ -381,7 +428,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     Matrix tlde = evaluate_columns_over(polys, log_B);
     ms.lde = clk.lap();
     // 3. row hashes, Merkle tree, commit [a5, a6, a8]
-    MerkleTree ttree = commit_to_rows(tlde);
+    MerkleTree ttree = commit_to_rows(tlde, false);
     wdigest(proof.commitments, ttree.root());
     coin.reseed(ttree.root());
     ms.trace_commit = clk.lap();
@@ -423,7 +470,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     Matrix clde(ctx, (int)(C * F::DEG), N);
     for (int d = 0; d < F::DEG; d++)
         ctx->ntt_forward(hbuf.get() + (size_t)d * ceN, n, clde.data.get() + (size_t)d * N, (size_t)F::DEG * N, (int)C, log_N, log_B);
-    MerkleTree ctree = commit_to_rows(clde);
+    MerkleTree ctree = commit_to_rows(clde, false);
     wdigest(proof.commitments, ctree.root());
     coin.reseed(ctree.root());
     ms.comp_commit = clk.lap();
@@ -482,18 +529,9 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         uint64_t dom = N;
         for (int l = 0; l <= layers; l++) {
             const size_t rows = dom / Fd;
-            const uint64_t* comp[2] = {fri_vals[l].get(), fri_vals[l].get() + (F::DEG > 1 ? dom : 0)};
-            fri_trees.emplace_back(ctx, rows >= 2 ? rows : 1);
+            const FriSrc fsrc{fri_vals[l].get(), fri_vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd};
+            fri_trees.push_back(commit_fri_layer(fsrc));
             MerkleTree& t = fri_trees.back();
-            if (rows >= 2) {
-                ctx->hash_fri_rows(comp, F::DEG, rows, (int)Fd, t.leaves());
-                ctx->merkle_build(t.nodes.get(), rows);
-                AERO_HIP(hipMemcpyAsync(&t.root_host, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
-            } else {
-                ctx->hash_fri_rows(comp, F::DEG, 1, (int)Fd, t.nodes.get() + 1);
-                AERO_HIP(hipMemcpyAsync(&t.root_host, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
-            }
-            ctx->sync();
             wdigest(proof.commitments, t.root());
             coin.reseed(t.root());
             const T alpha = coin.draw<F>();

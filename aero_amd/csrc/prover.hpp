@@ -77,13 +77,20 @@ struct Matrix {
 };
 
 // Device Merkle tree: nodes[1] = root, leaves at nodes[n + j].
+// `skip` = number of lowest levels that are NOT stored (0 or 3): nodes then holds only heap indices < 2n >> skip and the
+// openings recompute the few low nodes they need from the leaf source (which must outlive the tree).
 struct MerkleTree {
     DevBuf<Digest> nodes;
     size_t n = 0;
+    int skip = 0;
+    int src_kind = 0;          // 0 none (everything stored), 1 RowSrc, 2 FriSrc
+    RowSrc row_src{};
+    FriSrc fri_src{};
     Digest root_host{};
     MerkleTree() {}
-    MerkleTree(Context* ctx, size_t leaves) : nodes(ctx, 2 * leaves), n(leaves) {}
-    Digest* leaves() const { return nodes.get() + n; }
+    MerkleTree(Context* ctx, size_t leaves, int skip_levels = 0) : nodes(ctx, (2 * leaves) >> skip_levels), n(leaves), skip(skip_levels) {}
+    size_t stored_limit() const { return (2 * n) >> skip; }
+    Digest* leaves() const { return nodes.get() + n; }   // only valid when skip == 0
     const Digest& root() const { return root_host; }
     int depth() const { int d = 0; while (((size_t)1 << d) < n) d++; return d; }
 };
@@ -113,14 +120,17 @@ public:
     Bytes prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_inputs_out);
     StageMs last_stage_ms;
     bool collect_stage_times = false;   // adds a stream sync per stage
+    bool low_level_skip = false;        // do not store the 3 lowest Merkle levels of large trees (memory saver)
 
     // ---- stage-level entry points (the reference's split API; also what the C ABI exposes) ----
     // interpolate_columns: evaluations on <w_n> -> polys (bit-reversed coefficients pre-scaled by 7^i)
     Matrix interpolate_columns(const uint64_t* trace_dev, uint32_t width, int log_n);
     // evaluate_columns_over: polys -> LDE over 7<w_N>, natural row order
     Matrix evaluate_columns_over(const Matrix& polys, int log_blowup);
-    // row hashes + MerkleTree::new
-    MerkleTree commit_to_rows(const Matrix& lde);
+    // row hashes + MerkleTree::new. keep_low_levels = false drops the 3 lowest levels (recomputed on demand from `lde`,
+    // which must then outlive the tree).
+    MerkleTree commit_to_rows(const Matrix& lde, bool keep_low_levels = true);
+    MerkleTree commit_fri_layer(const FriSrc& src, bool keep_low_levels = false);
 
 private:
     template <class F> Bytes prove_impl(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_out);
@@ -131,6 +141,8 @@ private:
 // BatchMerkleProof node selection (winter-crypto 0.4 MerkleTree::prove_batch restated):
 // returns, per vector, the node indices (into the 2n-slot node array) whose digests are serialised.
 std::vector<std::vector<uint64_t>> batch_proof_indices(size_t n_leaves, const std::vector<uint64_t>& positions);
+// serialised BatchMerkleProof nodes for `positions` (u8 #vectors, per vector u8 len + digests)
+Bytes open_batch(Context* ctx, const MerkleTree& tree, const std::vector<uint64_t>& positions);
 std::vector<uint64_t> fold_positions(const std::vector<uint64_t>& positions, uint64_t source_domain, uint64_t folding_factor);
 int num_fri_layers(uint64_t domain, uint64_t fold, uint64_t max_remainder);
 

@@ -1,0 +1,96 @@
+// Throughput of candidate Goldilocks add / sub / mul implementations on gfx950 (8 independent chains per thread).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_field.hip -o tools/ubench_field
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include "../aero_amd/csrc/gl.cuh"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef uint32_t u32; typedef uint64_t u64;
+static constexpr u32 EPS32 = 0xFFFFFFFFu;
+__device__ __forceinline__ u64 mk(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+namespace B {
+__device__ __forceinline__ u64 add(u64 a, u64 b) {
+    u32 c1, c2, c;
+    u32 s0 = __builtin_addc((u32)a, (u32)b, 0u, &c); u32 s1 = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c, &c1);
+    u32 t0 = __builtin_addc(s0, EPS32, 0u, &c); u32 t1 = __builtin_addc(s1, 0u, c, &c2);
+    return (c1 | c2) ? mk(t0, t1) : mk(s0, s1);
+}
+__device__ __forceinline__ u64 sub(u64 a, u64 b) {
+    u32 c, c1;
+    u32 d0 = __builtin_subc((u32)a, (u32)b, 0u, &c); u32 d1 = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), c, &c1);
+    u32 t0 = __builtin_subc(d0, EPS32, 0u, &c); u32 t1 = __builtin_subc(d1, 0u, c, &c);
+    return c1 ? mk(t0, t1) : mk(d0, d1);
+}
+__device__ __forceinline__ u64 mul(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 t = (u64)a0 * b0;
+    u64 u = (u64)a0 * b1 + (t >> 32);
+    u64 v = (u64)a1 * b0 + (u32)u;
+    u64 w = (u64)a1 * b1 + ((u >> 32) + (v >> 32));
+    u32 x0 = (u32)t, x1 = (u32)v, x2 = (u32)w, x3 = (u32)(w >> 32);
+    u32 c, bo;
+    u32 l0 = __builtin_subc(x0, x3, 0u, &c); u32 l1 = __builtin_subc(x1, 0u, c, &bo);
+    u32 m = 0u - bo;
+    l0 = __builtin_subc(l0, m, 0u, &c); l1 = __builtin_subc(l1, 0u, c, &c);
+    u32 e0 = __builtin_subc(0u, x2, 0u, &c); u32 e1 = __builtin_subc(x2, 0u, c, &c);
+    u32 ca;
+    u32 r0 = __builtin_addc(l0, e0, 0u, &c); u32 r1 = __builtin_addc(l1, e1, c, &ca);
+    u32 m2 = 0u - ca;
+    r0 = __builtin_addc(r0, m2, 0u, &c); r1 = __builtin_addc(r1, 0u, c, &c);
+    u32 c2;
+    u32 t0 = __builtin_addc(r0, EPS32, 0u, &c); u32 t1 = __builtin_addc(r1, 0u, c, &c2);
+    return c2 ? mk(t0, t1) : mk(r0, r1);
+}
+}
+namespace Cc {   // u64-typed with 128-bit product, reduction written on u64 with __builtin overflow
+__device__ __forceinline__ u64 mul(u64 a, u64 b) {
+    u64 lo = a * b, hi = __umul64hi(a, b);
+    u64 hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
+    u64 t0; bool bo = __builtin_usubl_overflow(lo, hh, &t0);
+    t0 -= bo ? 0xFFFFFFFFull : 0;
+    u64 t1 = (hl << 32) - hl;
+    u64 r; bool ca = __builtin_uaddl_overflow(t0, t1, &r);
+    r += ca ? 0xFFFFFFFFull : 0;
+    u64 t; bool c2 = __builtin_uaddl_overflow(r, 0xFFFFFFFFull, &t);
+    return c2 ? t : r;
+}
+}
+#define BENCH(NAME, MULF, ADDF, SUBF, KIND)                                                        \
+__global__ __launch_bounds__(256) void NAME(u64* out, int iters) {                                 \
+    u64 x[8], k = (blockIdx.x * 0xD1B54A32D192ED03ull + 3) % gl::P;                                \
+    for (int u = 0; u < 8; u++) x[u] = (threadIdx.x * 0x9E3779B97F4A7C15ull + u) % gl::P;         \
+    for (int i = 0; i < iters; i++) {                                                              \
+        _Pragma("unroll") for (int r = 0; r < 4; r++)                                              \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                            \
+            if (KIND == 0) x[u] = MULF(x[u], k); if (KIND == 1) x[u] = ADDF(x[u], k); if (KIND == 2) x[u] = SUBF(x[u], k); } } \
+    u64 r = 0; for (int u = 0; u < 8; u++) r ^= x[u];                                              \
+    out[blockIdx.x * 256 + threadIdx.x] = r; }
+BENCH(a_mul, gl::mul, gl::add, gl::sub, 0) BENCH(a_add, gl::mul, gl::add, gl::sub, 1) BENCH(a_sub, gl::mul, gl::add, gl::sub, 2)
+BENCH(b_mul, B::mul, B::add, B::sub, 0) BENCH(b_add, B::mul, B::add, B::sub, 1) BENCH(b_sub, B::mul, B::add, B::sub, 2)
+BENCH(c_mul, Cc::mul, B::add, B::sub, 0)
+__global__ void check(u64* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    u64 a = (i * 0x9E3779B97F4A7C15ull) % gl::P, b = ((i + 7) * 0xD1B54A32D192ED03ull) % gl::P;
+    if (i < 4) { a = gl::P - 1 - i; b = gl::P - 1; } if (i == 5) { a = 0; } if (i == 6) { a = 0xFFFFFFFFull; b = 0xFFFFFFFF00000000ull; }
+    bool ok = B::mul(a, b) == gl::mul(a, b) && B::add(a, b) == gl::add(a, b) && B::sub(a, b) == gl::sub(a, b) && B::sub(b, a) == gl::sub(b, a) && Cc::mul(a, b) == gl::mul(a, b);
+    u64 c3 = (a ^ (b >> 3)) % gl::P;
+    ok = ok && B::mul(B::sub(a, b), c3) == gl::mul(gl::sub(a, b), c3) && B::sub(B::mul(a, b), c3) == gl::sub(gl::mul(a, b), c3) && B::sub(c3, B::mul(a, b)) == gl::sub(c3, gl::mul(a, b))
+        && B::add(B::mul(B::sub(a, c3), b), B::mul(B::sub(b, c3), a)) == gl::add(gl::mul(gl::sub(a, c3), b), gl::mul(gl::sub(b, c3), a));
+    if (!ok) atomicAdd((unsigned long long*)out, 1ull);
+}
+int main() {
+    const int blocks = 256 * 16, iters = 128;
+    u64* out; CK(hipMalloc(&out, blocks * 256 * 8));
+    CK(hipMemset(out, 0, 8)); hipLaunchKernelGGL(check, dim3(4096), dim3(256), 0, 0, out, 1 << 20); u64 bad; CK(hipMemcpy(&bad, out, 8, hipMemcpyDeviceToHost)); printf("mismatches vs gl::  : %llu\n", (unsigned long long)bad);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](const char* name, auto kern) {
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters); CK(hipDeviceSynchronize());
+        float best = 1e9;
+        for (int r = 0; r < 3; r++) { CK(hipEventRecord(e0)); hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms; }
+        printf("%-20s %8.3f ms  %9.1f Gop/s\n", name, best, iters * 32.0 * blocks * 256.0 / (best * 1e-3) / 1e9);
+    };
+    timeit("A mul (current)", a_mul); timeit("B mul (carry chain)", b_mul); timeit("C mul (u64 ovf)", c_mul);
+    timeit("A add (current)", a_add); timeit("B add (carry chain)", b_add);
+    timeit("A sub (current)", a_sub); timeit("B sub (carry chain)", b_sub);
+    return 0;
+}
