@@ -83,6 +83,10 @@ public:
     void* dev_alloc(size_t bytes);       // lives until the context dies (tables)
     void* scratch_alloc(size_t bytes);   // released by scratch_reset() (stream-ordered reuse)
     void scratch_reset();
+    // pinned host staging (bump allocator) for small async H2D parameter blocks and D2H results; a block stays valid
+    // until stage_reset(), which callers issue only after a stream synchronisation
+    void* stage_alloc(size_t bytes);
+    void stage_reset() { stage_off = 0; }
     size_t bytes_in_use = 0, bytes_peak = 0;
 
     void check_launch(const char* what);
@@ -129,6 +133,8 @@ private:
     std::multimap<size_t, void*> free_blocks;
     std::map<void*, size_t> live_blocks;
     std::vector<void*> persistent, scratch;
+    uint8_t* stage_base = nullptr;
+    size_t stage_cap = 0, stage_off = 0;
 };
 
 // RAII device buffer from the context pool

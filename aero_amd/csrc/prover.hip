@@ -29,6 +29,7 @@ Context::~Context() {
     for (auto& kv : free_blocks) (void)hipFree(kv.second);
     for (auto& kv : live_blocks) (void)hipFree(kv.first);
     for (void* p : persistent) (void)hipFree(p);
+    if (stage_base) (void)hipHostFree(stage_base);
     for (auto& r : kt_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (hipEvent_t e : kt_pool) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
@@ -78,6 +79,18 @@ void* Context::scratch_alloc(size_t bytes) {
 void Context::scratch_reset() {
     for (void* p : scratch) pool_free(p);
     scratch.clear();
+}
+void* Context::stage_alloc(size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (!stage_base) {
+        stage_cap = (size_t)8 << 20;
+        AERO_HIP(hipHostMalloc((void**)&stage_base, stage_cap, hipHostMallocDefault));
+    }
+    if (bytes > stage_cap) fail("staging request too large", ST_INTERNAL);
+    if (stage_off + bytes > stage_cap) { sync(); stage_off = 0; }   // wrap only when every earlier copy has completed
+    void* p = stage_base + stage_off;
+    stage_off += bytes;
+    return p;
 }
 void Context::check_launch(const char* what) {
     hipError_t e = hipGetLastError();
@@ -249,6 +262,19 @@ std::vector<std::vector<uint64_t>> batch_proof_indices(size_t n, const std::vect
 }
 
 // digests for a batch opening gathered from the device tree -> serialised BatchMerkleProof nodes
+static Bytes serialize_batch(const std::vector<std::vector<uint64_t>>& idx, const Digest* digests) {
+    Bytes out;
+    if (idx.size() > 255) fail("batch opening: too many paths", ST_UNSUPPORTED);
+    out.push_back((uint8_t)idx.size());
+    size_t k = 0;
+    for (auto& v : idx) {
+        if (v.size() > 255) fail("batch opening: too many nodes", ST_UNSUPPORTED);
+        out.push_back((uint8_t)v.size());
+        for (size_t i = 0; i < v.size(); i++) wdigest(out, digests[k++]);
+    }
+    return out;
+}
+
 Bytes open_batch(Context* ctx, const MerkleTree& tree, const std::vector<uint64_t>& positions) {
     auto idx = batch_proof_indices(tree.n, positions);
     // stored nodes are gathered, unstored low nodes are recomputed from the leaf source; both land in one buffer
@@ -320,8 +346,10 @@ MerkleTree Prover::commit_to_rows(const Matrix& lde, bool keep_low_levels) {
         ctx_->hash_rows(lde.data.get(), lde.rows, lde.cols, lde.rows, t.leaves());
         ctx_->merkle_build(t.nodes.get(), t.n);
     }
-    AERO_HIP(hipMemcpyAsync(&t.root_host, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx_->stream));
+    Digest* h = (Digest*)ctx_->stage_alloc(sizeof(Digest));
+    AERO_HIP(hipMemcpyAsync(h, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx_->stream));
     ctx_->sync();
+    t.root_host = *h;
     return t;
 }
 MerkleTree Prover::commit_fri_layer(const FriSrc& src, bool keep_low_levels) {
@@ -344,8 +372,10 @@ MerkleTree Prover::commit_fri_layer(const FriSrc& src, bool keep_low_levels) {
         ctx_->hash_fri_rows(src, t.leaves());
         ctx_->merkle_build(t.nodes.get(), rows);
     }
-    AERO_HIP(hipMemcpyAsync(&t.root_host, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx_->stream));
+    Digest* h = (Digest*)ctx_->stage_alloc(sizeof(Digest));
+    AERO_HIP(hipMemcpyAsync(h, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx_->stream));
     ctx_->sync();
+    t.root_host = *h;
     return t;
 }
 
@@ -358,11 +388,28 @@ template <class F> static Digest hash_e(const typename F::T* v, size_t n) {
     flatten<F>(v, n, f);
     return b2s::hash_elements(f.data(), (uint32_t)f.size());
 }
-template <class T> static T* upload(Context* ctx, const std::vector<T>& v) {
-    T* d = (T*)ctx->scratch_alloc(v.size() * sizeof(T) + 8);
-    if (!v.empty()) AERO_HIP(hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    return d;
-}
+// Several small host arrays -> ONE pinned staging block -> ONE async H2D copy; pointers are handed out afterwards.
+struct ParamPack {
+    Context* ctx;
+    struct Item { const void* src; size_t bytes, off; };
+    std::vector<Item> items;
+    size_t total = 0;
+    uint8_t* dev = nullptr;
+    explicit ParamPack(Context* c) : ctx(c) {}
+    template <class T> size_t add(const std::vector<T>& v) {
+        Item it{v.data(), v.size() * sizeof(T), total};
+        items.push_back(it);
+        total += (it.bytes + 15) & ~(size_t)15;
+        return items.size() - 1;
+    }
+    void commit() {
+        uint8_t* host = (uint8_t*)ctx->stage_alloc(total + 16);
+        for (auto& it : items) if (it.bytes) memcpy(host + it.off, it.src, it.bytes);
+        dev = (uint8_t*)ctx->scratch_alloc(total + 16);
+        AERO_HIP(hipMemcpyAsync(dev, host, total + 16, hipMemcpyHostToDevice, ctx->stream));
+    }
+    template <class T> const T* ptr(size_t id) const { return reinterpret_cast<const T*>(dev + items[id].off); }
+};
 
 struct StageClock {
     Context* ctx; bool on; std::chrono::steady_clock::time_point t0;
@@ -397,6 +444,8 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         if (rem * 8 * F::DEG > 0xffff) fail("prove: FRI remainder does not fit the proof's u16 length prefix", ST_UNSUPPORTED);
     }
     StageMs ms;
+    ctx->sync();
+    ctx->stage_reset();
     StageClock clk(ctx, collect_stage_times);
     auto t_start = std::chrono::steady_clock::now();
 
@@ -443,8 +492,8 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         FibConsArgs<F> a{};
         a.lde = tlde.data.get(); a.N = N; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)B; a.ce_step = (uint32_t)(B / C);
         a.first = 0; a.count = ceN;
-        a.ta = upload(ctx, ta); a.tb = upload(ctx, tb); a.ba = upload(ctx, ba); a.bb = upload(ctx, bb);
-        a.results = upload(ctx, air.results);
+        ParamPack pp(ctx);
+        const size_t i_ta = pp.add(ta), i_tb = pp.add(tb), i_ba = pp.add(ba), i_bb = pp.add(bb), i_res = pp.add(air.results);
         a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.twi_lo = tce->lo_inv; a.twi_hi = tce->hi_inv; a.tw_h = tce->h;
         a.gen_inv = gen_inv; a.k7 = gl::pow(gl::GEN, ceN);
         std::vector<uint64_t> xn(C), zn(C);
@@ -454,7 +503,10 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             xn[k] = gl::inv(xnk);
             zn[k] = gl::inv(gl::sub(xnk, 1));
         }
-        a.xn_inv = upload(ctx, xn); a.zn_inv = upload(ctx, zn);
+        const size_t i_xn = pp.add(xn), i_zn = pp.add(zn);
+        pp.commit();
+        a.ta = pp.ptr<T>(i_ta); a.tb = pp.ptr<T>(i_tb); a.ba = pp.ptr<T>(i_ba); a.bb = pp.ptr<T>(i_bb);
+        a.results = pp.ptr<uint64_t>(i_res); a.xn_inv = pp.ptr<uint64_t>(i_xn); a.zn_inv = pp.ptr<uint64_t>(i_zn);
         a.w_last = gl::pow(g, n - 1);
         a.out_cols = nullptr;
         for (int d = 0; d < F::DEG; d++) a.out_h[d] = hbuf.get() + (size_t)d * ceN;
@@ -516,8 +568,11 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         a.tlde = tlde.data.get(); a.clde = clde.data.get(); a.N = N; a.W = W; a.C = (uint32_t)C;
         a.tw_lo = tN->lo_fwd; a.tw_hi = tN->hi_fwd; a.tw_h = tN->h;
         a.z = z; a.z_next = z_next; a.z_c = z_c; a.z_conj = F::conj(z); a.lambda = lambda; a.mu = mu;
-        a.ood_cur = upload(ctx, ood_cur); a.ood_next = upload(ctx, ood_next); a.ood_h = upload(ctx, ood_h);
-        a.da = upload(ctx, da); a.db = upload(ctx, db); a.dg = upload(ctx, dg); a.dc = upload(ctx, dc);
+        ParamPack pp(ctx);
+        const size_t i0 = pp.add(ood_cur), i1 = pp.add(ood_next), i2 = pp.add(ood_h), i3 = pp.add(da), i4 = pp.add(db), i5 = pp.add(dg), i6 = pp.add(dc);
+        pp.commit();
+        a.ood_cur = pp.ptr<T>(i0); a.ood_next = pp.ptr<T>(i1); a.ood_h = pp.ptr<T>(i2);
+        a.da = pp.ptr<T>(i3); a.db = pp.ptr<T>(i4); a.dg = pp.ptr<T>(i5); a.dc = pp.ptr<T>(i6);
         for (int d = 0; d < F::DEG; d++) a.out[d] = fri_vals[0].get() + (size_t)d * N;
         launch_deep<F>(ctx, a);
     }
@@ -560,50 +615,82 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     }
     ms.grind = clk.lap();
 
-    // 11. queries [a17]
+    // 11. queries [a17]: every position / node index is known up front, so all gathers are issued behind ONE upload and
+    //     read back with ONE download (one stream synchronisation for the whole opening phase).
     std::vector<uint64_t> pos = coin.draw_integers(opt_.num_queries, N);
     {
-        const int Q = (int)pos.size();
-        DevBuf<uint64_t> d_pos(ctx, Q);
-        AERO_HIP(hipMemcpyAsync(d_pos.get(), pos.data(), Q * 8, hipMemcpyHostToDevice, ctx->stream));
-        const size_t tw = W, cw = C * F::DEG;
-        DevBuf<uint64_t> d_rows(ctx, Q * (tw + cw));
-        launch_gather_rows(ctx, tlde.data.get(), N, (int)tw, d_pos.get(), Q, d_rows.get());
-        launch_gather_rows(ctx, clde.data.get(), N, (int)cw, d_pos.get(), Q, d_rows.get() + Q * tw);
-        std::vector<uint64_t> rows(Q * (tw + cw));
-        AERO_HIP(hipMemcpyAsync(rows.data(), d_rows.get(), rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        const size_t Q = pos.size(), tw = W, cw = C * F::DEG;
+        std::vector<std::vector<uint64_t>> fpos(layers);
+        {
+            std::vector<uint64_t> fp = pos;
+            uint64_t dom = N;
+            for (int l = 0; l < layers; l++) { fp = fold_positions(fp, dom, Fd); fpos[l] = fp; dom /= Fd; }
+        }
+        const uint64_t rem_dom = N / [&] { uint64_t d = 1; for (int l = 0; l < layers; l++) d *= Fd; return d; }();
+        // node index plans per tree: trace, composition, FRI layers
+        std::vector<const MerkleTree*> trees{&ttree, &ctree};
+        std::vector<std::vector<std::vector<uint64_t>>> plans{batch_proof_indices(ttree.n, pos), batch_proof_indices(ctree.n, pos)};
+        for (int l = 0; l < layers; l++) { trees.push_back(&fri_trees[l]); plans.push_back(batch_proof_indices(fri_trees[l].n, fpos[l])); }
+        bool all_stored = true;
+        for (size_t t = 0; t < trees.size(); t++) for (auto& v : plans[t]) for (uint64_t i : v) if (i >= trees[t]->stored_limit()) all_stored = false;
+        // index block (u64): [pos | fpos_0.. | node indices tree 0 | tree 1 | ...]
+        std::vector<uint64_t> idx(pos);
+        std::vector<size_t> fpos_off(layers), plan_off(trees.size()), plan_cnt(trees.size());
+        for (int l = 0; l < layers; l++) { fpos_off[l] = idx.size(); idx.insert(idx.end(), fpos[l].begin(), fpos[l].end()); }
+        for (size_t t = 0; t < trees.size(); t++) {
+            plan_off[t] = idx.size();
+            if (all_stored) for (auto& v : plans[t]) idx.insert(idx.end(), v.begin(), v.end());
+            plan_cnt[t] = idx.size() - plan_off[t];
+        }
+        // value block (u64): [trace rows | comp rows | fri rows per layer | remainder | digests (4 u64 each) per tree]
+        size_t voff = 0;
+        const size_t off_trows = voff; voff += Q * tw;
+        const size_t off_crows = voff; voff += Q * cw;
+        std::vector<size_t> off_frows(layers);
+        for (int l = 0; l < layers; l++) { off_frows[l] = voff; voff += fpos[l].size() * Fd * F::DEG; }
+        const size_t off_rem = voff; voff += (size_t)F::DEG * rem_dom;
+        std::vector<size_t> off_dig(trees.size());
+        for (size_t t = 0; t < trees.size(); t++) { off_dig[t] = voff; voff += plan_cnt[t] * 4; }
+        uint64_t* h_idx = (uint64_t*)ctx->stage_alloc(idx.size() * 8);
+        memcpy(h_idx, idx.data(), idx.size() * 8);
+        uint64_t* h_val = (uint64_t*)ctx->stage_alloc(voff * 8);
+        DevBuf<uint64_t> d_idx(ctx, idx.size()), d_val(ctx, voff);
+        AERO_HIP(hipMemcpyAsync(d_idx.get(), h_idx, idx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        launch_gather_rows(ctx, tlde.data.get(), N, (int)tw, d_idx.get(), (int)Q, d_val.get() + off_trows);
+        launch_gather_rows(ctx, clde.data.get(), N, (int)cw, d_idx.get(), (int)Q, d_val.get() + off_crows);
+        {
+            uint64_t dom = N;
+            for (int l = 0; l < layers; l++) {
+                const size_t rows = dom / Fd;
+                launch_gather_fri_rows(ctx, fri_vals[l].get(), fri_vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd,
+                                       d_idx.get() + fpos_off[l], (int)fpos[l].size(), d_val.get() + off_frows[l]);
+                dom = rows;
+            }
+        }
+        AERO_HIP(hipMemcpyAsync(d_val.get() + off_rem, fri_vals[layers].get(), (size_t)F::DEG * rem_dom * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (all_stored)
+            for (size_t t = 0; t < trees.size(); t++)
+                if (plan_cnt[t]) launch_gather_digests(ctx, trees[t]->nodes.get(), d_idx.get() + plan_off[t], (int)plan_cnt[t],
+                                                       reinterpret_cast<Digest*>(d_val.get() + off_dig[t]));
+        AERO_HIP(hipMemcpyAsync(h_val, d_val.get(), voff * 8, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
+        auto paths = [&](size_t t, const std::vector<uint64_t>& p) {
+            return all_stored ? serialize_batch(plans[t], reinterpret_cast<const Digest*>(h_val + off_dig[t])) : open_batch(ctx, *trees[t], p);
+        };
         QueriesBytes tq;
-        for (size_t i = 0; i < (size_t)Q * tw; i++) w64(tq.values, rows[i]);
-        tq.paths = open_batch(ctx, ttree, pos);
+        for (size_t i = 0; i < Q * tw; i++) w64(tq.values, h_val[off_trows + i]);
+        tq.paths = paths(0, pos);
         proof.trace_queries.push_back(tq);
-        for (size_t i = 0; i < (size_t)Q * cw; i++) w64(proof.constraint_queries.values, rows[Q * tw + i]);
-        proof.constraint_queries.paths = open_batch(ctx, ctree, pos);
-    }
-    {
-        std::vector<uint64_t> fp = pos;
-        uint64_t dom = N;
+        for (size_t i = 0; i < Q * cw; i++) w64(proof.constraint_queries.values, h_val[off_crows + i]);
+        proof.constraint_queries.paths = paths(1, pos);
         for (int l = 0; l < layers; l++) {
-            fp = fold_positions(fp, dom, Fd);
-            const size_t rows = dom / Fd;
-            const int Q = (int)fp.size();
-            DevBuf<uint64_t> d_pos(ctx, Q), d_vals(ctx, Q * Fd * F::DEG);
-            AERO_HIP(hipMemcpyAsync(d_pos.get(), fp.data(), Q * 8, hipMemcpyHostToDevice, ctx->stream));
-            launch_gather_fri_rows(ctx, fri_vals[l].get(), fri_vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd, d_pos.get(), Q, d_vals.get());
-            std::vector<uint64_t> vals(Q * Fd * F::DEG);
-            AERO_HIP(hipMemcpyAsync(vals.data(), d_vals.get(), vals.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-            ctx->sync();
             QueriesBytes q;
-            for (uint64_t v : vals) w64(q.values, v);
-            q.paths = open_batch(ctx, fri_trees[l], fp);
+            for (size_t i = 0; i < fpos[l].size() * Fd * F::DEG; i++) w64(q.values, h_val[off_frows[l] + i]);
+            q.paths = paths(2 + l, fpos[l]);
             proof.fri_layers.push_back(q);
-            dom = rows;
         }
         // remainder = last layer's evaluations in natural order
-        std::vector<uint64_t> rem((size_t)F::DEG * dom);
-        AERO_HIP(hipMemcpyAsync(rem.data(), fri_vals[layers].get(), rem.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->sync();
-        for (size_t i = 0; i < dom; i++) for (int d = 0; d < F::DEG; d++) w64(proof.fri_remainder, rem[(size_t)d * dom + i]);
+        for (size_t i = 0; i < rem_dom; i++) for (int d = 0; d < F::DEG; d++) w64(proof.fri_remainder, h_val[off_rem + (size_t)d * rem_dom + i]);
     }
     ms.queries = clk.lap();
     ctx->scratch_reset();

@@ -12,6 +12,7 @@
 // Field inversions are batched per thread (Montgomery trick over the thread's K rows).
 #include "aero_internal.hpp"
 #include "stark_kernels.hpp"
+#include "dft_small.cuh"
 
 namespace aero {
 
@@ -280,8 +281,39 @@ template <class F> __global__ __launch_bounds__(256) void fri_fold_kernel(FoldAr
     acc = F::mulb(acc, a.fold_inv);
     for (int d = 0; d < F::DEG; d++) a.out[d][i] = F::comp(acc, d);
 }
+// Same fold with the inverse DFT done as radix-2 butterflies in registers (fold = 2, 4, 8): the inverse DFT leaves
+// F * c_k at position bitrev(k); constant twiddles are powers of two (dft_small.cuh).
+template <class F, int LOGF> __global__ __launch_bounds__(256) void fri_fold_fft_kernel(FoldArgs<F> a) {
+    typedef typename F::T T;
+    constexpr int FD = 1 << LOGF;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.rows) return;
+    uint64_t y0[FD], y1[FD];
+#pragma unroll
+    for (int j = 0; j < FD; j++) {
+        y0[j] = a.in[0][i + (size_t)j * a.rows];
+        if (F::DEG > 1) y1[j] = a.in[1][i + (size_t)j * a.rows];
+    }
+    dft_dif_inv<LOGF>(y0);
+    if (F::DEG > 1) dft_dif_inv<LOGF>(y1);
+    const uint64_t xinv = gl::mul(a.gen_inv, tw2(a.twi_lo, a.twi_hi, (uint32_t)i, a.tw_h));
+    const T r = F::mulb(a.alpha, xinv);
+    T acc = F::zero();
+#pragma unroll
+    for (int k = FD - 1; k >= 0; k--) {
+        const int p = (int)gl::bitrev((uint32_t)k, LOGF);
+        acc = F::add(F::mul(acc, r), F::make(y0[p], F::DEG > 1 ? y1[p] : 0));
+    }
+    acc = F::mulb(acc, a.fold_inv);
+    for (int d = 0; d < F::DEG; d++) a.out[d][i] = F::comp(acc, d);
+}
 template <class F> void launch_fri_fold(Context* ctx, const FoldArgs<F>& a) {
-    AERO_LAUNCH(ctx, "fri_fold_kernel", a.rows * 8 * F::DEG * ((size_t)a.fold + 1), (fri_fold_kernel<F>), dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, a);
+    const dim3 grid((unsigned)((a.rows + 255) / 256)), block(256);
+    const size_t bytes = a.rows * 8 * F::DEG * ((size_t)a.fold + 1);
+    if (a.fold == 8) AERO_LAUNCH(ctx, "fri_fold_kernel", bytes, (fri_fold_fft_kernel<F, 3>), grid, block, 0, a);
+    else if (a.fold == 4) AERO_LAUNCH(ctx, "fri_fold_kernel", bytes, (fri_fold_fft_kernel<F, 2>), grid, block, 0, a);
+    else if (a.fold == 2) AERO_LAUNCH(ctx, "fri_fold_kernel", bytes, (fri_fold_fft_kernel<F, 1>), grid, block, 0, a);
+    else AERO_LAUNCH(ctx, "fri_fold_kernel", bytes, (fri_fold_kernel<F>), grid, block, 0, a);
     ctx->check_launch("fri_fold");
 }
 template void launch_fri_fold<FB>(Context*, const FoldArgs<FB>&);
