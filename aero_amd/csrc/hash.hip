@@ -141,17 +141,23 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(Digest* nodes, size_t
     store_digest(&nodes[i], b2s::merge(l, r));
 }
 
-// top of the tree in one workgroup: level `m` (<= 256 nodes) down to the root, staged through LDS
-__global__ __launch_bounds__(256) void merkle_top_kernel(Digest* nodes, int m) {
+// L <= 9 levels in one launch, one workgroup per subtree: workgroup b owns node r = m + b and its 2^L descendants L
+// levels below (heap indices (r << L) + j), staged through LDS. Lane utilisation is poor (2^L - 1 compressions on
+// L * 2^(L-1) lane slots), so this is used only where a level has too few nodes to fill the chip anyway: there the cost
+// is the serial latency of one compression per level (~2.4 us with one wave per SIMD) and one launch instead of L.
+__global__ __launch_bounds__(256) void merkle_multi_kernel(Digest* nodes, size_t m, int L) {
     __shared__ Digest buf[512];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * m; i += 256) buf[i] = nodes[2 * m + i];   // children of level m: nodes[2m .. 4m)
+    const size_t r = m + blockIdx.x;
+    const int nchild = 1 << L;
+    for (int i = tid; i < nchild; i += 256) buf[i] = load_digest(&nodes[(r << L) + i]);
     __syncthreads();
-    for (int w = m; w >= 1; w >>= 1) {
-        Digest d;
-        if (tid < w) d = b2s::merge(buf[2 * tid], buf[2 * tid + 1]);
+    for (int d = L - 1; d >= 0; d--) {
+        const int w = 1 << d;
+        Digest v;
+        if (tid < w) v = b2s::merge(buf[2 * tid], buf[2 * tid + 1]);
         __syncthreads();
-        if (tid < w) { buf[tid] = d; nodes[w + tid] = d; }
+        if (tid < w) { buf[tid] = v; store_digest(&nodes[(r << d) + tid], v); }
         __syncthreads();
     }
 }
@@ -190,12 +196,20 @@ void Context::hash_fri_rows(const FriSrc& src, Digest* leaves) {
 
 // levels above a stored level of `c` nodes (heap indices [c, 2c)) up to the root
 void Context::merkle_upper(Digest* nodes, size_t c) {
-    while (c > 512) {   // c is a power of two >= 1024
+    // throughput regime: 3 levels per launch, one thread per subtree of 8
+    while (c > ((size_t)1 << 17)) {
         size_t m = c / 8;
         AERO_LAUNCH(this, "merkle_up3_kernel", c * 32 + (c - m) * 32, merkle_up3_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, nodes, m);
         c = m;
     }
-    if (c >= 2) AERO_LAUNCH(this, "merkle_top_kernel", c * 64, merkle_top_kernel, dim3(1), dim3(256), 0, nodes, (int)(c / 2));
+    // latency regime: up to 9 levels per launch, one workgroup per subtree
+    while (c > 1) {
+        int L = 0;
+        while (L < 9 && ((size_t)1 << (L + 1)) <= c) L++;
+        size_t m = c >> L;
+        AERO_LAUNCH(this, "merkle_multi_kernel", c * 64, merkle_multi_kernel, dim3((unsigned)m), dim3(256), 0, nodes, m, L);
+        c = m;
+    }
     check_launch("merkle_upper");
 }
 

@@ -96,6 +96,12 @@ template <class F> static void f_flatten(const typename F::T* v, size_t n, Col& 
     for (size_t i = 0; i < n; i++) for (int k = 0; k < F::DEG; k++) out.push_back(F::comp(v[i], k));
 }
 template <class F> static Digest f_hash(const typename F::T* v, size_t n) {
+    if (n * F::DEG <= 64) {   // hot path (FRI rows): no heap traffic
+        uint64_t flat[64];
+        size_t k = 0;
+        for (size_t i = 0; i < n; i++) for (int d = 0; d < F::DEG; d++) flat[k++] = F::comp(v[i], d);
+        return hash_elements(flat, k);
+    }
     Col flat; f_flatten<F>(v, n, flat);
     return hash_elements(flat.data(), flat.size());
 }
@@ -169,7 +175,8 @@ struct MerkleTree {
         n = leaves.size();
         if (n < 2 || (n & (n - 1))) throw Err("merkle: leaf count must be a power of two >= 2");
         t.resize(2 * n);
-        std::copy(leaves.begin(), leaves.end(), t.begin() + n);
+#pragma omp parallel for schedule(static) if (n >= 4096)
+        for (size_t i = 0; i < n; i++) t[n + i] = leaves[i];
         for (size_t lvl = n / 2; lvl >= 1; lvl /= 2) {
 #pragma omp parallel for schedule(static) if (lvl >= 4096)
             for (size_t i = lvl; i < 2 * lvl; i++) t[i] = merge(t[2 * i], t[2 * i + 1]);
@@ -421,9 +428,14 @@ template <class F> static typename F::T lagrange_eval(const uint64_t* xs, const 
 // NTT (natural order in, natural order out). Radix-2 DIT after a bit-reversal; twiddles w^k, k < n/2.
 static void bit_reverse(uint64_t* a, size_t n) {
     int lg = ilog2(n);
+    if (lg == 0) return;
     for (size_t i = 0; i < n; i++) {
-        size_t j = 0;
-        for (int b = 0; b < lg; b++) if (i >> b & 1) j |= (size_t)1 << (lg - 1 - b);
+        uint64_t x = i;   // byte-swap + bit tricks: reverse 64 bits, keep the top lg
+        x = __builtin_bswap64(x);
+        x = ((x & 0xF0F0F0F0F0F0F0F0ull) >> 4) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+        x = ((x & 0xCCCCCCCCCCCCCCCCull) >> 2) | ((x & 0x3333333333333333ull) << 2);
+        x = ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
+        size_t j = (size_t)(x >> (64 - lg));
         if (i < j) std::swap(a[i], a[j]);
     }
 }

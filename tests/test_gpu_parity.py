@@ -288,4 +288,4 @@ def test_stage_and_kernel_timers(ctx):
     ctx.set_stage_timing(False)
     ctx.set_kernel_timing(False)
     assert ms["total"] > 0 and abs(sum(v for k, v in ms.items() if k != "total") - ms["total"]) < 0.25 * ms["total"] + 1.0
-    assert "ntt_fwd_pass" in rep and rep["merkle_top_kernel"][0] >= 1 and rep["ntt_fwd_pass"][2] > 0
+    assert "ntt_fwd_pass" in rep and rep["merkle_multi_kernel"][0] >= 1 and rep["ntt_fwd_pass"][2] > 0
