@@ -44,6 +44,41 @@ WORKLOADS = {
 }
 
 
+def rank_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def timed_steps(step, steps, barrier):
+    """Exactly `steps` calls of step() bracketed by barrier() on both sides; returns this rank's wall-clock seconds."""
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(dt, dist, device):
+    """MAX-reduce of the per-rank timing (the slowest rank defines the job's wall-clock)."""
+    if dist is None:
+        return dt
+    import torch
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_value(cells_per_proof, steps, world, dt):
+    """Whole-job throughput: every rank proves `steps` independent traces (weak scaling)."""
+    return cells_per_proof * steps * world / dt
+
+
+def cpu_thread_candidates(cores):
+    """Thread counts tried for the CPU baseline: the oracle's OpenMP loops stop scaling well before 256 threads."""
+    c = sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores})
+    return [t for t in c if t >= 1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,9 +91,7 @@ def main():
     ap.add_argument("--stages", action="store_true", help="also print per-stage ms and the per-kernel table to stderr")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = rank_env()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -107,23 +140,19 @@ def main():
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
     ctx.set_kernel_timing(True, only_kernel=dominant)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        proof, pub = ctx.prove_fib(dev, opt)
-    barrier()
-    dt = time.perf_counter() - t0
+    last = {}
+
+    def step():
+        last["proof"], last["pub"] = ctx.prove_fib(dev, opt)
+
+    dt = timed_steps(step, args.steps, barrier)
     dom_rep = ctx.kernel_timing_report().get(dominant, (0, 0.0, 0.0))
     ctx.set_kernel_timing(False)
-    assert proof == first_proof, "non-deterministic proof bytes"
-
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    assert last["proof"] == first_proof, "non-deterministic proof bytes"
+    dt = max_over_ranks(dt, dist, "cuda")
 
     cells = (1 << log_n) * width
-    value = cells * args.steps * world / dt
+    value = aggregate_value(cells, args.steps, world, dt)
     out = {
         "metric": "trace_cells_per_sec",
         "value": value,
@@ -185,13 +214,21 @@ def main():
             sys.stdout.flush()
             from tests import oracle_lib
             orc = oracle_lib.load()
-            cores = os.cpu_count() or 1
+            ncpu = os.cpu_count() or 1
+            # pick the thread count on a 2^16 probe (also warms the thread pool), then time the sample with it
+            best = None
+            for t in cpu_thread_candidates(ncpu):
+                orc.set_threads(t)
+                orc.prove_fib(width, min(14, log_n), opt.to_list())
+                _, _, probe = orc.prove_fib(width, min(16, log_n), opt.to_list())
+                if best is None or probe["total"] < best[1]:
+                    best = (t, probe["total"])
+            cores = best[0]
             orc.set_threads(cores)
             if args.cpu_sample_log_n:
                 s_log_n = min(args.cpu_sample_log_n, log_n)
             else:
-                _, _, probe = orc.prove_fib(width, min(16, log_n), opt.to_list())   # also warms the thread pool
-                projected = probe["total"] * (1 << max(log_n - 16, 0)) * 1.3
+                projected = best[1] * (1 << max(log_n - 16, 0)) * 1.3
                 s_log_n = log_n if projected <= 40.0 else min(18, log_n)
             t1 = time.perf_counter()
             cproof, cpub, ctimes = orc.prove_fib(width, s_log_n, opt.to_list())
@@ -201,7 +238,7 @@ def main():
             out["cpu_baseline"] = {
                 "value": (1 << s_log_n) * width / ctimes["total"], "unit": "cells/s", "cores": cores, "kind": "port",
                 "sample": f"one complete proof of a 2^{s_log_n} x {width} Fibonacci trace with the same options "
-                          f"(OpenMP, {cores} threads; prover time {ctimes['total']:.2f} s, wall {cdt:.2f} s incl. trace generation)",
+                          f"(OpenMP, best of {cpu_thread_candidates(ncpu)} threads on a 2^16 probe = {cores}; host has {ncpu} logical CPUs; prover time {ctimes['total']:.2f} s, wall {cdt:.2f} s incl. trace generation)",
             }
         print(json.dumps(out), flush=True)
 
