@@ -162,20 +162,26 @@ __global__ __launch_bounds__(256) void merkle_multi_kernel(Digest* nodes, size_t
     }
 }
 
-// Recompute unstored low nodes for openings: out[q] = digest of heap node idx[q] (height h < skip above the leaves).
-template <class Src> __global__ void merkle_recompute_kernel(Src src, size_t n, const uint64_t* idx, int count, Digest* out) {
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= count) return;
-    uint64_t node = idx[q];
+// Recompute unstored low nodes for openings: out[q] = digest of heap node idx[q] (height h < 3 above the leaves).
+// 8 lanes cooperate on one node: each lane hashes one leaf of the (at most 8-leaf) subtree, partners are fetched with
+// wave shuffles, so the latency is one leaf hash plus h merges instead of 2^(h+1) - 1 serial compressions.
+template <class Src> __global__ __launch_bounds__(256) void merkle_recompute_kernel(Src src, size_t n, const uint64_t* idx, int count, Digest* out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int q = t >> 3, lane8 = t & 7;
+    const bool live = q < count;
+    uint64_t node = live ? idx[q] : n;
     int h = 0;
-    while ((node << h) < n) h++;              // node << h lands in [n, 2n)
+    while ((node << h) < n) h++;              // node << h lands in [n, 2n); h <= 3
     const size_t first = (node << h) - n;
-    Digest d[8];
-    const int cnt = 1 << h;                   // h <= 3
-    for (int i = 0; i < cnt; i++) d[i] = leaf_digest(src, first + i);
-    for (int w = cnt / 2; w >= 1; w >>= 1)
-        for (int i = 0; i < w; i++) d[i] = b2s::merge(d[2 * i], d[2 * i + 1]);
-    out[q] = d[0];
+    const int cnt = 1 << h;
+    Digest d = leaf_digest(src, first + (lane8 < cnt ? lane8 : 0));
+    for (int lvl = 0; lvl < 3; lvl++) {       // uniform trip count: every lane takes part in the shuffles
+        Digest o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) o.w[k] = __shfl_xor((int)d.w[k], 1 << lvl);
+        if (lvl < h && ((lane8 >> lvl) & 1) == 0) d = b2s::merge(d, o);
+    }
+    if (live && lane8 == 0) out[q] = d;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,7 +242,7 @@ template void Context::merkle_commit<FriSrc>(const FriSrc&, size_t, Digest*, int
 
 template <class Src> void Context::merkle_recompute(const Src& src, size_t n, const uint64_t* idx_dev, int count, Digest* out_dev) {
     if (count <= 0) return;
-    AERO_LAUNCH(this, "merkle_recompute_kernel", 0, (merkle_recompute_kernel<Src>), dim3((count + 63) / 64), dim3(64), 0, src, n, idx_dev, count, out_dev);
+    AERO_LAUNCH(this, "merkle_recompute_kernel", 0, (merkle_recompute_kernel<Src>), dim3((count * 8 + 255) / 256), dim3(256), 0, src, n, idx_dev, count, out_dev);
     check_launch("merkle_recompute");
 }
 template void Context::merkle_recompute<RowSrc>(const RowSrc&, size_t, const uint64_t*, int, Digest*);

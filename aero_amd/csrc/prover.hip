@@ -337,7 +337,7 @@ MerkleTree Prover::commit_to_rows(const Matrix& lde, bool keep_low_levels) {
     const RowSrc src{lde.data.get(), lde.rows, lde.cols};
     // narrow rows: fused leaf hashing + 3 levels per thread; wide rows: coalesced row-hash pass, then the tree
     const bool fused = lde.cols <= 4 && lde.rows >= ((size_t)1 << 18);
-    const int skip = (fused && !keep_low_levels && low_level_skip) ? 3 : 0;
+    const int skip = (fused && !keep_low_levels && low_level_skip) ? 3 : 0;   // never stores 7/8 of the digests
     MerkleTree t(ctx_, lde.rows, skip);
     if (skip) { t.src_kind = 1; t.row_src = src; }
     if (fused) {
@@ -631,16 +631,22 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         std::vector<const MerkleTree*> trees{&ttree, &ctree};
         std::vector<std::vector<std::vector<uint64_t>>> plans{batch_proof_indices(ttree.n, pos), batch_proof_indices(ctree.n, pos)};
         for (int l = 0; l < layers; l++) { trees.push_back(&fri_trees[l]); plans.push_back(batch_proof_indices(fri_trees[l].n, fpos[l])); }
-        bool all_stored = true;
-        for (size_t t = 0; t < trees.size(); t++) for (auto& v : plans[t]) for (uint64_t i : v) if (i >= trees[t]->stored_limit()) all_stored = false;
-        // index block (u64): [pos | fpos_0.. | node indices tree 0 | tree 1 | ...]
+        // index block (u64): [pos | fpos_0.. | per tree: stored node indices, then unstored (recomputed) node indices]
         std::vector<uint64_t> idx(pos);
-        std::vector<size_t> fpos_off(layers), plan_off(trees.size()), plan_cnt(trees.size());
+        std::vector<size_t> fpos_off(layers), plan_off(trees.size()), plan_cnt(trees.size()), plan_hi(trees.size());
+        std::vector<std::vector<size_t>> plan_slot(trees.size());   // item k of the plan (in plan order) -> slot in the tree's block
         for (int l = 0; l < layers; l++) { fpos_off[l] = idx.size(); idx.insert(idx.end(), fpos[l].begin(), fpos[l].end()); }
         for (size_t t = 0; t < trees.size(); t++) {
             plan_off[t] = idx.size();
-            if (all_stored) for (auto& v : plans[t]) idx.insert(idx.end(), v.begin(), v.end());
-            plan_cnt[t] = idx.size() - plan_off[t];
+            std::vector<uint64_t> hi, lo;
+            for (auto& v : plans[t]) for (uint64_t i : v) (i < trees[t]->stored_limit() ? hi : lo).push_back(i);
+            size_t nh = 0, nl = 0;
+            for (auto& v : plans[t]) for (uint64_t i : v) plan_slot[t].push_back(i < trees[t]->stored_limit() ? nh++ : hi.size() + nl++);
+            if (!lo.empty() && trees[t]->src_kind == 0) fail("batch opening: tree has unstored levels but no leaf source", ST_INTERNAL);
+            idx.insert(idx.end(), hi.begin(), hi.end());
+            idx.insert(idx.end(), lo.begin(), lo.end());
+            plan_hi[t] = hi.size();
+            plan_cnt[t] = hi.size() + lo.size();
         }
         // value block (u64): [trace rows | comp rows | fri rows per layer | remainder | digests (4 u64 each) per tree]
         size_t voff = 0;
@@ -668,14 +674,22 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             }
         }
         AERO_HIP(hipMemcpyAsync(d_val.get() + off_rem, fri_vals[layers].get(), (size_t)F::DEG * rem_dom * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        if (all_stored)
-            for (size_t t = 0; t < trees.size(); t++)
-                if (plan_cnt[t]) launch_gather_digests(ctx, trees[t]->nodes.get(), d_idx.get() + plan_off[t], (int)plan_cnt[t],
-                                                       reinterpret_cast<Digest*>(d_val.get() + off_dig[t]));
+        for (size_t t = 0; t < trees.size(); t++) {
+            Digest* dout = reinterpret_cast<Digest*>(d_val.get() + off_dig[t]);
+            const int nh = (int)plan_hi[t], nl = (int)(plan_cnt[t] - plan_hi[t]);
+            if (nh) launch_gather_digests(ctx, trees[t]->nodes.get(), d_idx.get() + plan_off[t], nh, dout);
+            if (nl) {
+                if (trees[t]->src_kind == 1) ctx->merkle_recompute(trees[t]->row_src, trees[t]->n, d_idx.get() + plan_off[t] + nh, nl, dout + nh);
+                else ctx->merkle_recompute(trees[t]->fri_src, trees[t]->n, d_idx.get() + plan_off[t] + nh, nl, dout + nh);
+            }
+        }
         AERO_HIP(hipMemcpyAsync(h_val, d_val.get(), voff * 8, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
-        auto paths = [&](size_t t, const std::vector<uint64_t>& p) {
-            return all_stored ? serialize_batch(plans[t], reinterpret_cast<const Digest*>(h_val + off_dig[t])) : open_batch(ctx, *trees[t], p);
+        auto paths = [&](size_t t, const std::vector<uint64_t>&) {
+            const Digest* raw = reinterpret_cast<const Digest*>(h_val + off_dig[t]);
+            std::vector<Digest> ordered(plan_slot[t].size());
+            for (size_t k = 0; k < ordered.size(); k++) ordered[k] = raw[plan_slot[t][k]];
+            return serialize_batch(plans[t], ordered.data());
         };
         QueriesBytes tq;
         for (size_t i = 0; i < Q * tw; i++) w64(tq.values, h_val[off_trows + i]);

@@ -120,7 +120,7 @@ public:
     Bytes prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_inputs_out);
     StageMs last_stage_ms;
     bool collect_stage_times = false;   // adds a stream sync per stage
-    bool low_level_skip = false;        // do not store the 3 lowest Merkle levels of large trees (memory saver)
+    bool low_level_skip = true;         // large trees: the 3 lowest Merkle levels are not stored but recomputed by the openings
 
     // ---- stage-level entry points (the reference's split API; also what the C ABI exposes) ----
     // interpolate_columns: evaluations on <w_n> -> polys (bit-reversed coefficients pre-scaled by 7^i)
