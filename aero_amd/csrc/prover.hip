@@ -563,9 +563,12 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     std::vector<DevBuf<uint64_t>> fri_vals;
     fri_vals.emplace_back(ctx, (size_t)F::DEG * N);
     {
+        // deg(DEEP) < n: evaluate it on the n-point coset 7<w_n> (every blowup-th LDE row), interpolate (the plain inverse
+        // transform of values on 7<w_n> yields exactly the 7^i-prescaled coefficients), extend like any other column.
         NttTables* tN = ctx->ntt_tables(log_N);
+        DevBuf<uint64_t> dsm(ctx, (size_t)F::DEG * n);
         DeepArgs<F> a{};
-        a.tlde = tlde.data.get(); a.clde = clde.data.get(); a.N = N; a.W = W; a.C = (uint32_t)C;
+        a.tlde = tlde.data.get(); a.clde = clde.data.get(); a.N = N; a.count = n; a.row_step = (uint32_t)B; a.W = W; a.C = (uint32_t)C;
         a.tw_lo = tN->lo_fwd; a.tw_hi = tN->hi_fwd; a.tw_h = tN->h;
         a.z = z; a.z_next = z_next; a.z_c = z_c; a.z_conj = F::conj(z); a.lambda = lambda; a.mu = mu;
         ParamPack pp(ctx);
@@ -573,8 +576,10 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         pp.commit();
         a.ood_cur = pp.ptr<T>(i0); a.ood_next = pp.ptr<T>(i1); a.ood_h = pp.ptr<T>(i2);
         a.da = pp.ptr<T>(i3); a.db = pp.ptr<T>(i4); a.dg = pp.ptr<T>(i5); a.dc = pp.ptr<T>(i6);
-        for (int d = 0; d < F::DEG; d++) a.out[d] = fri_vals[0].get() + (size_t)d * N;
+        for (int d = 0; d < F::DEG; d++) a.out[d] = dsm.get() + (size_t)d * n;
         launch_deep<F>(ctx, a);
+        ctx->ntt_inverse(dsm.get(), n, F::DEG, log_n, 1, 1, 1, 0);
+        ctx->ntt_forward(dsm.get(), n, fri_vals[0].get(), N, F::DEG, log_N, log_B);
     }
     ms.deep = clk.lap();
 

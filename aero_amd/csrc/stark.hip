@@ -200,7 +200,9 @@ template void launch_eval_bitrev<FB>(Context*, const uint64_t*, size_t, size_t, 
 template void launch_eval_bitrev<FQ>(Context*, const uint64_t*, size_t, size_t, int, int, int, gl::E2, gl::E2, int, gl::E2*);
 
 // ------------------------------------------------------------------------------------------------
-// DEEP composition over the LDE domain (composer.cairo:48-316 is the verifier-side mirror):
+// DEEP composition (composer.cairo:48-316 is the verifier-side mirror), evaluated on every row_step-th LDE row.
+// The DEEP polynomial has degree < n, so the prover evaluates it on the n-point coset 7<w_n> only (row_step = blowup: 1/8
+// of the field inversions) and extends it to the LDE domain with one more column NTT:
 //   deep(x) = [ sum_i a_i (T_i(x) - T_i(z)) / (x - z) + sum_i b_i (T_i(x) - T_i(z g)) / (x - z g)
 //             (+ sum_i c_i (T_i(x) - conj T_i(z)) / (x - conj z)  when E = F_p^2)
 //             + sum_c d_c (H_c(x) - H_c(z^C)) / (x - z^C) ] * (lambda + mu x)
@@ -208,13 +210,13 @@ template <class F, int K> __global__ __launch_bounds__(256) void deep_kernel(Dee
     typedef typename F::T T;
     constexpr int ND = F::DEG > 1 ? 4 : 3;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t nthreads = a.N / K;
+    const size_t nthreads = a.count / K;
     if (t >= nthreads) return;
     T den[ND * K], pre[ND * K];
     uint64_t xs[K];
 #pragma unroll
     for (int q = 0; q < K; q++) {
-        const size_t r = t + (size_t)q * nthreads;
+        const size_t r = (t + (size_t)q * nthreads) * a.row_step;
         const uint64_t x = gl::mul(gl::GEN, tw2(a.tw_lo, a.tw_hi, (uint32_t)r, a.tw_h));
         xs[q] = x;
         const T xe = F::from(x);
@@ -229,7 +231,7 @@ template <class F, int K> __global__ __launch_bounds__(256) void deep_kernel(Dee
     for (int i = ND * K - 1; i >= 0; i--) { T v = F::mul(ia, pre[i]); ia = F::mul(ia, den[i]); den[i] = v; }
 #pragma unroll
     for (int q = 0; q < K; q++) {
-        const size_t r = t + (size_t)q * nthreads;
+        const size_t m = t + (size_t)q * nthreads, r = m * a.row_step;
         T s1 = F::zero(), s2 = F::zero(), s3 = F::zero();
         for (uint32_t c = 0; c < a.W; c++) {
             const T v = F::from(a.tlde[(size_t)c * a.N + r]);
@@ -246,14 +248,15 @@ template <class F, int K> __global__ __launch_bounds__(256) void deep_kernel(Dee
         }
         acc = F::add(acc, F::mul(sc, den[ND * q + 2]));
         acc = F::mul(acc, F::add(a.lambda, F::mulb(a.mu, xs[q])));
-        for (int d = 0; d < F::DEG; d++) a.out[d][r] = F::comp(acc, d);
+        for (int d = 0; d < F::DEG; d++) a.out[d][m] = F::comp(acc, d);
     }
 }
 template <class F> void launch_deep(Context* ctx, const DeepArgs<F>& a) {
-    if (a.N % 4 == 0 && a.N >= 4096)
-        AERO_LAUNCH(ctx, "deep_kernel", a.N * 8 * ((size_t)a.W + (size_t)a.C * F::DEG + F::DEG), (deep_kernel<F, 4>), dim3((unsigned)((a.N / 4 + 255) / 256)), dim3(256), 0, a);
+    const size_t bytes = a.count * 8 * ((size_t)a.W + (size_t)a.C * F::DEG + F::DEG);
+    if (a.count % 4 == 0 && a.count >= 4096)
+        AERO_LAUNCH(ctx, "deep_kernel", bytes, (deep_kernel<F, 4>), dim3((unsigned)((a.count / 4 + 255) / 256)), dim3(256), 0, a);
     else
-        AERO_LAUNCH(ctx, "deep_kernel", a.N * 8 * ((size_t)a.W + (size_t)a.C * F::DEG + F::DEG), (deep_kernel<F, 1>), dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, a);
+        AERO_LAUNCH(ctx, "deep_kernel", bytes, (deep_kernel<F, 1>), dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, a);
     ctx->check_launch("deep");
 }
 template void launch_deep<FB>(Context*, const DeepArgs<FB>&);

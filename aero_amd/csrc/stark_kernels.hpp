@@ -40,7 +40,9 @@ template <class F> struct DeepArgs {
     typedef typename F::T T;
     const uint64_t* tlde;   // W x N
     const uint64_t* clde;   // (C*DEG) x N
-    size_t N;
+    size_t N;                        // LDE rows (column stride of tlde / clde)
+    size_t count;                    // points evaluated: LDE rows m * row_step, m < count (output index m)
+    uint32_t row_step;
     uint32_t W, C;
     const uint64_t *tw_lo, *tw_hi;   // two-level table of w_N
     int tw_h;
