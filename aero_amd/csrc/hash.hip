@@ -22,6 +22,8 @@
 //     need from the committed data; this only saves memory (measured: no time gain), so it is off by default.
 // Measured on MI355X (tools/bench_hash.hip, 2^23 x 2 matrix): every variant lands at 30-36 G compressions/s against
 // 40-42 G/s for compressions that never leave registers (tools/ubench_valu.hip).
+#include <type_traits>
+
 #include "aero_internal.hpp"
 
 namespace aero {
@@ -80,6 +82,23 @@ __device__ __forceinline__ Digest leaf_digest(const FriSrc& s, size_t i) {
     return state_digest(st);
 }
 
+// Straight-line leaf hash for a compile-time column count (no loop: lets the 8-leaf kernel keep its digests in VGPRs;
+// with the runtime-width loop the compiler declined the outer unroll and spilled the digest array to scratch, which
+// showed up as 270 MB of extra HBM writes per 2^23-row tree in the PMC counters).
+template <int NC> __device__ __forceinline__ Digest leaf_digest_fixed(const RowSrc& s, size_t j) {
+    b2s::State st;
+    b2s::init(st);
+#pragma unroll
+    for (int c = 0; c < NC; c += 2) {
+        const bool two = c + 1 < NC;
+        const uint64_t e0 = s.cols[(size_t)c * s.stride + j];
+        const uint64_t e1 = two ? s.cols[(size_t)(c + 1) * s.stride + j] : 0;
+        const uint32_t t = (uint32_t)(two ? c + 2 : c + 1) * 32;
+        b2s::compress_elems(st, e0, e1, two, t, t == (uint32_t)NC * 32);
+    }
+    return state_digest(st);
+}
+
 // Builds the 3 levels above 8 digests (children left to right, heap index of child 0 = child_base). The node at height
 // h above the children and position p inside this subtree goes to nodes[(child_base >> h) + p]; only heights >=
 // min_store_h are written. Fully unrolled: 7 compression bodies, every digest stays in VGPRs.
@@ -108,6 +127,18 @@ template <class Src> __global__ __launch_bounds__(256) void merkle_leaf8_kernel(
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         d[i] = leaf_digest(src, first + i);
+        if (skip == 0) store_digest(&nodes[n + first + i], d[i]);
+    }
+    build3(d, nodes, n + first, skip > 1 ? skip : 1);
+}
+template <int NC> __global__ __launch_bounds__(256) void merkle_leaf8_rows_kernel(RowSrc src, Digest* nodes, size_t n, int skip) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n / 8) return;
+    const size_t first = t * 8;
+    Digest d[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        d[i] = leaf_digest_fixed<NC>(src, first + i);
         if (skip == 0) store_digest(&nodes[n + first + i], d[i]);
     }
     build3(d, nodes, n + first, skip > 1 ? skip : 1);
@@ -233,8 +264,18 @@ template <class Src> void Context::merkle_commit(const Src& src, size_t n, Diges
     if (n < 8 || (n & (n - 1))) fail("merkle_commit: leaf count must be a power of two >= 8");
     if (skip != 0 && skip != 3) fail("merkle_commit: skip must be 0 or 3", ST_INTERNAL);
     const size_t stored = skip ? (n / 8) * 32 : (n + n / 2 + n / 4 + n / 8) * 32;
-    AERO_LAUNCH(this, "merkle_leaf8_kernel", n * src_leaf_bytes(src) + stored, (merkle_leaf8_kernel<Src>), dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0,
-                src, nodes, n, skip);
+    const dim3 grid((unsigned)((n / 8 + 255) / 256)), block(256);
+    const size_t abytes = n * src_leaf_bytes(src) + stored;
+    bool done = false;
+    if constexpr (std::is_same<Src, RowSrc>::value) {
+        done = true;
+        if (src.ncols == 1) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<1>), grid, block, 0, src, nodes, n, skip);
+        else if (src.ncols == 2) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<2>), grid, block, 0, src, nodes, n, skip);
+        else if (src.ncols == 3) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<3>), grid, block, 0, src, nodes, n, skip);
+        else if (src.ncols == 4) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<4>), grid, block, 0, src, nodes, n, skip);
+        else done = false;
+    }
+    if (!done) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_kernel<Src>), grid, block, 0, src, nodes, n, skip);
     merkle_upper(nodes, n / 8);
 }
 template void Context::merkle_commit<RowSrc>(const RowSrc&, size_t, Digest*, int);
