@@ -4,7 +4,7 @@ sys.path.insert(0, '/root/repo')
 import aero_amd
 opt = aero_amd.ProofOptions.with_96_bit_security()
 trace = aero_amd.fib_trace(2, 20)
-for S in (1, 2, 3, 4):
+for S in (1, 2, 4, 6, 8):
     ctxs = [aero_amd.Context(0) for _ in range(S)]
     devs = [c.trace_upload(trace) for c in ctxs]
     for c, d in zip(ctxs, devs):

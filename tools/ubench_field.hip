@@ -42,6 +42,46 @@ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
     return c2 ? mk(t0, t1) : mk(r0, r1);
 }
 }
+namespace D {   // product by the compiler (4 x v_mad_u64_u32), reduction + canonicalisation hand-written on VOP2 carry chains
+__device__ __forceinline__ u64 mul(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1 + (t >> 32);
+    const u64 v = (u64)a1 * b0 + (u32)u;
+    const u64 w = (u64)a1 * b1 + ((u >> 32) + (v >> 32));
+    const u32 x0 = (u32)t, x1 = (u32)v, x2 = (u32)w, x3 = (u32)(w >> 32), z = 0;
+    u32 r0, r1, l0, l1, m, e0, e1, t0, t1;
+    asm("v_sub_co_u32 %[l0], vcc, %[x0], %[x3]\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %[l1], vcc, 0, %[x1], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %[m], vcc, 0, %[z], vcc\n\t"
+        "v_sub_co_u32 %[l0], vcc, %[l0], %[m]\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %[l1], vcc, 0, %[l1], vcc\n\t"
+        "v_sub_co_u32 %[e0], vcc, 0, %[x2]\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %[e1], vcc, 0, %[x2], vcc\n\t"
+        "v_add_co_u32 %[r0], vcc, %[l0], %[e0]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %[r1], vcc, %[l1], %[e1], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %[m], vcc, 0, %[z], vcc\n\t"
+        "v_add_co_u32 %[r0], vcc, %[r0], %[m]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %[r1], vcc, 0, %[r1], vcc\n\t"
+        "v_add_co_u32 %[t0], vcc, -1, %[r0]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %[t1], vcc, 0, %[r1], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %[r0], %[r0], %[t0], vcc\n\t"
+        "v_cndmask_b32 %[r1], %[r1], %[t1], vcc"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [l0] "=&v"(l0), [l1] "=&v"(l1), [m] "=&v"(m), [e0] "=&v"(e0), [e1] "=&v"(e1), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [z] "v"(z)
+        : "vcc");
+    return mk(r0, r1);
+}
+}
 namespace Cc {   // u64-typed with 128-bit product, reduction written on u64 with __builtin overflow
 __device__ __forceinline__ u64 mul(u64 a, u64 b) {
     u64 lo = a * b, hi = __umul64hi(a, b);
@@ -68,11 +108,12 @@ __global__ __launch_bounds__(256) void NAME(u64* out, int iters) {              
 BENCH(a_mul, gl::mul, gl::add, gl::sub, 0) BENCH(a_add, gl::mul, gl::add, gl::sub, 1) BENCH(a_sub, gl::mul, gl::add, gl::sub, 2)
 BENCH(b_mul, B::mul, B::add, B::sub, 0) BENCH(b_add, B::mul, B::add, B::sub, 1) BENCH(b_sub, B::mul, B::add, B::sub, 2)
 BENCH(c_mul, Cc::mul, B::add, B::sub, 0)
+BENCH(d_mul, D::mul, B::add, B::sub, 0)
 __global__ void check(u64* out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
     u64 a = (i * 0x9E3779B97F4A7C15ull) % gl::P, b = ((i + 7) * 0xD1B54A32D192ED03ull) % gl::P;
     if (i < 4) { a = gl::P - 1 - i; b = gl::P - 1; } if (i == 5) { a = 0; } if (i == 6) { a = 0xFFFFFFFFull; b = 0xFFFFFFFF00000000ull; }
-    bool ok = B::mul(a, b) == gl::mul(a, b) && B::add(a, b) == gl::add(a, b) && B::sub(a, b) == gl::sub(a, b) && B::sub(b, a) == gl::sub(b, a) && Cc::mul(a, b) == gl::mul(a, b);
+    bool ok = B::mul(a, b) == gl::mul(a, b) && B::add(a, b) == gl::add(a, b) && B::sub(a, b) == gl::sub(a, b) && B::sub(b, a) == gl::sub(b, a) && Cc::mul(a, b) == gl::mul(a, b) && D::mul(a, b) == gl::mul(a, b);
     u64 c3 = (a ^ (b >> 3)) % gl::P;
     ok = ok && B::mul(B::sub(a, b), c3) == gl::mul(gl::sub(a, b), c3) && B::sub(B::mul(a, b), c3) == gl::sub(gl::mul(a, b), c3) && B::sub(c3, B::mul(a, b)) == gl::sub(c3, gl::mul(a, b))
         && B::add(B::mul(B::sub(a, c3), b), B::mul(B::sub(b, c3), a)) == gl::add(gl::mul(gl::sub(a, c3), b), gl::mul(gl::sub(b, c3), a));
@@ -89,7 +130,7 @@ int main() {
         for (int r = 0; r < 3; r++) { CK(hipEventRecord(e0)); hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms; }
         printf("%-20s %8.3f ms  %9.1f Gop/s\n", name, best, iters * 32.0 * blocks * 256.0 / (best * 1e-3) / 1e9);
     };
-    timeit("A mul (current)", a_mul); timeit("B mul (carry chain)", b_mul); timeit("C mul (u64 ovf)", c_mul);
+    timeit("A mul (current)", a_mul); timeit("B mul (carry chain)", b_mul); timeit("C mul (u64 ovf)", c_mul); timeit("D mul (asm reduce)", d_mul);
     timeit("A add (current)", a_add); timeit("B add (carry chain)", b_add);
     timeit("A sub (current)", a_sub); timeit("B sub (carry chain)", b_sub);
     return 0;
