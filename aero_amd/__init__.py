@@ -291,6 +291,21 @@ class Context:
         lib().aero_free(proof)
         return data, pub.tolist()
 
+    def prove_fib_sharded(self, comm, trace: "Matrix", options: ProofOptions):
+        """ONE proof proven cooperatively by comm.world GPUs (aero_prove_fib_sharded); `comm` = aero_amd.shard.TorchComm.
+        Every rank passes the whole trace and gets the same bytes as prove_fib. Returns (proof_bytes, public_inputs)."""
+        proof = u8p()
+        plen = C.c_size_t(0)
+        w, _ = trace.shape
+        pub = np.zeros(w // 2, np.uint64)
+        rc = lib().aero_prove_fib_sharded(self.h, C.byref(comm.struct), trace.h, C.byref(options), C.byref(proof), C.byref(plen), _p64(pub))
+        if rc != 0 and getattr(comm, "last_error", None) is not None:
+            raise AeroError(rc, f"{lib().aero_last_error(self.h).decode()} ({comm.last_error!r})")
+        self._ck(rc)
+        data = C.string_at(proof, plen.value)
+        lib().aero_free(proof)
+        return data, pub.tolist()
+
     # ---- instrumentation
     def set_stage_timing(self, on):
         self._ck(lib().aero_set_stage_timing(self.h, C.c_int32(1 if on else 0)))

@@ -267,7 +267,7 @@ static void eval_constraints_fib(Context* c, const Matrix& lde, uint32_t log_blo
     a.ba = (const T*)up(ba.data(), na * sizeof(T)); a.bb = (const T*)up(bb.data(), na * sizeof(T));
     a.results = (const uint64_t*)up(res.data(), res.size() * 8);
     a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.twi_lo = tce->lo_inv; a.twi_hi = tce->hi_inv; a.tw_h = tce->h;
-    a.gen_inv = gl::inv(gl::GEN); a.k7 = gl::pow(gl::GEN, ceN);
+    a.offset = gl::GEN; a.gen_inv = gl::inv(gl::GEN); a.k7 = gl::pow(gl::GEN, ceN);
     std::vector<uint64_t> xn(C), zn(C);
     uint64_t g7n = gl::pow(gl::GEN, n), wC = gl::root_of_unity(ilog2u(C));
     for (size_t k = 0; k < C; k++) { uint64_t xnk = gl::mul(g7n, gl::pow(wC, k)); xn[k] = gl::inv(xnk); zn[k] = gl::inv(gl::sub(xnk, 1)); }
@@ -333,10 +333,19 @@ int32_t aero_grind(aero_ctx* ctx, const uint8_t seed[32], uint32_t bits, uint64_
 
 // ---- whole proof ----------------------------------------------------------------------------------------
 static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, int log_n, const aero_proof_options* o, uint8_t** proof,
-                     size_t* proof_len, uint64_t* pub_out) {
+                     size_t* proof_len, uint64_t* pub_out, const aero_comm* comm = nullptr) {
     REQUIRE(o && proof && proof_len, "prove: null argument");
     ProofOptions po{o->num_queries, o->blowup_factor, o->grinding_factor, o->hash_fn, o->field_extension, o->fri_folding_factor, o->fri_log_max_remainder};
     Prover p(ctx->c, po);
+    if (comm) {
+        REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "prove_fib_sharded: bad rank / world");
+        REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "prove_fib_sharded: missing exchange callback");
+        ShardComm sc;
+        sc.rank = comm->rank; sc.world = comm->world; sc.user = comm->user;
+        sc.all_to_all = comm->all_to_all; sc.all_gather = comm->all_gather; sc.all_reduce_sum_u64 = comm->all_reduce_sum_u64;
+        sc.min_peer_digests = comm->min_peer_digests ? comm->min_peer_digests : 64;
+        p.set_comm(sc);
+    }
     p.collect_stage_times = ctx->stage_timing;
     std::vector<uint64_t> pub;
     Bytes b = p.prove(trace_dev, width, log_n, &pub);
@@ -355,6 +364,15 @@ int32_t aero_prove_fib(aero_ctx* ctx, const aero_matrix* trace, const aero_proof
         REQUIRE(trace, "prove_fib: null trace");
         REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0, "prove_fib: trace length must be a power of two");
         do_prove(ctx, trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows), options, proof, proof_len, pub_out);
+    });
+}
+int32_t aero_prove_fib_sharded(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_proof_options* options,
+                               uint8_t** proof, size_t* proof_len, uint64_t* pub_out) {
+    return guard(ctx, [&] {
+        REQUIRE(comm, "prove_fib_sharded: null comm");
+        REQUIRE(trace, "prove_fib_sharded: null trace");
+        REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0, "prove_fib_sharded: trace length must be a power of two");
+        do_prove(ctx, trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows), options, proof, proof_len, pub_out, comm);
     });
 }
 int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n, const aero_proof_options* options,

@@ -423,6 +423,49 @@ struct StageClock {
     }
 };
 
+// ---- exchange helpers (sharded proof only) -----------------------------------------------------------
+void Prover::comm_all_to_all(const void* send, void* recv, size_t bytes) {
+    ctx_->sync();
+    if (!comm_.all_to_all || comm_.all_to_all(comm_.user, send, recv, bytes) != 0) fail("sharded prove: all_to_all exchange failed", ST_COMM);
+}
+void Prover::comm_all_gather(const void* send, void* recv, size_t bytes) {
+    ctx_->sync();
+    if (!comm_.all_gather || comm_.all_gather(comm_.user, send, recv, bytes) != 0) fail("sharded prove: all_gather exchange failed", ST_COMM);
+}
+void Prover::comm_all_reduce(uint64_t* buf, size_t count) {
+    ctx_->sync();
+    if (!comm_.all_reduce_sum_u64 || comm_.all_reduce_sum_u64(comm_.user, buf, count) != 0) fail("sharded prove: all_reduce exchange failed", ST_COMM);
+}
+// Leaf digests of this rank's coset (local leaf t = global leaf t*G + rank) -> every rank ends up with the digests of the
+// contiguous global range [rank*L, (rank+1)*L), builds that subtree, and the G subtree roots are all-gathered; the top
+// log2 G levels are hashed on the host by every rank.
+Commitment Prover::commit_exchange(DevBuf<Digest>& local, size_t L) {
+    Context* ctx = ctx_;
+    const int G = comm_.world;
+    if (L < (size_t)G || L % G) fail("sharded prove: commitment too small for this many ranks");
+    Commitment c;
+    c.sharded = true;
+    c.n_global = L * G;
+    DevBuf<Digest> recv(ctx, L);
+    comm_all_to_all(local.get(), recv.get(), (L / G) * sizeof(Digest));   // chunk r = my leaves t in [r*L/G, (r+1)*L/G)
+    c.tree = MerkleTree(ctx, L);
+    if (L >= 2) {
+        launch_interleave_digests(ctx, recv.get(), L / G, c.tree.leaves(), G, L / G);
+        ctx->merkle_build(c.tree.nodes.get(), L);
+    } else {
+        AERO_HIP(hipMemcpyAsync(c.tree.nodes.get() + 1, recv.get(), sizeof(Digest), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    DevBuf<Digest> roots(ctx, G);
+    comm_all_gather(c.tree.nodes.get() + 1, roots.get(), sizeof(Digest));
+    c.top.assign(2 * (size_t)G, Digest{});
+    AERO_HIP(hipMemcpyAsync(c.top.data() + G, roots.get(), G * sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    for (int i = G - 1; i >= 1; i--) c.top[i] = b2s::merge(c.top[2 * i], c.top[2 * i + 1]);
+    c.root = c.top[1];
+    c.tree.root_host = c.top[G + comm_.rank];
+    return c;
+}
+
 template <class F>
 Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::vector<uint64_t>* pub_out) {
     typedef typename F::T T;
@@ -443,6 +486,19 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         if (rem < Fd) fail("prove: FRI remainder smaller than the folding factor");
         if (rem * 8 * F::DEG > 0xffff) fail("prove: FRI remainder does not fit the proof's u16 length prefix", ST_UNSUPPORTED);
     }
+    // ---- shard geometry: this rank owns LDE rows j = rank (mod G), the coset h <w_M>, h = 7 w_N^rank, M = N / G.
+    // Every stage below is the single-GPU algorithm on that coset (offset h, local blowup B / G); G = 1 is the whole domain.
+    const int G = comm_.world, rank = comm_.rank;
+    if (G < 1 || (G & (G - 1)) || rank < 0 || rank >= G) fail("sharded prove: world must be a power of two and 0 <= rank < world");
+    if ((size_t)G > B) fail("sharded prove: more ranks than the blowup factor (each rank owns whole cosets of the trace domain)");
+    const int log_G = ilog2(G);
+    const size_t M = N / G, Bl = B / G;
+    const int log_M = log_N - log_G, log_Bl = log_B - log_G;
+    if (G > 1 && M < (size_t)G) fail("sharded prove: LDE domain too small for this many ranks");
+    const uint64_t h = gl::mul(gl::GEN, gl::pow(gl::root_of_unity(log_N), (uint64_t)rank));
+    const uint64_t h_inv = gl::inv(h);
+    const uint32_t min_peer = comm_.min_peer_digests ? comm_.min_peer_digests : 64;
+
     StageMs ms;
     ctx->sync();
     ctx->stage_reset();
@@ -470,16 +526,33 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     const uint64_t g = gl::root_of_unity(log_n);
     const uint64_t gen_inv = gl::inv(gl::GEN);
 
-    // 1. interpolate_columns [a3]
-    Matrix polys = interpolate_columns(trace_dev, W, log_n);
+    // commitment to the rows of a (local) LDE matrix
+    auto commit_matrix = [&](const Matrix& lde) {
+        Commitment c;
+        if (G == 1) {
+            c.tree = commit_to_rows(lde, false);
+            c.n_global = lde.rows;
+            c.root = c.tree.root();
+            return c;
+        }
+        DevBuf<Digest> local(ctx, lde.rows);
+        ctx->hash_rows(lde.data.get(), lde.rows, lde.cols, lde.rows, local.get());
+        return commit_exchange(local, lde.rows);
+    };
+
+    // 1. interpolate_columns [a3]: coefficient i scaled by h^i, so the coset LDE below needs no shift pass
+    Matrix polys(ctx, (int)W, n);
+    AERO_HIP(hipMemcpyAsync(polys.data.get(), trace_dev, (size_t)W * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0);
     ms.interpolate = clk.lap();
-    // 2. evaluate_columns_over [a4]
-    Matrix tlde = evaluate_columns_over(polys, log_B);
+    // 2. evaluate_columns_over [a4] (this rank's coset: M rows)
+    Matrix tlde(ctx, (int)W, M);
+    ctx->ntt_forward(polys.data.get(), n, tlde.data.get(), M, (int)W, log_M, log_Bl);
     ms.lde = clk.lap();
     // 3. row hashes, Merkle tree, commit [a5, a6, a8]
-    MerkleTree ttree = commit_to_rows(tlde, false);
-    wdigest(proof.commitments, ttree.root());
-    coin.reseed(ttree.root());
+    Commitment tcom = commit_matrix(tlde);
+    wdigest(proof.commitments, tcom.root);
+    coin.reseed(tcom.root);
     ms.trace_commit = clk.lap();
 
     // 4. constraint composition coefficients + evaluation + division (fused) [a9, a10, a11]
@@ -488,18 +561,29 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     for (size_t i = 0; i < air.num_assertions(); i++) { ba.push_back(coin.draw<F>()); bb.push_back(coin.draw<F>()); }
     DevBuf<uint64_t> hbuf(ctx, (size_t)F::DEG * ceN);   // H evaluations, then coefficients: [DEG][ceN]
     {
+        // H (degree < C*n) is interpolated from its values on h<w_ce>: every (M/ce_n)-th row of this rank's LDE, or - when
+        // the shard is smaller than the constraint domain - a dedicated extension of the trace polynomials onto h<w_ce>.
+        Matrix celde;
+        const uint64_t* frame_src = tlde.data.get();
+        size_t frame_rows = M;
+        if (M < ceN) {
+            celde = Matrix(ctx, (int)W, ceN);
+            ctx->ntt_forward(polys.data.get(), n, celde.data.get(), ceN, (int)W, log_ce, log_ce - log_n);
+            frame_src = celde.data.get();
+            frame_rows = ceN;
+        }
         NttTables* tce = ctx->ntt_tables(log_ce);
         FibConsArgs<F> a{};
-        a.lde = tlde.data.get(); a.N = N; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)B; a.ce_step = (uint32_t)(B / C);
+        a.lde = frame_src; a.N = frame_rows; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)(frame_rows / n); a.ce_step = (uint32_t)(frame_rows / ceN);
         a.first = 0; a.count = ceN;
         ParamPack pp(ctx);
         const size_t i_ta = pp.add(ta), i_tb = pp.add(tb), i_ba = pp.add(ba), i_bb = pp.add(bb), i_res = pp.add(air.results);
         a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.twi_lo = tce->lo_inv; a.twi_hi = tce->hi_inv; a.tw_h = tce->h;
-        a.gen_inv = gen_inv; a.k7 = gl::pow(gl::GEN, ceN);
+        a.offset = h; a.gen_inv = h_inv; a.k7 = gl::pow(h, ceN);
         std::vector<uint64_t> xn(C), zn(C);
-        uint64_t g7n = gl::pow(gl::GEN, n), wC = gl::root_of_unity(ilog2(C));
+        uint64_t hn = gl::pow(h, n), wC = gl::root_of_unity(ilog2(C));
         for (size_t k = 0; k < C; k++) {
-            uint64_t xnk = gl::mul(g7n, gl::pow(wC, k));
+            uint64_t xnk = gl::mul(hn, gl::pow(wC, k));
             xn[k] = gl::inv(xnk);
             zn[k] = gl::inv(gl::sub(xnk, 1));
         }
@@ -513,28 +597,28 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         launch_fib_constraints<F>(ctx, a, 1);
     }
     ms.constraints = clk.lap();
-    // 5. composition polynomial: interpolate over the coset; coefficient I gets 7^-I (coset) * 7^(I >> log C)
+    // 5. composition polynomial: interpolate over the coset; coefficient I gets h^-I (coset) * h^(I >> log C)
     //    (pre-scaling of column coefficient i = I >> log C for the column LDE). In bit-reversed order the C column
     //    polynomials are the C contiguous chunks of the buffer: no split pass (H(x) = sum_c x^c H_c(x^C)).
-    ctx->ntt_inverse(hbuf.get(), ceN, F::DEG, log_ce, 1, gen_inv, gl::GEN, ilog2(C));
+    ctx->ntt_inverse(hbuf.get(), ceN, F::DEG, log_ce, 1, h_inv, h, ilog2(C));
     ms.composition = clk.lap();
     // 6. composition commitment [a12]: column c*DEG + d <- chunk c of component d
-    Matrix clde(ctx, (int)(C * F::DEG), N);
+    Matrix clde(ctx, (int)(C * F::DEG), M);
     for (int d = 0; d < F::DEG; d++)
-        ctx->ntt_forward(hbuf.get() + (size_t)d * ceN, n, clde.data.get() + (size_t)d * N, (size_t)F::DEG * N, (int)C, log_N, log_B);
-    MerkleTree ctree = commit_to_rows(clde, false);
-    wdigest(proof.commitments, ctree.root());
-    coin.reseed(ctree.root());
+        ctx->ntt_forward(hbuf.get() + (size_t)d * ceN, n, clde.data.get() + (size_t)d * M, (size_t)F::DEG * M, (int)C, log_M, log_Bl);
+    Commitment ccom = commit_matrix(clde);
+    wdigest(proof.commitments, ccom.root);
+    coin.reseed(ccom.root);
     ms.comp_commit = clk.lap();
 
-    // 7. OOD frame [a13]. Coefficients are pre-scaled by 7^i, so evaluate at point / 7.
+    // 7. OOD frame [a13]. Coefficients are pre-scaled by h^i, so evaluate at point / h.
     const T z = coin.draw<F>();
     const T z_next = F::mulb(z, g), z_c = gl::fpow<F>(z, C);
     std::vector<T> ood(2 * W + C);
     {
         DevBuf<T> d_out(ctx, 2 * W + C);
-        launch_eval_bitrev<F>(ctx, polys.data.get(), n, 0, (int)W, 1, log_n, F::mulb(z, gen_inv), F::mulb(z_next, gen_inv), 2, d_out.get());
-        launch_eval_bitrev<F>(ctx, hbuf.get(), n, ceN, (int)C, F::DEG, log_n, F::mulb(z_c, gen_inv), F::zero(), 1, d_out.get() + 2 * W);
+        launch_eval_bitrev<F>(ctx, polys.data.get(), n, 0, (int)W, 1, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get());
+        launch_eval_bitrev<F>(ctx, hbuf.get(), n, ceN, (int)C, F::DEG, log_n, F::mulb(z_c, h_inv), F::zero(), 1, d_out.get() + 2 * W);
         AERO_HIP(hipMemcpyAsync(ood.data(), d_out.get(), ood.size() * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
     }
@@ -559,17 +643,17 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     for (uint32_t i = 0; i < W; i++) { da[i] = coin.draw<F>(); db[i] = coin.draw<F>(); dg[i] = coin.draw<F>(); }
     for (size_t i = 0; i < C; i++) dc[i] = coin.draw<F>();
     const T lambda = coin.draw<F>(), mu = coin.draw<F>();
-    // FRI evaluations per layer: [DEG][dom] component arrays, natural order
+    // FRI evaluations per layer: [DEG][dom] component arrays, natural order (dom = this rank's share while the layer is sharded)
     std::vector<DevBuf<uint64_t>> fri_vals;
-    fri_vals.emplace_back(ctx, (size_t)F::DEG * N);
+    fri_vals.emplace_back(ctx, (size_t)F::DEG * M);
     {
-        // deg(DEEP) < n: evaluate it on the n-point coset 7<w_n> (every blowup-th LDE row), interpolate (the plain inverse
-        // transform of values on 7<w_n> yields exactly the 7^i-prescaled coefficients), extend like any other column.
-        NttTables* tN = ctx->ntt_tables(log_N);
+        // deg(DEEP) < n: evaluate it on the n-point coset h<w_n> (every (M/n)-th LDE row), interpolate (the plain inverse
+        // transform of values on h<w_n> yields exactly the h^i-prescaled coefficients), extend like any other column.
+        NttTables* tM = ctx->ntt_tables(log_M);
         DevBuf<uint64_t> dsm(ctx, (size_t)F::DEG * n);
         DeepArgs<F> a{};
-        a.tlde = tlde.data.get(); a.clde = clde.data.get(); a.N = N; a.count = n; a.row_step = (uint32_t)B; a.W = W; a.C = (uint32_t)C;
-        a.tw_lo = tN->lo_fwd; a.tw_hi = tN->hi_fwd; a.tw_h = tN->h;
+        a.tlde = tlde.data.get(); a.clde = clde.data.get(); a.N = M; a.count = n; a.row_step = (uint32_t)Bl; a.W = W; a.C = (uint32_t)C;
+        a.tw_lo = tM->lo_fwd; a.tw_hi = tM->hi_fwd; a.tw_h = tM->h; a.offset = h;
         a.z = z; a.z_next = z_next; a.z_c = z_c; a.z_conj = F::conj(z); a.lambda = lambda; a.mu = mu;
         ParamPack pp(ctx);
         const size_t i0 = pp.add(ood_cur), i1 = pp.add(ood_next), i2 = pp.add(ood_h), i3 = pp.add(da), i4 = pp.add(db), i5 = pp.add(dg), i6 = pp.add(dc);
@@ -579,21 +663,46 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         for (int d = 0; d < F::DEG; d++) a.out[d] = dsm.get() + (size_t)d * n;
         launch_deep<F>(ctx, a);
         ctx->ntt_inverse(dsm.get(), n, F::DEG, log_n, 1, 1, 1, 0);
-        ctx->ntt_forward(dsm.get(), n, fri_vals[0].get(), N, F::DEG, log_N, log_B);
+        ctx->ntt_forward(dsm.get(), n, fri_vals[0].get(), M, F::DEG, log_M, log_Bl);
     }
     ms.deep = clk.lap();
 
-    // 9. FRI commit phase [a15]: layers + 1 rounds (the last commits the remainder)
-    std::vector<MerkleTree> fri_trees;
+    // 9. FRI commit phase [a15]: layers + 1 rounds (the last commits the remainder). A sharded layer of global domain Dom
+    //    is this rank's coset 7 w_Dom^rank <w_(Dom/G)> (the fold groups {i + j*Dom/F} stay inside one coset); once the
+    //    per-peer digest exchange would drop below min_peer digests the layer is all-gathered and the rest runs unsharded.
+    std::vector<Commitment> fri_coms;
+    std::vector<char> fri_sharded;
     {
-        uint64_t dom = N;
+        uint64_t Dom = N;
+        bool sharded = G > 1;
         for (int l = 0; l <= layers; l++) {
-            const size_t rows = dom / Fd;
+            if (sharded && (l == layers || Dom / Fd / G / G < min_peer)) {
+                const size_t Lc = Dom / G;
+                DevBuf<uint64_t> all(ctx, (size_t)F::DEG * Dom), full(ctx, (size_t)F::DEG * Dom);
+                comm_all_gather(fri_vals[l].get(), all.get(), (size_t)F::DEG * Lc * 8);     // [rank][component][t]
+                for (int d = 0; d < F::DEG; d++)
+                    launch_interleave_u64(ctx, all.get() + (size_t)d * Lc, (size_t)F::DEG * Lc, full.get() + (size_t)d * Dom, G, Lc);
+                fri_vals[l] = std::move(full);
+                sharded = false;
+            }
+            const int parts = sharded ? G : 1;
+            const size_t dom = Dom / parts, rows = dom / Fd;          // local domain / local leaf count
             const FriSrc fsrc{fri_vals[l].get(), fri_vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd};
-            fri_trees.push_back(commit_fri_layer(fsrc));
-            MerkleTree& t = fri_trees.back();
-            wdigest(proof.commitments, t.root());
-            coin.reseed(t.root());
+            fri_sharded.push_back(sharded);
+            if (sharded) {
+                DevBuf<Digest> local(ctx, rows);
+                ctx->hash_fri_rows(fsrc, local.get());
+                fri_coms.push_back(commit_exchange(local, rows));
+            } else {
+                Commitment c;
+                c.tree = commit_fri_layer(fsrc);
+                c.n_global = rows;
+                c.root = c.tree.root();
+                fri_coms.push_back(std::move(c));
+            }
+            const Digest root = fri_coms.back().root;
+            wdigest(proof.commitments, root);
+            coin.reseed(root);
             const T alpha = coin.draw<F>();
             if (l == layers) break;   // alpha drawn after the remainder commitment is unused
             fri_vals.emplace_back(ctx, (size_t)F::DEG * rows);
@@ -603,11 +712,13 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             if (F::DEG == 1) { a.in[1] = a.in[0]; a.out[1] = a.out[0]; }
             a.rows = rows; a.fold = (int)Fd; a.alpha = alpha;
             a.twi_lo = td->lo_inv; a.twi_hi = td->hi_inv; a.tw_h = td->h;
-            a.gen_inv = gen_inv; a.fold_inv = gl::inv(Fd);
+            // row t of a sharded layer sits at x = 7 w_Dom^(t*G + rank) = (7 w_Dom^rank) * w_dom^t
+            a.gen_inv = sharded ? gl::inv(gl::mul(gl::GEN, gl::pow(gl::root_of_unity(ilog2(Dom)), (uint64_t)rank))) : gen_inv;
+            a.fold_inv = gl::inv(Fd);
             uint64_t wFi = gl::inv(gl::root_of_unity(ilog2(Fd)));
             for (size_t m = 0; m < Fd; m++) a.dft[m] = gl::pow(wFi, m);
             launch_fri_fold<F>(ctx, a);
-            dom = rows;
+            Dom /= Fd;
         }
     }
     ms.fri = clk.lap();
@@ -621,7 +732,8 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     ms.grind = clk.lap();
 
     // 11. queries [a17]: every position / node index is known up front, so all gathers are issued behind ONE upload and
-    //     read back with ONE download (one stream synchronisation for the whole opening phase).
+    //     read back with ONE download (one stream synchronisation for the whole opening phase). Sharded: every rank lays
+    //     out the same value block, fills the items it owns (zeros elsewhere) and ONE all-reduce completes it everywhere.
     std::vector<uint64_t> pos = coin.draw_integers(opt_.num_queries, N);
     {
         const size_t Q = pos.size(), tw = W, cw = C * F::DEG;
@@ -632,22 +744,40 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             for (int l = 0; l < layers; l++) { fp = fold_positions(fp, dom, Fd); fpos[l] = fp; dom /= Fd; }
         }
         const uint64_t rem_dom = N / [&] { uint64_t d = 1; for (int l = 0; l < layers; l++) d *= Fd; return d; }();
-        // node index plans per tree: trace, composition, FRI layers
-        std::vector<const MerkleTree*> trees{&ttree, &ctree};
-        std::vector<std::vector<std::vector<uint64_t>>> plans{batch_proof_indices(ttree.n, pos), batch_proof_indices(ctree.n, pos)};
-        for (int l = 0; l < layers; l++) { trees.push_back(&fri_trees[l]); plans.push_back(batch_proof_indices(fri_trees[l].n, fpos[l])); }
+        // node index plans per tree (global heap indices): trace, composition, FRI layers
+        std::vector<const Commitment*> coms{&tcom, &ccom};
+        std::vector<std::vector<std::vector<uint64_t>>> plans{batch_proof_indices(N, pos), batch_proof_indices(N, pos)};
+        for (int l = 0; l < layers; l++) { coms.push_back(&fri_coms[l]); plans.push_back(batch_proof_indices(fri_coms[l].n_global, fpos[l])); }
+        // position of a row / node in this rank's arrays, GATHER_SKIP when another rank owns it
+        auto local_row = [&](uint64_t p, bool sharded) -> uint64_t {
+            if (!sharded) return (G == 1 || rank == 0) ? p : GATHER_SKIP;
+            return (p & (uint64_t)(G - 1)) == (uint64_t)rank ? p >> log_G : GATHER_SKIP;
+        };
+        auto local_node = [&](uint64_t gidx, const Commitment& c) -> uint64_t {
+            if (!c.sharded) return (G == 1 || rank == 0) ? gidx : GATHER_SKIP;
+            if (gidx < 2 * (uint64_t)G) return GATHER_SKIP;              // top levels: filled in from the host copy
+            int d = 63 - __builtin_clzll(gidx);
+            const uint64_t o = gidx - (1ull << d), sub_bits = d - log_G;
+            return (o >> sub_bits) == (uint64_t)rank ? (1ull << sub_bits) + (o & ((1ull << sub_bits) - 1)) : GATHER_SKIP;
+        };
         // index block (u64): [pos | fpos_0.. | per tree: stored node indices, then unstored (recomputed) node indices]
-        std::vector<uint64_t> idx(pos);
-        std::vector<size_t> fpos_off(layers), plan_off(trees.size()), plan_cnt(trees.size()), plan_hi(trees.size());
-        std::vector<std::vector<size_t>> plan_slot(trees.size());   // item k of the plan (in plan order) -> slot in the tree's block
-        for (int l = 0; l < layers; l++) { fpos_off[l] = idx.size(); idx.insert(idx.end(), fpos[l].begin(), fpos[l].end()); }
-        for (size_t t = 0; t < trees.size(); t++) {
+        std::vector<uint64_t> idx;
+        for (uint64_t p : pos) idx.push_back(local_row(p, G > 1));
+        std::vector<size_t> fpos_off(layers), plan_off(coms.size()), plan_cnt(coms.size()), plan_hi(coms.size());
+        std::vector<std::vector<size_t>> plan_slot(coms.size());   // item k of the plan (in plan order) -> slot in the tree's block
+        for (int l = 0; l < layers; l++) { fpos_off[l] = idx.size(); for (uint64_t p : fpos[l]) idx.push_back(local_row(p, fri_sharded[l])); }
+        for (size_t t = 0; t < coms.size(); t++) {
             plan_off[t] = idx.size();
+            const MerkleTree& tree = coms[t]->tree;
+            if (G > 1 && tree.skip) fail("sharded prove: tree with unstored levels", ST_INTERNAL);
             std::vector<uint64_t> hi, lo;
-            for (auto& v : plans[t]) for (uint64_t i : v) (i < trees[t]->stored_limit() ? hi : lo).push_back(i);
+            for (auto& v : plans[t]) for (uint64_t i : v) {
+                const bool stored = G > 1 || i < tree.stored_limit();
+                (stored ? hi : lo).push_back(G > 1 ? local_node(i, *coms[t]) : i);
+            }
             size_t nh = 0, nl = 0;
-            for (auto& v : plans[t]) for (uint64_t i : v) plan_slot[t].push_back(i < trees[t]->stored_limit() ? nh++ : hi.size() + nl++);
-            if (!lo.empty() && trees[t]->src_kind == 0) fail("batch opening: tree has unstored levels but no leaf source", ST_INTERNAL);
+            for (auto& v : plans[t]) for (uint64_t i : v) plan_slot[t].push_back((G > 1 || i < tree.stored_limit()) ? nh++ : hi.size() + nl++);
+            if (!lo.empty() && tree.src_kind == 0) fail("batch opening: tree has unstored levels but no leaf source", ST_INTERNAL);
             idx.insert(idx.end(), hi.begin(), hi.end());
             idx.insert(idx.end(), lo.begin(), lo.end());
             plan_hi[t] = hi.size();
@@ -660,52 +790,61 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         std::vector<size_t> off_frows(layers);
         for (int l = 0; l < layers; l++) { off_frows[l] = voff; voff += fpos[l].size() * Fd * F::DEG; }
         const size_t off_rem = voff; voff += (size_t)F::DEG * rem_dom;
-        std::vector<size_t> off_dig(trees.size());
-        for (size_t t = 0; t < trees.size(); t++) { off_dig[t] = voff; voff += plan_cnt[t] * 4; }
+        std::vector<size_t> off_dig(coms.size());
+        for (size_t t = 0; t < coms.size(); t++) { off_dig[t] = voff; voff += plan_cnt[t] * 4; }
         uint64_t* h_idx = (uint64_t*)ctx->stage_alloc(idx.size() * 8);
         memcpy(h_idx, idx.data(), idx.size() * 8);
         uint64_t* h_val = (uint64_t*)ctx->stage_alloc(voff * 8);
         DevBuf<uint64_t> d_idx(ctx, idx.size()), d_val(ctx, voff);
         AERO_HIP(hipMemcpyAsync(d_idx.get(), h_idx, idx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        launch_gather_rows(ctx, tlde.data.get(), N, (int)tw, d_idx.get(), (int)Q, d_val.get() + off_trows);
-        launch_gather_rows(ctx, clde.data.get(), N, (int)cw, d_idx.get(), (int)Q, d_val.get() + off_crows);
+        launch_gather_rows(ctx, tlde.data.get(), M, (int)tw, d_idx.get(), (int)Q, d_val.get() + off_trows);
+        launch_gather_rows(ctx, clde.data.get(), M, (int)cw, d_idx.get(), (int)Q, d_val.get() + off_crows);
         {
-            uint64_t dom = N;
+            uint64_t Dom = N;
             for (int l = 0; l < layers; l++) {
-                const size_t rows = dom / Fd;
+                const size_t dom = Dom / (fri_sharded[l] ? G : 1), rows = dom / Fd;
                 launch_gather_fri_rows(ctx, fri_vals[l].get(), fri_vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd,
                                        d_idx.get() + fpos_off[l], (int)fpos[l].size(), d_val.get() + off_frows[l]);
-                dom = rows;
+                Dom /= Fd;
             }
         }
-        AERO_HIP(hipMemcpyAsync(d_val.get() + off_rem, fri_vals[layers].get(), (size_t)F::DEG * rem_dom * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        for (size_t t = 0; t < trees.size(); t++) {
+        if (G == 1 || rank == 0)
+            AERO_HIP(hipMemcpyAsync(d_val.get() + off_rem, fri_vals[layers].get(), (size_t)F::DEG * rem_dom * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        else
+            AERO_HIP(hipMemsetAsync(d_val.get() + off_rem, 0, (size_t)F::DEG * rem_dom * 8, ctx->stream));
+        for (size_t t = 0; t < coms.size(); t++) {
+            const MerkleTree& tree = coms[t]->tree;
             Digest* dout = reinterpret_cast<Digest*>(d_val.get() + off_dig[t]);
             const int nh = (int)plan_hi[t], nl = (int)(plan_cnt[t] - plan_hi[t]);
-            if (nh) launch_gather_digests(ctx, trees[t]->nodes.get(), d_idx.get() + plan_off[t], nh, dout);
+            if (nh) launch_gather_digests(ctx, tree.nodes.get(), d_idx.get() + plan_off[t], nh, dout);
             if (nl) {
-                if (trees[t]->src_kind == 1) ctx->merkle_recompute(trees[t]->row_src, trees[t]->n, d_idx.get() + plan_off[t] + nh, nl, dout + nh);
-                else ctx->merkle_recompute(trees[t]->fri_src, trees[t]->n, d_idx.get() + plan_off[t] + nh, nl, dout + nh);
+                if (tree.src_kind == 1) ctx->merkle_recompute(tree.row_src, tree.n, d_idx.get() + plan_off[t] + nh, nl, dout + nh);
+                else ctx->merkle_recompute(tree.fri_src, tree.n, d_idx.get() + plan_off[t] + nh, nl, dout + nh);
             }
         }
+        if (G > 1) comm_all_reduce(d_val.get(), voff);
         AERO_HIP(hipMemcpyAsync(h_val, d_val.get(), voff * 8, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
-        auto paths = [&](size_t t, const std::vector<uint64_t>&) {
+        auto paths = [&](size_t t) {
             const Digest* raw = reinterpret_cast<const Digest*>(h_val + off_dig[t]);
             std::vector<Digest> ordered(plan_slot[t].size());
-            for (size_t k = 0; k < ordered.size(); k++) ordered[k] = raw[plan_slot[t][k]];
+            size_t k = 0;
+            for (auto& v : plans[t]) for (uint64_t i : v) {
+                ordered[k] = (coms[t]->sharded && i < 2 * (uint64_t)G) ? coms[t]->top[i] : raw[plan_slot[t][k]];
+                k++;
+            }
             return serialize_batch(plans[t], ordered.data());
         };
         QueriesBytes tq;
         for (size_t i = 0; i < Q * tw; i++) w64(tq.values, h_val[off_trows + i]);
-        tq.paths = paths(0, pos);
+        tq.paths = paths(0);
         proof.trace_queries.push_back(tq);
         for (size_t i = 0; i < Q * cw; i++) w64(proof.constraint_queries.values, h_val[off_crows + i]);
-        proof.constraint_queries.paths = paths(1, pos);
+        proof.constraint_queries.paths = paths(1);
         for (int l = 0; l < layers; l++) {
             QueriesBytes q;
             for (size_t i = 0; i < fpos[l].size() * Fd * F::DEG; i++) w64(q.values, h_val[off_frows[l] + i]);
-            q.paths = paths(2 + l, fpos[l]);
+            q.paths = paths(2 + l);
             proof.fri_layers.push_back(q);
         }
         // remainder = last layer's evaluations in natural order

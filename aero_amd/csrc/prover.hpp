@@ -112,9 +112,30 @@ struct StageMs {   // per-stage wall time (ms) of the last prove(), names after 
            fri = 0, grind = 0, queries = 0, total = 0;
 };
 
+// Exchange steps of a proof sharded over `world` GPUs (include/aero_stark.h: aero_comm). Rank k owns the LDE rows
+// j = k (mod world) = the coset 7 w_N^k <w_(N/world)>; world == 1 means the whole domain and no exchange.
+struct ShardComm {
+    int rank = 0, world = 1;
+    void* user = nullptr;
+    int32_t (*all_to_all)(void*, const void*, void*, uint64_t) = nullptr;
+    int32_t (*all_gather)(void*, const void*, void*, uint64_t) = nullptr;
+    int32_t (*all_reduce_sum_u64)(void*, void*, uint64_t) = nullptr;
+    uint32_t min_peer_digests = 64;
+};
+// A commitment as the opening phase sees it: either a whole tree on this GPU, or this rank's contiguous subtree of
+// n_global / world leaves plus the top log2(world) levels (host copy, heap order: top[1] = root, top[world + r] = subtree r).
+struct Commitment {
+    MerkleTree tree;
+    bool sharded = false;
+    size_t n_global = 0;
+    std::vector<Digest> top;
+    Digest root{};
+};
+
 class Prover {
 public:
     Prover(Context* ctx, const ProofOptions& opt) : ctx_(ctx), opt_(opt) { opt_.validate(); }
+    void set_comm(const ShardComm& c) { comm_ = c; }
     const ProofOptions& options() const { return opt_; }
     // trace: device, column-major W x 2^log_n (not modified). Returns StarkProof::to_bytes().
     Bytes prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_inputs_out);
@@ -134,8 +155,14 @@ public:
 
 private:
     template <class F> Bytes prove_impl(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_out);
+    // sharded commitment: `local` = this rank's coset leaves (count L); returns the subtree over global leaves [rank*L, (rank+1)*L)
+    Commitment commit_exchange(DevBuf<Digest>& local, size_t L);
+    void comm_all_to_all(const void* send, void* recv, size_t bytes);
+    void comm_all_gather(const void* send, void* recv, size_t bytes);
+    void comm_all_reduce(uint64_t* buf, size_t count);
     Context* ctx_;
     ProofOptions opt_;
+    ShardComm comm_;
 };
 
 // BatchMerkleProof node selection (winter-crypto 0.4 MerkleTree::prove_batch restated):

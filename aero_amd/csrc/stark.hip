@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
         const size_t rn = (r + a.blowup) & (a.N - 1);
         const uint64_t w = tw2(a.tw_lo, a.tw_hi, (uint32_t)s, a.tw_h);       // w_ce^s
         const uint64_t wi = tw2(a.twi_lo, a.twi_hi, (uint32_t)s, a.tw_h);    // w_ce^-s
-        const uint64_t x = gl::mul(gl::GEN, w);
+        const uint64_t x = gl::mul(a.offset, w);
         xs[q] = x;
         // degree adjustments without exponentiation: x^ce_n = 7^ce_n is constant on the coset
         //   x^adj_t = x^(ce_n - 1)     = K7 * x^-1
@@ -217,7 +217,7 @@ template <class F, int K> __global__ __launch_bounds__(256) void deep_kernel(Dee
 #pragma unroll
     for (int q = 0; q < K; q++) {
         const size_t r = (t + (size_t)q * nthreads) * a.row_step;
-        const uint64_t x = gl::mul(gl::GEN, tw2(a.tw_lo, a.tw_hi, (uint32_t)r, a.tw_h));
+        const uint64_t x = gl::mul(a.offset, tw2(a.tw_lo, a.tw_hi, (uint32_t)r, a.tw_h));
         xs[q] = x;
         const T xe = F::from(x);
         den[ND * q] = F::sub(xe, a.z); den[ND * q + 1] = F::sub(xe, a.z_next); den[ND * q + 2] = F::sub(xe, a.z_c);
@@ -364,7 +364,8 @@ __global__ void gather_rows_kernel(const uint64_t* cols, size_t col_stride, int 
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= npos * ncols) return;
     int q = t / ncols, c = t % ncols;
-    out[t] = cols[(size_t)c * col_stride + pos[q]];
+    const uint64_t p = pos[q];
+    out[t] = p == GATHER_SKIP ? 0 : cols[(size_t)c * col_stride + p];
 }
 // FRI rows: out[q][j][d] = comp[d][pos[q] + j*rows]
 __global__ void gather_fri_rows_kernel(const uint64_t* c0, const uint64_t* c1, int deg, size_t rows, int fold, const uint64_t* pos, int npos, uint64_t* out) {
@@ -372,12 +373,15 @@ __global__ void gather_fri_rows_kernel(const uint64_t* c0, const uint64_t* c1, i
     if (t >= npos * fold * deg) return;
     int d = t % deg, j = (t / deg) % fold, q = t / (deg * fold);
     const uint64_t* c = d ? c1 : c0;
-    out[t] = c[pos[q] + (size_t)j * rows];
+    const uint64_t p = pos[q];
+    out[t] = p == GATHER_SKIP ? 0 : c[p + (size_t)j * rows];
 }
 __global__ void gather_digests_kernel(const Digest* nodes, const uint64_t* idx, int n, Digest* out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    out[t] = nodes[idx[t]];
+    const uint64_t i = idx[t];
+    Digest z{};
+    out[t] = i == GATHER_SKIP ? z : nodes[i];
 }
 void launch_gather_rows(Context* ctx, const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out) {
     int n = npos * ncols;
@@ -392,6 +396,24 @@ void launch_gather_fri_rows(Context* ctx, const uint64_t* c0, const uint64_t* c1
 void launch_gather_digests(Context* ctx, const Digest* nodes, const uint64_t* idx, int n, Digest* out) {
     AERO_LAUNCH(ctx, "gather_digests_kernel", 0, gather_digests_kernel, dim3((n + 255) / 256), dim3(256), 0, nodes, idx, n, out);
     ctx->check_launch("gather_digests");
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Merge `parts` equally long pieces into interleaved order (coset shards -> natural order): out[u*parts + k] = in[k*src_stride + u].
+// One thread per u: `parts` coalesced read streams, one contiguous write of parts*sizeof(T) bytes per thread.
+template <class T> __global__ __launch_bounds__(256) void interleave_kernel(const T* __restrict__ in, size_t src_stride, T* __restrict__ out, int parts, size_t len) {
+    const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= len) return;
+    for (int k = 0; k < parts; k++) out[u * parts + k] = in[(size_t)k * src_stride + u];
+}
+void launch_interleave_digests(Context* ctx, const Digest* in, size_t src_stride, Digest* out, int parts, size_t len) {
+    AERO_LAUNCH(ctx, "interleave_kernel", 2 * len * parts * sizeof(Digest), (interleave_kernel<Digest>), dim3((unsigned)((len + 255) / 256)), dim3(256), 0, in, src_stride, out, parts, len);
+    ctx->check_launch("interleave_digests");
+}
+void launch_interleave_u64(Context* ctx, const uint64_t* in, size_t src_stride, uint64_t* out, int parts, size_t len) {
+    AERO_LAUNCH(ctx, "interleave_kernel", 2 * len * parts * 8, (interleave_kernel<uint64_t>), dim3((unsigned)((len + 255) / 256)), dim3(256), 0, in, src_stride, out, parts, len);
+    ctx->check_launch("interleave_u64");
 }
 
 }  // namespace aero

@@ -14,9 +14,10 @@ template <class F> struct FibConsArgs {
     const uint64_t* results;      // W/2 public results (device)
     const uint64_t *tw_lo, *tw_hi, *twi_lo, *twi_hi;   // two-level tables of w_ce and its inverse
     int tw_h;
-    uint64_t gen_inv, k7;         // 7^-1, 7^ce_n
-    const uint64_t* xn_inv;       // C entries: (7^n w_C^k)^-1
-    const uint64_t* zn_inv;       // C entries: (7^n w_C^k - 1)^-1
+    uint64_t offset;              // domain offset h (7, or 7 w_N^rank for one coset shard of the LDE domain)
+    uint64_t gen_inv, k7;         // h^-1, h^ce_n
+    const uint64_t* xn_inv;       // C entries: (h^n w_C^k)^-1
+    const uint64_t* zn_inv;       // C entries: (h^n w_C^k - 1)^-1
     uint64_t w_last;              // w_n^(n-1)
     uint64_t* out_cols;           // MODE 0: (3*DEG) x count, column-major
     uint64_t* out_h[2];           // MODE 1: DEG component arrays of ce_n values
@@ -46,6 +47,7 @@ template <class F> struct DeepArgs {
     uint32_t W, C;
     const uint64_t *tw_lo, *tw_hi;   // two-level table of w_N
     int tw_h;
+    uint64_t offset;                 // domain offset h: row r <-> x = h w_N^r
     T z, z_next, z_c, z_conj, lambda, mu;
     const T *ood_cur, *ood_next, *ood_h, *da, *db, *dg, *dc;   // device
     uint64_t* out[2];
@@ -61,7 +63,7 @@ template <class F> struct FoldArgs {
     T alpha;
     const uint64_t *twi_lo, *twi_hi;   // two-level table of w_dom^-1
     int tw_h;
-    uint64_t gen_inv, fold_inv;
+    uint64_t gen_inv, fold_inv;        // inverse of the domain offset (7, or 7 w_dom^rank for a coset shard), 1/fold
     uint64_t dft[16];                  // w_F^-m, m < fold
 };
 template <class F> void launch_fri_fold(Context* ctx, const FoldArgs<F>& a);
@@ -70,5 +72,10 @@ uint64_t run_grind(Context* ctx, const Digest& seed, uint32_t bits);
 void launch_gather_rows(Context* ctx, const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out);
 void launch_gather_fri_rows(Context* ctx, const uint64_t* c0, const uint64_t* c1, int deg, size_t rows, int fold, const uint64_t* pos, int npos, uint64_t* out);
 void launch_gather_digests(Context* ctx, const Digest* nodes, const uint64_t* idx, int n, Digest* out);
+// In all three gathers an index of GATHER_SKIP yields zeros (the item belongs to another shard).
+constexpr uint64_t GATHER_SKIP = ~0ull;
+// out[u * parts + k] = in[k * src_stride + u], u < len: merges `parts` equally long pieces into their interleaved order
+void launch_interleave_digests(Context* ctx, const Digest* in, size_t src_stride, Digest* out, int parts, size_t len);
+void launch_interleave_u64(Context* ctx, const uint64_t* in, size_t src_stride, uint64_t* out, int parts, size_t len);
 
 }  // namespace aero

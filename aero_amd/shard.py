@@ -1,0 +1,79 @@
+"""Exchange steps of a sharded proof (include/aero_stark.h: aero_comm) carried by torch.distributed.
+
+One process per GPU; backend "nccl" (= RCCL over xGMI) on a multi-GPU node, "gloo" when several ranks share one GPU
+(tests on a 1-GPU box). The library hands the callbacks raw DEVICE pointers; they are wrapped as torch tensors through
+`__cuda_array_interface__` (no copy), so the collectives run directly on the prover's buffers. This file is plumbing:
+the sharding itself (coset geometry, what is exchanged and when) lives in aero_amd/csrc/prover.hip.
+"""
+import ctypes as C
+
+_A2A = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+_AG = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+_AR = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64)
+
+
+class CommStruct(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _A2A), ("all_gather", _AG),
+                ("all_reduce_sum_u64", _AR), ("min_peer_digests", C.c_uint32)]
+
+
+class _DevPtr:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3, "strides": None}
+
+
+class TorchComm:
+    """aero_comm whose callbacks run torch.distributed collectives on the default (or given) process group."""
+
+    def __init__(self, device=0, group=None, min_peer_digests=0):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.device = torch.device("cuda", device)
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.calls = {"all_to_all": 0, "all_gather": 0, "all_reduce": 0}
+        self.bytes_sent = 0
+        self.last_error = None
+        # keep the CFUNCTYPE objects alive for as long as the struct is in use
+        self._a2a, self._ag, self._ar = _A2A(self._all_to_all), _AG(self._all_gather), _AR(self._all_reduce)
+        self.struct = CommStruct(self.rank, self.world, None, self._a2a, self._ag, self._ar, min_peer_digests)
+
+    def _t(self, ptr, nbytes):
+        return self.torch.as_tensor(_DevPtr(ptr, nbytes), device=self.device)
+
+    def _guard(self, fn):
+        try:
+            fn()
+            self.torch.cuda.synchronize(self.device)
+            return 0
+        except Exception as e:  # the C side turns a non-zero status into AERO_E_COMM
+            self.last_error = e
+            return 1
+
+    def _all_to_all(self, _user, send, recv, nbytes):
+        def run():
+            n = int(nbytes) * self.world
+            self.dist.all_to_all_single(self._t(recv, n), self._t(send, n), group=self.group)
+            self.calls["all_to_all"] += 1
+            self.bytes_sent += int(nbytes) * (self.world - 1)
+        return self._guard(run)
+
+    def _all_gather(self, _user, send, recv, nbytes):
+        def run():
+            out, inp = self._t(recv, int(nbytes) * self.world), self._t(send, int(nbytes))
+            try:
+                self.dist.all_gather_into_tensor(out, inp, group=self.group)
+            except (RuntimeError, NotImplementedError):
+                self.dist.all_gather(list(out.chunk(self.world)), inp, group=self.group)
+            self.calls["all_gather"] += 1
+            self.bytes_sent += int(nbytes) * (self.world - 1)
+        return self._guard(run)
+
+    def _all_reduce(self, _user, buf, count):
+        def run():
+            t = self._t(buf, int(count) * 8).view(self.torch.int64)   # wrapping two's-complement sum == u64 sum
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.calls["all_reduce"] += 1
+            self.bytes_sent += int(count) * 8
+        return self._guard(run)

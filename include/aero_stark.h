@@ -134,6 +134,35 @@ int32_t aero_prove_fib(aero_ctx* ctx, const aero_matrix* trace, const aero_proof
 /* Same with the trace in host memory (includes the host-to-device copy). */
 int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n,
                             const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
+/* ---- one proof sharded over the GPUs of a node ------------------------------------------------------------------------------ */
+/* The exchange steps of a sharded proof, supplied by the host (one process per GPU; torch.distributed over RCCL in this
+ * repo's harness, `ncclSend/Recv`-style bindings from Rust). The reference has no multi-device prover; its parallel
+ * decomposition is the worker pool of aero-sdk/miden-wasm/src/proving_worker.rs:276-321 (row-hash batches) and :374-437
+ * (constraint fragments), whose gather step these callbacks replace. All buffers are DEVICE pointers on the context's GPU.
+ * Each callback must return only when `recv` (or `buf`) is complete and safe to read from any stream of the device;
+ * the library synchronises its own stream before calling. Return 0 on success.
+ *   all_to_all ........ send = world chunks of `bytes` (chunk r goes to rank r); recv = world chunks (chunk r came from rank r)
+ *   all_gather ........ send = `bytes`; recv = world chunks of `bytes` in rank order
+ *   all_reduce_sum_u64  in-place wrapping sum of `count` u64 over all ranks
+ * min_peer_digests: a FRI layer stays sharded while every rank still sends at least this many leaf digests to every peer;
+ * smaller layers are all-gathered once and finished redundantly on every rank (0 = default 64). */
+typedef struct aero_comm {
+    int32_t rank, world; /* world = power of two, <= blowup factor */
+    void* user;
+    int32_t (*all_to_all)(void* user, const void* send, void* recv, uint64_t bytes);
+    int32_t (*all_gather)(void* user, const void* send, void* recv, uint64_t bytes);
+    int32_t (*all_reduce_sum_u64)(void* user, void* buf, uint64_t count);
+    uint32_t min_peer_digests;
+} aero_comm;
+/* `Prover::prove` + `to_bytes` for ONE trace proven cooperatively by comm->world GPUs (BASELINE config 4). Rank k owns
+ * the LDE rows j = k (mod world), i.e. the coset 7 w_N^k <w_(N/world)>: LDEs, row hashing, constraint evaluation, DEEP
+ * and FRI folds are local; per commitment the ranks exchange leaf digests (all_to_all) so that each builds one
+ * contiguous Merkle subtree, and all-gather the subtree roots — the only collective on the transcript's critical path.
+ * Every rank passes the whole trace (device) and receives the identical proof bytes, which are byte-identical to
+ * aero_prove_fib's. */
+int32_t aero_prove_fib_sharded(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_proof_options* options,
+                               uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
+
 /* bincode ProofData{input_bytes, proof_bytes} = u64 len || inputs || u64 len || proof
  * (miden-proof-generator/src/lib.rs:1-6, main.rs:49-51). */
 int32_t aero_proof_container(const uint8_t* inputs, size_t inputs_len, const uint8_t* proof, size_t proof_len, uint8_t** out,

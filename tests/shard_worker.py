@@ -1,0 +1,48 @@
+"""One rank of a sharded proof (spawned by test_gpu_sharded.py; several ranks may share one GPU over gloo).
+
+argv: out_dir cases_json. env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT. Every rank proves every case cooperatively and
+writes <out_dir>/case<i>.rank<r>.bin; rank 0 also writes the single-GPU proof of the same case as case<i>.single.bin.
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    out_dir, cases = sys.argv[1], json.loads(sys.argv[2])
+    import torch
+    import torch.distributed as dist
+    import aero_amd
+    from aero_amd.shard import TorchComm
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    ndev = torch.cuda.device_count()
+    dev = rank % ndev
+    torch.cuda.set_device(dev)
+    backend = "nccl" if ndev >= world else "gloo"
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    ctx = aero_amd.Context(dev)
+    for i, case in enumerate(cases):
+        opts = aero_amd.ProofOptions(*case["options"])
+        comm = TorchComm(device=dev, min_peer_digests=case.get("min_peer", 0))
+        trace = ctx.trace_upload(aero_amd.fib_trace(case["width"], case["log_n"]))
+        proof, pub = ctx.prove_fib_sharded(comm, trace, opts)
+        with open(os.path.join(out_dir, f"case{i}.rank{rank}.bin"), "wb") as f:
+            f.write(proof)
+        if rank == 0:
+            single, pub1 = ctx.prove_fib(trace, opts)
+            assert pub1 == pub
+            with open(os.path.join(out_dir, f"case{i}.single.bin"), "wb") as f:
+                f.write(single)
+            with open(os.path.join(out_dir, f"case{i}.comm.json"), "w") as f:
+                json.dump({"calls": comm.calls, "bytes_sent": comm.bytes_sent, "backend": backend}, f)
+        trace.free()
+        dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

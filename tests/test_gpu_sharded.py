@@ -1,0 +1,101 @@
+"""ONE proof sharded over several ranks (aero_prove_fib_sharded) must be byte-identical to the single-GPU proof and to
+the CPU oracle's. On a 1-GPU box the ranks share the GPU and exchange over gloo; the exchange code path (device
+pointers -> torch.distributed collectives) is the one a multi-GPU node runs with backend "nccl"."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT = [27, 8, 16, 4, 1, 8, 8]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(world, cases, tmp_path, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world))
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), str(tmp_path), json.dumps(cases)],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0].decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    res = []
+    for i in range(len(cases)):
+        single = open(tmp_path / f"case{i}.single.bin", "rb").read()
+        per_rank = [open(tmp_path / f"case{i}.rank{r}.bin", "rb").read() for r in range(world)]
+        res.append((single, per_rank, json.load(open(tmp_path / f"case{i}.comm.json"))))
+    return res
+
+
+def check(oracle, world, cases, tmp_path):
+    for case, (single, per_rank, comm) in zip(cases, run_world(world, cases, tmp_path)):
+        for r, p in enumerate(per_rank):
+            assert p == single, f"world {world} rank {r}: sharded proof differs from the single-GPU proof for {case}"
+        ref = oracle.prove_fib(case["width"], case["log_n"], case["options"])[0]
+        assert single == ref, f"proof differs from the oracle for {case}"
+        assert comm["calls"]["all_reduce"] == 1, "the opening phase must need exactly one all-reduce"
+        # one digest exchange + one root all-gather per sharded commitment; at most one extra all-gather (FRI un-shard)
+        assert comm["calls"]["all_gather"] in (comm["calls"]["all_to_all"], comm["calls"]["all_to_all"] + 1)
+        assert comm["calls"]["all_to_all"] >= 2
+
+
+CASES_SMALL = [
+    {"width": 2, "log_n": 10, "options": DEFAULT},
+    {"width": 2, "log_n": 10, "options": DEFAULT, "min_peer": 1},
+    {"width": 4, "log_n": 12, "options": [27, 8, 16, 4, 2, 8, 8], "min_peer": 1},        # quadratic extension
+    {"width": 6, "log_n": 11, "options": [20, 8, 8, 4, 1, 4, 6], "min_peer": 2},         # fold 4
+    {"width": 2, "log_n": 9, "options": [16, 16, 4, 4, 1, 2, 5], "min_peer": 1},         # blowup 16, fold 2
+    {"width": 72, "log_n": 10, "options": DEFAULT, "min_peer": 4},                       # Miden-width rows
+    {"width": 2, "log_n": 3, "options": [4, 8, 0, 4, 1, 2, 3], "min_peer": 1},           # smallest trace
+]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_proof_identical_small(oracle, world, tmp_path):
+    check(oracle, world, CASES_SMALL, tmp_path)
+
+
+def test_sharded_proof_identical_config2_shape(oracle, tmp_path):
+    """2^16 rows with the default sharding threshold (three sharded FRI layers at world 2), base and quadratic field."""
+    cases = [{"width": 2, "log_n": 16, "options": DEFAULT}, {"width": 2, "log_n": 16, "options": [27, 8, 16, 4, 2, 8, 8]}]
+    check(oracle, 2, cases, tmp_path)
+    check(oracle, 8, cases[:1], tmp_path)
+
+
+def test_sharded_rejects_bad_world(tmp_path):
+    """world must be a power of two not larger than the blowup factor; a missing callback is refused."""
+    import ctypes as C
+    import aero_amd
+    from aero_amd.shard import CommStruct
+    ctx = aero_amd.Context(0)
+    trace = ctx.trace_upload(aero_amd.fib_trace(2, 6))
+    opts = aero_amd.ProofOptions(*DEFAULT)
+    proof, plen = aero_amd.u8p(), C.c_size_t(0)
+    for rank, world in [(0, 3), (0, 16), (2, 2), (-1, 2)]:
+        cs = CommStruct(rank, world, None)
+        rc = aero_amd.lib().aero_prove_fib_sharded(ctx.h, C.byref(cs), trace.h, C.byref(opts), C.byref(proof), C.byref(plen), None)
+        assert rc == -1, (rank, world, rc)
+    trace.free()
+    ctx.close()
