@@ -114,6 +114,8 @@ public:
     void hash_fri_rows(const FriSrc& src, Digest* leaves);
     // nodes[n + i] already hold the leaves; fills nodes[1 .. n-1]
     void merkle_build(Digest* nodes, size_t n);
+    // same when the leaf level holds 2^log_parts pieces in arrival order (leaf u in slot n + (u mod parts)*(n/parts) + u/parts)
+    void merkle_build_parts(Digest* nodes, size_t n, int log_parts);
     // levels above a stored level of c nodes (heap indices [c, 2c)) up to the root
     void merkle_upper(Digest* nodes, size_t c);
     // fused leaf hashing + whole tree; the lowest `skip` (0 or 3) levels are not stored (nodes holds 2n >> skip slots)

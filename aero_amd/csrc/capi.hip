@@ -343,7 +343,7 @@ static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, i
         ShardComm sc;
         sc.rank = comm->rank; sc.world = comm->world; sc.user = comm->user;
         sc.all_to_all = comm->all_to_all; sc.all_gather = comm->all_gather; sc.all_reduce_sum_u64 = comm->all_reduce_sum_u64;
-        sc.min_peer_digests = comm->min_peer_digests ? comm->min_peer_digests : 64;
+        sc.min_peer_digests = comm->min_peer_digests ? comm->min_peer_digests : 2048;
         p.set_comm(sc);
     }
     p.collect_stage_times = ctx->stage_timing;

@@ -156,6 +156,22 @@ __global__ __launch_bounds__(256) void merkle_up3_kernel(Digest* nodes, size_t m
     build3(d, nodes, child_base, 1);
 }
 
+// Same, for the subtree a rank of a sharded proof builds from exchanged leaf digests: the leaf level holds 2^log_parts
+// pieces (one per source rank, in arrival order) instead of the interleaved natural order, i.e. leaf u sits in slot
+// n + (u mod parts) * (n / parts) + u / parts. Reading through that permutation saves a reordering pass over the leaves.
+__global__ __launch_bounds__(256) void merkle_up3_parts_kernel(Digest* nodes, size_t n, int log_parts) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n / 8) return;
+    const size_t piece = n >> log_parts, pmask = ((size_t)1 << log_parts) - 1;
+    Digest d[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const size_t u = t * 8 + i;
+        d[i] = load_digest(&nodes[n + (u & pmask) * piece + (u >> log_parts)]);
+    }
+    build3(d, nodes, n + t * 8, 1);
+}
+
 // one plain row-hash pass (wide matrices, and the C-ABI hashing seam): lane <-> row, coalesced column reads
 template <class Src> __global__ __launch_bounds__(256) void hash_rows_kernel(Src src, size_t rows, Digest* leaves) {
     size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -253,6 +269,12 @@ void Context::merkle_upper(Digest* nodes, size_t c) {
 void Context::merkle_build(Digest* nodes, size_t n) {
     if (n < 2 || (n & (n - 1))) fail("merkle_build: leaf count must be a power of two >= 2");
     merkle_upper(nodes, n);
+}
+
+void Context::merkle_build_parts(Digest* nodes, size_t n, int log_parts) {
+    if (n < 8 || (n & (n - 1)) || (n >> log_parts) == 0) fail("merkle_build_parts: leaf count must be a power of two >= 8 and >= parts");
+    AERO_LAUNCH(this, "merkle_up3_kernel", n * 32 + (n - n / 8) * 32, merkle_up3_parts_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, nodes, n, log_parts);
+    merkle_upper(nodes, n / 8);
 }
 
 template <class Src> static size_t src_leaf_bytes(const Src&);

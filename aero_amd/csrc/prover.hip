@@ -137,6 +137,8 @@ std::string Context::kt_report() {
     return out;
 }
 
+static int ilog2(uint64_t x) { int r = 0; while ((1ull << r) < x) r++; return r; }
+
 // ================================================================================================
 // options, coin, proof bytes
 void ProofOptions::validate() const {
@@ -316,7 +318,6 @@ Bytes open_batch(Context* ctx, const MerkleTree& tree, const std::vector<uint64_
 
 // ================================================================================================
 // stage-level API
-static int ilog2(uint64_t x) { int r = 0; while ((1ull << r) < x) r++; return r; }
 
 Matrix Prover::interpolate_columns(const uint64_t* trace_dev, uint32_t width, int log_n) {
     size_t n = (size_t)1 << log_n;
@@ -446,14 +447,21 @@ Commitment Prover::commit_exchange(DevBuf<Digest>& local, size_t L) {
     Commitment c;
     c.sharded = true;
     c.n_global = L * G;
-    DevBuf<Digest> recv(ctx, L);
-    comm_all_to_all(local.get(), recv.get(), (L / G) * sizeof(Digest));   // chunk r = my leaves t in [r*L/G, (r+1)*L/G)
     c.tree = MerkleTree(ctx, L);
-    if (L >= 2) {
-        launch_interleave_digests(ctx, recv.get(), L / G, c.tree.leaves(), G, L / G);
-        ctx->merkle_build(c.tree.nodes.get(), L);
+    if (L >= 8) {
+        // the pieces land straight in the leaf level (arrival order); the tree is built through the leaf permutation
+        comm_all_to_all(local.get(), c.tree.leaves(), (L / G) * sizeof(Digest));   // chunk r = my leaves t in [r*L/G, (r+1)*L/G)
+        c.leaf_parts_log = ilog2(G);
+        ctx->merkle_build_parts(c.tree.nodes.get(), L, c.leaf_parts_log);
     } else {
-        AERO_HIP(hipMemcpyAsync(c.tree.nodes.get() + 1, recv.get(), sizeof(Digest), hipMemcpyDeviceToDevice, ctx->stream));
+        DevBuf<Digest> recv(ctx, L);
+        comm_all_to_all(local.get(), recv.get(), (L / G) * sizeof(Digest));
+        if (L >= 2) {
+            launch_interleave_digests(ctx, recv.get(), L / G, c.tree.leaves(), G, L / G);
+            ctx->merkle_build(c.tree.nodes.get(), L);
+        } else {
+            AERO_HIP(hipMemcpyAsync(c.tree.nodes.get() + 1, recv.get(), sizeof(Digest), hipMemcpyDeviceToDevice, ctx->stream));
+        }
     }
     DevBuf<Digest> roots(ctx, G);
     comm_all_gather(c.tree.nodes.get() + 1, roots.get(), sizeof(Digest));
@@ -497,7 +505,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     if (G > 1 && M < (size_t)G) fail("sharded prove: LDE domain too small for this many ranks");
     const uint64_t h = gl::mul(gl::GEN, gl::pow(gl::root_of_unity(log_N), (uint64_t)rank));
     const uint64_t h_inv = gl::inv(h);
-    const uint32_t min_peer = comm_.min_peer_digests ? comm_.min_peer_digests : 64;
+    const uint32_t min_peer = comm_.min_peer_digests ? comm_.min_peer_digests : 2048;
 
     StageMs ms;
     ctx->sync();
@@ -758,7 +766,11 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             if (gidx < 2 * (uint64_t)G) return GATHER_SKIP;              // top levels: filled in from the host copy
             int d = 63 - __builtin_clzll(gidx);
             const uint64_t o = gidx - (1ull << d), sub_bits = d - log_G;
-            return (o >> sub_bits) == (uint64_t)rank ? (1ull << sub_bits) + (o & ((1ull << sub_bits) - 1)) : GATHER_SKIP;
+            if ((o >> sub_bits) != (uint64_t)rank) return GATHER_SKIP;
+            const uint64_t u = o & ((1ull << sub_bits) - 1), L = 1ull << sub_bits;
+            if (L == c.tree.n && c.leaf_parts_log)             // leaf level stored as pieces in arrival order
+                return L + (u & ((1ull << c.leaf_parts_log) - 1)) * (L >> c.leaf_parts_log) + (u >> c.leaf_parts_log);
+            return L + u;
         };
         // index block (u64): [pos | fpos_0.. | per tree: stored node indices, then unstored (recomputed) node indices]
         std::vector<uint64_t> idx;

@@ -120,7 +120,7 @@ struct ShardComm {
     int32_t (*all_to_all)(void*, const void*, void*, uint64_t) = nullptr;
     int32_t (*all_gather)(void*, const void*, void*, uint64_t) = nullptr;
     int32_t (*all_reduce_sum_u64)(void*, void*, uint64_t) = nullptr;
-    uint32_t min_peer_digests = 64;
+    uint32_t min_peer_digests = 2048;
 };
 // A commitment as the opening phase sees it: either a whole tree on this GPU, or this rank's contiguous subtree of
 // n_global / world leaves plus the top log2(world) levels (host copy, heap order: top[1] = root, top[world + r] = subtree r).
@@ -128,6 +128,7 @@ struct Commitment {
     MerkleTree tree;
     bool sharded = false;
     size_t n_global = 0;
+    int leaf_parts_log = 0;   // > 0: the subtree's leaf level is stored as 2^k pieces in arrival order (Context::merkle_build_parts)
     std::vector<Digest> top;
     Digest root{};
 };

@@ -77,3 +77,45 @@ class TorchComm:
             self.calls["all_reduce"] += 1
             self.bytes_sent += int(count) * 8
         return self._guard(run)
+
+
+class LoopbackComm:
+    """Timing aid for a 1-GPU box: an aero_comm for rank `rank` of `world` whose exchanges stay on the device (all_to_all
+    copies send -> recv, all_gather replicates the local piece, all_reduce is a no-op). The proof it yields is NOT valid
+    (peers' digests are replaced by this rank's own) but the rank performs exactly the kernels, transfers sizes and host
+    round trips of a real sharded run, so its wall-clock is the per-rank compute time of a `world`-GPU proof."""
+
+    def __init__(self, rank, world, device=0, min_peer_digests=0):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.rank, self.world = rank, world
+        self.calls = {"all_to_all": 0, "all_gather": 0, "all_reduce": 0}
+        self.bytes_sent = 0
+        self.last_error = None
+        self._a2a, self._ag, self._ar = _A2A(self._all_to_all), _AG(self._all_gather), _AR(self._all_reduce)
+        self.struct = CommStruct(rank, world, None, self._a2a, self._ag, self._ar, min_peer_digests)
+
+    def _t(self, ptr, nbytes):
+        return self.torch.as_tensor(_DevPtr(ptr, nbytes), device=self.device)
+
+    def _all_to_all(self, _user, send, recv, nbytes):
+        n = int(nbytes) * self.world
+        self._t(recv, n).copy_(self._t(send, n))
+        self.torch.cuda.synchronize(self.device)
+        self.calls["all_to_all"] += 1
+        self.bytes_sent += int(nbytes) * (self.world - 1)
+        return 0
+
+    def _all_gather(self, _user, send, recv, nbytes):
+        n = int(nbytes)
+        self._t(recv, n * self.world).view(self.world, n).copy_(self._t(send, n).unsqueeze(0).expand(self.world, n))
+        self.torch.cuda.synchronize(self.device)
+        self.calls["all_gather"] += 1
+        self.bytes_sent += n * (self.world - 1)
+        return 0
+
+    def _all_reduce(self, _user, buf, count):
+        self.calls["all_reduce"] += 1
+        self.bytes_sent += int(count) * 8
+        return 0

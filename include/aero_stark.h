@@ -145,7 +145,7 @@ int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint
  *   all_gather ........ send = `bytes`; recv = world chunks of `bytes` in rank order
  *   all_reduce_sum_u64  in-place wrapping sum of `count` u64 over all ranks
  * min_peer_digests: a FRI layer stays sharded while every rank still sends at least this many leaf digests to every peer;
- * smaller layers are all-gathered once and finished redundantly on every rank (0 = default 64). */
+ * smaller layers are all-gathered once and finished redundantly on every rank (0 = default 2048 = 64 KiB messages). */
 typedef struct aero_comm {
     int32_t rank, world; /* world = power of two, <= blowup factor */
     void* user;

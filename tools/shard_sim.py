@@ -1,0 +1,47 @@
+"""Per-rank compute time of a sharded proof, measured on ONE GPU with loopback exchanges (aero_amd.shard.LoopbackComm).
+usage: python tools/shard_sim.py [log_n ...]   -> JSON lines (one per log_n / world)"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+torch.cuda.init()   # torch bundles its own HIP runtime: it must initialise before libaero_stark's
+import aero_amd
+from aero_amd.shard import LoopbackComm
+
+
+def main():
+    logs = [int(a) for a in sys.argv[1:]] or [20]
+    ctx = aero_amd.Context(0)
+    opts = aero_amd.ProofOptions.with_96_bit_security()
+    for log_n in logs:
+        trace = ctx.trace_upload(aero_amd.fib_trace(2, log_n))
+        reps = 7 if log_n <= 20 else 3
+        base = None
+        for world in (1, 2, 4, 8):
+            for rank in sorted({0, world - 1}):
+                comm = LoopbackComm(rank, world)
+                ts = []
+                for i in range(reps + 1):
+                    t0 = time.perf_counter()
+                    ctx.prove_fib_sharded(comm, trace, opts)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                ts = sorted(ts[1:])
+                ms = ts[len(ts) // 2]
+                ctx.set_stage_timing(True)
+                ctx.prove_fib_sharded(comm, trace, opts)
+                st = ctx.last_stage_ms()
+                ctx.set_stage_timing(False)
+                if world == 1:
+                    base = ms
+                print(json.dumps({"log_n": log_n, "world": world, "rank": rank, "ms": round(ms, 3), "speedup_vs_1": round(base / ms, 2),
+                                  "exchanges": dict(comm.calls), "bytes_sent_per_proof": comm.bytes_sent // (reps + 2),
+                                  "stages_ms": {k: round(v, 3) for k, v in st.items()}}), flush=True)
+        trace.free()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
