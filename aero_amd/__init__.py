@@ -306,6 +306,22 @@ class Context:
         lib().aero_free(proof)
         return data, pub.tolist()
 
+    def prove_fib_aux(self, trace: "Matrix", aux_width, aux_rands, options: ProofOptions, comm=None):
+        """FibAir plus one auxiliary segment of `aux_width` columns built from `aux_rands` coin elements
+        (aero_prove_fib_aux); comm = None or a shard communicator. Returns (proof_bytes, public_inputs)."""
+        proof = u8p()
+        plen = C.c_size_t(0)
+        w, _ = trace.shape
+        pub = np.zeros(w // 2, np.uint64)
+        rc = lib().aero_prove_fib_aux(self.h, C.byref(comm.struct) if comm is not None else None, trace.h, C.c_uint32(aux_width),
+                                      C.c_uint32(aux_rands), C.byref(options), C.byref(proof), C.byref(plen), _p64(pub))
+        if rc != 0 and getattr(comm, "last_error", None) is not None:
+            raise AeroError(rc, f"{lib().aero_last_error(self.h).decode()} ({comm.last_error!r})")
+        self._ck(rc)
+        data = C.string_at(proof, plen.value)
+        lib().aero_free(proof)
+        return data, pub.tolist()
+
     # ---- instrumentation
     def set_stage_timing(self, on):
         self._ck(lib().aero_set_stage_timing(self.h, C.c_int32(1 if on else 0)))

@@ -333,10 +333,11 @@ int32_t aero_grind(aero_ctx* ctx, const uint8_t seed[32], uint32_t bits, uint64_
 
 // ---- whole proof ----------------------------------------------------------------------------------------
 static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, int log_n, const aero_proof_options* o, uint8_t** proof,
-                     size_t* proof_len, uint64_t* pub_out, const aero_comm* comm = nullptr) {
+                     size_t* proof_len, uint64_t* pub_out, const aero_comm* comm = nullptr, uint32_t aux_width = 0, uint32_t aux_rands = 0) {
     REQUIRE(o && proof && proof_len, "prove: null argument");
     ProofOptions po{o->num_queries, o->blowup_factor, o->grinding_factor, o->hash_fn, o->field_extension, o->fri_folding_factor, o->fri_log_max_remainder};
     Prover p(ctx->c, po);
+    p.set_aux_segment(aux_width, aux_rands);
     if (comm) {
         REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "prove_fib_sharded: bad rank / world");
         REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "prove_fib_sharded: missing exchange callback");
@@ -373,6 +374,14 @@ int32_t aero_prove_fib_sharded(aero_ctx* ctx, const aero_comm* comm, const aero_
         REQUIRE(trace, "prove_fib_sharded: null trace");
         REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0, "prove_fib_sharded: trace length must be a power of two");
         do_prove(ctx, trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows), options, proof, proof_len, pub_out, comm);
+    });
+}
+int32_t aero_prove_fib_aux(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, uint32_t aux_width, uint32_t aux_rands,
+                           const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out) {
+    return guard(ctx, [&] {
+        REQUIRE(trace, "prove_fib_aux: null trace");
+        REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0, "prove_fib_aux: trace length must be a power of two");
+        do_prove(ctx, trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows), options, proof, proof_len, pub_out, comm, aux_width, aux_rands);
     });
 }
 int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n, const aero_proof_options* options,

@@ -484,6 +484,9 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     const size_t N = n * B, C = FibAir::ce_blowup_factor(), ceN = C * n;
     const int log_N = log_n + log_B, log_ce = ilog2(ceN);
     if (W < 2 || (W & 1) || W > 254) fail("prove: FibAir needs an even column count in [2, 254]");
+    const uint32_t A = aux_width_, R = aux_rands_;
+    if (A > 255 - W || (A && (R == 0 || R > 255))) fail("prove: auxiliary segment needs 1..255 random elements and main + aux width <= 255");
+    const uint32_t TW = W + A;
     if (B < C) fail("prove: blowup factor smaller than the constraint evaluation blowup");
     if (log_N > gl::TWO_ADICITY) fail("prove: LDE domain exceeds the field's two-adicity (2^32)");
     if (log_n < 3) fail("prove: trace must have at least 8 rows");
@@ -515,7 +518,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
 
     // 0. AIR, public inputs, channel [proving_worker.rs:248-268]
     FibAir air;
-    air.width = W; air.log_n = log_n; air.results.resize(W / 2);
+    air.width = W; air.log_n = log_n; air.results.resize(W / 2); air.aux_width = A; air.aux_rands = R;
     {
         // results[k] = trace[2k+1][n-1]
         DevBuf<uint64_t> d_pos(ctx, 1), d_row(ctx, W);
@@ -530,7 +533,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     if (pub_out) *pub_out = air.results;
     HostCoin coin = HostCoin::from_elements(air.results.data(), (uint32_t)air.results.size());
     StarkProof proof;
-    proof.main_width = (uint8_t)W; proof.log_n = (uint8_t)log_n; proof.options = opt_;
+    proof.main_width = (uint8_t)W; proof.aux_width = (uint8_t)A; proof.aux_rands = (uint8_t)R; proof.log_n = (uint8_t)log_n; proof.options = opt_;
     const uint64_t g = gl::root_of_unity(log_n);
     const uint64_t gen_inv = gl::inv(gl::GEN);
 
@@ -561,6 +564,27 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     Commitment tcom = commit_matrix(tlde);
     wdigest(proof.commitments, tcom.root);
     coin.reseed(tcom.root);
+    // 3b. auxiliary segment [a8; stark_verifier.cairo:266-294]: draw the random elements, build the columns (prefix products
+    //     over the rows), then interpolate / extend / commit them like the main segment
+    std::vector<T> rands;
+    Matrix apolys, alde;
+    Commitment acom;
+    const T* d_rands = nullptr;
+    if (A) {
+        for (uint32_t i = 0; i < R; i++) rands.push_back(coin.draw<F>());
+        ParamPack pp(ctx);
+        const size_t ir = pp.add(rands);
+        pp.commit();
+        d_rands = pp.ptr<T>(ir);
+        apolys = Matrix(ctx, (int)(A * F::DEG), n);
+        launch_aux_columns<F>(ctx, trace_dev, n, W, A, R, d_rands, apolys.data.get());
+        ctx->ntt_inverse(apolys.data.get(), n, (int)(A * F::DEG), log_n, 1, h, 1, 0);
+        alde = Matrix(ctx, (int)(A * F::DEG), M);
+        ctx->ntt_forward(apolys.data.get(), n, alde.data.get(), M, (int)(A * F::DEG), log_M, log_Bl);
+        acom = commit_matrix(alde);
+        wdigest(proof.commitments, acom.root);
+        coin.reseed(acom.root);
+    }
     ms.trace_commit = clk.lap();
 
     // 4. constraint composition coefficients + evaluation + division (fused) [a9, a10, a11]
@@ -571,14 +595,20 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     {
         // H (degree < C*n) is interpolated from its values on h<w_ce>: every (M/ce_n)-th row of this rank's LDE, or - when
         // the shard is smaller than the constraint domain - a dedicated extension of the trace polynomials onto h<w_ce>.
-        Matrix celde;
+        Matrix celde, acelde;
         const uint64_t* frame_src = tlde.data.get();
+        const uint64_t* aux_src = A ? alde.data.get() : nullptr;
         size_t frame_rows = M;
         if (M < ceN) {
             celde = Matrix(ctx, (int)W, ceN);
             ctx->ntt_forward(polys.data.get(), n, celde.data.get(), ceN, (int)W, log_ce, log_ce - log_n);
             frame_src = celde.data.get();
             frame_rows = ceN;
+            if (A) {
+                acelde = Matrix(ctx, (int)(A * F::DEG), ceN);
+                ctx->ntt_forward(apolys.data.get(), n, acelde.data.get(), ceN, (int)(A * F::DEG), log_ce, log_ce - log_n);
+                aux_src = acelde.data.get();
+            }
         }
         NttTables* tce = ctx->ntt_tables(log_ce);
         FibConsArgs<F> a{};
@@ -588,15 +618,17 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         const size_t i_ta = pp.add(ta), i_tb = pp.add(tb), i_ba = pp.add(ba), i_bb = pp.add(bb), i_res = pp.add(air.results);
         a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.twi_lo = tce->lo_inv; a.twi_hi = tce->hi_inv; a.tw_h = tce->h;
         a.offset = h; a.gen_inv = h_inv; a.k7 = gl::pow(h, ceN);
-        std::vector<uint64_t> xn(C), zn(C);
+        std::vector<uint64_t> xn(C), zn(C), xnp(C);
         uint64_t hn = gl::pow(h, n), wC = gl::root_of_unity(ilog2(C));
         for (size_t k = 0; k < C; k++) {
             uint64_t xnk = gl::mul(hn, gl::pow(wC, k));
+            xnp[k] = xnk;
             xn[k] = gl::inv(xnk);
             zn[k] = gl::inv(gl::sub(xnk, 1));
         }
-        const size_t i_xn = pp.add(xn), i_zn = pp.add(zn);
+        const size_t i_xn = pp.add(xn), i_zn = pp.add(zn), i_xnp = pp.add(xnp);
         pp.commit();
+        a.aux = aux_src; a.A = A; a.R = R; a.rands = d_rands; a.xn = pp.ptr<uint64_t>(i_xnp);
         a.ta = pp.ptr<T>(i_ta); a.tb = pp.ptr<T>(i_tb); a.ba = pp.ptr<T>(i_ba); a.bb = pp.ptr<T>(i_bb);
         a.results = pp.ptr<uint64_t>(i_res); a.xn_inv = pp.ptr<uint64_t>(i_xn); a.zn_inv = pp.ptr<uint64_t>(i_zn);
         a.w_last = gl::pow(g, n - 1);
@@ -622,33 +654,35 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     // 7. OOD frame [a13]. Coefficients are pre-scaled by h^i, so evaluate at point / h.
     const T z = coin.draw<F>();
     const T z_next = F::mulb(z, g), z_c = gl::fpow<F>(z, C);
-    std::vector<T> ood(2 * W + C);
+    std::vector<T> ood(2 * W + C + 2 * A);
     {
-        DevBuf<T> d_out(ctx, 2 * W + C);
+        DevBuf<T> d_out(ctx, 2 * W + C + 2 * A);
+        if (A) launch_eval_bitrev<F>(ctx, apolys.data.get(), (size_t)F::DEG * n, n, (int)A, F::DEG, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get() + 2 * W + C);
         launch_eval_bitrev<F>(ctx, polys.data.get(), n, 0, (int)W, 1, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get());
         launch_eval_bitrev<F>(ctx, hbuf.get(), n, ceN, (int)C, F::DEG, log_n, F::mulb(z_c, h_inv), F::zero(), 1, d_out.get() + 2 * W);
         AERO_HIP(hipMemcpyAsync(ood.data(), d_out.get(), ood.size() * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
     }
-    std::vector<T> ood_cur(W), ood_next(W), ood_h(C);
+    std::vector<T> ood_cur(TW), ood_next(TW), ood_h(C);
     for (uint32_t c = 0; c < W; c++) { ood_cur[c] = ood[2 * c]; ood_next[c] = ood[2 * c + 1]; }
+    for (uint32_t c = 0; c < A; c++) { ood_cur[W + c] = ood[2 * W + C + 2 * c]; ood_next[W + c] = ood[2 * W + C + 2 * c + 1]; }
     for (size_t c = 0; c < C; c++) ood_h[c] = ood[2 * W + c];
     {
         std::vector<uint64_t> f;
-        flatten<F>(ood_cur.data(), W, f); flatten<F>(ood_next.data(), W, f);
+        flatten<F>(ood_cur.data(), TW, f); flatten<F>(ood_next.data(), TW, f);
         for (uint64_t v : f) w64(proof.ood_trace_states, v);
         f.clear();
         flatten<F>(ood_h.data(), C, f);
         for (uint64_t v : f) w64(proof.ood_evaluations, v);
     }
-    coin.reseed(hash_e<F>(ood_cur.data(), W));
-    coin.reseed(hash_e<F>(ood_next.data(), W));
+    coin.reseed(hash_e<F>(ood_cur.data(), TW));
+    coin.reseed(hash_e<F>(ood_next.data(), TW));
     coin.reseed(hash_e<F>(ood_h.data(), C));
     ms.ood = clk.lap();
 
     // 8. DEEP composition [a14]
-    std::vector<T> da(W), db(W), dg(W), dc(C);
-    for (uint32_t i = 0; i < W; i++) { da[i] = coin.draw<F>(); db[i] = coin.draw<F>(); dg[i] = coin.draw<F>(); }
+    std::vector<T> da(TW), db(TW), dg(TW), dc(C);
+    for (uint32_t i = 0; i < TW; i++) { da[i] = coin.draw<F>(); db[i] = coin.draw<F>(); dg[i] = coin.draw<F>(); }
     for (size_t i = 0; i < C; i++) dc[i] = coin.draw<F>();
     const T lambda = coin.draw<F>(), mu = coin.draw<F>();
     // FRI evaluations per layer: [DEG][dom] component arrays, natural order (dom = this rank's share while the layer is sharded)
@@ -660,7 +694,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         NttTables* tM = ctx->ntt_tables(log_M);
         DevBuf<uint64_t> dsm(ctx, (size_t)F::DEG * n);
         DeepArgs<F> a{};
-        a.tlde = tlde.data.get(); a.clde = clde.data.get(); a.N = M; a.count = n; a.row_step = (uint32_t)Bl; a.W = W; a.C = (uint32_t)C;
+        a.tlde = tlde.data.get(); a.clde = clde.data.get(); a.alde = A ? alde.data.get() : nullptr; a.A = A; a.N = M; a.count = n; a.row_step = (uint32_t)Bl; a.W = W; a.C = (uint32_t)C;
         a.tw_lo = tM->lo_fwd; a.tw_hi = tM->hi_fwd; a.tw_h = tM->h; a.offset = h;
         a.z = z; a.z_next = z_next; a.z_c = z_c; a.z_conj = F::conj(z); a.lambda = lambda; a.mu = mu;
         ParamPack pp(ctx);
@@ -744,7 +778,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     //     out the same value block, fills the items it owns (zeros elsewhere) and ONE all-reduce completes it everywhere.
     std::vector<uint64_t> pos = coin.draw_integers(opt_.num_queries, N);
     {
-        const size_t Q = pos.size(), tw = W, cw = C * F::DEG;
+        const size_t Q = pos.size(), tw = W, aw = (size_t)A * F::DEG, cw = C * F::DEG;
         std::vector<std::vector<uint64_t>> fpos(layers);
         {
             std::vector<uint64_t> fp = pos;
@@ -755,6 +789,8 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         // node index plans per tree (global heap indices): trace, composition, FRI layers
         std::vector<const Commitment*> coms{&tcom, &ccom};
         std::vector<std::vector<std::vector<uint64_t>>> plans{batch_proof_indices(N, pos), batch_proof_indices(N, pos)};
+        const size_t fri_tree0 = A ? 3 : 2;          // tree order: trace, composition, [aux], FRI layers
+        if (A) { coms.push_back(&acom); auto aux_plan = plans[0]; plans.push_back(std::move(aux_plan)); }
         for (int l = 0; l < layers; l++) { coms.push_back(&fri_coms[l]); plans.push_back(batch_proof_indices(fri_coms[l].n_global, fpos[l])); }
         // position of a row / node in this rank's arrays, GATHER_SKIP when another rank owns it
         auto local_row = [&](uint64_t p, bool sharded) -> uint64_t {
@@ -799,6 +835,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         size_t voff = 0;
         const size_t off_trows = voff; voff += Q * tw;
         const size_t off_crows = voff; voff += Q * cw;
+        const size_t off_arows = voff; voff += Q * aw;
         std::vector<size_t> off_frows(layers);
         for (int l = 0; l < layers; l++) { off_frows[l] = voff; voff += fpos[l].size() * Fd * F::DEG; }
         const size_t off_rem = voff; voff += (size_t)F::DEG * rem_dom;
@@ -811,6 +848,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         AERO_HIP(hipMemcpyAsync(d_idx.get(), h_idx, idx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         launch_gather_rows(ctx, tlde.data.get(), M, (int)tw, d_idx.get(), (int)Q, d_val.get() + off_trows);
         launch_gather_rows(ctx, clde.data.get(), M, (int)cw, d_idx.get(), (int)Q, d_val.get() + off_crows);
+        if (A) launch_gather_rows(ctx, alde.data.get(), M, (int)aw, d_idx.get(), (int)Q, d_val.get() + off_arows);
         {
             uint64_t Dom = N;
             for (int l = 0; l < layers; l++) {
@@ -851,12 +889,18 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         for (size_t i = 0; i < Q * tw; i++) w64(tq.values, h_val[off_trows + i]);
         tq.paths = paths(0);
         proof.trace_queries.push_back(tq);
+        if (A) {
+            QueriesBytes aq;
+            for (size_t i = 0; i < Q * aw; i++) w64(aq.values, h_val[off_arows + i]);
+            aq.paths = paths(2);
+            proof.trace_queries.push_back(aq);
+        }
         for (size_t i = 0; i < Q * cw; i++) w64(proof.constraint_queries.values, h_val[off_crows + i]);
         proof.constraint_queries.paths = paths(1);
         for (int l = 0; l < layers; l++) {
             QueriesBytes q;
             for (size_t i = 0; i < fpos[l].size() * Fd * F::DEG; i++) w64(q.values, h_val[off_frows[l] + i]);
-            q.paths = paths(2 + l);
+            q.paths = paths(fri_tree0 + l);
             proof.fri_layers.push_back(q);
         }
         // remainder = last layer's evaluations in natural order

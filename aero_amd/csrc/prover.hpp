@@ -97,13 +97,17 @@ struct MerkleTree {
 
 // Built-in AIR: FibAir(W). Pair k = columns (2k, 2k+1) = (a, b); a' = a + b, b' = b + a';
 // seeds (1+2k, 2+2k); assertions a(0), b(0), b(n-1) = results[k]; public inputs = results.
+// Optional auxiliary segment (synthetic stand-in for Miden's multiset-check columns): aux_width columns
+// over E built after the main commitment from aux_rands coin elements, p_c(0) = 1, p_c(i+1) = p_c(i) * (r_(c mod R) +
+// main_(c mod W)(i)); one degree-2 transition constraint and the assertion p_c(0) = 1 per column.
 struct FibAir {
     uint32_t width = 0;
     int log_n = 0;
     std::vector<uint64_t> results;
+    uint32_t aux_width = 0, aux_rands = 0;
     size_t trace_length() const { return (size_t)1 << log_n; }
-    size_t num_transition_constraints() const { return width; }
-    size_t num_assertions() const { return width + width / 2; }
+    size_t num_transition_constraints() const { return width + aux_width; }
+    size_t num_assertions() const { return width + width / 2 + aux_width; }
     static size_t ce_blowup_factor() { return 2; }
 };
 
@@ -137,6 +141,7 @@ class Prover {
 public:
     Prover(Context* ctx, const ProofOptions& opt) : ctx_(ctx), opt_(opt) { opt_.validate(); }
     void set_comm(const ShardComm& c) { comm_ = c; }
+    void set_aux_segment(uint32_t aux_width, uint32_t aux_rands) { aux_width_ = aux_width; aux_rands_ = aux_width ? aux_rands : 0; }
     const ProofOptions& options() const { return opt_; }
     // trace: device, column-major W x 2^log_n (not modified). Returns StarkProof::to_bytes().
     Bytes prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_inputs_out);
@@ -164,6 +169,7 @@ private:
     Context* ctx_;
     ProofOptions opt_;
     ShardComm comm_;
+    uint32_t aux_width_ = 0, aux_rands_ = 0;
 };
 
 // BatchMerkleProof node selection (winter-crypto 0.4 MerkleTree::prove_batch restated):

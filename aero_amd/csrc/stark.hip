@@ -66,6 +66,20 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
             g0 = F::add(g0, F::mulb(F::add(a.ba[2 * k + 1], F::mulb(a.bb[2 * k + 1], xb)), gl::sub(cb, 2 + 2 * (uint64_t)k)));
             g1 = F::add(g1, F::mulb(F::add(a.ba[a.W + k], F::mulb(a.bb[a.W + k], xb)), gl::sub(cb, a.results[k])));
         }
+        if (a.A) {
+            // auxiliary transition constraints (degree 2): adjustment x^n, constant on each of the C cosets of <w_n>
+            const uint64_t xx = a.xn[s & (a.C - 1)];
+            for (uint32_t c = 0; c < a.A; c++) {
+                const size_t o = (size_t)(c * F::DEG) * a.N;
+                const T pc = F::make(a.aux[o + r], F::DEG > 1 ? a.aux[o + a.N + r] : 0);
+                const T pn = F::make(a.aux[o + rn], F::DEG > 1 ? a.aux[o + a.N + rn] : 0);
+                const uint64_t m = a.lde[(size_t)(c % a.W) * a.N + r];
+                const T t = F::sub(pn, F::mul(pc, F::add(a.rands[c % a.R], F::from(m))));
+                acc = F::add(acc, F::mul(F::add(a.ta[a.W + c], F::mulb(a.tb[a.W + c], xx)), t));
+                const uint32_t bi = a.W + a.W / 2 + c;
+                g0 = F::add(g0, F::mul(F::add(a.ba[bi], F::mulb(a.bb[bi], xb)), F::sub(pc, F::one())));
+            }
+        }
         num[q][0] = acc; num[q][1] = g0; num[q][2] = g1;
         if (MODE == 0) {
             const size_t o = s - a.first;
@@ -103,12 +117,13 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
 
 template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F>& a, int mode) {
     size_t cnt = a.count;
+    const size_t in_cols = (size_t)a.W + (size_t)a.A * F::DEG;
     if (mode == 0) {
-        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * ((size_t)a.W + 3 * F::DEG), (fib_constraints_kernel<F, 0, 1>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, a);
+        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + 3 * F::DEG), (fib_constraints_kernel<F, 0, 1>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, a);
     } else if (cnt % 4 == 0) {
-        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * ((size_t)a.W + F::DEG), (fib_constraints_kernel<F, 1, 4>), dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, a);
+        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 4>), dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, a);
     } else {
-        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * ((size_t)a.W + F::DEG), (fib_constraints_kernel<F, 1, 1>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, a);
+        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 1>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, a);
     }
     ctx->check_launch("fib_constraints");
 }
@@ -239,6 +254,12 @@ template <class F, int K> __global__ __launch_bounds__(256) void deep_kernel(Dee
             s2 = F::add(s2, F::mul(F::sub(v, a.ood_next[c]), a.db[c]));
             if (F::DEG > 1) s3 = F::add(s3, F::mul(F::sub(v, F::conj(a.ood_cur[c])), a.dg[c]));
         }
+        for (uint32_t c = 0; c < a.A; c++) {   // aux columns are E-valued: no conjugate term
+            const size_t o = (size_t)(c * F::DEG) * a.N;
+            const T v = F::make(a.alde[o + r], F::DEG > 1 ? a.alde[o + a.N + r] : 0);
+            s1 = F::add(s1, F::mul(F::sub(v, a.ood_cur[a.W + c]), a.da[a.W + c]));
+            s2 = F::add(s2, F::mul(F::sub(v, a.ood_next[a.W + c]), a.db[a.W + c]));
+        }
         T acc = F::add(F::mul(s1, den[ND * q]), F::mul(s2, den[ND * q + 1]));
         if (F::DEG > 1) acc = F::add(acc, F::mul(s3, den[ND * q + 3]));
         T sc = F::zero();
@@ -252,7 +273,7 @@ template <class F, int K> __global__ __launch_bounds__(256) void deep_kernel(Dee
     }
 }
 template <class F> void launch_deep(Context* ctx, const DeepArgs<F>& a) {
-    const size_t bytes = a.count * 8 * ((size_t)a.W + (size_t)a.C * F::DEG + F::DEG);
+    const size_t bytes = a.count * 8 * ((size_t)a.W + ((size_t)a.C + a.A) * F::DEG + F::DEG);
     if (a.count % 4 == 0 && a.count >= 4096)
         AERO_LAUNCH(ctx, "deep_kernel", bytes, (deep_kernel<F, 4>), dim3((unsigned)((a.count / 4 + 255) / 256)), dim3(256), 0, a);
     else
@@ -321,6 +342,90 @@ template <class F> void launch_fri_fold(Context* ctx, const FoldArgs<F>& a) {
 }
 template void launch_fri_fold<FB>(Context*, const FoldArgs<FB>&);
 template void launch_fri_fold<FQ>(Context*, const FoldArgs<FQ>&);
+
+// ------------------------------------------------------------------------------------------------
+// Auxiliary segment: prefix products over the rows. Three launches: per-block totals, exclusive scan of the block totals,
+// per-row values. A thread owns AUX_K consecutive rows, a workgroup AUX_K * 256; the factor of row i is
+// rands[c mod R] + trace[c mod W][i] (rows >= n contribute 1).
+constexpr int AUX_K = 8;
+template <class F> __device__ __forceinline__ typename F::T aux_factor(const uint64_t* __restrict__ col, typename F::T r, size_t i, size_t n) {
+    return i < n ? F::add(r, F::from(col[i])) : F::one();
+}
+// inclusive scan of one value per thread over the workgroup (Hillis-Steele through LDS); returns this thread's inclusive value
+template <class F> __device__ __forceinline__ typename F::T block_scan_mul(typename F::T v, typename F::T* sh) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        typename F::T u = sh[t];
+        if (t >= off) u = F::mul(sh[t - off], u);
+        __syncthreads();
+        sh[t] = u;
+        __syncthreads();
+    }
+    return sh[t];
+}
+template <class F> __global__ __launch_bounds__(256) void aux_block_totals_kernel(const uint64_t* trace, size_t n, uint32_t W, uint32_t R,
+                                                                               const typename F::T* rands, typename F::T* totals) {
+    typedef typename F::T T;
+    __shared__ T sh[256];
+    const uint32_t c = blockIdx.y;
+    const uint64_t* col = trace + (size_t)(c % W) * n;
+    const T r = rands[c % R];
+    const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * AUX_K;
+    T p = F::one();
+#pragma unroll
+    for (int k = 0; k < AUX_K; k++) p = F::mul(p, aux_factor<F>(col, r, first + k, n));
+    const T inc = block_scan_mul<F>(p, sh);
+    if (threadIdx.x == 255) totals[(size_t)c * gridDim.x + blockIdx.x] = inc;
+}
+// in place: totals[c][b] <- product of totals[c][0..b) (one workgroup per column)
+template <class F> __global__ __launch_bounds__(256) void aux_scan_totals_kernel(typename F::T* totals, uint32_t nblk) {
+    typedef typename F::T T;
+    __shared__ T sh[256];
+    T* row = totals + (size_t)blockIdx.x * nblk;
+    const uint32_t per = (nblk + 255) / 256, lo = threadIdx.x * per;
+    T p = F::one();
+    for (uint32_t i = lo; i < lo + per && i < nblk; i++) p = F::mul(p, row[i]);
+    const T inc = block_scan_mul<F>(p, sh);
+    T run = threadIdx.x == 0 ? F::one() : sh[threadIdx.x - 1];
+    (void)inc;
+    for (uint32_t i = lo; i < lo + per && i < nblk; i++) { const T v = row[i]; row[i] = run; run = F::mul(run, v); }
+}
+template <class F> __global__ __launch_bounds__(256) void aux_apply_kernel(const uint64_t* trace, size_t n, uint32_t W, uint32_t R,
+                                                                        const typename F::T* rands, const typename F::T* totals, uint64_t* out) {
+    typedef typename F::T T;
+    __shared__ T sh[256];
+    const uint32_t c = blockIdx.y;
+    const uint64_t* col = trace + (size_t)(c % W) * n;
+    const T r = rands[c % R];
+    const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * AUX_K;
+    T f[AUX_K];
+    T p = F::one();
+#pragma unroll
+    for (int k = 0; k < AUX_K; k++) { f[k] = aux_factor<F>(col, r, first + k, n); p = F::mul(p, f[k]); }
+    block_scan_mul<F>(p, sh);
+    T run = totals[(size_t)c * gridDim.x + blockIdx.x];
+    if (threadIdx.x) run = F::mul(run, sh[threadIdx.x - 1]);
+#pragma unroll
+    for (int k = 0; k < AUX_K; k++) {
+        if (first + k < n)
+            for (int d = 0; d < F::DEG; d++) out[((size_t)c * F::DEG + d) * n + first + k] = F::comp(run, d);
+        run = F::mul(run, f[k]);
+    }
+}
+template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, size_t n, uint32_t W, uint32_t A, uint32_t R,
+                                           const typename F::T* rands_dev, uint64_t* out) {
+    typedef typename F::T T;
+    const uint32_t nblk = (uint32_t)((n + (size_t)AUX_K * 256 - 1) / ((size_t)AUX_K * 256));
+    T* totals = (T*)ctx->scratch_alloc(sizeof(T) * (size_t)A * nblk);
+    AERO_LAUNCH(ctx, "aux_columns_kernel", (size_t)A * n * 8, (aux_block_totals_kernel<F>), dim3(nblk, A), dim3(256), 0, trace, n, W, R, rands_dev, totals);
+    AERO_LAUNCH(ctx, "aux_columns_kernel", 0, (aux_scan_totals_kernel<F>), dim3(A), dim3(256), 0, totals, nblk);
+    AERO_LAUNCH(ctx, "aux_columns_kernel", (size_t)A * n * 8 * (1 + F::DEG), (aux_apply_kernel<F>), dim3(nblk, A), dim3(256), 0, trace, n, W, R, rands_dev, totals, out);
+    ctx->check_launch("aux_columns");
+}
+template void launch_aux_columns<FB>(Context*, const uint64_t*, size_t, uint32_t, uint32_t, uint32_t, const uint64_t*, uint64_t*);
+template void launch_aux_columns<FQ>(Context*, const uint64_t*, size_t, uint32_t, uint32_t, uint32_t, const gl::E2*, uint64_t*);
 
 // ------------------------------------------------------------------------------------------------
 // Grinding (random.cairo:282-316 mirror): smallest nonce >= 1 whose BLAKE2s(seed || LE64(nonce)) has at least

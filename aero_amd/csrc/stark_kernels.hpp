@@ -10,7 +10,7 @@ template <class F> struct FibConsArgs {
     size_t N;
     uint32_t W, C, blowup, ce_step;
     size_t first, count;       // ce rows [first, first + count)
-    const T *ta, *tb, *ba, *bb;   // composition coefficient pairs (device): transition[W], boundary[W + W/2]
+    const T *ta, *tb, *ba, *bb;   // composition coefficient pairs (device): transition[W + A], boundary[W + W/2 + A]
     const uint64_t* results;      // W/2 public results (device)
     const uint64_t *tw_lo, *tw_hi, *twi_lo, *twi_hi;   // two-level tables of w_ce and its inverse
     int tw_h;
@@ -19,6 +19,12 @@ template <class F> struct FibConsArgs {
     const uint64_t* xn_inv;       // C entries: (h^n w_C^k)^-1
     const uint64_t* zn_inv;       // C entries: (h^n w_C^k - 1)^-1
     uint64_t w_last;              // w_n^(n-1)
+    // auxiliary segment (A = 0: none): A columns over E stored as A*DEG base columns (index c*DEG + d) with the same row
+    // count / stride as `lde`; p_c' = p_c * (rands[c mod R] + main[c mod W]); p_c(0) = 1
+    const uint64_t* aux;
+    uint32_t A, R;
+    const T* rands;               // R elements (device)
+    const uint64_t* xn;           // C entries: h^n w_C^k = x^n on the constraint domain (degree adjustment of the aux group)
     uint64_t* out_cols;           // MODE 0: (3*DEG) x count, column-major
     uint64_t* out_h[2];           // MODE 1: DEG component arrays of ce_n values
 };
@@ -41,6 +47,8 @@ template <class F> struct DeepArgs {
     typedef typename F::T T;
     const uint64_t* tlde;   // W x N
     const uint64_t* clde;   // (C*DEG) x N
+    const uint64_t* alde;   // (A*DEG) x N auxiliary segment columns (E-valued, component columns), or nullptr
+    uint32_t A;
     size_t N;                        // LDE rows (column stride of tlde / clde)
     size_t count;                    // points evaluated: LDE rows m * row_step, m < count (output index m)
     uint32_t row_step;
@@ -49,7 +57,7 @@ template <class F> struct DeepArgs {
     int tw_h;
     uint64_t offset;                 // domain offset h: row r <-> x = h w_N^r
     T z, z_next, z_c, z_conj, lambda, mu;
-    const T *ood_cur, *ood_next, *ood_h, *da, *db, *dg, *dc;   // device
+    const T *ood_cur, *ood_next, *ood_h, *da, *db, *dg, *dc;   // device; ood_cur/ood_next/da/db/dg cover main then aux columns
     uint64_t* out[2];
 };
 template <class F> void launch_deep(Context* ctx, const DeepArgs<F>& a);
@@ -67,6 +75,12 @@ template <class F> struct FoldArgs {
     uint64_t dft[16];                  // w_F^-m, m < fold
 };
 template <class F> void launch_fri_fold(Context* ctx, const FoldArgs<F>& a);
+
+// Auxiliary segment columns (a synthetic stand-in for Miden's multiset-check columns): for c < A
+//   p_c(0) = 1,  p_c(i+1) = p_c(i) * (rands[c mod R] + trace[c mod W][i])      (a prefix product over the rows, in E)
+// out = (A*DEG) x n column-major component columns (index c*DEG + d).
+template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, size_t n, uint32_t W, uint32_t A, uint32_t R,
+                                           const typename F::T* rands_dev, uint64_t* out);
 
 uint64_t run_grind(Context* ctx, const Digest& seed, uint32_t bits);
 void launch_gather_rows(Context* ctx, const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out);

@@ -163,6 +163,19 @@ typedef struct aero_comm {
 int32_t aero_prove_fib_sharded(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_proof_options* options,
                                uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
 
+/* ---- auxiliary trace segment ---------------------------------------------------------------------------------------------------- */
+/* `Prover::prove` for FibAir extended by ONE auxiliary segment, the step the fork's `commit_to_trace_and_validate`
+ * (proving_worker.rs:323-332) performs per aux segment: after the main commitment `aux_rands` elements are drawn from the
+ * coin, the AIR builds `aux_width` columns over E from them, the columns are interpolated / extended / committed like the
+ * main segment (second trace root, second trace-query block, aux columns in the OOD frame and the DEEP composition:
+ * src/stark_verifier/stark_verifier.cairo:117-130,266-294, composer.cairo:196-316). The Miden AIR that defines the real
+ * columns is absent from the reference mount; the built-in stand-in is the multiset-check shape: p_c(0) = 1,
+ * p_c(i+1) = p_c(i) * (r_(c mod aux_rands) + main_(c mod width)(i)), one degree-2 transition constraint and the
+ * assertion p_c(0) = 1 per column. comm may be NULL (single GPU) or describe a sharded run (see above).
+ * aux_width = 0 is exactly aero_prove_fib / aero_prove_fib_sharded. */
+int32_t aero_prove_fib_aux(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, uint32_t aux_width, uint32_t aux_rands,
+                           const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
+
 /* bincode ProofData{input_bytes, proof_bytes} = u64 len || inputs || u64 len || proof
  * (miden-proof-generator/src/lib.rs:1-6, main.rs:49-51). */
 int32_t aero_proof_container(const uint8_t* inputs, size_t inputs_len, const uint8_t* proof, size_t proof_len, uint8_t** out,

@@ -55,7 +55,7 @@ static std::vector<Digest> hash_rows(const std::vector<Col>& cols, size_t rows) 
 
 template <class F>
 static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& opt, Col* pub_out,
-                       StageTimes* times = nullptr, ProverArtifacts<F>* art = nullptr) {
+                       StageTimes* times = nullptr, ProverArtifacts<F>* art = nullptr, uint32_t A = 0, uint32_t R = 0) {
     typedef typename F::T T;
     const uint32_t W = (uint32_t)trace.size();
     const size_t n = (size_t)1 << log_n, B = opt.blowup, N = n * B, Fd = opt.fri_fold;
@@ -66,16 +66,17 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
     if (opt.hash_fn != HASH_BLAKE2S_256) throw Err("prove: only Blake2s_256 is supported");
     if (ilog2(N) > TWO_ADICITY) throw Err("prove: LDE domain exceeds field two-adicity");
     for (auto& c : trace) if (c.size() != n) throw Err("prove: ragged trace");
+    if (A > 255 - W || (A && (R == 0 || R > 255))) throw Err("prove: bad auxiliary segment shape");
     StageTimes tm; double t0 = now_s(), t1;
 
     // 0. AIR + channel [proving_worker.rs:248-268]
-    FibAir air; air.W = W; air.log_n = log_n;
+    FibAir air; air.W = W; air.log_n = log_n; air.A = A; air.R = A ? R : 0;
     for (uint32_t k = 0; k < W / 2; k++) air.results.push_back(trace[2 * k + 1][n - 1]);
     if (pub_out) *pub_out = air.results;
     Coin coin = Coin::from_pub_elements(air.results.data(), air.results.size());
     const uint64_t g = gl_root_of_unity(log_n), gN = gl_root_of_unity(ilog2(N));
     Proof pr;
-    pr.main_width = (uint8_t)W; pr.aux_width = 0; pr.aux_rands = 0; pr.log_n = (uint8_t)log_n;
+    pr.main_width = (uint8_t)W; pr.aux_width = (uint8_t)A; pr.aux_rands = (uint8_t)(A ? R : 0); pr.log_n = (uint8_t)log_n;
     pr.modulus.resize(8); for (int i = 0; i < 8; i++) pr.modulus[i] = (uint8_t)(P >> (8 * i));
     pr.opt = opt;
 
@@ -92,6 +93,28 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
     MerkleTree ttree(tleaves);
     wbytes(pr.commitments, Bytes(ttree.root().b, ttree.root().b + 32));
     coin.reseed(ttree.root());
+    // 3b. auxiliary segment [a8; stark_verifier.cairo:266-294]: draw R elements, build the columns, commit like the main segment
+    std::vector<T> rands;
+    std::vector<Col> apolys(A * F::DEG), alde(A * F::DEG);    // component columns, index c*DEG + k
+    std::vector<Digest> aleaves;
+    MerkleTree atree;
+    if (A) {
+        for (uint32_t i = 0; i < R; i++) rands.push_back(coin.draw<F>());
+        for (auto& c : apolys) c.resize(n);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (uint32_t c = 0; c < A; c++) {
+            T p = F::one();
+            for (size_t i = 0; i < n; i++) {
+                for (int k = 0; k < F::DEG; k++) apolys[c * F::DEG + k][i] = F::comp(p, k);
+                p = F::mul(p, F::add(rands[c % R], F::from(trace[c % W][i])));
+            }
+        }
+        for (size_t c = 0; c < A * F::DEG; c++) { intt(apolys[c].data(), n, true); alde[c] = lde(apolys[c].data(), n, B, GEN); }
+        aleaves = hash_rows(alde, N);
+        atree = MerkleTree(aleaves);
+        wbytes(pr.commitments, Bytes(atree.root().b, atree.root().b + 32));
+        coin.reseed(atree.root());
+    }
     t1 = now_s(); tm.trace_commit = t1 - t0; t0 = t1;
 
     // 4. constraint evaluation over the ce domain [a9, a10]
@@ -102,13 +125,19 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
 #pragma omp parallel
     {
         std::vector<uint64_t> cur(W), nxt(W);
+        std::vector<T> acur(A), anxt(A);
 #pragma omp for schedule(static)
         for (size_t s = 0; s < ceN; s++) {
             size_t r = s * ce_step, rn = (r + B) % N;     // frame = (row j, row j + blowup mod N)
             for (uint32_t c = 0; c < W; c++) { cur[c] = tlde[c][r]; nxt[c] = tlde[c][rn]; }
+            for (uint32_t c = 0; c < A; c++) {
+                uint64_t a0[2] = {alde[c * F::DEG][r], F::DEG > 1 ? alde[c * F::DEG + F::DEG - 1][r] : 0};
+                uint64_t a1[2] = {alde[c * F::DEG][rn], F::DEG > 1 ? alde[c * F::DEG + F::DEG - 1][rn] : 0};
+                acur[c] = F::make(a0); anxt[c] = F::make(a1);
+            }
             uint64_t x = gl_mul(GEN, gl_pow(gce, s));
             T o[3];
-            fib_eval_point<F, FB>(air, cb, cc, cur.data(), nxt.data(), x, o);
+            fib_eval_point<F, FB>(air, cb, cc, cur.data(), nxt.data(), x, o, acur.data(), anxt.data(), rands.data());
             ce[0][s] = o[0]; ce[1][s] = o[1]; ce[2][s] = o[2];
         }
     }
@@ -161,9 +190,19 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
     // 7. OOD frame [a13]
     T z = coin.draw<F>();
     T z_next = F::mulb(z, g), zC = f_pow<F>(z, C);
-    std::vector<T> ood_cur(W), ood_next(W), ood_h(C);
+    const size_t TW = W + A;
+    std::vector<T> ood_cur(TW), ood_next(TW), ood_h(C);
 #pragma omp parallel for schedule(dynamic, 1)
     for (uint32_t c = 0; c < W; c++) { ood_cur[c] = horner<F>(polys[c].data(), n, z); ood_next[c] = horner<F>(polys[c].data(), n, z_next); }
+    for (uint32_t c = 0; c < A; c++) {   // aux column polynomials have E-valued coefficients: recombine the components
+        T a0 = F::zero(), a1 = F::zero();
+        for (int k = 0; k < F::DEG; k++) {
+            uint64_t basis[2] = {k == 0 ? 1ULL : 0ULL, k == 1 ? 1ULL : 0ULL};
+            a0 = F::add(a0, F::mul(horner<F>(apolys[c * F::DEG + k].data(), n, z), F::make(basis)));
+            a1 = F::add(a1, F::mul(horner<F>(apolys[c * F::DEG + k].data(), n, z_next), F::make(basis)));
+        }
+        ood_cur[W + c] = a0; ood_next[W + c] = a1;
+    }
     for (size_t c = 0; c < C; c++) {
         // H_c has E-valued coefficients: evaluate component polynomials and recombine (a0 + a1*phi)
         T acc = F::zero();
@@ -175,19 +214,19 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
         ood_h[c] = acc;
     }
     {
-        Col flat; f_flatten<F>(ood_cur.data(), W, flat); f_flatten<F>(ood_next.data(), W, flat);
+        Col flat; f_flatten<F>(ood_cur.data(), TW, flat); f_flatten<F>(ood_next.data(), TW, flat);
         for (uint64_t v : flat) w64(pr.ood_trace_states, v);
         Col fh; f_flatten<F>(ood_h.data(), C, fh);
         for (uint64_t v : fh) w64(pr.ood_evaluations, v);
     }
-    coin.reseed(f_hash<F>(ood_cur.data(), W));
-    coin.reseed(f_hash<F>(ood_next.data(), W));
+    coin.reseed(f_hash<F>(ood_cur.data(), TW));
+    coin.reseed(f_hash<F>(ood_next.data(), TW));
     coin.reseed(f_hash<F>(ood_h.data(), C));
     t1 = now_s(); tm.ood = t1 - t0; t0 = t1;
 
     // 8. DEEP composition over the LDE domain [a14]
-    std::vector<T> da(W), db(W), dg(W), dc(C);
-    for (uint32_t i = 0; i < W; i++) { da[i] = coin.draw<F>(); db[i] = coin.draw<F>(); dg[i] = coin.draw<F>(); }
+    std::vector<T> da(TW), db(TW), dg(TW), dc(C);
+    for (uint32_t i = 0; i < TW; i++) { da[i] = coin.draw<F>(); db[i] = coin.draw<F>(); dg[i] = coin.draw<F>(); }
     for (size_t i = 0; i < C; i++) dc[i] = coin.draw<F>();
     T lambda = coin.draw<F>(), mu = coin.draw<F>();
     T z_conj = F::conj(z);
@@ -219,6 +258,12 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
                     s1 = F::add(s1, F::mul(F::sub(v, ood_cur[c]), da[c]));
                     s2 = F::add(s2, F::mul(F::sub(v, ood_next[c]), db[c]));
                     if (F::DEG > 1) s3 = F::add(s3, F::mul(F::sub(v, F::conj(ood_cur[c])), dg[c]));
+                }
+                for (uint32_t c = 0; c < A; c++) {   // aux columns live in E: no conjugate term (composer.cairo:196-316)
+                    uint64_t comp[2] = {alde[c * F::DEG][r], F::DEG > 1 ? alde[c * F::DEG + F::DEG - 1][r] : 0};
+                    T v = F::make(comp);
+                    s1 = F::add(s1, F::mul(F::sub(v, ood_cur[W + c]), da[W + c]));
+                    s2 = F::add(s2, F::mul(F::sub(v, ood_next[W + c]), db[W + c]));
                 }
                 T t = F::add(F::mul(s1, d[ND * i]), F::mul(s2, d[ND * i + 1]));
                 if (F::DEG > 1) t = F::add(t, F::mul(s3, d[ND * i + 3]));
@@ -313,6 +358,12 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
         q.paths = batch_serialize(batch_prove(ttree, pos));
         pr.trace_queries.push_back(q);
     }
+    if (A) {
+        Proof::Q q;
+        for (uint64_t p : pos) for (size_t c = 0; c < A * F::DEG; c++) w64(q.values, alde[c][p]);
+        q.paths = batch_serialize(batch_prove(atree, pos));
+        pr.trace_queries.push_back(q);
+    }
     {
         Proof::Q& q = pr.constraint_queries;
         for (uint64_t p : pos) for (size_t c = 0; c < C * F::DEG; c++) w64(q.values, clde[c][p]);
@@ -351,9 +402,10 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
     return pr.to_bytes();
 }
 
-static Bytes prove_fib_any(const std::vector<Col>& trace, int log_n, const Options& opt, Col* pub_out, StageTimes* times = nullptr) {
-    if (opt.field_ext == EXT_NONE) return prove_fib<FB>(trace, log_n, opt, pub_out, times);
-    if (opt.field_ext == EXT_QUADRATIC) return prove_fib<FQ>(trace, log_n, opt, pub_out, times);
+static Bytes prove_fib_any(const std::vector<Col>& trace, int log_n, const Options& opt, Col* pub_out, StageTimes* times = nullptr,
+                           uint32_t A = 0, uint32_t R = 0) {
+    if (opt.field_ext == EXT_NONE) return prove_fib<FB>(trace, log_n, opt, pub_out, times, nullptr, A, R);
+    if (opt.field_ext == EXT_QUADRATIC) return prove_fib<FQ>(trace, log_n, opt, pub_out, times, nullptr, A, R);
     throw Err("prove: unsupported field extension");
 }
 

@@ -503,11 +503,18 @@ template <class F> static typename F::T horner(const uint64_t* c, size_t n, type
 // everything except the OOD constraint check is verified — exactly what src/stark_verifier does.
 enum AirKind { AIR_OPAQUE = 0, AIR_FIB = 1 };
 
+// Optional auxiliary segment (a synthetic stand-in for Miden's multiset-check columns, whose
+// AIR is absent from the mount): A columns over E, built after the main commitment from R random elements drawn from the
+// coin: p_c(0) = 1, p_c(i+1) = p_c(i) * (r_(c mod R) + main_(c mod W)(i)); one degree-2 transition constraint and one
+// assertion p_c(0) = 1 per aux column. Transcript order, proof layout, OOD frame (main || aux) and DEEP coefficient order
+// follow stark_verifier.cairo:117-130,266-294 (pinned by fib.bin, which has one aux segment); the constraint set itself
+// is restatement-defined.
 struct FibAir {
     uint32_t W; int log_n; Col results;   // results[k] = b_k(n-1)
+    uint32_t A = 0, R = 0;                // aux columns / aux random elements (A > 0 requires R > 0)
     size_t n() const { return (size_t)1 << log_n; }
-    size_t num_transition() const { return W; }
-    size_t num_assertions() const { return W + W / 2; }
+    size_t num_transition() const { return W + A; }
+    size_t num_assertions() const { return W + W / 2 + A; }
     static size_t ce_blowup() { return 2; }   // max(next_pow2(degree 1), MIN_BLOWUP 2)
     static Col seed(uint32_t k) { return Col{1 + 2 * (uint64_t)k, 2 + 2 * (uint64_t)k}; }
 };
@@ -532,13 +539,16 @@ static std::vector<Col> fib_trace(uint32_t W, int log_n) {
 //  * assertions sorted by (stride = 0, first_step, column); one boundary group per (stride, first_step):
 //    group 0 = step 0 (all W columns), group 1 = step n-1 (odd columns); divisor x - w^step, adjustment
 //    adj_b = (ce_n - 1 + 1) - (n - 1). Coefficient pairs are consumed in that sorted order.
+//  * aux transition constraints (degree 2) form their own degree group: adj_x = (ce_n - 1 + (n - 1)) - 2(n - 1);
+//    coefficient pairs: main transition, aux transition, main assertions (sorted as above), aux assertions (step 0, by column).
 struct FibCombine {
-    uint64_t adj_t, adj_b;
+    uint64_t adj_t, adj_b, adj_x;
     template <class F> struct Coeffs { std::vector<typename F::T> ta, tb, ba, bb; };
     explicit FibCombine(const FibAir& air) {
         uint64_t n = air.n(), ce_n = n * FibAir::ce_blowup();
         adj_t = (ce_n - 1 + (n - 1)) - (n - 1);
         adj_b = (ce_n - 1 + 1) - (n - 1);
+        adj_x = (ce_n - 1 + (n - 1)) - 2 * (n - 1);
     }
 };
 template <class F> static typename FibCombine::Coeffs<F> draw_constraint_coeffs(Coin& coin, size_t nt, size_t na) {
@@ -554,7 +564,8 @@ template <class F> static typename FibCombine::Coeffs<F> draw_constraint_coeffs(
 template <class F, class FV>
 static void fib_eval_point(const FibAir& air, const FibCombine& cb, const typename FibCombine::Coeffs<F>& cc,
                            const typename FV::T* cur, const typename FV::T* nxt, typename FV::T x,
-                           typename F::T out[3]) {
+                           typename F::T out[3], const typename F::T* acur = nullptr, const typename F::T* anxt = nullptr,
+                           const typename F::T* rands = nullptr) {
     // F is the coefficient field, FV the field of the frame values; products land in F (FV is F or the base field).
     auto lift = [](typename FV::T v) { uint64_t c[2] = {FV::comp(v, 0), FV::DEG > 1 ? FV::comp(v, 1) : 0}; return F::make(c); };
     typename F::T xt = f_pow<F>(lift(x), cb.adj_t), xb = f_pow<F>(lift(x), cb.adj_b);
@@ -566,8 +577,19 @@ static void fib_eval_point(const FibAir& air, const FibCombine& cb, const typena
         acc = F::add(acc, F::mul(F::add(cc.ta[2 * k], F::mul(cc.tb[2 * k], xt)), lift(t0)));
         acc = F::add(acc, F::mul(F::add(cc.ta[2 * k + 1], F::mul(cc.tb[2 * k + 1], xt)), lift(t1)));
     }
+    if (air.A) {
+        typename F::T xx = f_pow<F>(lift(x), cb.adj_x);
+        for (uint32_t c = 0; c < air.A; c++) {
+            typename F::T t = F::sub(anxt[c], F::mul(acur[c], F::add(rands[c % air.R], lift(cur[c % air.W]))));
+            acc = F::add(acc, F::mul(F::add(cc.ta[air.W + c], F::mul(cc.tb[air.W + c], xx)), t));
+        }
+    }
     out[0] = acc;
     typename F::T g0 = F::zero(), g1 = F::zero();
+    for (uint32_t c = 0; c < air.A; c++) {
+        size_t idx = air.W + air.W / 2 + c;
+        g0 = F::add(g0, F::mul(F::add(cc.ba[idx], F::mul(cc.bb[idx], xb)), F::sub(acur[c], F::one())));
+    }
     for (uint32_t c = 0; c < air.W; c++) {
         uint64_t v = FibAir::seed(c / 2)[c & 1];
         g0 = F::add(g0, F::mul(F::add(cc.ba[c], F::mul(cc.bb[c], xb)), lift(FV::sub(cur[c], FV::from(v)))));
@@ -613,7 +635,8 @@ static void verify_impl(const Proof& pr, const Col& pub_elements, AirKind kind, 
     // 1. trace commitments (stark_verifier.cairo:117-130, 266-294)
     size_t ri = 0;
     coin.reseed(roots[ri++]);
-    if (A) { for (int i = 0; i < pr.aux_rands; i++) coin.draw<F>(); coin.reseed(roots[ri++]); }
+    std::vector<T> aux_rands;
+    if (A) { for (int i = 0; i < pr.aux_rands; i++) aux_rands.push_back(coin.draw<F>()); coin.reseed(roots[ri++]); }
     // constraint composition coefficients (air_instance.cairo:115-142). Draws never change the seed
     // (reseed resets the counter), so an opaque AIR may skip them.
     typename FibCombine::Coeffs<F> cc;
@@ -642,10 +665,11 @@ static void verify_impl(const Proof& pr, const Col& pub_elements, AirKind kind, 
     if (kind == AIR_FIB) {
         // OOD consistency check (commented out in stark_verifier.cairo:151-159,183-187; winter-verifier does it):
         // sum_groups numerator(z)/divisor(z)  ==  sum_c z^c * H_c(z^C)     (reduce_evaluations, :296-304)
-        if (W != fib->W || A != 0 || C != FibAir::ce_blowup() || pr.log_n != fib->log_n) throw Err("verify: proof shape does not match FibAir");
+        if (W != fib->W || A != fib->A || (A && (size_t)pr.aux_rands != fib->R) || C != FibAir::ce_blowup() || pr.log_n != fib->log_n)
+            throw Err("verify: proof shape does not match FibAir");
         FibCombine cb(*fib);
         T num[3];
-        fib_eval_point<F, F>(*fib, cb, cc, ood_cur.data(), ood_next.data(), z, num);
+        fib_eval_point<F, F>(*fib, cb, cc, ood_cur.data(), ood_next.data(), z, num, ood_cur.data() + W, ood_next.data() + W, aux_rands.data());
         T zn = f_pow<F>(z, n), wl = F::from(gl_pow(g, n - 1));
         T lhs = F::mul(num[0], F::mul(F::sub(z, wl), F::inv(F::sub(zn, F::one()))));
         lhs = F::add(lhs, F::mul(num[1], F::inv(F::sub(z, F::one()))));

@@ -53,12 +53,15 @@ def check(oracle, world, cases, tmp_path):
     for case, (single, per_rank, comm) in zip(cases, run_world(world, cases, tmp_path)):
         for r, p in enumerate(per_rank):
             assert p == single, f"world {world} rank {r}: sharded proof differs from the single-GPU proof for {case}"
-        ref = oracle.prove_fib(case["width"], case["log_n"], case["options"])[0]
+        if case.get("aux"):
+            ref = oracle.prove_fib_aux(case["width"], case["log_n"], case["aux"][0], case["aux"][1], case["options"])[0]
+        else:
+            ref = oracle.prove_fib(case["width"], case["log_n"], case["options"])[0]
         assert single == ref, f"proof differs from the oracle for {case}"
         assert comm["calls"]["all_reduce"] == 1, "the opening phase must need exactly one all-reduce"
         # one digest exchange + one root all-gather per sharded commitment; at most one extra all-gather (FRI un-shard)
         assert comm["calls"]["all_gather"] in (comm["calls"]["all_to_all"], comm["calls"]["all_to_all"] + 1)
-        assert comm["calls"]["all_to_all"] >= 2
+        assert comm["calls"]["all_to_all"] >= (3 if case.get("aux") else 2)
 
 
 CASES_SMALL = [
@@ -69,6 +72,8 @@ CASES_SMALL = [
     {"width": 2, "log_n": 9, "options": [16, 16, 4, 4, 1, 2, 5], "min_peer": 1},         # blowup 16, fold 2
     {"width": 72, "log_n": 10, "options": DEFAULT, "min_peer": 4},                       # Miden-width rows
     {"width": 2, "log_n": 3, "options": [4, 8, 0, 4, 1, 2, 3], "min_peer": 1},           # smallest trace
+    {"width": 2, "log_n": 10, "options": DEFAULT, "min_peer": 1, "aux": [3, 2]},         # auxiliary segment
+    {"width": 4, "log_n": 9, "options": [27, 8, 16, 4, 2, 8, 8], "min_peer": 1, "aux": [9, 16]},
 ]
 
 
