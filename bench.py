@@ -51,6 +51,11 @@ WORKLOADS = {
     "fib_2^24x2_blowup8_blake2s_base": (24, 2, {}),
     "fib_2^20x72_blowup8_blake2s_base": (20, 72, {}),
     "fib_2^16x2_blowup8_blake2s_base": (16, 2, {}),
+    # BASELINE configs[4] stand-in (the Miden AIR is absent from the reference mount): Miden's SHAPE — 72 main columns, one
+    # auxiliary segment of 9 columns built from 16 coin elements, 2^22 rows, FRI folding factor 4 — on the synthetic AIR
+    # (Fibonacci pairs + prefix-product aux columns). Labelled a stand-in wherever it is reported.
+    "standin_miden_shape_2^22x(72+9aux)_fold4": (22, 72, {"fri_folding_factor": 4, "aux": (9, 16)}),
+    "standin_miden_shape_2^18x(72+9aux)_fold4": (18, 72, {"fri_folding_factor": 4, "aux": (9, 16)}),
 }
 
 
@@ -92,8 +97,22 @@ def cpu_thread_candidates(cores):
 def make_options(aero_amd, over):
     opt = aero_amd.ProofOptions.with_96_bit_security()
     for k, v in over.items():
-        setattr(opt, k, v)
+        if k != "aux":
+            setattr(opt, k, v)
     return opt
+
+
+def trace_cols(width, over):
+    """Trace columns that count as cells: main columns plus auxiliary-segment columns."""
+    return width + (over["aux"][0] if over.get("aux") else 0)
+
+
+def prove_call(ctx, dev, opt, over, comm=None):
+    """One proof of the workload: plain FibAir, or FibAir + auxiliary segment when the workload names one."""
+    aux = over.get("aux")
+    if aux or comm is not None:
+        return ctx.prove_fib_aux(dev, aux[0] if aux else 0, aux[1] if aux else 0, opt, comm=comm)
+    return ctx.prove_fib(dev, opt)
 
 
 def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch):
@@ -114,26 +133,26 @@ def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch):
 
     proof = None
     for _ in range(max(1, warmup)):
-        proof, _ = ctx.prove_fib_sharded(comm, dev, opt)
-    single, _ = ctx.prove_fib(dev, opt)
+        proof, _ = prove_call(ctx, dev, opt, over, comm)
+    single, _ = prove_call(ctx, dev, opt, over)
     identical = proof == single
     calls0, sent0 = dict(comm.calls), comm.bytes_sent
-    dt = timed_steps(lambda: ctx.prove_fib_sharded(comm, dev, opt), steps, barrier)
+    dt = timed_steps(lambda: prove_call(ctx, dev, opt, over, comm), steps, barrier)
     dt = max_over_ranks(dt, dist, torch.device("cuda", device))
     calls1, sent1 = dict(comm.calls), comm.bytes_sent
     flag = torch.tensor([1 if identical else 0], dtype=torch.int32, device=torch.device("cuda", device))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     ctx.set_stage_timing(True)
-    ctx.prove_fib_sharded(comm, dev, opt)
+    prove_call(ctx, dev, opt, over, comm)
     stages = ctx.last_stage_ms()
     ctx.set_stage_timing(False)
     t1 = time.perf_counter()
     for _ in range(3):
-        ctx.prove_fib(dev, opt)
+        prove_call(ctx, dev, opt, over)
     single_ms = (time.perf_counter() - t1) * 1e3 / 3
     res = {
         "workload": workload, "world": world, "backend": dist.get_backend(), "gpus_visible": torch.cuda.device_count(),
-        "steps": steps, "ms_per_proof": 1e3 * dt / steps, "value": (1 << log_n) * width * steps / dt, "unit": "cells/s",
+        "steps": steps, "ms_per_proof": 1e3 * dt / steps, "value": (1 << log_n) * trace_cols(width, over) * steps / dt, "unit": "cells/s",
         "single_gpu_ms_same_process": single_ms, "speedup_vs_single_gpu": single_ms / (1e3 * dt / steps),
         "proof_identical_to_single_gpu_on_every_rank": bool(flag.item() == 1), "proof_bytes": len(proof),
         "exchanges_per_proof": {k: (calls1[k] - calls0[k]) // steps for k in calls1},
@@ -288,11 +307,11 @@ def main():
     proof = None
     for _ in range(args.warmup):
         for c, d in zip(ctxs, devs):
-            proof, pub = c.prove_fib(d, opt)
+            proof, pub = prove_call(c, d, opt, over)
     # one more untimed pass with every launch bracketed by HIP events: per-kernel table, picks the dominant kernel
     # (steady state: tables and code objects are already resident after the warmup)
     ctx.set_kernel_timing(True)
-    proof, pub = ctx.prove_fib(dev, opt)
+    proof, pub = prove_call(ctx, dev, opt, over)
     table = ctx.kernel_timing_report()
     ctx.set_kernel_timing(False)
     proof_len = len(proof)
@@ -303,7 +322,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     for _ in range(5):
-        ctx.prove_fib(dev, opt)
+        prove_call(ctx, dev, opt, over)
     single_ms = (time.perf_counter() - t1) * 1e3 / 5
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides. One step = one batch of S independent
@@ -313,7 +332,7 @@ def main():
 
     def worker(i):
         for _ in range(args.steps):
-            last[i] = ctxs[i].prove_fib(devs[i], opt)[0]
+            last[i] = prove_call(ctxs[i], devs[i], opt, over)[0]
 
     def all_steps():
         import threading
@@ -330,7 +349,7 @@ def main():
     assert all(p == first_proof for p in last), "non-deterministic proof bytes"
     dt = max_over_ranks(dt, dist, "cuda")
 
-    cells = (1 << log_n) * width * S                  # cells per step (batch of S traces)
+    cells = (1 << log_n) * trace_cols(width, over) * S   # cells per step (batch of S traces)
     value = aggregate_value(cells, args.steps, world, dt)
     out = {
         "metric": "trace_cells_per_sec",
@@ -348,10 +367,12 @@ def main():
         "config": {"workload": args.workload, "trace_rows": 1 << log_n, "trace_cols": width, "blowup": opt.blowup_factor,
                    "num_queries": opt.num_queries, "grinding": opt.grinding_factor, "fri_fold": opt.fri_folding_factor,
                    "field_extension": "quadratic" if opt.field_extension == 2 else "none", "hash": "blake2s_256",
+                   "aux_segment": ({"columns": over["aux"][0], "random_elements": over["aux"][1], "air": "synthetic stand-in (prefix-product columns); the Miden AIR is not in the reference mount"}
+                                   if over.get("aux") else None),
                    "proofs_per_step_per_gpu": S, "proof_bytes": proof_len,
                    "parallelism": f"{world} GPU(s) x {S} independent proofs in flight per GPU (one HIP stream each), no data-path collective"},
         "single_proof_ms": single_ms,
-        "single_proof_value": (1 << log_n) * width / (single_ms * 1e-3),
+        "single_proof_value": (1 << log_n) * trace_cols(width, over) / (single_ms * 1e-3),
     }
 
     if rank == 0:
@@ -397,7 +418,7 @@ def main():
                                 "frac_of_hbm_peak": value * bpc / 1e9 / world / HBM_PEAK_GBS}
         if args.stages:
             ctx.set_stage_timing(True)
-            ctx.prove_fib(dev, opt)
+            prove_call(ctx, dev, opt, over)
             print("stage ms:", json.dumps(ctx.last_stage_ms()), file=sys.stderr)
             ctx.set_stage_timing(False)
             w = 1
@@ -412,10 +433,12 @@ def main():
             ncpu = os.cpu_count() or 1
             # pick the thread count on a 2^16 probe (also warms the thread pool), then time the sample with it
             best = None
+            aux = over.get("aux") or (0, 0)
+            probe_log = min(14 if width > 8 else 16, log_n)
             for t in cpu_thread_candidates(ncpu):
                 orc.set_threads(t)
-                orc.prove_fib(width, min(14, log_n), opt.to_list())
-                _, _, probe = orc.prove_fib(width, min(16, log_n), opt.to_list())
+                orc.prove_fib_aux(width, min(12, log_n), aux[0], aux[1], opt.to_list())
+                _, _, probe = orc.prove_fib_aux(width, probe_log, aux[0], aux[1], opt.to_list())
                 if best is None or probe["total"] < best[1]:
                     best = (t, probe["total"])
             cores = best[0]
@@ -423,17 +446,20 @@ def main():
             if args.cpu_sample_log_n:
                 s_log_n = min(args.cpu_sample_log_n, log_n)
             else:
-                projected = best[1] * (1 << max(log_n - 16, 0)) * 1.3
-                s_log_n = log_n if projected <= 40.0 else min(18, log_n)
+                projected = best[1] * (1 << max(log_n - probe_log, 0)) * 1.3
+                s_log_n = log_n
+                while s_log_n > probe_log and projected > 40.0:
+                    s_log_n -= 1
+                    projected /= 2
             t1 = time.perf_counter()
-            cproof, cpub, ctimes = orc.prove_fib(width, s_log_n, opt.to_list())
+            cproof, cpub, ctimes = orc.prove_fib_aux(width, s_log_n, aux[0], aux[1], opt.to_list())
             cdt = time.perf_counter() - t1
             if s_log_n == log_n:
                 assert cproof == first_proof, "GPU and CPU proofs differ"
             out["cpu_baseline"] = {
-                "value": (1 << s_log_n) * width / ctimes["total"], "unit": "cells/s", "cores": cores, "kind": "port",
-                "sample": f"one complete proof of a 2^{s_log_n} x {width} Fibonacci trace with the same options "
-                          f"(OpenMP, best of {cpu_thread_candidates(ncpu)} threads on a 2^16 probe = {cores}; host has {ncpu} logical CPUs; prover time {ctimes['total']:.2f} s, wall {cdt:.2f} s incl. trace generation)",
+                "value": (1 << s_log_n) * trace_cols(width, over) / ctimes["total"], "unit": "cells/s", "cores": cores, "kind": "port",
+                "sample": f"one complete proof of a 2^{s_log_n} x {trace_cols(width, over)} trace of the same AIR with the same options "
+                          f"(OpenMP, best of {cpu_thread_candidates(ncpu)} threads on a 2^{probe_log} probe = {cores}; host has {ncpu} logical CPUs; prover time {ctimes['total']:.2f} s, wall {cdt:.2f} s incl. trace generation)",
             }
         check_world = args.sharded_check_world if args.sharded_check_world >= 0 else (world if world > 1 else 0)
         if check_world > 1:
