@@ -96,11 +96,22 @@ __device__ __forceinline__ void ntt_round(uint64_t* lds, int log_e, int log_tl, 
     __syncthreads();
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2 and TLBs). Handing XCD x the x-th contiguous
+// eighth of the tiles keeps the tiles that are in flight on one XCD next to each other in memory: a strided pass touches
+// R rows per tile, and neighbouring tiles share those rows' pages and DRAM rows.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t nblocks) {
+#ifdef AERO_NTT_LINEAR_TILES
+    return bid;
+#else
+    return (nblocks & 7u) ? bid : (bid & 7u) * (nblocks >> 3) + (bid >> 3);
+#endif
+}
+
 // Forward: decimation in time, bit-reversed input -> natural output (within the pass' index bits).
 __global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
     const int TL = 1 << a.log_tl, log_e = a.log_r + a.log_tl, E = 1 << log_e;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
     const uint32_t tiles_per_b = 1u << (a.log_s - a.log_tl);       // S / TL
     const uint32_t b = tile >> (a.log_s - a.log_tl);
     const uint32_t lo0 = (tile & (tiles_per_b - 1)) << a.log_tl;
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
 __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
     const int TL = 1 << a.log_tl, log_e = a.log_r + a.log_tl, E = 1 << log_e;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
     const uint32_t tiles_per_b = 1u << (a.log_s - a.log_tl);
     const uint32_t b = tile >> (a.log_s - a.log_tl);
     const uint32_t lo0 = (tile & (tiles_per_b - 1)) << a.log_tl;

@@ -202,24 +202,45 @@ def spawn_sharded_check(world, workloads, steps, warmup, timeout_s):
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
     cmd = [sys.executable, os.path.abspath(__file__), "--shard-worker", "--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup),
            "--sharded-workloads", workloads]
-    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    import tempfile
+    logdir = tempfile.mkdtemp(prefix="aero_shard_")
+    logs = [open(os.path.join(logdir, f"rank{r}.log"), "wb") for r in range(world)]
+    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=logs[r], stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL)
              for r in range(world)]
     t_end = time.time() + timeout_s
-    outs = [b""] * world
+    timed_out = False
+    for p in procs:
+        try:
+            p.wait(timeout=max(1.0, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            break
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+            p.wait()
+    for f in logs:
+        f.close()
+
+    def tail(r, nbytes=600):
+        try:
+            with open(os.path.join(logdir, f"rank{r}.log"), "rb") as f:
+                return f.read()[-nbytes:].decode(errors="replace")
+        except OSError:
+            return ""
+
+    text = ""
     try:
-        for r, p in enumerate(procs):
-            outs[r] = p.communicate(timeout=max(1.0, t_end - time.time()))[0]
-    except subprocess.TimeoutExpired:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-        return {"error": f"timeout after {timeout_s} s"}
-    text = outs[0].decode(errors="replace")
+        with open(os.path.join(logdir, "rank0.log"), "rb") as f:
+            text = f.read().decode(errors="replace")
+    except OSError:
+        pass
     for line in text.splitlines():
         if line.startswith("SHARDED_RESULT "):
             return {"results": json.loads(line[len("SHARDED_RESULT "):])}
     rc = [p.returncode for p in procs]
-    return {"error": f"no result (exit codes {rc}): " + text[-400:]}
+    why = f"timeout after {timeout_s} s" if timed_out else f"no result (exit codes {rc})"
+    return {"error": why, "rank0_log_tail": tail(0), "last_rank_log_tail": tail(world - 1)}
 
 
 def main():
@@ -243,6 +264,9 @@ def main():
                          "off; on a 1-GPU box the ranks share the GPU over gloo, which checks the path but not its speed)")
     ap.add_argument("--sharded-workloads", default="fib_2^20x2_blowup8_blake2s_base,fib_2^24x2_blowup8_blake2s_base")
     ap.add_argument("--sharded-timeout", type=float, default=240.0)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing aid for a 1-GPU box: every rank uses cuda:0 and the ranks talk over gloo (exercises the whole "
+                         "N > 1 control flow; the numbers then describe N processes sharing one GPU)")
     ap.add_argument("--shard-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.shard_worker:
@@ -258,11 +282,16 @@ def main():
     import aero_amd
 
     dist = None
+    if args.share_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -347,7 +376,7 @@ def main():
     dom_rep = ctx.kernel_timing_report().get(dominant, (0, 0.0, 0.0))
     ctx.set_kernel_timing(False)
     assert all(p == first_proof for p in last), "non-deterministic proof bytes"
-    dt = max_over_ranks(dt, dist, "cuda")
+    dt = max_over_ranks(dt, dist, "cpu" if args.share_gpu else "cuda")
 
     cells = (1 << log_n) * trace_cols(width, over) * S   # cells per step (batch of S traces)
     value = aggregate_value(cells, args.steps, world, dt)

@@ -1,0 +1,54 @@
+"""The complete `bench.py --gpus 2` control flow (what the driver launches with torch.distributed.run at N > 1): timed
+region, max over ranks, rank-0 JSON line, the sharded-proof side measurement in its own worker group, ranks > 0 waiting on
+the store. On the 1-GPU test box both ranks share cuda:0 over gloo (--share-gpu); the numbers are meaningless, the flow
+and the JSON contract are what is checked."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = "fib_2^16x2_blowup8_blake2s_base"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(extra, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--share-gpu", "--workload", SMALL] + extra
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, stdin=subprocess.DEVNULL, timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 must print exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_replica_mode_two_ranks_with_sharded_side_measurement():
+    out = _run(["--concurrent", "2", "--sharded-workloads", SMALL, "--sharded-timeout", "200"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert "cpu_baseline" not in out                      # rank 0, N == 1 only
+    sp = out["sharded_proof"]
+    assert "results" in sp, sp
+    res = sp["results"][0]
+    assert res["world"] == 2 and res["proof_identical_to_single_gpu_on_every_rank"] is True
+    assert res["exchanges_per_proof"]["all_reduce"] == 1
+
+
+def test_sharded_mode_two_ranks():
+    out = _run(["--mode", "sharded"])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["value"] > 0
+    assert out["sharded_proof"]["proof_identical_to_single_gpu_on_every_rank"] is True
