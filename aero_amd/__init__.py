@@ -169,6 +169,35 @@ class MerkleTree:
             pass
 
 
+class FriLayers:
+    """Device FRI layers kept by aero_fri_build_layers (winter-fri FriProver after build_layers)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    def open(self, positions) -> bytes:
+        """Serialised FriProof (the FRI section of StarkProof::to_bytes) for LDE-domain query positions."""
+        pos = np.ascontiguousarray(positions, np.uint64)
+        out = u8p()
+        n = C.c_size_t(0)
+        self.ctx._ck(lib().aero_fri_open(self.ctx.h, self.h, _p64(pos), C.c_uint32(pos.size), C.byref(out), C.byref(n)))
+        data = C.string_at(out, n.value)
+        lib().aero_free(out)
+        return data
+
+    def free(self):
+        if self.h:
+            lib().aero_fri_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Context:
     """One GPU + one HIP stream + a device memory pool."""
 
@@ -269,6 +298,32 @@ class Context:
         n = C.c_uint64(0)
         self._ck(lib().aero_grind(self.h, _p8(s), C.c_uint32(bits), C.byref(n)))
         return n.value
+
+    # ---- composition polynomial / DEEP / FRI layers (the stages inside prove_after_constraint_eval)
+    def composition_poly_fib(self, numer_cols: np.ndarray, log_n: int, field_extension=1) -> Matrix:
+        a = np.ascontiguousarray(numer_cols, np.uint64)
+        h = C.c_void_p()
+        self._ck(lib().aero_composition_poly_fib(self.h, _p64(a), C.c_uint32(log_n), C.c_uint8(field_extension), C.byref(h)))
+        return Matrix(self, h)
+
+    def deep_compose(self, trace_lde: Matrix, comp_lde: Matrix, log_blowup, z, ood_frame, ood_evals, coeffs, field_extension=1) -> Matrix:
+        # dtype given at conversion: lists of Python ints >= 2^63 must not pass through float64
+        arr = [np.array(v, dtype=np.uint64, ndmin=1) for v in (z, ood_frame, ood_evals, coeffs)]
+        h = C.c_void_p()
+        self._ck(lib().aero_deep_compose(self.h, trace_lde.h, comp_lde.h, C.c_uint32(log_blowup), C.c_uint8(field_extension),
+                                         _p64(arr[0]), _p64(arr[1]), _p64(arr[2]), _p64(arr[3]), C.byref(h)))
+        return Matrix(self, h)
+
+    def fri_build_layers(self, evals: Matrix, options: ProofOptions, seed: bytes):
+        """Returns (FriLayers handle, [roots], coin seed after the remainder commitment)."""
+        s_in = np.frombuffer(seed, np.uint8).copy()
+        roots = np.zeros(32 * 40, np.uint8)
+        n = C.c_uint32(0)
+        s_out = np.zeros(32, np.uint8)
+        h = C.c_void_p()
+        self._ck(lib().aero_fri_build_layers(self.h, evals.h, C.byref(options), _p8(s_in), _p8(roots), C.c_size_t(roots.size), C.byref(n),
+                                             _p8(s_out), C.byref(h)))
+        return FriLayers(self, h), [roots[32 * i:32 * i + 32].tobytes() for i in range(n.value)], s_out.tobytes()
 
     # ---- whole proof
     def prove_fib(self, trace, options: ProofOptions):

@@ -26,6 +26,13 @@ struct aero_tree {
     explicit aero_tree(aero_ctx* ctx) : keep(ctx->keep) {}
 };
 
+struct aero_fri {
+    std::shared_ptr<Context> keep;
+    FriLayers fl;
+    ProofOptions opt{};
+    explicit aero_fri(aero_ctx* ctx) : keep(ctx->keep) {}
+};
+
 static thread_local std::string g_create_err;
 
 template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
@@ -294,6 +301,144 @@ int32_t aero_eval_constraints_fib(aero_ctx* ctx, const aero_matrix* trace_lde, u
         else fail("eval_constraints_fib: field extension must be 1 (None) or 2 (Quadratic)", ST_UNSUPPORTED);
     });
 }
+
+}  // extern "C"
+
+// ---- composition polynomial / DEEP / FRI layers ------------------------------------------------------------------
+template <class F> static void composition_poly_fib(aero_ctx* ctx, const uint64_t* numer_cols, uint32_t log_n, aero_matrix** out) {
+    Context* c = ctx->c;
+    const size_t n = (size_t)1 << log_n, C = FibAir::ce_blowup_factor(), ceN = C * n;
+    const int log_ce = ilog2u(ceN);
+    for (size_t i = 0; i < 3 * F::DEG * ceN; i++) REQUIRE(numer_cols[i] < gl::P, "composition_poly_fib: non-canonical element");
+    DevBuf<uint64_t> d_cols(c, 3 * F::DEG * ceN);
+    AERO_HIP(hipMemcpyAsync(d_cols.get(), numer_cols, 3 * F::DEG * ceN * 8, hipMemcpyHostToDevice, c->stream));
+    auto m = new aero_matrix(ctx);
+    std::unique_ptr<aero_matrix> guard_m(m);
+    m->m = Matrix(c, (int)(C * F::DEG), n);     // [DEG][ce_n] = columns ordered [component][c]
+    NttTables* tce = c->ntt_tables(log_ce);
+    FibDivideArgs<F> a{};
+    a.cols = d_cols.get(); a.ce_n = ceN; a.C = (uint32_t)C;
+    a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.tw_h = tce->h;
+    a.offset = gl::GEN; a.w_last = gl::pow(gl::root_of_unity((int)log_n), n - 1);
+    std::vector<uint64_t> zn(C);
+    const uint64_t g7n = gl::pow(gl::GEN, n), wC = gl::root_of_unity(ilog2u(C));
+    for (size_t k = 0; k < C; k++) zn[k] = gl::inv(gl::sub(gl::mul(g7n, gl::pow(wC, k)), 1));
+    uint64_t* d_zn = (uint64_t*)c->scratch_alloc(C * 8 + 8);
+    AERO_HIP(hipMemcpyAsync(d_zn, zn.data(), C * 8, hipMemcpyHostToDevice, c->stream));
+    a.zn_inv = d_zn;
+    for (int d = 0; d < F::DEG; d++) a.out_h[d] = m->m.data.get() + (size_t)d * ceN;
+    launch_fib_divide<F>(c, a);
+    ProofOptions po = ProofOptions::with_96_bit_security();
+    Prover p(c, po);
+    p.composition_from_evaluations(m->m.data.get(), F::DEG, log_ce, ilog2u(C), gl::GEN);
+    c->sync();
+    c->scratch_reset();
+    *out = guard_m.release();
+}
+template <class F> static typename F::T rd_elem(const uint64_t*& p, const char* what) {
+    uint64_t c0 = *p++, c1 = F::DEG > 1 ? *p++ : 0;
+    if (c0 >= gl::P || c1 >= gl::P) fail(std::string(what) + ": non-canonical element");
+    return F::make(c0, c1);
+}
+template <class F>
+static void deep_compose_abi(aero_ctx* ctx, const Matrix& tlde, const Matrix& clde, uint32_t log_blowup, const uint64_t* z, const uint64_t* ood_frame,
+                             const uint64_t* ood_evals, const uint64_t* coeffs, aero_matrix** out) {
+    Context* c = ctx->c;
+    const size_t N = tlde.rows, W = tlde.cols;
+    REQUIRE(clde.rows == N && clde.cols % F::DEG == 0 && clde.cols > 0, "deep_compose: composition LDE shape does not match");
+    const size_t C = clde.cols / F::DEG;
+    REQUIRE((N >> log_blowup) >= 8 && ((N >> log_blowup) << log_blowup) == N, "deep_compose: LDE rows are not trace_length << log_blowup");
+    const int log_n = ilog2u(N >> log_blowup);
+    DeepInputs<F> in;
+    in.z = rd_elem<F>(z, "deep_compose");
+    in.ood_cur.resize(W); in.ood_next.resize(W); in.ood_h.resize(C);
+    in.da.resize(W); in.db.resize(W); in.dg.resize(W); in.dc.resize(C);
+    for (size_t i = 0; i < W; i++) in.ood_cur[i] = rd_elem<F>(ood_frame, "deep_compose");
+    for (size_t i = 0; i < W; i++) in.ood_next[i] = rd_elem<F>(ood_frame, "deep_compose");
+    for (size_t i = 0; i < C; i++) in.ood_h[i] = rd_elem<F>(ood_evals, "deep_compose");
+    for (size_t i = 0; i < W; i++) { in.da[i] = rd_elem<F>(coeffs, "deep_compose"); in.db[i] = rd_elem<F>(coeffs, "deep_compose"); in.dg[i] = rd_elem<F>(coeffs, "deep_compose"); }
+    for (size_t i = 0; i < C; i++) in.dc[i] = rd_elem<F>(coeffs, "deep_compose");
+    in.lambda = rd_elem<F>(coeffs, "deep_compose"); in.mu = rd_elem<F>(coeffs, "deep_compose");
+    ProofOptions po = ProofOptions::with_96_bit_security();
+    Prover p(c, po);
+    auto m = new aero_matrix(ctx);
+    std::unique_ptr<aero_matrix> guard_m(m);
+    m->m.data = p.deep_compose<F>(tlde.data.get(), clde.data.get(), nullptr, (uint32_t)W, 0, (uint32_t)C, log_n, (int)log_blowup, gl::GEN, in);
+    m->m.rows = N; m->m.cols = F::DEG;
+    c->sync();
+    c->scratch_reset();
+    *out = guard_m.release();
+}
+extern "C" {
+int32_t aero_composition_poly_fib(aero_ctx* ctx, const uint64_t* numer_cols, uint32_t log_n, uint8_t field_extension, aero_matrix** comp_polys) {
+    return guard(ctx, [&] {
+        REQUIRE(numer_cols && comp_polys, "composition_poly_fib: null argument");
+        REQUIRE(log_n >= 3 && log_n <= 28, "composition_poly_fib: log_n out of range");
+        if (field_extension == EXT_NONE) composition_poly_fib<gl::FB>(ctx, numer_cols, log_n, comp_polys);
+        else if (field_extension == EXT_QUADRATIC) composition_poly_fib<gl::FQ>(ctx, numer_cols, log_n, comp_polys);
+        else fail("composition_poly_fib: field extension must be 1 (None) or 2 (Quadratic)", ST_UNSUPPORTED);
+    });
+}
+int32_t aero_deep_compose(aero_ctx* ctx, const aero_matrix* trace_lde, const aero_matrix* comp_lde, uint32_t log_blowup, uint8_t field_extension,
+                          const uint64_t* z, const uint64_t* ood_frame, const uint64_t* ood_evals, const uint64_t* coeffs, aero_matrix** deep_evals) {
+    return guard(ctx, [&] {
+        REQUIRE(trace_lde && comp_lde && z && ood_frame && ood_evals && coeffs && deep_evals, "deep_compose: null argument");
+        REQUIRE(log_blowup >= 1 && log_blowup <= 7, "deep_compose: log_blowup must be in [1,7]");
+        if (field_extension == EXT_NONE) deep_compose_abi<gl::FB>(ctx, trace_lde->m, comp_lde->m, log_blowup, z, ood_frame, ood_evals, coeffs, deep_evals);
+        else if (field_extension == EXT_QUADRATIC) deep_compose_abi<gl::FQ>(ctx, trace_lde->m, comp_lde->m, log_blowup, z, ood_frame, ood_evals, coeffs, deep_evals);
+        else fail("deep_compose: field extension must be 1 (None) or 2 (Quadratic)", ST_UNSUPPORTED);
+    });
+}
+int32_t aero_fri_build_layers(aero_ctx* ctx, const aero_matrix* evals, const aero_proof_options* o, const uint8_t seed_in[32], uint8_t* roots_out,
+                              size_t roots_cap, uint32_t* num_roots, uint8_t seed_out[32], aero_fri** out) {
+    return guard(ctx, [&] {
+        REQUIRE(evals && o && seed_in && roots_out && num_roots && seed_out && out, "fri_build_layers: null argument");
+        ProofOptions po{o->num_queries, o->blowup_factor, o->grinding_factor, o->hash_fn, o->field_extension, o->fri_folding_factor, o->fri_log_max_remainder};
+        Prover p(ctx->c, po);
+        const int deg = po.field_extension == EXT_QUADRATIC ? 2 : 1;
+        const Matrix& m = evals->m;
+        REQUIRE(m.cols == deg, "fri_build_layers: evaluations must have one column per extension component");
+        REQUIRE(m.rows >= 2 && (m.rows & (m.rows - 1)) == 0, "fri_build_layers: domain size must be a power of two");
+        const int layers = num_fri_layers(m.rows, po.fri_folding_factor, 1ull << po.fri_log_max_remainder);
+        REQUIRE(roots_cap >= (size_t)(layers + 1) * 32, "fri_build_layers: roots buffer too small");
+        HostCoin coin;
+        memcpy(coin.seed.w, seed_in, 32);
+        DevBuf<uint64_t> copy(ctx->c, (size_t)deg * m.rows);     // the layers own their evaluations
+        AERO_HIP(hipMemcpyAsync(copy.get(), m.data.get(), (size_t)deg * m.rows * 8, hipMemcpyDeviceToDevice, ctx->c->stream));
+        auto f = new aero_fri(ctx);
+        std::unique_ptr<aero_fri> guard_f(f);
+        f->opt = po;
+        Bytes roots;
+        if (deg == 1) f->fl = p.fri_build_layers<gl::FB>(std::move(copy), m.rows, coin, &roots);
+        else f->fl = p.fri_build_layers<gl::FQ>(std::move(copy), m.rows, coin, &roots);
+        memcpy(roots_out, roots.data(), roots.size());
+        *num_roots = (uint32_t)(roots.size() / 32);
+        memcpy(seed_out, coin.seed.w, 32);
+        ctx->c->scratch_reset();
+        *out = guard_f.release();
+    });
+}
+int32_t aero_fri_open(aero_ctx* ctx, const aero_fri* fri, const uint64_t* positions, uint32_t k, uint8_t** out, size_t* out_len) {
+    return guard(ctx, [&] {
+        REQUIRE(fri && positions && out && out_len && k > 0, "fri_open: null argument");
+        std::vector<uint64_t> pos(positions, positions + k);
+        for (uint64_t q : pos) REQUIRE(q < fri->fl.lde_size, "fri_open: position out of range");
+        Prover p(ctx->c, fri->opt);
+        Bytes b = fri->fl.deg == 1 ? p.fri_open<gl::FB>(fri->fl, pos) : p.fri_open<gl::FQ>(fri->fl, pos);
+        uint8_t* buf = (uint8_t*)malloc(b.size());
+        if (!buf) throw std::bad_alloc();
+        memcpy(buf, b.data(), b.size());
+        *out = buf; *out_len = b.size();
+    });
+}
+void aero_fri_free(aero_ctx* ctx, aero_fri* fri) {
+    if (!fri) return;
+    if (ctx && ctx->c) (void)hipSetDevice(ctx->c->device);
+    delete fri;
+}
+}  // extern "C"
+
+extern "C" {
 
 // ---- FRI / grinding ---------------------------------------------------------------------------------
 int32_t aero_fri_fold(aero_ctx* ctx, const uint64_t* values, uint64_t dom, uint32_t fold, uint64_t alpha, uint64_t* out) {

@@ -474,6 +474,128 @@ Commitment Prover::commit_exchange(DevBuf<Digest>& local, size_t L) {
     return c;
 }
 
+// ---- stage functions shared by prove_impl and the C ABI ---------------------------------------------------
+void Prover::composition_from_evaluations(uint64_t* hbuf, int deg, int log_ce, int log_c, uint64_t h) {
+    // interpolate over the coset: coefficient I gets h^-I (coset) * h^(I >> log C) (pre-scaling of column coefficient
+    // i = I >> log C for the column LDE). In bit-reversed order the C column polynomials are the C contiguous chunks of
+    // the buffer: no split pass (H(x) = sum_c x^c H_c(x^C)).
+    ctx_->ntt_inverse(hbuf, (size_t)1 << log_ce, deg, log_ce, 1, gl::inv(h), h, log_c);
+}
+
+template <class F>
+DevBuf<uint64_t> Prover::deep_compose(const uint64_t* tlde, const uint64_t* clde, const uint64_t* alde, uint32_t W, uint32_t A, uint32_t C,
+                                      int log_n, int log_bl, uint64_t h, const DeepInputs<F>& in) {
+    typedef typename F::T T;
+    Context* ctx = ctx_;
+    const size_t n = (size_t)1 << log_n, M = n << log_bl;
+    const int log_M = log_n + log_bl;
+    if (in.ood_cur.size() != W + A || in.ood_next.size() != W + A || in.ood_h.size() != C || in.da.size() != W + A ||
+        in.db.size() != W + A || in.dg.size() != W + A || in.dc.size() != C)
+        fail("deep_compose: coefficient / OOD vector sizes do not match the trace shape");
+    // deg(DEEP) < n: evaluate it on the n-point coset h<w_n> (every (M/n)-th LDE row), interpolate (the plain inverse
+    // transform of values on h<w_n> yields exactly the h^i-prescaled coefficients), extend like any other column.
+    DevBuf<uint64_t> out(ctx, (size_t)F::DEG * M);
+    NttTables* tM = ctx->ntt_tables(log_M);
+    DevBuf<uint64_t> dsm(ctx, (size_t)F::DEG * n);
+    DeepArgs<F> a{};
+    a.tlde = tlde; a.clde = clde; a.alde = alde; a.A = A; a.N = M; a.count = n; a.row_step = (uint32_t)1 << log_bl; a.W = W; a.C = C;
+    a.tw_lo = tM->lo_fwd; a.tw_hi = tM->hi_fwd; a.tw_h = tM->h; a.offset = h;
+    a.z = in.z; a.z_next = F::mulb(in.z, gl::root_of_unity(log_n)); a.z_c = gl::fpow<F>(in.z, C); a.z_conj = F::conj(in.z);
+    a.lambda = in.lambda; a.mu = in.mu;
+    ParamPack pp(ctx);
+    const size_t i0 = pp.add(in.ood_cur), i1 = pp.add(in.ood_next), i2 = pp.add(in.ood_h), i3 = pp.add(in.da), i4 = pp.add(in.db), i5 = pp.add(in.dg), i6 = pp.add(in.dc);
+    pp.commit();
+    a.ood_cur = pp.ptr<T>(i0); a.ood_next = pp.ptr<T>(i1); a.ood_h = pp.ptr<T>(i2);
+    a.da = pp.ptr<T>(i3); a.db = pp.ptr<T>(i4); a.dg = pp.ptr<T>(i5); a.dc = pp.ptr<T>(i6);
+    for (int d = 0; d < F::DEG; d++) a.out[d] = dsm.get() + (size_t)d * n;
+    launch_deep<F>(ctx, a);
+    ctx->ntt_inverse(dsm.get(), n, F::DEG, log_n, 1, 1, 1, 0);
+    ctx->ntt_forward(dsm.get(), n, out.get(), M, F::DEG, log_M, log_bl);
+    return out;
+}
+template DevBuf<uint64_t> Prover::deep_compose<FB>(const uint64_t*, const uint64_t*, const uint64_t*, uint32_t, uint32_t, uint32_t, int, int, uint64_t, const DeepInputs<FB>&);
+template DevBuf<uint64_t> Prover::deep_compose<FQ>(const uint64_t*, const uint64_t*, const uint64_t*, uint32_t, uint32_t, uint32_t, int, int, uint64_t, const DeepInputs<FQ>&);
+
+template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, uint64_t N, HostCoin& coin, Bytes* roots) {
+    typedef typename F::T T;
+    Context* ctx = ctx_;
+    const size_t Fd = opt_.fri_folding_factor;
+    FriLayers fl;
+    fl.lde_size = N; fl.deg = F::DEG; fl.fold = (int)Fd;
+    fl.layers = num_fri_layers(N, Fd, 1ull << opt_.fri_log_max_remainder);
+    {
+        uint64_t rem = N;
+        for (int l = 0; l < fl.layers; l++) rem /= Fd;
+        if (rem < Fd) fail("FRI: remainder smaller than the folding factor");
+    }
+    fl.vals.push_back(std::move(evals));
+    const uint64_t gen_inv = gl::inv(gl::GEN);
+    uint64_t dom = N;
+    for (int l = 0; l <= fl.layers; l++) {
+        const size_t rows = dom / Fd;
+        const FriSrc fsrc{fl.vals[l].get(), fl.vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd};
+        Commitment c;
+        c.tree = commit_fri_layer(fsrc);
+        c.n_global = rows;
+        c.root = c.tree.root();
+        if (roots) wdigest(*roots, c.root);
+        coin.reseed(c.root);
+        fl.coms.push_back(std::move(c));
+        const T alpha = coin.draw<F>();
+        if (l == fl.layers) break;   // alpha drawn after the remainder commitment is unused
+        fl.vals.emplace_back(ctx, (size_t)F::DEG * rows);
+        NttTables* td = ctx->ntt_tables(ilog2(dom));
+        FoldArgs<F> a{};
+        for (int d = 0; d < F::DEG; d++) { a.in[d] = fl.vals[l].get() + (size_t)d * dom; a.out[d] = fl.vals[l + 1].get() + (size_t)d * rows; }
+        if (F::DEG == 1) { a.in[1] = a.in[0]; a.out[1] = a.out[0]; }
+        a.rows = rows; a.fold = (int)Fd; a.alpha = alpha;
+        a.twi_lo = td->lo_inv; a.twi_hi = td->hi_inv; a.tw_h = td->h;
+        a.gen_inv = gen_inv; a.fold_inv = gl::inv(Fd);
+        uint64_t wFi = gl::inv(gl::root_of_unity(ilog2(Fd)));
+        for (size_t m = 0; m < Fd; m++) a.dft[m] = gl::pow(wFi, m);
+        launch_fri_fold<F>(ctx, a);
+        dom = rows;
+    }
+    return fl;
+}
+template FriLayers Prover::fri_build_layers<FB>(DevBuf<uint64_t>&&, uint64_t, HostCoin&, Bytes*);
+template FriLayers Prover::fri_build_layers<FQ>(DevBuf<uint64_t>&&, uint64_t, HostCoin&, Bytes*);
+
+template <class F> Bytes Prover::fri_open(const FriLayers& fl, const std::vector<uint64_t>& positions) {
+    Context* ctx = ctx_;
+    const size_t Fd = fl.fold;
+    Bytes out;
+    w8(out, (uint8_t)fl.layers);
+    std::vector<uint64_t> fp = positions;
+    uint64_t dom = fl.lde_size;
+    for (int l = 0; l < fl.layers; l++) {
+        fp = fold_positions(fp, dom, Fd);
+        const size_t rows = dom / Fd, cnt = fp.size() * Fd * F::DEG;
+        DevBuf<uint64_t> d_pos(ctx, fp.size()), d_val(ctx, cnt);
+        std::vector<uint64_t> vals(cnt);
+        AERO_HIP(hipMemcpyAsync(d_pos.get(), fp.data(), fp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        launch_gather_fri_rows(ctx, fl.vals[l].get(), fl.vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd, d_pos.get(), (int)fp.size(), d_val.get());
+        AERO_HIP(hipMemcpyAsync(vals.data(), d_val.get(), cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        Bytes vb;
+        for (uint64_t v : vals) w64(vb, v);
+        const Bytes paths = open_batch(ctx, fl.coms[l].tree, fp);
+        w32(out, vb.size()); wb(out, vb);
+        w32(out, paths.size()); wb(out, paths);
+        dom = rows;
+    }
+    std::vector<uint64_t> rem((size_t)F::DEG * dom);
+    AERO_HIP(hipMemcpyAsync(rem.data(), fl.vals[fl.layers].get(), rem.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    Bytes rb;
+    for (size_t i = 0; i < dom; i++) for (int d = 0; d < F::DEG; d++) w64(rb, rem[(size_t)d * dom + i]);
+    w16(out, rb.size()); wb(out, rb);
+    w8(out, 0);
+    return out;
+}
+template Bytes Prover::fri_open<FB>(const FriLayers&, const std::vector<uint64_t>&);
+template Bytes Prover::fri_open<FQ>(const FriLayers&, const std::vector<uint64_t>&);
+
 template <class F>
 Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::vector<uint64_t>* pub_out) {
     typedef typename F::T T;
@@ -640,7 +762,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     // 5. composition polynomial: interpolate over the coset; coefficient I gets h^-I (coset) * h^(I >> log C)
     //    (pre-scaling of column coefficient i = I >> log C for the column LDE). In bit-reversed order the C column
     //    polynomials are the C contiguous chunks of the buffer: no split pass (H(x) = sum_c x^c H_c(x^C)).
-    ctx->ntt_inverse(hbuf.get(), ceN, F::DEG, log_ce, 1, h_inv, h, ilog2(C));
+    composition_from_evaluations(hbuf.get(), F::DEG, log_ce, ilog2(C), h);
     ms.composition = clk.lap();
     // 6. composition commitment [a12]: column c*DEG + d <- chunk c of component d
     Matrix clde(ctx, (int)(C * F::DEG), M);
@@ -687,25 +809,11 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     const T lambda = coin.draw<F>(), mu = coin.draw<F>();
     // FRI evaluations per layer: [DEG][dom] component arrays, natural order (dom = this rank's share while the layer is sharded)
     std::vector<DevBuf<uint64_t>> fri_vals;
-    fri_vals.emplace_back(ctx, (size_t)F::DEG * M);
     {
-        // deg(DEEP) < n: evaluate it on the n-point coset h<w_n> (every (M/n)-th LDE row), interpolate (the plain inverse
-        // transform of values on h<w_n> yields exactly the h^i-prescaled coefficients), extend like any other column.
-        NttTables* tM = ctx->ntt_tables(log_M);
-        DevBuf<uint64_t> dsm(ctx, (size_t)F::DEG * n);
-        DeepArgs<F> a{};
-        a.tlde = tlde.data.get(); a.clde = clde.data.get(); a.alde = A ? alde.data.get() : nullptr; a.A = A; a.N = M; a.count = n; a.row_step = (uint32_t)Bl; a.W = W; a.C = (uint32_t)C;
-        a.tw_lo = tM->lo_fwd; a.tw_hi = tM->hi_fwd; a.tw_h = tM->h; a.offset = h;
-        a.z = z; a.z_next = z_next; a.z_c = z_c; a.z_conj = F::conj(z); a.lambda = lambda; a.mu = mu;
-        ParamPack pp(ctx);
-        const size_t i0 = pp.add(ood_cur), i1 = pp.add(ood_next), i2 = pp.add(ood_h), i3 = pp.add(da), i4 = pp.add(db), i5 = pp.add(dg), i6 = pp.add(dc);
-        pp.commit();
-        a.ood_cur = pp.ptr<T>(i0); a.ood_next = pp.ptr<T>(i1); a.ood_h = pp.ptr<T>(i2);
-        a.da = pp.ptr<T>(i3); a.db = pp.ptr<T>(i4); a.dg = pp.ptr<T>(i5); a.dc = pp.ptr<T>(i6);
-        for (int d = 0; d < F::DEG; d++) a.out[d] = dsm.get() + (size_t)d * n;
-        launch_deep<F>(ctx, a);
-        ctx->ntt_inverse(dsm.get(), n, F::DEG, log_n, 1, 1, 1, 0);
-        ctx->ntt_forward(dsm.get(), n, fri_vals[0].get(), M, F::DEG, log_M, log_Bl);
+        DeepInputs<F> in;
+        in.z = z; in.ood_cur = ood_cur; in.ood_next = ood_next; in.ood_h = ood_h;
+        in.da = da; in.db = db; in.dg = dg; in.dc = dc; in.lambda = lambda; in.mu = mu;
+        fri_vals.push_back(deep_compose<F>(tlde.data.get(), clde.data.get(), A ? alde.data.get() : nullptr, W, A, (uint32_t)C, log_n, log_Bl, h, in));
     }
     ms.deep = clk.lap();
 
@@ -714,9 +822,14 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     //    per-peer digest exchange would drop below min_peer digests the layer is all-gathered and the rest runs unsharded.
     std::vector<Commitment> fri_coms;
     std::vector<char> fri_sharded;
-    {
+    if (G == 1) {
+        FriLayers fl = fri_build_layers<F>(std::move(fri_vals[0]), N, coin, &proof.commitments);
+        fri_vals = std::move(fl.vals);
+        fri_coms = std::move(fl.coms);
+        fri_sharded.assign(layers + 1, 0);
+    } else {
         uint64_t Dom = N;
-        bool sharded = G > 1;
+        bool sharded = true;
         for (int l = 0; l <= layers; l++) {
             if (sharded && (l == layers || Dom / Fd / G / G < min_peer)) {
                 const size_t Lc = Dom / G;

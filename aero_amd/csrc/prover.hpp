@@ -137,6 +137,23 @@ struct Commitment {
     Digest root{};
 };
 
+// Inputs of the DEEP composition [a14]: the OOD point, the OOD frame (main then aux columns) and composition values, and
+// the coefficients in draw order (3 per trace column, one per composition column, then lambda, mu).
+template <class F> struct DeepInputs {
+    typedef typename F::T T;
+    T z;
+    std::vector<T> ood_cur, ood_next, ood_h, da, db, dg, dc;
+    T lambda, mu;
+};
+// Result of the FRI commit phase [a15]: evaluations per layer ([DEG][dom] component arrays, natural order; the last entry
+// is the remainder layer) and one commitment per layer incl. the remainder.
+struct FriLayers {
+    std::vector<DevBuf<uint64_t>> vals;
+    std::vector<Commitment> coms;
+    uint64_t lde_size = 0;
+    int deg = 1, fold = 0, layers = 0;
+};
+
 class Prover {
 public:
     Prover(Context* ctx, const ProofOptions& opt) : ctx_(ctx), opt_(opt) { opt_.validate(); }
@@ -158,6 +175,20 @@ public:
     // which must then outlive the tree).
     MerkleTree commit_to_rows(const Matrix& lde, bool keep_low_levels = true);
     MerkleTree commit_fri_layer(const FriSrc& src, bool keep_low_levels = false);
+
+    // H on the constraint domain (components [DEG][ce_n], evaluations on h<w_ce>) -> coefficients of the C column
+    // polynomials, in place: chunk c of component d = column c (internal form, pre-scaled by h^i)   [a11]
+    void composition_from_evaluations(uint64_t* hbuf, int deg, int log_ce, int log_c, uint64_t h);
+    // DEEP composition over the coset h<w_M>, M = n << log_bl: evaluates on every (M/n)-th row, interpolates, extends.
+    // tlde: W x M, clde: (C*DEG) x M (column c*DEG + d), alde: (A*DEG) x M or nullptr. Returns [DEG][M].   [a14]
+    template <class F>
+    DevBuf<uint64_t> deep_compose(const uint64_t* tlde, const uint64_t* clde, const uint64_t* alde, uint32_t W, uint32_t A, uint32_t C, int log_n,
+                                  int log_bl, uint64_t h, const DeepInputs<F>& in);
+    // FRI commit phase on one GPU: per layer transpose-hash-commit, reseed, draw alpha, fold; `roots` receives every
+    // commitment (layers + remainder) in order.   [a15]
+    template <class F> FriLayers fri_build_layers(DevBuf<uint64_t>&& evals, uint64_t N, HostCoin& coin, Bytes* roots);
+    // serialised FriProof for LDE-domain query positions: u8 #layers, per layer Queries, u16 remainder, u8 0   [a17]
+    template <class F> Bytes fri_open(const FriLayers& fl, const std::vector<uint64_t>& positions);
 
 private:
     template <class F> Bytes prove_impl(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_out);

@@ -130,6 +130,31 @@ template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F
 template void launch_fib_constraints<FB>(Context*, const FibConsArgs<FB>&, int);
 template void launch_fib_constraints<FQ>(Context*, const FibConsArgs<FQ>&, int);
 
+// Division of stored numerator columns by their divisors (the unfused form of MODE 1 above; C-ABI stage entry point).
+template <class F> __global__ __launch_bounds__(256) void fib_divide_kernel(FibDivideArgs<F> a) {
+    typedef typename F::T T;
+    const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.ce_n) return;
+    const uint64_t x = gl::mul(a.offset, tw2(a.tw_lo, a.tw_hi, (uint32_t)s, a.tw_h));
+    const uint64_t d0 = gl::sub(x, 1), d1 = gl::sub(x, a.w_last);
+    const uint64_t inv01 = gl::inv(gl::mul(d0, d1));
+    const uint64_t i0 = gl::mul(inv01, d1), i1 = gl::mul(inv01, d0);
+    const uint64_t tdiv = gl::mul(d1, a.zn_inv[s & (a.C - 1)]);
+    T num[3];
+    for (int c = 0; c < 3; c++)
+        num[c] = F::make(a.cols[(size_t)(c * F::DEG) * a.ce_n + s], F::DEG > 1 ? a.cols[(size_t)(c * F::DEG + 1) * a.ce_n + s] : 0);
+    T h = F::mulb(num[0], tdiv);
+    h = F::add(h, F::mulb(num[1], i0));
+    h = F::add(h, F::mulb(num[2], i1));
+    for (int d = 0; d < F::DEG; d++) a.out_h[d][s] = F::comp(h, d);
+}
+template <class F> void launch_fib_divide(Context* ctx, const FibDivideArgs<F>& a) {
+    AERO_LAUNCH(ctx, "fib_divide_kernel", a.ce_n * 8 * 4 * F::DEG, (fib_divide_kernel<F>), dim3((unsigned)((a.ce_n + 255) / 256)), dim3(256), 0, a);
+    ctx->check_launch("fib_divide");
+}
+template void launch_fib_divide<FB>(Context*, const FibDivideArgs<FB>&);
+template void launch_fib_divide<FQ>(Context*, const FibDivideArgs<FQ>&);
+
 // ------------------------------------------------------------------------------------------------
 // Evaluate polynomials stored as bit-reversed coefficient vectors at up to 2 points:
 //   out[col][pt] = sum_p coeff[col][p] * y_pt^(rev_L(p)).

@@ -30,6 +30,20 @@ template <class F> struct FibConsArgs {
 };
 template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F>& a, int mode);
 
+// The division step of `ConstraintEvaluationTable::into_poly` for FibAir: H(x) = sum over the three divisor columns of
+// numerator / divisor on the constraint-evaluation domain (row s <-> x = offset * w_ce^s).
+template <class F> struct FibDivideArgs {
+    const uint64_t* cols;       // (3*DEG) x ce_n numerators: [transition, boundary(step 0), boundary(step n-1)] x components
+    size_t ce_n;
+    uint32_t C;
+    const uint64_t *tw_lo, *tw_hi;   // two-level table of w_ce
+    int tw_h;
+    uint64_t offset, w_last;
+    const uint64_t* zn_inv;     // C entries: (offset^n w_C^k - 1)^-1
+    uint64_t* out_h[2];
+};
+template <class F> void launch_fib_divide(Context* ctx, const FibDivideArgs<F>& a);
+
 template <class F> struct EvalArgs {
     typedef typename F::T T;
     const uint64_t* coeffs;

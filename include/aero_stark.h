@@ -117,7 +117,40 @@ int32_t aero_eval_constraints_fib(aero_ctx* ctx, const aero_matrix* trace_lde, u
                                   const uint64_t* coeffs, uint8_t field_extension, uint32_t fragment_offset,
                                   uint32_t num_fragments, uint64_t* out_cols, uint64_t* frag_index_out);
 
+/* ---- composition polynomial, DEEP composition (the stages inside the fork's `prove_after_constraint_eval`,
+ *      proving_worker.rs:344-352; bodies in winter-prover 0.4) --------------------------------------------------------------- */
+/* `ConstraintEvaluationTable::into_poly` -> `CompositionPoly` for FibAir: numer_cols = the 3*deg numerator columns of
+ * aero_eval_constraints_fib over the WHOLE constraint domain (ce_n = 2 * 2^log_n values each, host); every column is divided
+ * by its divisor ((x^n - 1)/(x - w^(n-1)), x - 1, x - w^(n-1)), the columns are summed, interpolated over the coset and
+ * split into the 2 column polynomials H(x) = H_0(x^2) + x H_1(x^2). Output: matrix of 2*deg columns x 2^log_n rows in the
+ * backend's internal polynomial form (input to aero_evaluate_columns_over / aero_poly_eval); column order [component][c]. */
+int32_t aero_composition_poly_fib(aero_ctx* ctx, const uint64_t* numer_cols, uint32_t log_n, uint8_t field_extension,
+                                  aero_matrix** comp_polys);
+/* DEEP composition over the LDE domain (winter-prover `DeepCompositionPoly`; verifier-side mirror
+ * src/stark_verifier/composer.cairo:48-316). trace_lde: W columns; comp_lde: C*deg columns, column c*deg + d = component d of
+ * composition column c (the order in which rows are hashed). All field elements are `deg` u64 each (deg = 1, or 2 for the
+ * quadratic extension): z; ood_frame = current row (W) then next row (W) of trace evaluations at z and z*g; ood_evals = C
+ * values H_c(z^C); coeffs in draw order = 3 per trace column (alpha, beta, gamma), one per composition column, lambda, mu.
+ * Output: deg columns x N rows (component columns of the DEEP evaluations, natural order) = FRI layer 0. */
+int32_t aero_deep_compose(aero_ctx* ctx, const aero_matrix* trace_lde, const aero_matrix* comp_lde, uint32_t log_blowup,
+                          uint8_t field_extension, const uint64_t* z, const uint64_t* ood_frame, const uint64_t* ood_evals,
+                          const uint64_t* coeffs, aero_matrix** deep_evals);
+
 /* ---- FRI and grinding ------------------------------------------------------------------------------------------------- */
+/* `FriProver::build_layers(channel, evaluations)` (winter-fri 0.4; verifier mirror fri_verifier.cairo:56-82,243-340): per layer
+ * transpose to rows of `fold` values, hash, commit, reseed the coin with the root, draw alpha, fold; the remainder is
+ * committed the same way. evals = deg columns x N rows (aero_deep_compose output). seed_in = coin seed before the first FRI
+ * commitment (draws never change the seed; reseeding resets the counter). roots_out receives (layers + 1) * 32 bytes;
+ * seed_out the coin seed after the remainder commitment. The handle keeps every layer for aero_fri_open. */
+typedef struct aero_fri aero_fri;
+int32_t aero_fri_build_layers(aero_ctx* ctx, const aero_matrix* evals, const aero_proof_options* options, const uint8_t seed_in[32],
+                              uint8_t* roots_out, size_t roots_cap, uint32_t* num_roots, uint8_t seed_out[32], aero_fri** out);
+/* `FriProver::build_proof(positions)`: the serialised FriProof exactly as it sits in StarkProof::to_bytes — u8 #layers, per
+ * layer u32 len + values, u32 len + BatchMerkleProof nodes, then u16 len + remainder, u8 0. positions are
+ * LDE-domain query positions (folded per layer, duplicates dropped keeping the first: miden-to-cairo-parser/src/lib.rs:421-436). */
+int32_t aero_fri_open(aero_ctx* ctx, const aero_fri* fri, const uint64_t* positions, uint32_t k, uint8_t** out, size_t* out_len);
+void aero_fri_free(aero_ctx* ctx, aero_fri* fri);
+
 /* One FRI layer fold over the base field (winter-fri `apply_drp`, mirrored by src/stark_verifier/fri/
  * fri_verifier.cairo:305-315): values = dom evaluations in natural order over 7 * <w_dom>; out = dom/fold values. */
 int32_t aero_fri_fold(aero_ctx* ctx, const uint64_t* values, uint64_t dom, uint32_t fold, uint64_t alpha, uint64_t* out);
