@@ -91,7 +91,7 @@ int32_t aero_trace_upload(aero_ctx* ctx, const uint64_t* col_major, uint32_t wid
         try {
             h->m = Matrix(ctx->c, (int)width, n);
             AERO_HIP(hipMemcpyAsync(h->m.data.get(), col_major, (size_t)width * n * 8, hipMemcpyHostToDevice, ctx->c->stream));
-            ctx->c->sync();
+            if (!all_canonical(ctx->c, h->m.data.get(), (size_t)width * n)) fail("trace_upload: trace holds a non-canonical field element (>= p)");
         } catch (...) { delete h; throw; }
         *out = h;
     });
@@ -537,6 +537,7 @@ int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint
         size_t n = (size_t)1 << log_n;
         DevBuf<uint64_t> d(ctx->c, (size_t)width * n);
         AERO_HIP(hipMemcpyAsync(d.get(), trace_col_major, (size_t)width * n * 8, hipMemcpyHostToDevice, ctx->c->stream));
+        if (!all_canonical(ctx->c, d.get(), (size_t)width * n)) fail("prove_fib_host: trace holds a non-canonical field element (>= p)");
         do_prove(ctx, d.get(), width, (int)log_n, options, proof, proof_len, pub_out);
     });
 }

@@ -1,4 +1,4 @@
-// Radix-2 Goldilocks NTT for gfx950: batched column transforms staged through LDS.
+// Goldilocks NTT for gfx950: batched column transforms staged through LDS, radix-8 butterflies in registers.
 //
 // Replaces, for the reference's stage 1 (/root/reference/aero-sdk/miden-wasm/src/proving_worker.rs:271-274):
 //   main_trace.interpolate_columns()            -> interpolate (evaluations on <w_n>  -> coefficients)

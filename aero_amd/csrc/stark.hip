@@ -489,6 +489,30 @@ uint64_t run_grind(Context* ctx, const Digest& seed, uint32_t bits) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Input validation: field elements handed over by the host must be canonical (winter's BaseElement::new reduces on
+// construction; this boundary takes raw u64 and refuses anything >= p instead of silently computing with it).
+__global__ __launch_bounds__(256) void canonical_check_kernel(const uint64_t* __restrict__ v, size_t count, unsigned int* bad) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    unsigned int any = 0;
+    for (; i < count; i += stride) any |= v[i] >= gl::P ? 1u : 0u;
+    if (any) atomicOr(bad, 1u);
+}
+bool all_canonical(Context* ctx, const uint64_t* vals, size_t count) {
+    if (count == 0) return true;
+    DevBuf<unsigned int> d_bad(ctx, 1);
+    AERO_HIP(hipMemsetAsync(d_bad.get(), 0, 4, ctx->stream));
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    AERO_LAUNCH(ctx, "canonical_check_kernel", count * 8, canonical_check_kernel, dim3((unsigned)blocks), dim3(256), 0, vals, count, d_bad.get());
+    ctx->check_launch("canonical_check");
+    unsigned int bad = 0;
+    AERO_HIP(hipMemcpyAsync(&bad, d_bad.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    return bad == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Query gathers: rows of a column-major matrix at given positions; digests at given node indices.
 __global__ void gather_rows_kernel(const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;

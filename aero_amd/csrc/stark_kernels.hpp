@@ -96,6 +96,9 @@ template <class F> void launch_fri_fold(Context* ctx, const FoldArgs<F>& a);
 template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, size_t n, uint32_t W, uint32_t A, uint32_t R,
                                            const typename F::T* rands_dev, uint64_t* out);
 
+// true iff every one of the `count` device values is a canonical field element (< p); synchronises the stream
+bool all_canonical(Context* ctx, const uint64_t* vals, size_t count);
+
 uint64_t run_grind(Context* ctx, const Digest& seed, uint32_t bits);
 void launch_gather_rows(Context* ctx, const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out);
 void launch_gather_fri_rows(Context* ctx, const uint64_t* c0, const uint64_t* c1, int deg, size_t rows, int fold, const uint64_t* pos, int npos, uint64_t* out);

@@ -289,3 +289,16 @@ def test_stage_and_kernel_timers(ctx):
     ctx.set_kernel_timing(False)
     assert ms["total"] > 0 and abs(sum(v for k, v in ms.items() if k != "total") - ms["total"]) < 0.25 * ms["total"] + 1.0
     assert "ntt_fwd_pass" in rep and rep["merkle_multi_kernel"][0] >= 1 and rep["ntt_fwd_pass"][2] > 0
+
+
+def test_non_canonical_trace_is_refused(ctx):
+    """Raw u64 >= p is not a field element: the boundary refuses it instead of computing with it (winter's
+    BaseElement::new would have reduced it on construction)."""
+    t = aero_amd.fib_trace(2, 8)
+    t[1, 200] = P
+    with pytest.raises(aero_amd.AeroError):
+        ctx.trace_upload(t)
+    with pytest.raises(aero_amd.AeroError):
+        ctx.prove_fib(t, opts())
+    t[1, 200] = P - 1                      # largest canonical value is fine (the proof is simply not FibAir-valid)
+    ctx.trace_upload(t).free()
