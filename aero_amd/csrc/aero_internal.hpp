@@ -103,6 +103,9 @@ public:
     // ---- NTT (ntt.hip) ----
     NttTables* ntt_tables(int log_n);
     void ensure_small_twiddles();
+    // pass-boundary twiddle table of a register-only strided pass (ntt.hip), cached per (size, stride, radix, direction)
+    const uint64_t* pass_twiddles(int log_n, int log_s, int log_r, bool inverse);
+    bool reg_passes = true;    // strided passes of radix 16..64 run entirely in registers (AERO_NTT_REG=0: LDS passes only)
     void ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad);
     void ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift);
 
@@ -125,6 +128,7 @@ public:
 
     // internal state
     std::map<int, NttTables> ntt_tabs;
+    std::map<uint64_t, uint64_t*> pass_tabs;
     uint64_t *tw4096_fwd = nullptr, *tw4096_inv = nullptr;
 
 private:

@@ -84,5 +84,73 @@ template <int RB> __device__ __forceinline__ void dft_dif_inv(uint64_t (&y)[1 <<
     }
 }
 
+// ---- DFTs of up to 64 points entirely in registers -----------------------------------------------------------------------
+// 2 has order 192 in this field and the 64-th root of unity the NTT uses is w_64 = 2^39 (w_32 = 2^78, w_16 = 2^156 = -2^60,
+// w_8 = 2^120 = -2^24, w_4 = 2^48): every twiddle of a transform of up to 64 points is a power of two, i.e. a shift plus one
+// short reduction. x * 2^K for a compile-time K in [0, 96), x canonical, with phi = 2^32, phi^2 = phi - 1, phi^3 = -1:
+//   (y0, y1, y2) = 32-bit limbs of x << (K mod 32)            (y2 < 2^(K mod 32))
+//   K < 32:  y0 + y1 phi + y2 (phi - 1)            K < 64:  y0 phi + y1 (phi - 1) - y2            K < 96:  y0 (phi - 1) - y1 - y2 phi
+template <int K> __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
+    static_assert(K >= 0 && K < 96, "mul_pow2: exponent out of range");
+    if constexpr (K == 0) return x;
+    else if constexpr (K == 24) return mul_2_24(x);
+    else if constexpr (K == 48) return mul_w4(x);
+    else if constexpr (K == 72) return mul_2_72(x);
+    else {
+        constexpr int q = K / 32, r = K % 32;
+        const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+        const uint32_t y0 = x0 << r;
+        const uint32_t y1 = r ? ((x0 >> ((32 - r) & 31)) | (x1 << r)) : x1;
+        const uint32_t y2 = r ? (x1 >> ((32 - r) & 31)) : 0u;
+        if constexpr (q == 0) {
+            uint64_t lo = gl::mk64(y0, y1);
+            lo = lo >= gl::P ? lo - gl::P : lo;
+            return add(lo, ((uint64_t)y2 << 32) - y2);
+        } else if constexpr (q == 1) {
+            return sub(add(gl::mk64(0u, y0), ((uint64_t)y1 << 32) - y1), (uint64_t)y2);
+        } else {
+            return sub(((uint64_t)y0 << 32) - y0, gl::mk64(y1, y2));
+        }
+    }
+}
+// v * w_64^E for a compile-time E in [0, 64) folded into the butterfly: returns (u + t, u - t) with t = v * 2^(39 E mod 192);
+// exponents >= 96 are a negation (2^96 = -1), which swaps the two outputs instead of costing anything.
+template <int E> __device__ __forceinline__ void bfly_w64(uint64_t& u, uint64_t& v) {
+    constexpr int K = (39 * E) % 192;
+    if constexpr (K < 96) { const uint64_t t = mul_pow2<K>(v); const uint64_t a = add(u, t), b = sub(u, t); u = a; v = b; }
+    else { const uint64_t t = mul_pow2<K - 96>(v); const uint64_t a = sub(u, t), b = add(u, t); u = a; v = b; }
+}
+// inverse direction: (u, v) -> (u + v, (u - v) * w_64^-E); w_64^-E = 2^(192 - 39 E mod 192)
+template <int E> __device__ __forceinline__ void bfly_w64_inv(uint64_t& u, uint64_t& v) {
+    constexpr int K = (192 - (39 * E) % 192) % 192;
+    const uint64_t a = add(u, v);
+    if constexpr (K < 96) v = mul_pow2<K>(sub(u, v));
+    else v = mul_pow2<K - 96>(sub(v, u));
+    u = a;
+}
+// One radix-2 stage T (sub-transform size 2^T) of an in-register transform of 2^LOG points, fully unrolled at compile time.
+template <int LOG, int T, int I, bool INV> struct StageUnroll {
+    static __device__ __forceinline__ void run(uint64_t (&y)[1 << LOG]) {
+        constexpr int half = 1 << (T - 1);
+        constexpr int j = I & (half - 1), grp = I >> (T - 1);
+        constexpr int lo = (grp << T) + j, hi = lo + half;
+        constexpr int E = j * (64 >> T);          // w_(2^T)^j = w_64^(j * 64 / 2^T)
+        if constexpr (!INV) bfly_w64<E>(y[lo], y[hi]);
+        else bfly_w64_inv<E>(y[lo], y[hi]);
+        if constexpr (I + 1 < (1 << (LOG - 1))) StageUnroll<LOG, T, I + 1, INV>::run(y);
+    }
+};
+// Forward: decimation in time, bit-reversed input -> natural output (same convention as dft_dit, any LOG <= 6).
+template <int LOG, int T = 1> __device__ __forceinline__ void dft_dit_reg(uint64_t (&y)[1 << LOG]) {
+    static_assert(LOG >= 1 && LOG <= 6, "register DFT of up to 64 points");
+    StageUnroll<LOG, T, 0, false>::run(y);
+    if constexpr (T < LOG) dft_dit_reg<LOG, T + 1>(y);
+}
+// Inverse up to the factor 2^LOG: decimation in frequency with inverse roots, natural input -> bit-reversed output.
+template <int LOG, int T = LOG> __device__ __forceinline__ void dft_dif_inv_reg(uint64_t (&y)[1 << LOG]) {
+    static_assert(LOG >= 1 && LOG <= 6, "register DFT of up to 64 points");
+    StageUnroll<LOG, T, 0, true>::run(y);
+    if constexpr (T > 1) dft_dif_inv_reg<LOG, T - 1>(y);
+}
 
 }  // namespace aero

@@ -51,6 +51,7 @@ struct PassArgs {
     const uint64_t* tw_lo;    // two-level table of w_n (or its inverse)
     const uint64_t* tw_hi;
     int tw_h;
+    const uint64_t* tw_pass;  // register passes only: pass-boundary twiddles, row b * R + k
     // inverse contiguous pass only: out[p] *= ktab[k] * blockfac(block)
     const uint64_t* ktab;     // R entries: c0 * (a^(2^(L-r)) * b^(2^(L-r-shift)))^rev_r(k)
     uint64_t sc_a, sc_b;      // per-block factor = a^rev(block) * b^(rev(block) >> shift)
@@ -194,6 +195,63 @@ __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Strided passes of radix <= 64 entirely in registers: a thread owns one column position `lo` of a block and the R = 2^LOGR
+// values at stride S; the R-point transform needs no LDS because every twiddle of a transform of up to 64 points is a power of
+// two in this field (dft_small.cuh). Consecutive threads own consecutive addresses, so each of the R loads / stores of a
+// wavefront is one contiguous 512-byte segment. The pass-boundary twiddle depends on (block, row) only: it comes from a small
+// per-pass table (2^(log_n - log_s) entries, row b * R + k = w^(S * rev(b) * k)) that every lane of a workgroup reads at the
+// same address.
+template <int LOGR> __global__ __launch_bounds__(256) void ntt_fwd_strided_reg(PassArgs a) {
+    constexpr int R = 1 << LOGR;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;            // over 2^(log_n - LOGR) threads per column
+    const size_t lo = t & (((size_t)1 << a.log_s) - 1);
+    const uint32_t b = (uint32_t)(((size_t)blockIdx.x * 256) >> a.log_s);   // S >= 256: uniform over the workgroup (scalar twiddle loads)
+    const size_t base = lo + (((size_t)b << LOGR) << a.log_s);
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    uint64_t y[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
+    dft_dit_reg<LOGR>(y);
+    if (!a.first && b) {
+        const uint64_t* tw = a.tw_pass + ((size_t)b << LOGR);
+#pragma unroll
+        for (int k = 1; k < R; k++) y[k] = mul(y[k], tw[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
+}
+template <int LOGR> __global__ __launch_bounds__(256) void ntt_inv_strided_reg(PassArgs a) {
+    constexpr int R = 1 << LOGR;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t lo = t & (((size_t)1 << a.log_s) - 1);
+    const uint32_t b = (uint32_t)(((size_t)blockIdx.x * 256) >> a.log_s);   // S >= 256: uniform over the workgroup (scalar twiddle loads)
+    const size_t base = lo + (((size_t)b << LOGR) << a.log_s);
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    uint64_t y[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
+    if (!a.first && b) {
+        const uint64_t* tw = a.tw_pass + ((size_t)b << LOGR);
+#pragma unroll
+        for (int k = 1; k < R; k++) y[k] = mul(y[k], tw[k]);
+    }
+    dft_dif_inv_reg<LOGR>(y);
+#pragma unroll
+    for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
+}
+// tab[(b << log_r) + k] = root^((S * rev(b) * k) mod n), rev over bbits = log_n - log_s - log_r bits
+__global__ void fill_pass_twiddles(uint64_t* tab, int log_n, int log_s, int log_r, uint64_t root) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << (log_n - log_s))) return;
+    const uint32_t b = i >> log_r, k = i & ((1u << log_r) - 1);
+    const uint32_t rb = gl::bitrev(b, log_n - log_s - log_r);
+    const uint64_t e = (((uint64_t)rb * k) << log_s) & (((uint64_t)1 << log_n) - 1);
+    tab[i] = gl::pow(root, e);
+}
+
 // tab[k] = c0 * abase^rev(k) * bbase^(rev(k) >> bshift), rev over `bits` bits, k < 2^bits
 __global__ void fill_pow_bitrev(uint64_t* tab, int bits, uint64_t abase, uint64_t bbase, int bshift, uint64_t c0) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -228,6 +286,20 @@ NttTables* Context::ntt_tables(int log_n) {
     check_launch("ntt tables");
     ntt_tabs[log_n] = t;
     return &ntt_tabs[log_n];
+}
+
+const uint64_t* Context::pass_twiddles(int log_n, int log_s, int log_r, bool inverse) {
+    const uint64_t key = ((uint64_t)log_n << 24) | ((uint64_t)log_s << 16) | ((uint64_t)log_r << 8) | (inverse ? 1 : 0);
+    auto it = pass_tabs.find(key);
+    if (it != pass_tabs.end()) return it->second;
+    const uint32_t count = 1u << (log_n - log_s);
+    uint64_t* tab = (uint64_t*)dev_alloc((size_t)count * 8);
+    uint64_t w = gl::root_of_unity(log_n);
+    if (inverse) w = gl::inv(w);
+    AERO_LAUNCH(this, "fill_pass_twiddles", 0, fill_pass_twiddles, dim3((count + 255) / 256), dim3(256), 0, tab, log_n, log_s, log_r, w);
+    check_launch("pass twiddles");
+    pass_tabs[key] = tab;
+    return tab;
 }
 
 void Context::ensure_small_twiddles() {
@@ -274,9 +346,18 @@ void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         a.log_pad = q == 0 ? log_pad : 0;
         a.first = (q + 1 == plan.size());
         a.tw_r = tw4096_fwd; a.tw_lo = t->lo_fwd; a.tw_hi = t->hi_fwd; a.tw_h = t->h;
+        const size_t abytes = (size_t)ncols * 8 * ((((size_t)1 << log_out) >> a.log_pad) + ((size_t)1 << log_out));
+        if (q > 0 && reg_passes && a.log_r >= 4 && a.log_r <= 6 && log_out - a.log_r >= 8) {
+            if (!a.first) a.tw_pass = pass_twiddles(log_out, a.log_s, a.log_r, false);
+            dim3 rgrid((unsigned)((((size_t)1 << log_out) >> a.log_r) / 256), ncols);
+            if (a.log_r == 6) AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_strided_reg<6>, rgrid, dim3(256), 0, a);
+            else if (a.log_r == 5) AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_strided_reg<5>, rgrid, dim3(256), 0, a);
+            else AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_strided_reg<4>, rgrid, dim3(256), 0, a);
+            continue;
+        }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
         dim3 grid((unsigned)(((size_t)1 << log_out) / E), ncols);
-        AERO_LAUNCH(this, "ntt_fwd_pass", (size_t)ncols * 8 * ((((size_t)1 << log_out) >> a.log_pad) + ((size_t)1 << log_out)), ntt_fwd_pass, grid, dim3(256), 0, a);
+        AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_pass, grid, dim3(256), 0, a);
     }
     check_launch("ntt_forward");
 }
@@ -308,6 +389,15 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
         a.first = (qi + 1 == plan.size());
         a.tw_r = tw4096_inv; a.tw_lo = t->lo_inv; a.tw_hi = t->hi_inv; a.tw_h = t->h;
         if (qi == 0) { a.ktab = ktab; a.sc_a = sa; a.sc_b = sb; a.sc_shift = shift; }
+        if (qi > 0 && reg_passes && a.log_r >= 4 && a.log_r <= 6 && log_n - a.log_r >= 8) {
+            if (!a.first) a.tw_pass = pass_twiddles(log_n, a.log_s, a.log_r, true);
+            dim3 rgrid((unsigned)((((size_t)1 << log_n) >> a.log_r) / 256), ncols);
+            const size_t abytes = (size_t)ncols * 16 * ((size_t)1 << log_n);
+            if (a.log_r == 6) AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<6>, rgrid, dim3(256), 0, a);
+            else if (a.log_r == 5) AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<5>, rgrid, dim3(256), 0, a);
+            else AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<4>, rgrid, dim3(256), 0, a);
+            continue;
+        }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
         dim3 grid((unsigned)(((size_t)1 << log_n) / E), ncols);
         AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass, grid, dim3(256), 0, a);

@@ -22,6 +22,7 @@ Context::Context(int dev) : device(dev) {
     if (dev < 0 || dev >= count) throw Error(ST_BAD_ARG, "device id out of range");
     AERO_HIP(hipSetDevice(dev));
     AERO_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (const char* e = getenv("AERO_NTT_REG")) reg_passes = e[0] != '0';
 }
 Context::~Context() {
     (void)hipSetDevice(device);
@@ -625,7 +626,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     if (G < 1 || (G & (G - 1)) || rank < 0 || rank >= G) fail("sharded prove: world must be a power of two and 0 <= rank < world");
     if ((size_t)G > B) fail("sharded prove: more ranks than the blowup factor (each rank owns whole cosets of the trace domain)");
     const int log_G = ilog2(G);
-    const size_t M = N / G, Bl = B / G;
+    const size_t M = N / G;
     const int log_M = log_N - log_G, log_Bl = log_B - log_G;
     if (G > 1 && M < (size_t)G) fail("sharded prove: LDE domain too small for this many ranks");
     const uint64_t h = gl::mul(gl::GEN, gl::pow(gl::root_of_unity(log_N), (uint64_t)rank));
