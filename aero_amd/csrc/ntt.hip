@@ -152,6 +152,75 @@ __global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Contiguous first pass of the forward transform with the global traffic moved into the rounds: the first round reads its
+// operands straight from global memory (zero-padded transforms: the broadcast coefficient), the last round applies the
+// pass-boundary twiddle and stores straight to global memory, so a tile crosses LDS once per round boundary only
+// (2 exchanges and 2 barriers for 9 butterfly stages instead of 4 and 5).
+template <int RB, bool FIRST, bool LAST>
+__device__ __forceinline__ void first_pass_round(const PassArgs& a, uint64_t* lds, const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                 size_t base, size_t cbase, int s, uint32_t rbk) {
+    constexpr int G = 1 << RB;
+    const int ngroups = 1 << (a.log_r - RB);
+    const int tsh = 12 - s - RB;
+    for (int g = threadIdx.x; g < ngroups; g += 256) {
+        const int b0 = (g & ((1 << s) - 1)) | ((g >> s) << (s + RB));
+        const int klow = b0 & ((1 << s) - 1);
+        uint64_t y[G];
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int p = b0 + (i << s);
+            y[i] = FIRST ? in[cbase + ((size_t)p >> a.log_pad)] : lds[skew(p)];
+        }
+        if (klow) {
+#pragma unroll
+            for (int i = 1; i < G; i++) y[i] = mul(y[i], a.tw_r[(uint32_t)(klow * (int)gl::bitrev((uint32_t)i, RB)) << tsh]);
+        }
+        dft_dit<RB>(y);
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int p = b0 + (i << s);
+            if (LAST) {
+                uint64_t v = y[i];
+                if (!a.first && rbk && p) {
+                    const uint32_t ex = (uint32_t)(((uint64_t)rbk * (uint32_t)p) & ((1ull << a.log_n) - 1));
+                    v = mul(v, tw_lookup(a.tw_lo, a.tw_hi, ex, a.tw_h));
+                }
+                out[base + p] = v;
+            } else {
+                lds[skew(p)] = y[i];
+            }
+        }
+    }
+}
+template <bool FIRST, bool LAST>
+__device__ __forceinline__ void first_pass_round_any(int rb, const PassArgs& a, uint64_t* lds, const uint64_t* in, uint64_t* out, size_t base,
+                                                     size_t cbase, int s, uint32_t rbk) {
+    if (rb == 3) first_pass_round<3, FIRST, LAST>(a, lds, in, out, base, cbase, s, rbk);
+    else if (rb == 2) first_pass_round<2, FIRST, LAST>(a, lds, in, out, base, cbase, s, rbk);
+    else first_pass_round<1, FIRST, LAST>(a, lds, in, out, base, cbase, s, rbk);
+}
+__global__ __launch_bounds__(256) void ntt_fwd_first_pass(PassArgs a) {
+    __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
+    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x);
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    const size_t base = (size_t)b << a.log_r, cbase = base >> a.log_pad;
+    const uint32_t rbk = gl::bitrev(b, a.log_n - a.log_r);
+    const int bits = a.log_r - a.log_pad, nrounds = (bits + 2) / 3;      // >= 1 (checked by the launcher)
+    int s = a.log_pad;
+    for (int rd = 0; rd < nrounds; rd++) {
+        const int rb = a.log_r - s >= 3 ? 3 : a.log_r - s;
+        const bool first = rd == 0, last = rd + 1 == nrounds;
+        if (first && last) first_pass_round_any<true, true>(rb, a, lds, in, out, base, cbase, s, rbk);
+        else if (first) first_pass_round_any<true, false>(rb, a, lds, in, out, base, cbase, s, rbk);
+        else if (last) first_pass_round_any<false, true>(rb, a, lds, in, out, base, cbase, s, rbk);
+        else first_pass_round_any<false, false>(rb, a, lds, in, out, base, cbase, s, rbk);
+        if (!last) __syncthreads();
+        s += rb;
+    }
+}
+
 // Inverse: exact mirror (decimation in frequency with inverse roots), natural input -> bit-reversed output.
 __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
@@ -357,6 +426,10 @@ void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
         dim3 grid((unsigned)(((size_t)1 << log_out) / E), ncols);
+        if (q == 0 && reg_passes && a.log_r > a.log_pad) {
+            AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_first_pass, grid, dim3(256), 0, a);
+            continue;
+        }
         AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_pass, grid, dim3(256), 0, a);
     }
     check_launch("ntt_forward");
