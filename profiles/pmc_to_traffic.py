@@ -16,15 +16,31 @@ import sys
 from collections import defaultdict
 
 
+# device function -> the name its launches carry in bench.py's per-kernel table (AERO_LAUNCH name)
+ALIASES = {
+    "merkle_leaf8_rows_kernel": "merkle_leaf8_kernel",
+    "ntt_fwd_strided_reg": "ntt_fwd_pass", "ntt_fwd_first_pass": "ntt_fwd_pass",
+    "ntt_inv_strided_reg": "ntt_inv_pass",
+    "merkle_up3_parts_kernel": "merkle_up3_kernel",
+    "fri_fold_fft_kernel": "fri_fold_kernel",
+    "aux_block_totals_kernel": "aux_columns_kernel", "aux_scan_totals_kernel": "aux_columns_kernel", "aux_apply_kernel": "aux_columns_kernel",
+}
+
+
+def launch_name(kernel_name):
+    name = re.sub(r"^void ", "", kernel_name).split("(")[0].replace("aero::", "")
+    base = re.sub(r"<.*", "", name)
+    if base == "hash_rows_kernel" and "FriSrc" in name:
+        return "hash_fri_rows_kernel"
+    return ALIASES.get(base, base)
+
+
 def per_kernel(path, counter):
     acc = defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"]
-        name = re.sub(r"^void ", "", name).split("(")[0].replace("aero::", "")
-        name = re.sub(r"<.*", "", name)
-        acc[name].append(float(r["Counter_Value"]))
+        acc[launch_name(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return acc
 
 
