@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic input: a batch of --concurrent (default 4) independent
+A "step" is one pass of the hot path over one batch of synthetic input: a batch of --concurrent (default 8) independent
 traces, each proven completely (one proof per trace, each on its own HIP stream so that the latency-bound tree tops
 and host round trips of one proof overlap the throughput-bound kernels of another). Every trace is the 2^20-row x
 2-column Fibonacci trace (BASELINE configs[1]: Goldilocks base field, blowup 8, blake2s, 27 queries,
@@ -252,9 +252,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=0,
                     help="trace size of the bounded CPU-baseline sample (0 = the full workload if a 2^16 probe projects <= 40 s, else 2^18)")
-    ap.add_argument("--concurrent", type=int, default=4,
+    ap.add_argument("--concurrent", type=int, default=0,
                     help="proofs in flight per GPU: a step proves a batch of this many independent traces, each on its own "
-                         "HIP stream (context) driven by its own host thread; 1 = strictly one proof at a time")
+                         "HIP stream (context) driven by its own host thread; 1 = strictly one proof at a time; 0 (default) = 8, "
+                         "fewer when 8 working sets would not fit comfortably in HBM (throughput plateaus at 8 on the 2^20 x 2 workload)")
     ap.add_argument("--stages", action="store_true", help="also print per-stage ms and the per-kernel table to stderr")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
                     help="N > 1: replicas = every GPU proves its own traces (weak scaling, default); sharded = ONE proof per step "
@@ -325,7 +326,12 @@ def main():
         dist.destroy_process_group()
         return
 
-    S = max(1, args.concurrent)
+    if args.concurrent > 0:
+        S = args.concurrent
+    else:
+        # working set of one proof ~ 1.5 x the LDE matrices (trace + aux + composition + DEEP columns) over N = blowup * n rows
+        est = 1.5 * 8 * (opt.blowup_factor << log_n) * (trace_cols(width, over) + 4)
+        S = int(max(1, min(8, (120 << 30) // est)))
     ctxs = [aero_amd.Context(local_rank) for _ in range(S)]
     trace = aero_amd.fib_trace(width, log_n)          # synthetic data, pure function of (width, log_n)
     devs = [c.trace_upload(trace) for c in ctxs]      # resident in HBM before the timed region
