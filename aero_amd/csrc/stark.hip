@@ -120,7 +120,7 @@ template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F
     const size_t in_cols = (size_t)a.W + (size_t)a.A * F::DEG;
     if (mode == 0) {
         AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + 3 * F::DEG), (fib_constraints_kernel<F, 0, 1>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, a);
-    } else if (cnt % 4 == 0) {
+    } else if (cnt % 4 == 0) {   // 4 rows per thread share one batched inversion (measured best of 4 / 2 / 1 in both fields)
         AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 4>), dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, a);
     } else {
         AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 1>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, a);
@@ -299,8 +299,13 @@ template <class F, int K> __global__ __launch_bounds__(256) void deep_kernel(Dee
 }
 template <class F> void launch_deep(Context* ctx, const DeepArgs<F>& a) {
     const size_t bytes = a.count * 8 * ((size_t)a.W + ((size_t)a.C + a.A) * F::DEG + F::DEG);
-    if (a.count % 4 == 0 && a.count >= 4096)
+    // rows per thread share one batched inversion; over F_p^2 four rows need 335 VGPRs + scratch (1 wave per SIMD), two fit
+    // (measured, 2^20 rows: F_p 78 / 65 / 90 us for 4 / 2 / 1 rows per thread, F_p^2 262 / 176 / 152 us)
+    const int K = F::DEG > 1 ? 1 : 2;
+    if (K == 4 && a.count % 4 == 0 && a.count >= 4096)
         AERO_LAUNCH(ctx, "deep_kernel", bytes, (deep_kernel<F, 4>), dim3((unsigned)((a.count / 4 + 255) / 256)), dim3(256), 0, a);
+    else if (K == 2 && a.count % 2 == 0 && a.count >= 4096)
+        AERO_LAUNCH(ctx, "deep_kernel", bytes, (deep_kernel<F, 2>), dim3((unsigned)((a.count / 2 + 255) / 256)), dim3(256), 0, a);
     else
         AERO_LAUNCH(ctx, "deep_kernel", bytes, (deep_kernel<F, 1>), dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, a);
     ctx->check_launch("deep");
