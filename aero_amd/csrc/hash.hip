@@ -131,16 +131,21 @@ template <class Src> __global__ __launch_bounds__(256) void merkle_leaf8_kernel(
     }
     build3(d, nodes, n + first, skip > 1 ? skip : 1);
 }
+// The 8 leaf hashes of a thread as straight-line code by construction: with two compressions per leaf (3 or 4 columns) the
+// compiler declines `#pragma unroll` on the leaf loop (23 compression bodies) and the digest array goes to scratch.
+template <int NC, int I> struct LeafUnroll {
+    static __device__ __forceinline__ void run(const RowSrc& src, size_t first, Digest (&d)[8], Digest* nodes, size_t n, int skip) {
+        d[I] = leaf_digest_fixed<NC>(src, first + I);
+        if (skip == 0) store_digest(&nodes[n + first + I], d[I]);
+        if constexpr (I + 1 < 8) LeafUnroll<NC, I + 1>::run(src, first, d, nodes, n, skip);
+    }
+};
 template <int NC> __global__ __launch_bounds__(256) void merkle_leaf8_rows_kernel(RowSrc src, Digest* nodes, size_t n, int skip) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n / 8) return;
     const size_t first = t * 8;
     Digest d[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        d[i] = leaf_digest_fixed<NC>(src, first + i);
-        if (skip == 0) store_digest(&nodes[n + first + i], d[i]);
-    }
+    LeafUnroll<NC, 0>::run(src, first, d, nodes, n, skip);
     build3(d, nodes, n + first, skip > 1 ? skip : 1);
 }
 
