@@ -56,6 +56,11 @@ class ProofOptions(C.Structure):
                 self.fri_folding_factor, self.fri_log_max_remainder]
 
 
+class FibAirDesc(C.Structure):
+    """aero_fib_air: the optional auxiliary segment of the built-in AIR."""
+    _fields_ = [("aux_width", C.c_uint32), ("aux_rands", C.c_uint32), ("aux_degree", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -361,15 +366,17 @@ class Context:
         lib().aero_free(proof)
         return data, pub.tolist()
 
-    def prove_fib_aux(self, trace: "Matrix", aux_width, aux_rands, options: ProofOptions, comm=None):
-        """FibAir plus one auxiliary segment of `aux_width` columns built from `aux_rands` coin elements
-        (aero_prove_fib_aux); comm = None or a shard communicator. Returns (proof_bytes, public_inputs)."""
+    def prove_fib_aux(self, trace: "Matrix", aux_width, aux_rands, options: ProofOptions, comm=None, aux_degree=2):
+        """FibAir plus one auxiliary segment of `aux_width` columns built from `aux_rands` coin elements, aux transition
+        constraint of degree `aux_degree` (aero_prove_fib_air); comm = None or a shard communicator.
+        Returns (proof_bytes, public_inputs)."""
         proof = u8p()
         plen = C.c_size_t(0)
         w, _ = trace.shape
         pub = np.zeros(w // 2, np.uint64)
-        rc = lib().aero_prove_fib_aux(self.h, C.byref(comm.struct) if comm is not None else None, trace.h, C.c_uint32(aux_width),
-                                      C.c_uint32(aux_rands), C.byref(options), C.byref(proof), C.byref(plen), _p64(pub))
+        air = FibAirDesc(aux_width, aux_rands, aux_degree)
+        rc = lib().aero_prove_fib_air(self.h, C.byref(comm.struct) if comm is not None else None, trace.h, C.byref(air),
+                                      C.byref(options), C.byref(proof), C.byref(plen), _p64(pub))
         if rc != 0 and getattr(comm, "last_error", None) is not None:
             raise AeroError(rc, f"{lib().aero_last_error(self.h).decode()} ({comm.last_error!r})")
         self._ck(rc)

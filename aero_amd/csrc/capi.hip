@@ -252,7 +252,7 @@ static void eval_constraints_fib(Context* c, const Matrix& lde, uint32_t log_blo
                                  uint32_t frag, uint32_t nfrags, uint64_t* out_cols, uint64_t* frag_index_out) {
     typedef typename F::T T;
     const uint32_t W = (uint32_t)lde.cols;
-    const size_t N = lde.rows, B = (size_t)1 << log_blowup, n = N / B, C = FibAir::ce_blowup_factor(), ceN = C * n;
+    const size_t N = lde.rows, B = (size_t)1 << log_blowup, n = N / B, C = FibAir::plain_ce_blowup_factor(), ceN = C * n;
     REQUIRE(W >= 2 && !(W & 1), "eval_constraints_fib: FibAir needs an even width");
     REQUIRE(B >= C && n >= 8, "eval_constraints_fib: bad blowup / trace length");
     REQUIRE(nfrags >= 1 && (nfrags & (nfrags - 1)) == 0 && ceN / nfrags >= 1 && frag < nfrags, "eval_constraints_fib: bad fragment spec");
@@ -307,7 +307,7 @@ int32_t aero_eval_constraints_fib(aero_ctx* ctx, const aero_matrix* trace_lde, u
 // ---- composition polynomial / DEEP / FRI layers ------------------------------------------------------------------
 template <class F> static void composition_poly_fib(aero_ctx* ctx, const uint64_t* numer_cols, uint32_t log_n, aero_matrix** out) {
     Context* c = ctx->c;
-    const size_t n = (size_t)1 << log_n, C = FibAir::ce_blowup_factor(), ceN = C * n;
+    const size_t n = (size_t)1 << log_n, C = FibAir::plain_ce_blowup_factor(), ceN = C * n;
     const int log_ce = ilog2u(ceN);
     for (size_t i = 0; i < 3 * F::DEG * ceN; i++) REQUIRE(numer_cols[i] < gl::P, "composition_poly_fib: non-canonical element");
     DevBuf<uint64_t> d_cols(c, 3 * F::DEG * ceN);
@@ -478,11 +478,12 @@ int32_t aero_grind(aero_ctx* ctx, const uint8_t seed[32], uint32_t bits, uint64_
 
 // ---- whole proof ----------------------------------------------------------------------------------------
 static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, int log_n, const aero_proof_options* o, uint8_t** proof,
-                     size_t* proof_len, uint64_t* pub_out, const aero_comm* comm = nullptr, uint32_t aux_width = 0, uint32_t aux_rands = 0) {
+                     size_t* proof_len, uint64_t* pub_out, const aero_comm* comm = nullptr, uint32_t aux_width = 0, uint32_t aux_rands = 0,
+                     uint32_t aux_degree = 2) {
     REQUIRE(o && proof && proof_len, "prove: null argument");
     ProofOptions po{o->num_queries, o->blowup_factor, o->grinding_factor, o->hash_fn, o->field_extension, o->fri_folding_factor, o->fri_log_max_remainder};
     Prover p(ctx->c, po);
-    p.set_aux_segment(aux_width, aux_rands);
+    p.set_aux_segment(aux_width, aux_rands, aux_degree);
     if (comm) {
         REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "prove_fib_sharded: bad rank / world");
         REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "prove_fib_sharded: missing exchange callback");
@@ -527,6 +528,15 @@ int32_t aero_prove_fib_aux(aero_ctx* ctx, const aero_comm* comm, const aero_matr
         REQUIRE(trace, "prove_fib_aux: null trace");
         REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0, "prove_fib_aux: trace length must be a power of two");
         do_prove(ctx, trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows), options, proof, proof_len, pub_out, comm, aux_width, aux_rands);
+    });
+}
+int32_t aero_prove_fib_air(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_fib_air* air, const aero_proof_options* options,
+                           uint8_t** proof, size_t* proof_len, uint64_t* pub_out) {
+    return guard(ctx, [&] {
+        REQUIRE(trace && air, "prove_fib_air: null argument");
+        REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0, "prove_fib_air: trace length must be a power of two");
+        do_prove(ctx, trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows), options, proof, proof_len, pub_out, comm, air->aux_width,
+                 air->aux_rands, air->aux_width ? air->aux_degree : 2);
     });
 }
 int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n, const aero_proof_options* options,

@@ -444,14 +444,16 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
     const int r1 = plan[0].log_r;
     // per-k table for the final (contiguous) pass
     uint64_t ninv = gl::inv((uint64_t)1 << log_n);
-    // natural index I = rev_r1(k) * 2^(L-r1) + rev(block): the k-dependent part of sa^I * sb^(I >> shift)
+    // natural index I = rev_r1(k) * 2^q + rev(block), q = L - r1 block bits: the k-dependent part of sa^I * sb^(I >> shift) is
+    //   q >= shift: (sa^(2^q) * sb^(2^(q-shift)))^rev(k)          (the block contributes sa^rb * sb^(rb >> shift))
+    //   q <  shift: (sa^(2^q))^rev(k) * sb^(rev(k) >> (shift-q))  (the block's bits are shifted out: it contributes sa^rb only)
+    const int q = log_n - r1;
     uint64_t abase, bbase = 1;
     int bshift = 0;
-    if (log_n - r1 >= shift) {
-        abase = gl::mul(gl::pow(sa, 1ull << (log_n - r1)), gl::pow(sb, 1ull << (log_n - r1 - shift)));
+    if (q >= shift) {
+        abase = gl::mul(gl::pow(sa, 1ull << q), gl::pow(sb, 1ull << (q - shift)));
     } else {
-        if (log_n != r1) fail("ntt_inverse: unsupported scale shift for this size", ST_INTERNAL);
-        abase = sa; bbase = sb; bshift = shift;       // single block: I = rev(k)
+        abase = gl::pow(sa, 1ull << q); bbase = sb; bshift = shift - q;
     }
     uint64_t* ktab = (uint64_t*)scratch_alloc(((size_t)1 << r1) * 8);
     AERO_LAUNCH(this, "fill_pow_bitrev", 0, fill_pow_bitrev, dim3(((1u << r1) + 255) / 256), dim3(256), 0, ktab, r1, abase, bbase, bshift, gl::mul(c0, ninv));

@@ -604,10 +604,13 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     AERO_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << log_n, B = opt_.blowup_factor, Fd = opt_.fri_folding_factor;
     const int log_B = ilog2(B);
-    const size_t N = n * B, C = FibAir::ce_blowup_factor(), ceN = C * n;
+    const uint32_t A = aux_width_, R = aux_rands_, D = aux_degree_;
+    if (A && (D < 2 || D > 8)) fail("prove: auxiliary constraint degree must be in [2, 8]");
+    FibAir air;
+    air.width = W; air.log_n = log_n; air.aux_width = A; air.aux_rands = R; air.aux_degree = D;
+    const size_t N = n * B, C = air.ce_blowup_factor(), ceN = C * n;
     const int log_N = log_n + log_B, log_ce = ilog2(ceN);
     if (W < 2 || (W & 1) || W > 254) fail("prove: FibAir needs an even column count in [2, 254]");
-    const uint32_t A = aux_width_, R = aux_rands_;
     if (A > 255 - W || (A && (R == 0 || R > 255))) fail("prove: auxiliary segment needs 1..255 random elements and main + aux width <= 255");
     const uint32_t TW = W + A;
     if (B < C) fail("prove: blowup factor smaller than the constraint evaluation blowup");
@@ -640,8 +643,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     auto t_start = std::chrono::steady_clock::now();
 
     // 0. AIR, public inputs, channel [proving_worker.rs:248-268]
-    FibAir air;
-    air.width = W; air.log_n = log_n; air.results.resize(W / 2); air.aux_width = A; air.aux_rands = R;
+    air.results.resize(W / 2);
     {
         // results[k] = trace[2k+1][n-1]
         DevBuf<uint64_t> d_pos(ctx, 1), d_row(ctx, W);
@@ -700,7 +702,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         pp.commit();
         d_rands = pp.ptr<T>(ir);
         apolys = Matrix(ctx, (int)(A * F::DEG), n);
-        launch_aux_columns<F>(ctx, trace_dev, n, W, A, R, d_rands, apolys.data.get());
+        launch_aux_columns<F>(ctx, trace_dev, n, W, A, R, D, d_rands, apolys.data.get());
         ctx->ntt_inverse(apolys.data.get(), n, (int)(A * F::DEG), log_n, 1, h, 1, 0);
         alde = Matrix(ctx, (int)(A * F::DEG), M);
         ctx->ntt_forward(apolys.data.get(), n, alde.data.get(), M, (int)(A * F::DEG), log_M, log_Bl);
@@ -745,13 +747,14 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         uint64_t hn = gl::pow(h, n), wC = gl::root_of_unity(ilog2(C));
         for (size_t k = 0; k < C; k++) {
             uint64_t xnk = gl::mul(hn, gl::pow(wC, k));
-            xnp[k] = xnk;
+            // aux degree adjustment x^((E + 1 - D) n + (D - 2)): the x^n part is constant on each coset of <w_n>
+            xnp[k] = gl::pow(xnk, C + 1 - D);
             xn[k] = gl::inv(xnk);
             zn[k] = gl::inv(gl::sub(xnk, 1));
         }
         const size_t i_xn = pp.add(xn), i_zn = pp.add(zn), i_xnp = pp.add(xnp);
         pp.commit();
-        a.aux = aux_src; a.A = A; a.R = R; a.rands = d_rands; a.xn = pp.ptr<uint64_t>(i_xnp);
+        a.aux = aux_src; a.A = A; a.R = R; a.D = D; a.rands = d_rands; a.xn = pp.ptr<uint64_t>(i_xnp);
         a.ta = pp.ptr<T>(i_ta); a.tb = pp.ptr<T>(i_tb); a.ba = pp.ptr<T>(i_ba); a.bb = pp.ptr<T>(i_bb);
         a.results = pp.ptr<uint64_t>(i_res); a.xn_inv = pp.ptr<uint64_t>(i_xn); a.zn_inv = pp.ptr<uint64_t>(i_zn);
         a.w_last = gl::pow(g, n - 1);
@@ -762,13 +765,24 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     ms.constraints = clk.lap();
     // 5. composition polynomial: interpolate over the coset; coefficient I gets h^-I (coset) * h^(I >> log C)
     //    (pre-scaling of column coefficient i = I >> log C for the column LDE). In bit-reversed order the C column
-    //    polynomials are the C contiguous chunks of the buffer: no split pass (H(x) = sum_c x^c H_c(x^C)).
+    //    polynomials are the C contiguous chunks of the buffer (chunk q = column bitrev(q)): no split pass
+    //    (H(x) = sum_c x^c H_c(x^C)).
     composition_from_evaluations(hbuf.get(), F::DEG, log_ce, ilog2(C), h);
     ms.composition = clk.lap();
     // 6. composition commitment [a12]: column c*DEG + d <- chunk c of component d
     Matrix clde(ctx, (int)(C * F::DEG), M);
-    for (int d = 0; d < F::DEG; d++)
-        ctx->ntt_forward(hbuf.get() + (size_t)d * ceN, n, clde.data.get() + (size_t)d * M, (size_t)F::DEG * M, (int)C, log_M, log_Bl);
+    // In bit-reversed coefficient order the low log2(C) bits of the coefficient index (= the column) are the HIGH bits of the
+    // position: column c is chunk bitrev(c). For C = 2 that is the identity and all columns of a component go in one launch.
+    const int log_C = ilog2(C);
+    for (int d = 0; d < F::DEG; d++) {
+        if (C == 2) {
+            ctx->ntt_forward(hbuf.get() + (size_t)d * ceN, n, clde.data.get() + (size_t)d * M, (size_t)F::DEG * M, (int)C, log_M, log_Bl);
+        } else {
+            for (size_t c = 0; c < C; c++)
+                ctx->ntt_forward(hbuf.get() + (size_t)d * ceN + (size_t)gl::bitrev((uint32_t)c, log_C) * n, n,
+                                 clde.data.get() + ((size_t)c * F::DEG + d) * M, M, 1, log_M, log_Bl);
+        }
+    }
     Commitment ccom = commit_matrix(clde);
     wdigest(proof.commitments, ccom.root);
     coin.reseed(ccom.root);
@@ -789,7 +803,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     std::vector<T> ood_cur(TW), ood_next(TW), ood_h(C);
     for (uint32_t c = 0; c < W; c++) { ood_cur[c] = ood[2 * c]; ood_next[c] = ood[2 * c + 1]; }
     for (uint32_t c = 0; c < A; c++) { ood_cur[W + c] = ood[2 * W + C + 2 * c]; ood_next[W + c] = ood[2 * W + C + 2 * c + 1]; }
-    for (size_t c = 0; c < C; c++) ood_h[c] = ood[2 * W + c];
+    for (size_t c = 0; c < C; c++) ood_h[c] = ood[2 * W + gl::bitrev((uint32_t)c, log_C)];   // evaluated in chunk order
     {
         std::vector<uint64_t> f;
         flatten<F>(ood_cur.data(), TW, f); flatten<F>(ood_next.data(), TW, f);

@@ -99,16 +99,21 @@ struct MerkleTree {
 // seeds (1+2k, 2+2k); assertions a(0), b(0), b(n-1) = results[k]; public inputs = results.
 // Optional auxiliary segment (synthetic stand-in for Miden's multiset-check columns): aux_width columns
 // over E built after the main commitment from aux_rands coin elements, p_c(0) = 1, p_c(i+1) = p_c(i) * (r_(c mod R) +
-// main_(c mod W)(i)); one degree-2 transition constraint and the assertion p_c(0) = 1 per column.
+// main_(c mod W)(i))^(D-1); one degree-D transition constraint and the assertion p_c(0) = 1 per column. D = 2 is the plain
+// multiset-check shape; larger D raises the constraint-evaluation blowup and the number of composition columns (8 for D in
+// [5, 8], the shape of the golden Miden proof).
 struct FibAir {
     uint32_t width = 0;
     int log_n = 0;
     std::vector<uint64_t> results;
     uint32_t aux_width = 0, aux_rands = 0;
+    uint32_t aux_degree = 2;   // aux transition constraint p' = p * (r + main)^(aux_degree - 1), degree in [2, 8]
     size_t trace_length() const { return (size_t)1 << log_n; }
     size_t num_transition_constraints() const { return width + aux_width; }
     size_t num_assertions() const { return width + width / 2 + aux_width; }
-    static size_t ce_blowup_factor() { return 2; }
+    // constraint-evaluation blowup = number of composition columns = max(next_pow2(max constraint degree), 2)
+    size_t ce_blowup_factor() const { size_t d = aux_width ? aux_degree : 1, e = 2; while (e < d) e <<= 1; return e; }
+    static size_t plain_ce_blowup_factor() { return 2; }   // FibAir without an auxiliary segment
 };
 
 struct StageMs {   // per-stage wall time (ms) of the last prove(), names after proving_worker.rs console labels
@@ -158,7 +163,9 @@ class Prover {
 public:
     Prover(Context* ctx, const ProofOptions& opt) : ctx_(ctx), opt_(opt) { opt_.validate(); }
     void set_comm(const ShardComm& c) { comm_ = c; }
-    void set_aux_segment(uint32_t aux_width, uint32_t aux_rands) { aux_width_ = aux_width; aux_rands_ = aux_width ? aux_rands : 0; }
+    void set_aux_segment(uint32_t aux_width, uint32_t aux_rands, uint32_t aux_degree = 2) {
+        aux_width_ = aux_width; aux_rands_ = aux_width ? aux_rands : 0; aux_degree_ = aux_degree;
+    }
     const ProofOptions& options() const { return opt_; }
     // trace: device, column-major W x 2^log_n (not modified). Returns StarkProof::to_bytes().
     Bytes prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_inputs_out);
@@ -200,7 +207,7 @@ private:
     Context* ctx_;
     ProofOptions opt_;
     ShardComm comm_;
-    uint32_t aux_width_ = 0, aux_rands_ = 0;
+    uint32_t aux_width_ = 0, aux_rands_ = 0, aux_degree_ = 2;
 };
 
 // BatchMerkleProof node selection (winter-crypto 0.4 MerkleTree::prove_batch restated):

@@ -68,13 +68,17 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
         }
         if (a.A) {
             // auxiliary transition constraints (degree 2): adjustment x^n, constant on each of the C cosets of <w_n>
-            const uint64_t xx = a.xn[s & (a.C - 1)];
+            uint64_t xx = a.xn[s & (a.C - 1)];
+            for (uint32_t e = 2; e < a.D; e++) xx = gl::mul(xx, x);
             for (uint32_t c = 0; c < a.A; c++) {
                 const size_t o = (size_t)(c * F::DEG) * a.N;
                 const T pc = F::make(a.aux[o + r], F::DEG > 1 ? a.aux[o + a.N + r] : 0);
                 const T pn = F::make(a.aux[o + rn], F::DEG > 1 ? a.aux[o + a.N + rn] : 0);
                 const uint64_t m = a.lde[(size_t)(c % a.W) * a.N + r];
-                const T t = F::sub(pn, F::mul(pc, F::add(a.rands[c % a.R], F::from(m))));
+                const T f1 = F::add(a.rands[c % a.R], F::from(m));
+                T f = f1;
+                for (uint32_t e = 2; e < a.D; e++) f = F::mul(f, f1);
+                const T t = F::sub(pn, F::mul(pc, f));
                 acc = F::add(acc, F::mul(F::add(a.ta[a.W + c], F::mulb(a.tb[a.W + c], xx)), t));
                 const uint32_t bi = a.W + a.W / 2 + c;
                 g0 = F::add(g0, F::mul(F::add(a.ba[bi], F::mulb(a.bb[bi], xb)), F::sub(pc, F::one())));
@@ -378,8 +382,12 @@ template void launch_fri_fold<FQ>(Context*, const FoldArgs<FQ>&);
 // per-row values. A thread owns AUX_K consecutive rows, a workgroup AUX_K * 256; the factor of row i is
 // rands[c mod R] + trace[c mod W][i] (rows >= n contribute 1).
 constexpr int AUX_K = 8;
-template <class F> __device__ __forceinline__ typename F::T aux_factor(const uint64_t* __restrict__ col, typename F::T r, size_t i, size_t n) {
-    return i < n ? F::add(r, F::from(col[i])) : F::one();
+template <class F> __device__ __forceinline__ typename F::T aux_factor(const uint64_t* __restrict__ col, typename F::T r, size_t i, size_t n, uint32_t D) {
+    if (i >= n) return F::one();
+    const typename F::T f1 = F::add(r, F::from(col[i]));
+    typename F::T f = f1;
+    for (uint32_t e = 2; e < D; e++) f = F::mul(f, f1);
+    return f;
 }
 // inclusive scan of one value per thread over the workgroup (Hillis-Steele through LDS); returns this thread's inclusive value
 template <class F> __device__ __forceinline__ typename F::T block_scan_mul(typename F::T v, typename F::T* sh) {
@@ -395,7 +403,7 @@ template <class F> __device__ __forceinline__ typename F::T block_scan_mul(typen
     }
     return sh[t];
 }
-template <class F> __global__ __launch_bounds__(256) void aux_block_totals_kernel(const uint64_t* trace, size_t n, uint32_t W, uint32_t R,
+template <class F> __global__ __launch_bounds__(256) void aux_block_totals_kernel(const uint64_t* trace, size_t n, uint32_t W, uint32_t R, uint32_t D,
                                                                                const typename F::T* rands, typename F::T* totals) {
     typedef typename F::T T;
     __shared__ T sh[256];
@@ -405,7 +413,7 @@ template <class F> __global__ __launch_bounds__(256) void aux_block_totals_kerne
     const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * AUX_K;
     T p = F::one();
 #pragma unroll
-    for (int k = 0; k < AUX_K; k++) p = F::mul(p, aux_factor<F>(col, r, first + k, n));
+    for (int k = 0; k < AUX_K; k++) p = F::mul(p, aux_factor<F>(col, r, first + k, n, D));
     const T inc = block_scan_mul<F>(p, sh);
     if (threadIdx.x == 255) totals[(size_t)c * gridDim.x + blockIdx.x] = inc;
 }
@@ -422,7 +430,7 @@ template <class F> __global__ __launch_bounds__(256) void aux_scan_totals_kernel
     (void)inc;
     for (uint32_t i = lo; i < lo + per && i < nblk; i++) { const T v = row[i]; row[i] = run; run = F::mul(run, v); }
 }
-template <class F> __global__ __launch_bounds__(256) void aux_apply_kernel(const uint64_t* trace, size_t n, uint32_t W, uint32_t R,
+template <class F> __global__ __launch_bounds__(256) void aux_apply_kernel(const uint64_t* trace, size_t n, uint32_t W, uint32_t R, uint32_t D,
                                                                         const typename F::T* rands, const typename F::T* totals, uint64_t* out) {
     typedef typename F::T T;
     __shared__ T sh[256];
@@ -433,7 +441,7 @@ template <class F> __global__ __launch_bounds__(256) void aux_apply_kernel(const
     T f[AUX_K];
     T p = F::one();
 #pragma unroll
-    for (int k = 0; k < AUX_K; k++) { f[k] = aux_factor<F>(col, r, first + k, n); p = F::mul(p, f[k]); }
+    for (int k = 0; k < AUX_K; k++) { f[k] = aux_factor<F>(col, r, first + k, n, D); p = F::mul(p, f[k]); }
     block_scan_mul<F>(p, sh);
     T run = totals[(size_t)c * gridDim.x + blockIdx.x];
     if (threadIdx.x) run = F::mul(run, sh[threadIdx.x - 1]);
@@ -444,18 +452,18 @@ template <class F> __global__ __launch_bounds__(256) void aux_apply_kernel(const
         run = F::mul(run, f[k]);
     }
 }
-template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, size_t n, uint32_t W, uint32_t A, uint32_t R,
+template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, size_t n, uint32_t W, uint32_t A, uint32_t R, uint32_t D,
                                            const typename F::T* rands_dev, uint64_t* out) {
     typedef typename F::T T;
     const uint32_t nblk = (uint32_t)((n + (size_t)AUX_K * 256 - 1) / ((size_t)AUX_K * 256));
     T* totals = (T*)ctx->scratch_alloc(sizeof(T) * (size_t)A * nblk);
-    AERO_LAUNCH(ctx, "aux_columns_kernel", (size_t)A * n * 8, (aux_block_totals_kernel<F>), dim3(nblk, A), dim3(256), 0, trace, n, W, R, rands_dev, totals);
+    AERO_LAUNCH(ctx, "aux_columns_kernel", (size_t)A * n * 8, (aux_block_totals_kernel<F>), dim3(nblk, A), dim3(256), 0, trace, n, W, R, D, rands_dev, totals);
     AERO_LAUNCH(ctx, "aux_columns_kernel", 0, (aux_scan_totals_kernel<F>), dim3(A), dim3(256), 0, totals, nblk);
-    AERO_LAUNCH(ctx, "aux_columns_kernel", (size_t)A * n * 8 * (1 + F::DEG), (aux_apply_kernel<F>), dim3(nblk, A), dim3(256), 0, trace, n, W, R, rands_dev, totals, out);
+    AERO_LAUNCH(ctx, "aux_columns_kernel", (size_t)A * n * 8 * (1 + F::DEG), (aux_apply_kernel<F>), dim3(nblk, A), dim3(256), 0, trace, n, W, R, D, rands_dev, totals, out);
     ctx->check_launch("aux_columns");
 }
-template void launch_aux_columns<FB>(Context*, const uint64_t*, size_t, uint32_t, uint32_t, uint32_t, const uint64_t*, uint64_t*);
-template void launch_aux_columns<FQ>(Context*, const uint64_t*, size_t, uint32_t, uint32_t, uint32_t, const gl::E2*, uint64_t*);
+template void launch_aux_columns<FB>(Context*, const uint64_t*, size_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint64_t*, uint64_t*);
+template void launch_aux_columns<FQ>(Context*, const uint64_t*, size_t, uint32_t, uint32_t, uint32_t, uint32_t, const gl::E2*, uint64_t*);
 
 // ------------------------------------------------------------------------------------------------
 // Grinding (random.cairo:282-316 mirror): smallest nonce >= 1 whose BLAKE2s(seed || LE64(nonce)) has at least

@@ -22,9 +22,9 @@ template <class F> struct FibConsArgs {
     // auxiliary segment (A = 0: none): A columns over E stored as A*DEG base columns (index c*DEG + d) with the same row
     // count / stride as `lde`; p_c' = p_c * (rands[c mod R] + main[c mod W]); p_c(0) = 1
     const uint64_t* aux;
-    uint32_t A, R;
+    uint32_t A, R, D;             // D = degree of the aux transition constraint: p' = p * (rand + main)^(D-1)
     const T* rands;               // R elements (device)
-    const uint64_t* xn;           // C entries: h^n w_C^k = x^n on the constraint domain (degree adjustment of the aux group)
+    const uint64_t* xn;           // C entries: (h^n w_C^k)^(C+1-D); times x^(D-2) = the degree adjustment x^((C+1-D)n + D-2) of the aux group
     uint64_t* out_cols;           // MODE 0: (3*DEG) x count, column-major
     uint64_t* out_h[2];           // MODE 1: DEG component arrays of ce_n values
 };
@@ -91,9 +91,9 @@ template <class F> struct FoldArgs {
 template <class F> void launch_fri_fold(Context* ctx, const FoldArgs<F>& a);
 
 // Auxiliary segment columns (a synthetic stand-in for Miden's multiset-check columns): for c < A
-//   p_c(0) = 1,  p_c(i+1) = p_c(i) * (rands[c mod R] + trace[c mod W][i])      (a prefix product over the rows, in E)
+//   p_c(0) = 1,  p_c(i+1) = p_c(i) * (rands[c mod R] + trace[c mod W][i])^(D-1)      (a prefix product over the rows, in E)
 // out = (A*DEG) x n column-major component columns (index c*DEG + d).
-template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, size_t n, uint32_t W, uint32_t A, uint32_t R,
+template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, size_t n, uint32_t W, uint32_t A, uint32_t R, uint32_t D,
                                            const typename F::T* rands_dev, uint64_t* out);
 
 // true iff every one of the `count` device values is a canonical field element (< p); synchronises the stream

@@ -52,10 +52,14 @@ WORKLOADS = {
     "fib_2^20x72_blowup8_blake2s_base": (20, 72, {}),
     "fib_2^16x2_blowup8_blake2s_base": (16, 2, {}),
     # BASELINE configs[4] stand-in (the Miden AIR is absent from the reference mount): Miden's SHAPE — 72 main columns, one
-    # auxiliary segment of 9 columns built from 16 coin elements, 2^22 rows, FRI folding factor 4 — on the synthetic AIR
-    # (Fibonacci pairs + prefix-product aux columns). Labelled a stand-in wherever it is reported.
-    "standin_miden_shape_2^22x(72+9aux)_fold4": (22, 72, {"fri_folding_factor": 4, "aux": (9, 16)}),
-    "standin_miden_shape_2^18x(72+9aux)_fold4": (18, 72, {"fri_folding_factor": 4, "aux": (9, 16)}),
+    # auxiliary segment of 9 columns built from 16 coin elements, constraints of degree 8 (=> constraint-evaluation blowup 8
+    # and 8 composition columns, as in the golden proof fib.bin), 2^22 rows, FRI folding factor 4 — on the synthetic AIR
+    # (Fibonacci pairs + prefix-product aux columns). Labelled a stand-in wherever it is reported. aux = (columns, random
+    # elements, constraint degree).
+    "standin_miden_shape_2^22x(72+9aux)_deg8_fold4": (22, 72, {"fri_folding_factor": 4, "aux": (9, 16, 8)}),
+    "standin_miden_shape_2^18x(72+9aux)_deg8_fold4": (18, 72, {"fri_folding_factor": 4, "aux": (9, 16, 8)}),
+    "standin_miden_shape_2^22x(72+9aux)_fold4": (22, 72, {"fri_folding_factor": 4, "aux": (9, 16, 2)}),
+    "standin_miden_shape_2^18x(72+9aux)_fold4": (18, 72, {"fri_folding_factor": 4, "aux": (9, 16, 2)}),
 }
 
 
@@ -111,7 +115,7 @@ def prove_call(ctx, dev, opt, over, comm=None):
     """One proof of the workload: plain FibAir, or FibAir + auxiliary segment when the workload names one."""
     aux = over.get("aux")
     if aux or comm is not None:
-        return ctx.prove_fib_aux(dev, aux[0] if aux else 0, aux[1] if aux else 0, opt, comm=comm)
+        return ctx.prove_fib_aux(dev, aux[0] if aux else 0, aux[1] if aux else 0, opt, comm=comm, aux_degree=aux[2] if aux else 2)
     return ctx.prove_fib(dev, opt)
 
 
@@ -402,7 +406,8 @@ def main():
         "config": {"workload": args.workload, "trace_rows": 1 << log_n, "trace_cols": width, "blowup": opt.blowup_factor,
                    "num_queries": opt.num_queries, "grinding": opt.grinding_factor, "fri_fold": opt.fri_folding_factor,
                    "field_extension": "quadratic" if opt.field_extension == 2 else "none", "hash": "blake2s_256",
-                   "aux_segment": ({"columns": over["aux"][0], "random_elements": over["aux"][1], "air": "synthetic stand-in (prefix-product columns); the Miden AIR is not in the reference mount"}
+                   "aux_segment": ({"columns": over["aux"][0], "random_elements": over["aux"][1], "constraint_degree": over["aux"][2],
+                                    "composition_columns": 2 if over["aux"][2] <= 2 else (4 if over["aux"][2] <= 4 else 8), "air": "synthetic stand-in (prefix-product columns); the Miden AIR is not in the reference mount"}
                                    if over.get("aux") else None),
                    "proofs_per_step_per_gpu": S, "proof_bytes": proof_len,
                    "parallelism": f"{world} GPU(s) x {S} independent proofs in flight per GPU (one HIP stream each), no data-path collective"},
@@ -468,12 +473,12 @@ def main():
             ncpu = os.cpu_count() or 1
             # pick the thread count on a 2^16 probe (also warms the thread pool), then time the sample with it
             best = None
-            aux = over.get("aux") or (0, 0)
+            aux = over.get("aux") or (0, 0, 2)
             probe_log = min(14 if width > 8 else 16, log_n)
             for t in cpu_thread_candidates(ncpu):
                 orc.set_threads(t)
-                orc.prove_fib_aux(width, min(12, log_n), aux[0], aux[1], opt.to_list())
-                _, _, probe = orc.prove_fib_aux(width, probe_log, aux[0], aux[1], opt.to_list())
+                orc.prove_fib_aux(width, min(12, log_n), aux[0], aux[1], opt.to_list(), D=aux[2])
+                _, _, probe = orc.prove_fib_aux(width, probe_log, aux[0], aux[1], opt.to_list(), D=aux[2])
                 if best is None or probe["total"] < best[1]:
                     best = (t, probe["total"])
             cores = best[0]
@@ -487,7 +492,7 @@ def main():
                     s_log_n -= 1
                     projected /= 2
             t1 = time.perf_counter()
-            cproof, cpub, ctimes = orc.prove_fib_aux(width, s_log_n, aux[0], aux[1], opt.to_list())
+            cproof, cpub, ctimes = orc.prove_fib_aux(width, s_log_n, aux[0], aux[1], opt.to_list(), D=aux[2])
             cdt = time.perf_counter() - t1
             if s_log_n == log_n:
                 assert cproof == first_proof, "GPU and CPU proofs differ"

@@ -209,6 +209,18 @@ int32_t aero_prove_fib_sharded(aero_ctx* ctx, const aero_comm* comm, const aero_
 int32_t aero_prove_fib_aux(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, uint32_t aux_width, uint32_t aux_rands,
                            const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
 
+/* Same with the degree of the auxiliary transition constraint as a parameter: p_c(i+1) = p_c(i) * (r + main)^(aux_degree - 1),
+ * aux_degree in [2, 8]. The constraint-evaluation blowup and the number of composition columns follow Winterfell's rule
+ * max(next_pow2(max constraint degree), 2): 2 / 4 / 8 for degree 2 / 3-4 / 5-8 — 8 is the shape of the reference's golden
+ * Miden proof (proofs/fib.bin carries 8 composition columns; stark_verifier.cairo:166-176). blowup_factor must be >= that. */
+typedef struct aero_fib_air {
+    uint32_t aux_width;   /* 0 = no auxiliary segment */
+    uint32_t aux_rands;
+    uint32_t aux_degree;  /* ignored when aux_width = 0 */
+} aero_fib_air;
+int32_t aero_prove_fib_air(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_fib_air* air,
+                           const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
+
 /* bincode ProofData{input_bytes, proof_bytes} = u64 len || inputs || u64 len || proof
  * (miden-proof-generator/src/lib.rs:1-6, main.rs:49-51). */
 int32_t aero_proof_container(const uint8_t* inputs, size_t inputs_len, const uint8_t* proof, size_t proof_len, uint8_t** out,

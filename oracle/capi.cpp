@@ -166,7 +166,7 @@ int orc_prove_fib(const uint64_t* trace, uint32_t W, int log_n, const uint8_t op
     } catch (std::exception& e) { return fail(e); }
 }
 // FibAir with an auxiliary segment of A columns built from R coin elements (oracle/stark.hpp: FibAir::A, R).
-int orc_prove_fib_aux(const uint64_t* trace, uint32_t W, int log_n, uint32_t A, uint32_t R, const uint8_t opt7[7], uint8_t** proof,
+int orc_prove_fib_aux(const uint64_t* trace, uint32_t W, int log_n, uint32_t A, uint32_t R, uint32_t D, const uint8_t opt7[7], uint8_t** proof,
                       size_t* proof_len, uint64_t* pub_out, double* times) {
     try {
         size_t n = (size_t)1 << log_n;
@@ -175,7 +175,7 @@ int orc_prove_fib_aux(const uint64_t* trace, uint32_t W, int log_n, uint32_t A, 
         else tr = fib_trace(W, log_n);
         Options o{opt7[0], opt7[1], opt7[2], opt7[3], opt7[4], opt7[5], opt7[6]};
         Col pub; StageTimes tm;
-        Bytes pf = prove_fib_any(tr, log_n, o, &pub, &tm, A, R);
+        Bytes pf = prove_fib_any(tr, log_n, o, &pub, &tm, A, R, D);
         *proof = (uint8_t*)malloc(pf.size()); memcpy(*proof, pf.data(), pf.size()); *proof_len = pf.size();
         if (pub_out) memcpy(pub_out, pub.data(), pub.size() * 8);
         if (times) { double t[12] = {tm.interpolate, tm.lde, tm.trace_commit, tm.constraints, tm.composition, tm.comp_commit, tm.ood, tm.deep, tm.fri, tm.grind, tm.queries, tm.total}; memcpy(times, t, sizeof t); }
@@ -183,10 +183,10 @@ int orc_prove_fib_aux(const uint64_t* trace, uint32_t W, int log_n, uint32_t A, 
     } catch (std::exception& e) { return fail(e); }
 }
 // Verify with the OOD constraint check for FibAir(W) + aux segment (A, R).
-int orc_verify_fib_aux(const uint8_t* proof, size_t len, const uint64_t* pub, size_t npub, uint32_t W, int log_n, uint32_t A, uint32_t R) {
+int orc_verify_fib_aux(const uint8_t* proof, size_t len, const uint64_t* pub, size_t npub, uint32_t W, int log_n, uint32_t A, uint32_t R, uint32_t D) {
     try {
         Col pe(pub, pub + npub);
-        FibAir air; air.W = W; air.log_n = log_n; air.results = pe; air.A = A; air.R = A ? R : 0;
+        FibAir air; air.W = W; air.log_n = log_n; air.results = pe; air.A = A; air.R = A ? R : 0; air.D = D;
         verify(Bytes(proof, proof + len), pe, AIR_FIB, &air, nullptr);
         return 0;
     } catch (std::exception& e) { return fail(e); }

@@ -55,11 +55,13 @@ static std::vector<Digest> hash_rows(const std::vector<Col>& cols, size_t rows) 
 
 template <class F>
 static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& opt, Col* pub_out,
-                       StageTimes* times = nullptr, ProverArtifacts<F>* art = nullptr, uint32_t A = 0, uint32_t R = 0) {
+                       StageTimes* times = nullptr, ProverArtifacts<F>* art = nullptr, uint32_t A = 0, uint32_t R = 0, uint32_t D = 2) {
     typedef typename F::T T;
     const uint32_t W = (uint32_t)trace.size();
     const size_t n = (size_t)1 << log_n, B = opt.blowup, N = n * B, Fd = opt.fri_fold;
-    const size_t C = FibAir::ce_blowup(), ceN = C * n, ce_step = B / C;
+    if (D < 2 || D > 8) throw Err("prove: aux constraint degree must be in [2, 8]");
+    FibAir shape; shape.W = W; shape.log_n = log_n; shape.A = A; shape.R = A ? R : 0; shape.D = D;
+    const size_t C = shape.ce_blowup(), ceN = C * n, ce_step = B / C;
     if (W < 2 || (W & 1) || W > 254) throw Err("prove: FibAir needs an even column count in [2, 254]");
     if (B < C || (B & (B - 1))) throw Err("prove: blowup must be a power of two >= 2");
     if (Fd != 2 && Fd != 4 && Fd != 8 && Fd != 16) throw Err("prove: unsupported FRI folding factor");
@@ -70,7 +72,7 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
     StageTimes tm; double t0 = now_s(), t1;
 
     // 0. AIR + channel [proving_worker.rs:248-268]
-    FibAir air; air.W = W; air.log_n = log_n; air.A = A; air.R = A ? R : 0;
+    FibAir air = shape;
     for (uint32_t k = 0; k < W / 2; k++) air.results.push_back(trace[2 * k + 1][n - 1]);
     if (pub_out) *pub_out = air.results;
     Coin coin = Coin::from_pub_elements(air.results.data(), air.results.size());
@@ -106,7 +108,7 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
             T p = F::one();
             for (size_t i = 0; i < n; i++) {
                 for (int k = 0; k < F::DEG; k++) apolys[c * F::DEG + k][i] = F::comp(p, k);
-                p = F::mul(p, F::add(rands[c % R], F::from(trace[c % W][i])));
+                p = F::mul(p, f_pow<F>(F::add(rands[c % R], F::from(trace[c % W][i])), D - 1));
             }
         }
         for (size_t c = 0; c < A * F::DEG; c++) { intt(apolys[c].data(), n, true); alde[c] = lde(apolys[c].data(), n, B, GEN); }
@@ -403,9 +405,9 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
 }
 
 static Bytes prove_fib_any(const std::vector<Col>& trace, int log_n, const Options& opt, Col* pub_out, StageTimes* times = nullptr,
-                           uint32_t A = 0, uint32_t R = 0) {
-    if (opt.field_ext == EXT_NONE) return prove_fib<FB>(trace, log_n, opt, pub_out, times, nullptr, A, R);
-    if (opt.field_ext == EXT_QUADRATIC) return prove_fib<FQ>(trace, log_n, opt, pub_out, times, nullptr, A, R);
+                           uint32_t A = 0, uint32_t R = 0, uint32_t D = 2) {
+    if (opt.field_ext == EXT_NONE) return prove_fib<FB>(trace, log_n, opt, pub_out, times, nullptr, A, R, D);
+    if (opt.field_ext == EXT_QUADRATIC) return prove_fib<FQ>(trace, log_n, opt, pub_out, times, nullptr, A, R, D);
     throw Err("prove: unsupported field extension");
 }
 

@@ -505,17 +505,20 @@ enum AirKind { AIR_OPAQUE = 0, AIR_FIB = 1 };
 
 // Optional auxiliary segment (a synthetic stand-in for Miden's multiset-check columns, whose
 // AIR is absent from the mount): A columns over E, built after the main commitment from R random elements drawn from the
-// coin: p_c(0) = 1, p_c(i+1) = p_c(i) * (r_(c mod R) + main_(c mod W)(i)); one degree-2 transition constraint and one
-// assertion p_c(0) = 1 per aux column. Transcript order, proof layout, OOD frame (main || aux) and DEEP coefficient order
+// coin: p_c(0) = 1, p_c(i+1) = p_c(i) * (r_(c mod R) + main_(c mod W)(i))^(D-1); one degree-D transition constraint and one
+// assertion p_c(0) = 1 per aux column. D = 2 is the plain multiset-check shape; D up to 8 raises the constraint-evaluation
+// blowup and the number of composition columns to 8, the shape of the golden Miden proof (fib.bin: 8 composition columns). Transcript order, proof layout, OOD frame (main || aux) and DEEP coefficient order
 // follow stark_verifier.cairo:117-130,266-294 (pinned by fib.bin, which has one aux segment); the constraint set itself
 // is restatement-defined.
 struct FibAir {
     uint32_t W; int log_n; Col results;   // results[k] = b_k(n-1)
     uint32_t A = 0, R = 0;                // aux columns / aux random elements (A > 0 requires R > 0)
+    uint32_t D = 2;                       // degree of the aux transition constraint: p' = p * (r + main)^(D-1), D in [2, 8]
     size_t n() const { return (size_t)1 << log_n; }
     size_t num_transition() const { return W + A; }
     size_t num_assertions() const { return W + W / 2 + A; }
-    static size_t ce_blowup() { return 2; }   // max(next_pow2(degree 1), MIN_BLOWUP 2)
+    // constraint-evaluation blowup = number of composition columns = max(next_pow2(max constraint degree), 2)
+    size_t ce_blowup() const { size_t d = A ? D : 1, e = 2; while (e < d) e <<= 1; return e; }
     static Col seed(uint32_t k) { return Col{1 + 2 * (uint64_t)k, 2 + 2 * (uint64_t)k}; }
 };
 // Synthetic trace generator (column-major W x n). Pure function of (W, log_n).
@@ -539,16 +542,16 @@ static std::vector<Col> fib_trace(uint32_t W, int log_n) {
 //  * assertions sorted by (stride = 0, first_step, column); one boundary group per (stride, first_step):
 //    group 0 = step 0 (all W columns), group 1 = step n-1 (odd columns); divisor x - w^step, adjustment
 //    adj_b = (ce_n - 1 + 1) - (n - 1). Coefficient pairs are consumed in that sorted order.
-//  * aux transition constraints (degree 2) form their own degree group: adj_x = (ce_n - 1 + (n - 1)) - 2(n - 1);
+//  * aux transition constraints (degree D) form their own degree group: adj_x = (ce_n - 1 + (n - 1)) - D(n - 1);
 //    coefficient pairs: main transition, aux transition, main assertions (sorted as above), aux assertions (step 0, by column).
 struct FibCombine {
     uint64_t adj_t, adj_b, adj_x;
     template <class F> struct Coeffs { std::vector<typename F::T> ta, tb, ba, bb; };
     explicit FibCombine(const FibAir& air) {
-        uint64_t n = air.n(), ce_n = n * FibAir::ce_blowup();
+        uint64_t n = air.n(), ce_n = n * air.ce_blowup();
         adj_t = (ce_n - 1 + (n - 1)) - (n - 1);
         adj_b = (ce_n - 1 + 1) - (n - 1);
-        adj_x = (ce_n - 1 + (n - 1)) - 2 * (n - 1);
+        adj_x = (ce_n - 1 + (n - 1)) - (uint64_t)air.D * (n - 1);
     }
 };
 template <class F> static typename FibCombine::Coeffs<F> draw_constraint_coeffs(Coin& coin, size_t nt, size_t na) {
@@ -580,7 +583,7 @@ static void fib_eval_point(const FibAir& air, const FibCombine& cb, const typena
     if (air.A) {
         typename F::T xx = f_pow<F>(lift(x), cb.adj_x);
         for (uint32_t c = 0; c < air.A; c++) {
-            typename F::T t = F::sub(anxt[c], F::mul(acur[c], F::add(rands[c % air.R], lift(cur[c % air.W]))));
+            typename F::T t = F::sub(anxt[c], F::mul(acur[c], f_pow<F>(F::add(rands[c % air.R], lift(cur[c % air.W])), air.D - 1)));
             acc = F::add(acc, F::mul(F::add(cc.ta[air.W + c], F::mul(cc.tb[air.W + c], xx)), t));
         }
     }
@@ -665,7 +668,7 @@ static void verify_impl(const Proof& pr, const Col& pub_elements, AirKind kind, 
     if (kind == AIR_FIB) {
         // OOD consistency check (commented out in stark_verifier.cairo:151-159,183-187; winter-verifier does it):
         // sum_groups numerator(z)/divisor(z)  ==  sum_c z^c * H_c(z^C)     (reduce_evaluations, :296-304)
-        if (W != fib->W || A != fib->A || (A && (size_t)pr.aux_rands != fib->R) || C != FibAir::ce_blowup() || pr.log_n != fib->log_n)
+        if (W != fib->W || A != fib->A || (A && (size_t)pr.aux_rands != fib->R) || C != fib->ce_blowup() || pr.log_n != fib->log_n)
             throw Err("verify: proof shape does not match FibAir");
         FibCombine cb(*fib);
         T num[3];

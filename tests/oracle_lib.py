@@ -225,8 +225,9 @@ class Oracle:
                  "grind", "queries", "total"]
         return data, pub.tolist(), dict(zip(names, times.tolist()))
 
-    def prove_fib_aux(self, W, log_n, A, R, opt7, trace=None):
-        """FibAir(W) with an auxiliary segment of A columns built from R coin elements. Returns (proof, pub, times)."""
+    def prove_fib_aux(self, W, log_n, A, R, opt7, trace=None, D=2):
+        """FibAir(W) with an auxiliary segment of A columns built from R coin elements, aux constraint degree D.
+        Returns (proof, pub, times)."""
         o = (C.c_uint8 * 7)(*opt7)
         proof = u8p(); plen = C.c_size_t(0)
         pub = np.zeros(W // 2, np.uint64); times = np.zeros(12, np.float64)
@@ -235,7 +236,7 @@ class Oracle:
             tr = np.ascontiguousarray(trace, np.uint64)
             assert tr.shape == (W, 1 << log_n)
         self._ck(self.lib.orc_prove_fib_aux(_p64(tr) if tr is not None else None, C.c_uint32(W), C.c_int(log_n), C.c_uint32(A),
-                                            C.c_uint32(R), o, C.byref(proof), C.byref(plen), _p64(pub),
+                                            C.c_uint32(R), C.c_uint32(D), o, C.byref(proof), C.byref(plen), _p64(pub),
                                             times.ctypes.data_as(C.POINTER(C.c_double))))
         data = C.string_at(proof, plen.value)
         self.lib.orc_free(proof)
@@ -243,12 +244,12 @@ class Oracle:
                  "grind", "queries", "total"]
         return data, pub.tolist(), dict(zip(names, times.tolist()))
 
-    def verify_fib_aux(self, proof: bytes, pub, W, log_n, A, R):
+    def verify_fib_aux(self, proof: bytes, pub, W, log_n, A, R, D=2):
         """Full verification incl. the OOD constraint check for FibAir(W) + aux segment (A, R); raises when rejected."""
         buf = np.frombuffer(proof, np.uint8)
         p = np.ascontiguousarray(pub, np.uint64)
         self._ck(self.lib.orc_verify_fib_aux(_p8(buf), C.c_size_t(len(proof)), _p64(p), C.c_size_t(p.size), C.c_uint32(W),
-                                             C.c_int(log_n), C.c_uint32(A), C.c_uint32(R)))
+                                             C.c_int(log_n), C.c_uint32(A), C.c_uint32(R), C.c_uint32(D)))
 
     def artifact(self, name: str, count: int) -> np.ndarray:
         out = np.zeros(count, np.uint64)

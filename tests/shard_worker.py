@@ -28,12 +28,12 @@ def main():
         opts = aero_amd.ProofOptions(*case["options"])
         comm = TorchComm(device=dev, min_peer_digests=case.get("min_peer", 0))
         trace = ctx.trace_upload(aero_amd.fib_trace(case["width"], case["log_n"]))
-        aux = case.get("aux") or [0, 0]
-        proof, pub = ctx.prove_fib_aux(trace, aux[0], aux[1], opts, comm=comm)
+        aux = (case.get("aux") or [0, 0]) + [2]
+        proof, pub = ctx.prove_fib_aux(trace, aux[0], aux[1], opts, comm=comm, aux_degree=aux[2])
         with open(os.path.join(out_dir, f"case{i}.rank{rank}.bin"), "wb") as f:
             f.write(proof)
         if rank == 0:
-            single, pub1 = ctx.prove_fib_aux(trace, aux[0], aux[1], opts)
+            single, pub1 = ctx.prove_fib_aux(trace, aux[0], aux[1], opts, aux_degree=aux[2])
             assert pub1 == pub
             with open(os.path.join(out_dir, f"case{i}.single.bin"), "wb") as f:
                 f.write(single)

@@ -51,6 +51,39 @@ def test_aux_proof_bytes_identical_to_oracle(ctx, oracle, log_n, width, A, R, kw
     dev.free()
 
 
+DEGREE_CASES = [
+    # log_n, width, aux_width, aux_rands, aux_degree, option overrides  (composition columns: 4 for degree 3-4, 8 for 5-8)
+    (8, 2, 1, 1, 3, {}),
+    (9, 2, 2, 3, 4, {"field_extension": 2}),
+    (10, 4, 3, 4, 5, {}),
+    (8, 2, 2, 2, 8, {"field_extension": 2}),
+    (12, 72, 9, 16, 8, {"fri_folding_factor": 4, "num_queries": 16}),        # Miden's shape incl. 8 composition columns
+    (14, 2, 2, 2, 8, {}),
+    (7, 2, 1, 1, 4, {"blowup_factor": 16, "fri_folding_factor": 4, "fri_log_max_remainder": 5, "num_queries": 20, "grinding_factor": 8}),
+]
+
+
+@pytest.mark.parametrize("log_n,width,A,R,D,kw", DEGREE_CASES)
+def test_aux_degree_proof_bytes_identical_to_oracle(ctx, oracle, log_n, width, A, R, D, kw):
+    o = opts(**kw)
+    dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
+    got, pub = ctx.prove_fib_aux(dev, A, R, o, aux_degree=D)
+    want, want_pub, _ = oracle.prove_fib_aux(width, log_n, A, R, o.to_list(), D=D)
+    assert pub == want_pub
+    assert got == want, "proof bytes differ"
+    oracle.verify_fib_aux(got, pub, width, log_n, A, R, D=D)
+    dev.free()
+
+
+def test_aux_degree_needs_enough_blowup(ctx):
+    dev = ctx.trace_upload(aero_amd.fib_trace(2, 8))
+    with pytest.raises(aero_amd.AeroError):
+        ctx.prove_fib_aux(dev, 1, 1, opts(blowup_factor=4, fri_folding_factor=4), aux_degree=8)   # needs 8 composition columns
+    with pytest.raises(aero_amd.AeroError):
+        ctx.prove_fib_aux(dev, 1, 1, opts(), aux_degree=9)
+    dev.free()
+
+
 def test_aux_zero_width_is_plain_proof(ctx):
     dev = ctx.trace_upload(aero_amd.fib_trace(2, 10))
     a, _ = ctx.prove_fib(dev, opts())

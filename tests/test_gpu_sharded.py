@@ -54,7 +54,8 @@ def check(oracle, world, cases, tmp_path):
         for r, p in enumerate(per_rank):
             assert p == single, f"world {world} rank {r}: sharded proof differs from the single-GPU proof for {case}"
         if case.get("aux"):
-            ref = oracle.prove_fib_aux(case["width"], case["log_n"], case["aux"][0], case["aux"][1], case["options"])[0]
+            ref = oracle.prove_fib_aux(case["width"], case["log_n"], case["aux"][0], case["aux"][1], case["options"],
+                                       D=(case["aux"][2] if len(case["aux"]) > 2 else 2))[0]
         else:
             ref = oracle.prove_fib(case["width"], case["log_n"], case["options"])[0]
         assert single == ref, f"proof differs from the oracle for {case}"
@@ -74,6 +75,7 @@ CASES_SMALL = [
     {"width": 2, "log_n": 3, "options": [4, 8, 0, 4, 1, 2, 3], "min_peer": 1},           # smallest trace
     {"width": 2, "log_n": 10, "options": DEFAULT, "min_peer": 1, "aux": [3, 2]},         # auxiliary segment
     {"width": 4, "log_n": 9, "options": [27, 8, 16, 4, 2, 8, 8], "min_peer": 1, "aux": [9, 16]},
+    {"width": 2, "log_n": 9, "options": DEFAULT, "min_peer": 1, "aux": [2, 3, 8]},      # degree 8: 8 composition columns
 ]
 
 

@@ -28,6 +28,29 @@ def test_aux_prove_verify(oracle, W, log_n, A, R, opt):
     oracle.verify(proof, pub, air_kind=0)
 
 
+@pytest.mark.parametrize("W,log_n,A,R,D,opt", [(2, 8, 1, 1, 3, DEFAULT), (2, 9, 2, 3, 5, DEFAULT), (4, 8, 3, 4, 8, QUAD),
+                                               (72, 7, 9, 16, 8, [27, 8, 8, 4, 1, 4, 5])])
+def test_aux_constraint_degree(oracle, W, log_n, A, R, D, opt):
+    """Aux constraints of degree D: 4 composition columns for D in 3..4, 8 for 5..8 (the golden proof's shape)."""
+    import struct
+    proof, pub, _ = oracle.prove_fib_aux(W, log_n, A, R, opt, D=D)
+    oracle.verify_fib_aux(proof, pub, W, log_n, A, R, D=D)
+    with pytest.raises(RuntimeError):
+        oracle.verify_fib_aux(proof, pub, W, log_n, A, R, D=2 if D != 2 else 3)
+    # OOD evaluations section length = composition columns * element bytes
+    off = 22
+    (clen,) = struct.unpack_from("<H", proof, off)
+    off += 2 + clen
+    for _ in range(6):
+        (l,) = struct.unpack_from("<I", proof, off)
+        off += 4 + l
+    (l,) = struct.unpack_from("<H", proof, off)
+    off += 2 + l
+    (l,) = struct.unpack_from("<H", proof, off)
+    deg = 2 if opt[4] == 2 else 1
+    assert l == (4 if D <= 4 else 8) * 8 * deg
+
+
 def test_aux_rejections(oracle):
     W, log_n, A, R = 2, 8, 3, 2
     proof, pub, _ = oracle.prove_fib_aux(W, log_n, A, R, DEFAULT)
