@@ -381,17 +381,21 @@ void Context::ensure_small_twiddles() {
     check_launch("small twiddles");
 }
 
-// Pass plan for a transform of 2^L points: first the contiguous pass (<= 12 bits), then strided passes.
-std::vector<NttPass> plan_passes(int L) {
+// Pass plan for a transform of 2^L points: first the contiguous pass (<= 12 bits), then strided passes. With register
+// passes every strided pass has radix <= 64 (one more pass over HBM beats a radix-128/256 pass through LDS: measured 2^25
+// points, 4 columns: 1162 us for the LDS radix-128 pass against 550 us for a register radix-64 pass); without them the
+// strided passes take up to 8 bits each through LDS tiles of R x TL = 4096 elements.
+std::vector<NttPass> plan_passes(int L, bool reg) {
     std::vector<NttPass> p;
     int r1 = L < 12 ? L : 12;
     p.push_back(NttPass{0, r1, 0});
     int rem = L - r1, s = r1;
     if (rem == 0) return p;
-    int npass = (rem + 7) / 8;
+    const int max_r = reg ? 6 : 8;
+    int npass = (rem + max_r - 1) / max_r;
     for (int i = 0; i < npass; i++) {
         int r = (rem + (npass - 1 - i)) / (npass - i);   // split as evenly as possible, larger radices first
-        p.push_back(NttPass{s, r, 12 - r});               // tile = R x TL = 4096 elements, TL = 4096 / R <= S
+        p.push_back(NttPass{s, r, 12 - r});               // LDS passes: tile = R x TL = 4096 elements, TL = 4096 / R <= S
         s += r;
         rem -= r;
     }
@@ -403,7 +407,7 @@ std::vector<NttPass> plan_passes(int L) {
 void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad) {
     ensure_small_twiddles();
     NttTables* t = ntt_tables(log_out);
-    std::vector<NttPass> plan = plan_passes(log_out);
+    std::vector<NttPass> plan = plan_passes(log_out, reg_passes);
     if (plan[0].log_r < log_pad) fail("ntt_forward: transform too small for the requested padding");
     for (size_t q = 0; q < plan.size(); q++) {
         PassArgs a{};
@@ -416,21 +420,27 @@ void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         a.first = (q + 1 == plan.size());
         a.tw_r = tw4096_fwd; a.tw_lo = t->lo_fwd; a.tw_hi = t->hi_fwd; a.tw_h = t->h;
         const size_t abytes = (size_t)ncols * 8 * ((((size_t)1 << log_out) >> a.log_pad) + ((size_t)1 << log_out));
-        if (q > 0 && reg_passes && a.log_r >= 4 && a.log_r <= 6 && log_out - a.log_r >= 8) {
+        if (q > 0 && reg_passes) {
             if (!a.first) a.tw_pass = pass_twiddles(log_out, a.log_s, a.log_r, false);
             dim3 rgrid((unsigned)((((size_t)1 << log_out) >> a.log_r) / 256), ncols);
-            if (a.log_r == 6) AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_strided_reg<6>, rgrid, dim3(256), 0, a);
-            else if (a.log_r == 5) AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_strided_reg<5>, rgrid, dim3(256), 0, a);
-            else AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_strided_reg<4>, rgrid, dim3(256), 0, a);
+            const char* nm = pass_names ? (a.log_r == 6 ? "ntt_fwd_reg6" : a.log_r == 5 ? "ntt_fwd_reg5" : a.log_r == 4 ? "ntt_fwd_reg4" : "ntt_fwd_reg123") : "ntt_fwd_pass";
+            switch (a.log_r) {
+                case 6: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<6>, rgrid, dim3(256), 0, a); break;
+                case 5: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<5>, rgrid, dim3(256), 0, a); break;
+                case 4: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<4>, rgrid, dim3(256), 0, a); break;
+                case 3: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<3>, rgrid, dim3(256), 0, a); break;
+                case 2: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<2>, rgrid, dim3(256), 0, a); break;
+                default: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<1>, rgrid, dim3(256), 0, a); break;
+            }
             continue;
         }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
         dim3 grid((unsigned)(((size_t)1 << log_out) / E), ncols);
         if (q == 0 && reg_passes && a.log_r > a.log_pad) {
-            AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_first_pass, grid, dim3(256), 0, a);
+            AERO_LAUNCH(this, pass_names ? "ntt_fwd_first" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass, grid, dim3(256), 0, a);
             continue;
         }
-        AERO_LAUNCH(this, "ntt_fwd_pass", abytes, ntt_fwd_pass, grid, dim3(256), 0, a);
+        AERO_LAUNCH(this, pass_names ? (a.log_r == 7 ? "ntt_fwd_lds7" : a.log_r == 8 ? "ntt_fwd_lds8" : "ntt_fwd_ldsX") : "ntt_fwd_pass", abytes, ntt_fwd_pass, grid, dim3(256), 0, a);
     }
     check_launch("ntt_forward");
 }
@@ -440,7 +450,7 @@ void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
 void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift) {
     ensure_small_twiddles();
     NttTables* t = ntt_tables(log_n);
-    std::vector<NttPass> plan = plan_passes(log_n);
+    std::vector<NttPass> plan = plan_passes(log_n, reg_passes);
     const int r1 = plan[0].log_r;
     // per-k table for the final (contiguous) pass
     uint64_t ninv = gl::inv((uint64_t)1 << log_n);
@@ -464,13 +474,18 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
         a.first = (qi + 1 == plan.size());
         a.tw_r = tw4096_inv; a.tw_lo = t->lo_inv; a.tw_hi = t->hi_inv; a.tw_h = t->h;
         if (qi == 0) { a.ktab = ktab; a.sc_a = sa; a.sc_b = sb; a.sc_shift = shift; }
-        if (qi > 0 && reg_passes && a.log_r >= 4 && a.log_r <= 6 && log_n - a.log_r >= 8) {
+        if (qi > 0 && reg_passes) {
             if (!a.first) a.tw_pass = pass_twiddles(log_n, a.log_s, a.log_r, true);
             dim3 rgrid((unsigned)((((size_t)1 << log_n) >> a.log_r) / 256), ncols);
             const size_t abytes = (size_t)ncols * 16 * ((size_t)1 << log_n);
-            if (a.log_r == 6) AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<6>, rgrid, dim3(256), 0, a);
-            else if (a.log_r == 5) AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<5>, rgrid, dim3(256), 0, a);
-            else AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<4>, rgrid, dim3(256), 0, a);
+            switch (a.log_r) {
+                case 6: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<6>, rgrid, dim3(256), 0, a); break;
+                case 5: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<5>, rgrid, dim3(256), 0, a); break;
+                case 4: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<4>, rgrid, dim3(256), 0, a); break;
+                case 3: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<3>, rgrid, dim3(256), 0, a); break;
+                case 2: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<2>, rgrid, dim3(256), 0, a); break;
+                default: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<1>, rgrid, dim3(256), 0, a); break;
+            }
             continue;
         }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
