@@ -1,0 +1,100 @@
+"""The sharding identities and the exchange pattern of the multi-GPU proof (aero_amd/csrc/prover.hip),
+checked on CPU with world_size-2 and -4 `gloo` processes and the oracle's primitives:
+  * rank k's LDE shard (rows j = k mod G) is the plain LDE, with blowup B/G, of the coefficients scaled by (w_N^k)^i;
+  * all-to-all of leaf digests + arrival-order interleave + one subtree per rank + all-gather of the subtree roots + log2 G
+    host levels reproduce the root of the tree over ALL rows;
+  * FRI fold groups stay inside a coset: folding a shard with the coset's offset gives the shard of the folded layer.
+The product code cannot run without a GPU (tests/test_gpu_sharded.py covers it there); this pins the algebra it relies on and
+the collectives' data layout under a real process group."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import json, os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch, torch.distributed as dist
+    from tests import oracle_lib
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    orc = oracle_lib.load()
+    orc.set_threads(1)
+    P = 0xFFFFFFFF00000001
+    G, B, log_n, W, fold = world, 8, 8, 3, 8
+    n, N = 1 << log_n, B << log_n
+    M = N // G
+    rng = np.random.default_rng(2024)                      # same stream on every rank: everybody knows the polynomials
+    coeffs = (rng.integers(0, P, size=(W, n), dtype=np.uint64))
+    wN = orc.root_of_unity(log_n + 3)
+
+    # ---- 1. coset LDE: scale coefficient i by (w_N^rank)^i, extend with blowup B / G
+    s = orc.pow(wN, rank)
+    scale = np.array([orc.pow(s, i) for i in range(n)], dtype=np.uint64)
+    local = np.stack([orc.lde(np.array([orc.mul(int(c), int(f)) for c, f in zip(coeffs[col], scale)], dtype=np.uint64), B // G)
+                      for col in range(W)])
+    full = np.stack([orc.lde(coeffs[col], B) for col in range(W)])
+    ok_lde = bool((local == full[:, rank::G]).all())
+
+    # ---- 2. commitment: local row digests -> all-to-all -> subtree -> all-gather of roots -> top levels
+    dig = torch.from_numpy(orc.hash_rows(local).copy())     # (M, 32) uint8, local leaf t = global leaf t*G + rank
+    recv = torch.empty_like(dig)
+    dist.all_to_all_single(recv, dig)                       # chunk r of `dig` -> rank r; chunk k of `recv` came from rank k
+    leaves = recv.numpy().reshape(G, M // G, 32).transpose(1, 0, 2).reshape(M, 32)   # leaf u'*G + k <- piece k, entry u'
+    sub = orc.merkle_nodes(np.ascontiguousarray(leaves))
+    roots = [torch.empty(32, dtype=torch.uint8) for _ in range(G)]
+    dist.all_gather(roots, torch.from_numpy(sub[1].copy()))
+    top = [None] * (2 * G)
+    for r in range(G):
+        top[G + r] = roots[r].numpy().tobytes()
+    for i in range(G - 1, 0, -1):
+        top[i] = orc.blake2s(top[2 * i] + top[2 * i + 1])
+    ref_nodes = orc.merkle_nodes(orc.hash_rows(full))
+    ok_root = top[1] == ref_nodes[1].tobytes()
+    ok_sub = sub[1].tobytes() == ref_nodes[G + rank].tobytes()          # my subtree = node G + rank of the full tree
+
+    # ---- 3. FRI fold locality: shard of the folded layer = fold of the shard with the coset offset 7 * w_N^rank
+    layer = rng.integers(0, P, size=N, dtype=np.uint64)
+    alpha = int(rng.integers(0, P, dtype=np.uint64))
+    folded = orc.fri_fold(layer, fold, alpha)
+    mine = orc.fri_fold(np.ascontiguousarray(layer[rank::G]), fold, orc.mul(alpha, orc.inv(orc.pow(wN, rank))))
+    ok_fold = bool((mine == folded[rank::G]).all())
+
+    res = [None] * world
+    dist.all_gather_object(res, (ok_lde, ok_root, ok_sub, ok_fold))
+    if rank == 0:
+        print(json.dumps({"world": world, "checks": res}))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_shard_identities_under_gloo(tmp_path, world):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["world"] == world
+    for rank, checks in enumerate(r["checks"]):
+        assert all(checks), f"rank {rank}: (coset LDE, root, subtree, fold locality) = {checks}"
