@@ -411,6 +411,7 @@ def main():
                                    if over.get("aux") else None),
                    "proofs_per_step_per_gpu": S, "proof_bytes": proof_len,
                    "parallelism": f"{world} GPU(s) x {S} independent proofs in flight per GPU (one HIP stream each), no data-path collective"},
+        "device_bytes_peak_per_proof_in_flight": ctx.memory_stats()[1],
         "single_proof_ms": single_ms,
         "single_proof_value": (1 << log_n) * trace_cols(width, over) / (single_ms * 1e-3),
     }
