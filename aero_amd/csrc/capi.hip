@@ -268,7 +268,7 @@ static void eval_constraints_fib(Context* c, const Matrix& lde, uint32_t log_blo
     const int log_ce = ilog2u(ceN);
     NttTables* tce = c->ntt_tables(log_ce);
     FibConsArgs<F> a{};
-    a.lde = lde.data.get(); a.N = N; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)B; a.ce_step = (uint32_t)(B / C);
+    a.lde = lde.data.get(); a.N = N; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)B; a.ce_step = (uint32_t)(B / C); a.xmask = (uint32_t)C - 1;
     a.first = first; a.count = rows;
     a.ta = (const T*)up(ta.data(), nt * sizeof(T)); a.tb = (const T*)up(tb.data(), nt * sizeof(T));
     a.ba = (const T*)up(ba.data(), na * sizeof(T)); a.bb = (const T*)up(bb.data(), na * sizeof(T));

@@ -718,14 +718,20 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     for (size_t i = 0; i < air.num_transition_constraints(); i++) { ta.push_back(coin.draw<F>()); tb.push_back(coin.draw<F>()); }
     for (size_t i = 0; i < air.num_assertions(); i++) { ba.push_back(coin.draw<F>()); bb.push_back(coin.draw<F>()); }
     DevBuf<uint64_t> hbuf(ctx, (size_t)F::DEG * ceN);   // H evaluations, then coefficients: [DEG][ceN]
+    bool h_on_global_coset = false;                     // evaluations are over 7<w_N> (all-gathered) instead of h<w_ce>
     {
-        // H (degree < C*n) is interpolated from its values on h<w_ce>: every (M/ce_n)-th row of this rank's LDE, or - when
-        // the shard is smaller than the constraint domain - a dedicated extension of the trace polynomials onto h<w_ce>.
+        // H (degree < C*n) is interpolated from its values on a coset of <w_ce>:
+        //  * one GPU, or a shard at least as large as the constraint domain: every (M/ce_n)-th row of this rank's LDE (h<w_ce>);
+        //  * sharded with constraint domain = LDE domain (C = blowup): every rank evaluates the rows of its own coset and the H
+        //    evaluations are all-gathered into natural order over 7<w_N> (8 N bytes per component in total);
+        //  * otherwise (shard smaller than a constraint domain that is itself smaller than the LDE domain): a dedicated
+        //    extension of the trace polynomials onto h<w_ce> (cheap: ce_n = C n <= N / 2).
+        const bool gather_h = G > 1 && ceN == N;
         Matrix celde, acelde;
         const uint64_t* frame_src = tlde.data.get();
         const uint64_t* aux_src = A ? alde.data.get() : nullptr;
         size_t frame_rows = M;
-        if (M < ceN) {
+        if (M < ceN && !gather_h) {
             celde = Matrix(ctx, (int)W, ceN);
             ctx->ntt_forward(polys.data.get(), n, celde.data.get(), ceN, (int)W, log_ce, log_ce - log_n);
             frame_src = celde.data.get();
@@ -736,18 +742,22 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
                 aux_src = acelde.data.get();
             }
         }
-        NttTables* tce = ctx->ntt_tables(log_ce);
+        // rows evaluated by this launch: the ce_n points of h<w_ce>, or (gather_h) the M rows of the coset h<w_M>
+        const size_t rows_eval = gather_h ? M : ceN;
+        const size_t xcount = gather_h ? M / n : C;             // distinct values of x^n over those rows
+        NttTables* tce = ctx->ntt_tables(ilog2(rows_eval));
         FibConsArgs<F> a{};
-        a.lde = frame_src; a.N = frame_rows; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)(frame_rows / n); a.ce_step = (uint32_t)(frame_rows / ceN);
-        a.first = 0; a.count = ceN;
+        a.lde = frame_src; a.N = frame_rows; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)(frame_rows / n); a.ce_step = (uint32_t)(frame_rows / rows_eval);
+        a.xmask = (uint32_t)xcount - 1;
+        a.first = 0; a.count = rows_eval;
         ParamPack pp(ctx);
         const size_t i_ta = pp.add(ta), i_tb = pp.add(tb), i_ba = pp.add(ba), i_bb = pp.add(bb), i_res = pp.add(air.results);
         a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.twi_lo = tce->lo_inv; a.twi_hi = tce->hi_inv; a.tw_h = tce->h;
-        a.offset = h; a.gen_inv = h_inv; a.k7 = gl::pow(h, ceN);
-        std::vector<uint64_t> xn(C), zn(C), xnp(C);
-        uint64_t hn = gl::pow(h, n), wC = gl::root_of_unity(ilog2(C));
-        for (size_t k = 0; k < C; k++) {
-            uint64_t xnk = gl::mul(hn, gl::pow(wC, k));
+        a.offset = h; a.gen_inv = h_inv; a.k7 = gl::pow(h, ceN);       // x^ce_n is constant on every coset of <w_ce>
+        std::vector<uint64_t> xn(xcount), zn(xcount), xnp(xcount);
+        uint64_t hn = gl::pow(h, n), wX = gl::root_of_unity(ilog2(xcount));
+        for (size_t k = 0; k < xcount; k++) {
+            uint64_t xnk = gl::mul(hn, gl::pow(wX, k));
             // aux degree adjustment x^((E + 1 - D) n + (D - 2)): the x^n part is constant on each coset of <w_n>
             xnp[k] = gl::pow(xnk, C + 1 - D);
             xn[k] = gl::inv(xnk);
@@ -760,15 +770,26 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         a.results = pp.ptr<uint64_t>(i_res); a.xn_inv = pp.ptr<uint64_t>(i_xn); a.zn_inv = pp.ptr<uint64_t>(i_zn);
         a.w_last = gl::pow(g, n - 1);
         a.out_cols = nullptr;
-        for (int d = 0; d < F::DEG; d++) a.out_h[d] = hbuf.get() + (size_t)d * ceN;
-        launch_fib_constraints<F>(ctx, a, 1);
+        if (!gather_h) {
+            for (int d = 0; d < F::DEG; d++) a.out_h[d] = hbuf.get() + (size_t)d * ceN;
+            launch_fib_constraints<F>(ctx, a, 1);
+        } else {
+            DevBuf<uint64_t> hloc(ctx, (size_t)F::DEG * M), hall(ctx, (size_t)F::DEG * N);
+            for (int d = 0; d < F::DEG; d++) a.out_h[d] = hloc.get() + (size_t)d * M;
+            launch_fib_constraints<F>(ctx, a, 1);
+            comm_all_gather(hloc.get(), hall.get(), (size_t)F::DEG * M * 8);          // [rank][component][t]
+            for (int d = 0; d < F::DEG; d++)
+                launch_interleave_u64(ctx, hall.get() + (size_t)d * M, (size_t)F::DEG * M, hbuf.get() + (size_t)d * N, G, M);
+        }
+        h_on_global_coset = gather_h;
     }
     ms.constraints = clk.lap();
     // 5. composition polynomial: interpolate over the coset; coefficient I gets h^-I (coset) * h^(I >> log C)
     //    (pre-scaling of column coefficient i = I >> log C for the column LDE). In bit-reversed order the C column
     //    polynomials are the C contiguous chunks of the buffer (chunk q = column bitrev(q)): no split pass
     //    (H(x) = sum_c x^c H_c(x^C)).
-    composition_from_evaluations(hbuf.get(), F::DEG, log_ce, ilog2(C), h);
+    if (!h_on_global_coset) composition_from_evaluations(hbuf.get(), F::DEG, log_ce, ilog2(C), h);
+    else ctx->ntt_inverse(hbuf.get(), ceN, F::DEG, log_ce, 1, gen_inv, h, ilog2(C));   // coset 7<w_N>, columns pre-scaled by h^i
     ms.composition = clk.lap();
     // 6. composition commitment [a12]: column c*DEG + d <- chunk c of component d
     Matrix clde(ctx, (int)(C * F::DEG), M);

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
         //   x^adj_b = x^(ce_n - n + 1) = K7 * x * (x^n)^-1,   x^n = 7^n * w_C^(s mod C)
         const uint64_t xinv = gl::mul(a.gen_inv, wi);
         const uint64_t xt = gl::mul(a.k7, xinv);
-        const uint64_t xb = gl::mul(gl::mul(a.k7, x), a.xn_inv[s & (a.C - 1)]);
+        const uint64_t xb = gl::mul(gl::mul(a.k7, x), a.xn_inv[s & a.xmask]);
         T acc = F::zero(), g0 = F::zero(), g1 = F::zero();
         for (uint32_t k = 0; k < a.W / 2; k++) {
             const uint64_t ca = a.lde[(size_t)(2 * k) * a.N + r], cb = a.lde[(size_t)(2 * k + 1) * a.N + r];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
         }
         if (a.A) {
             // auxiliary transition constraints (degree 2): adjustment x^n, constant on each of the C cosets of <w_n>
-            uint64_t xx = a.xn[s & (a.C - 1)];
+            uint64_t xx = a.xn[s & a.xmask];
             for (uint32_t e = 2; e < a.D; e++) xx = gl::mul(xx, x);
             for (uint32_t c = 0; c < a.A; c++) {
                 const size_t o = (size_t)(c * F::DEG) * a.N;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
         for (int q = 0; q < K; q++) {
             const size_t s = a.first + t + (size_t)q * nthreads;
             // 1 / ((x^n - 1) / (x - w^(n-1))) = (x - w^(n-1)) * zinv[s mod C]
-            const uint64_t tdiv = gl::mul(gl::sub(xs[q], a.w_last), a.zn_inv[s & (a.C - 1)]);
+            const uint64_t tdiv = gl::mul(gl::sub(xs[q], a.w_last), a.zn_inv[s & a.xmask]);
             T h = F::mulb(num[q][0], tdiv);
             h = F::add(h, F::mulb(num[q][1], den[2 * q]));
             h = F::add(h, F::mulb(num[q][2], den[2 * q + 1]));
