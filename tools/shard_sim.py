@@ -1,5 +1,6 @@
 """Per-rank compute time of a sharded proof, measured on ONE GPU with loopback exchanges (aero_amd.shard.LoopbackComm).
-usage: python tools/shard_sim.py [log_n ...]   -> JSON lines (one per log_n / world)"""
+usage: python tools/shard_sim.py [log_n ...]   -> JSON lines (one per log_n / world)
+       AERO_SIM_SHAPE=width,aux_width,aux_rands,aux_degree,fold selects another trace shape (default 2,0,0,2,8)"""
 import json
 import os
 import sys
@@ -14,10 +15,12 @@ from aero_amd.shard import LoopbackComm
 
 def main():
     logs = [int(a) for a in sys.argv[1:]] or [20]
+    W, A, R, D, fold = [int(v) for v in os.environ.get("AERO_SIM_SHAPE", "2,0,0,2,8").split(",")]
     ctx = aero_amd.Context(0)
     opts = aero_amd.ProofOptions.with_96_bit_security()
+    opts.fri_folding_factor = fold
     for log_n in logs:
-        trace = ctx.trace_upload(aero_amd.fib_trace(2, log_n))
+        trace = ctx.trace_upload(aero_amd.fib_trace(W, log_n))
         reps = 7 if log_n <= 20 else 3
         base = None
         for world in (1, 2, 4, 8):
@@ -26,17 +29,17 @@ def main():
                 ts = []
                 for i in range(reps + 1):
                     t0 = time.perf_counter()
-                    ctx.prove_fib_sharded(comm, trace, opts)
+                    ctx.prove_fib_aux(trace, A, R, opts, comm=comm, aux_degree=D)
                     ts.append((time.perf_counter() - t0) * 1e3)
                 ts = sorted(ts[1:])
                 ms = ts[len(ts) // 2]
                 ctx.set_stage_timing(True)
-                ctx.prove_fib_sharded(comm, trace, opts)
+                ctx.prove_fib_aux(trace, A, R, opts, comm=comm, aux_degree=D)
                 st = ctx.last_stage_ms()
                 ctx.set_stage_timing(False)
                 if world == 1:
                     base = ms
-                print(json.dumps({"log_n": log_n, "world": world, "rank": rank, "ms": round(ms, 3), "speedup_vs_1": round(base / ms, 2),
+                print(json.dumps({"log_n": log_n, "shape": [W, A, R, D, fold], "world": world, "rank": rank, "ms": round(ms, 3), "speedup_vs_1": round(base / ms, 2),
                                   "exchanges": dict(comm.calls), "bytes_sent_per_proof": comm.bytes_sent // (reps + 2),
                                   "stages_ms": {k: round(v, 3) for k, v in st.items()}}), flush=True)
         trace.free()
