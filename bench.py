@@ -267,8 +267,9 @@ def main():
     ap.add_argument("--sharded-check-world", type=int, default=-1,
                     help="ranks of the sharded-proof side measurement run after the timed region (default: N when N > 1, else "
                          "off; on a 1-GPU box the ranks share the GPU over gloo, which checks the path but not its speed)")
-    ap.add_argument("--sharded-workloads", default="fib_2^20x2_blowup8_blake2s_base,fib_2^24x2_blowup8_blake2s_base")
-    ap.add_argument("--sharded-timeout", type=float, default=240.0)
+    ap.add_argument("--sharded-workloads", default="fib_2^20x2_blowup8_blake2s_base,fib_2^24x2_blowup8_blake2s_base,"
+                                                     "standin_miden_shape_2^22x(72+9aux)_deg8_fold4")
+    ap.add_argument("--sharded-timeout", type=float, default=300.0)
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing aid for a 1-GPU box: every rank uses cuda:0 and the ranks talk over gloo (exercises the whole "
                          "N > 1 control flow; the numbers then describe N processes sharing one GPU)")
