@@ -85,9 +85,13 @@ CASES_SMALL = [
 ]
 
 
+# world 2 runs every case; worlds 4 and 8 interleaved subsets (every case runs at two world sizes, the aux / degree-8 cases at all)
+SUBSETS = {2: range(len(CASES_SMALL)), 4: [0, 2, 4, 6, 8, 9, 10], 8: [1, 3, 5, 7, 8, 9, 11]}
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_proof_identical_small(oracle, world, tmp_path):
-    check(oracle, world, CASES_SMALL, tmp_path)
+    check(oracle, world, [CASES_SMALL[i] for i in SUBSETS[world]], tmp_path)
 
 
 def test_sharded_proof_identical_config2_shape(oracle, tmp_path):
