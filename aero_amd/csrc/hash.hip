@@ -184,15 +184,6 @@ template <class Src> __global__ __launch_bounds__(256) void hash_rows_kernel(Src
     store_digest(&leaves[j], leaf_digest(src, j));
 }
 
-// one tree level: nodes[i] = merge(nodes[2i], nodes[2i+1]) for i in [m, 2m)
-__global__ __launch_bounds__(256) void merkle_level_kernel(Digest* nodes, size_t m) {
-    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= m) return;
-    size_t i = m + t;
-    Digest l = load_digest(&nodes[2 * i]), r = load_digest(&nodes[2 * i + 1]);
-    store_digest(&nodes[i], b2s::merge(l, r));
-}
-
 // L <= 9 levels in one launch, one workgroup per subtree: workgroup b owns node r = m + b and its 2^L descendants L
 // levels below (heap indices (r << L) + j), staged through LDS. Lane utilisation is poor (2^L - 1 compressions on
 // L * 2^(L-1) lane slots), so this is used only where a level has too few nodes to fill the chip anyway: there the cost
