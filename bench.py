@@ -498,10 +498,17 @@ def main():
             cdt = time.perf_counter() - t1
             if s_log_n == log_n:
                 assert cproof == first_proof, "GPU and CPU proofs differ"
+            # the reference binary itself runs Winterfell single-threaded: one thread on a smaller sample
+            orc.set_threads(1)
+            st_log = min(log_n, 16 if width <= 8 else 13)
+            _, _, st = orc.prove_fib_aux(width, st_log, aux[0], aux[1], opt.to_list(), D=aux[2])
+            orc.set_threads(cores)
             out["cpu_baseline"] = {
                 "value": (1 << s_log_n) * trace_cols(width, over) / ctimes["total"], "unit": "cells/s", "cores": cores, "kind": "port",
                 "sample": f"one complete proof of a 2^{s_log_n} x {trace_cols(width, over)} trace of the same AIR with the same options "
                           f"(OpenMP, best of {cpu_thread_candidates(ncpu)} threads on a 2^{probe_log} probe = {cores}; host has {ncpu} logical CPUs; prover time {ctimes['total']:.2f} s, wall {cdt:.2f} s incl. trace generation)",
+                "single_thread": {"value": (1 << st_log) * trace_cols(width, over) / st["total"], "unit": "cells/s",
+                                  "sample": f"one complete proof of a 2^{st_log} x {trace_cols(width, over)} trace, 1 thread"},
             }
         check_world = args.sharded_check_world if args.sharded_check_world >= 0 else (world if world > 1 else 0)
         if check_world > 1:
