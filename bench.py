@@ -448,6 +448,11 @@ def main():
                            "achieved_Gcomp_per_s": comp_per_launch / (1e-3 * s_ms / max(s_calls, 1)) / 1e9,
                            "in_register_ceiling_Gcomp_per_s": 41.0, "ceiling_source": "tools/ubench_valu.hip on MI355X"}
                           if dominant == "merkle_leaf8_kernel" else None),
+            "next_kernels": [{"kernel": k, "share_of_kernel_time": v[1] / total_ms if total_ms else None,
+                              "achieved": (v[2] / (v[1] * 1e-3)) / 1e9 if v[1] > 0 else 0.0,
+                              "frac": (v[2] / (v[1] * 1e-3)) / 1e9 / HBM_PEAK_GBS if v[1] > 0 else 0.0,
+                              "avg_launch_us": 1e3 * v[1] / max(v[0], 1)}
+                             for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[1:4]],
             "note": "field-arithmetic and BLAKE2s kernels on this path are integer-VALU bound (SQ counters: VALU issue ~95 % busy); "
                     "their HBM fraction is low by construction (DESIGN.md section 3)",
         }
