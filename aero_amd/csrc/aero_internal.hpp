@@ -105,6 +105,7 @@ public:
     void ensure_small_twiddles();
     // pass-boundary twiddle table of a register-only strided pass (ntt.hip), cached per (size, stride, radix, direction)
     const uint64_t* pass_twiddles(int log_n, int log_s, int log_r, bool inverse);
+    bool quad_tops = true;     // latency-bound tree tops: four lanes per BLAKE2s compression (AERO_QUAD_TOPS=0: one lane)
     bool pass_names = false;   // AERO_NTT_NAMES=1: forward passes are timed under per-variant names (diagnosis)
     bool reg_passes = true;    // strided passes of radix 16..64 run entirely in registers (AERO_NTT_REG=0: LDS passes only)
     void ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad);

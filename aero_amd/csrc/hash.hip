@@ -205,6 +205,90 @@ __global__ __launch_bounds__(256) void merkle_multi_kernel(Digest* nodes, size_t
     }
 }
 
+// Same subtree build with FOUR lanes per compression (a quad holds one column of the 4 x 4 BLAKE2s state each: lane j has
+// v[j], v[4+j], v[8+j], v[12+j]; the diagonal step rotates rows 1..3 across the quad with DPP quad_perm moves). A level then
+// costs ~1 us instead of the ~2.4 us of a whole compression on one lane - this kernel is latency-bound by construction (see
+// above), so shortening the dependent instruction chain is what counts. Message words are read from the LDS copy of the two
+// children through a per-lane, per-round index table held in registers.
+__constant__ uint8_t QUAD_SIGMA[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+#define QUAD_ROT1(x) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), 0x39, 0xf, 0xf, true))   // lane i <- lane (i + 1) & 3
+#define QUAD_ROT2(x) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), 0x4E, 0xf, 0xf, true))   // lane i <- lane (i + 2) & 3
+#define QUAD_ROT3(x) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), 0x93, 0xf, 0xf, true))   // lane i <- lane (i + 3) & 3
+#define QUAD_G(a, b, c, d, x, y)                          \
+    a = a + b + (x); d = b2s::rotr(d ^ a, 16);            \
+    c = c + d;       b = b2s::rotr(b ^ c, 12);            \
+    a = a + b + (y); d = b2s::rotr(d ^ a, 8);             \
+    c = c + d;       b = b2s::rotr(b ^ c, 7);
+// BLAKE2s(left || right) of the 16 message words at msg[0..16) (LDS), computed by the 4 lanes of a quad; lane j returns words
+// j (lo) and 4 + j (hi) of the digest. Every lane of the quad must call it (DPP moves), idle quads may pass any valid msg.
+__device__ __forceinline__ void quad_merge(const uint32_t* msg, int j, const uint32_t (&pk)[10], uint32_t& lo, uint32_t& hi) {
+    const uint32_t iv_lo[4] = {b2s::IV0, b2s::IV1, b2s::IV2, b2s::IV3}, iv_hi[4] = {b2s::IV4, b2s::IV5, b2s::IV6, b2s::IV7};
+    const uint32_t h_lo = (j == 0 ? b2s::IV0 ^ b2s::PARAM0 : j == 1 ? iv_lo[1] : j == 2 ? iv_lo[2] : iv_lo[3]);
+    const uint32_t h_hi = (j == 0 ? iv_hi[0] : j == 1 ? iv_hi[1] : j == 2 ? iv_hi[2] : iv_hi[3]);
+    uint32_t a = h_lo, b = h_hi;
+    uint32_t c = (j == 0 ? iv_lo[0] : j == 1 ? iv_lo[1] : j == 2 ? iv_lo[2] : iv_lo[3]);
+    uint32_t d = (j == 0 ? iv_hi[0] ^ 64u : j == 1 ? iv_hi[1] : j == 2 ? ~iv_hi[2] : iv_hi[3]);   // t = 64 bytes, last block
+    // the 4 message words of each round come from LDS through this lane's packed index table; none of the 40 reads depends
+    // on the G chain, so they are all in flight before it starts
+    uint32_t mw[10][4];
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) mw[r][k] = msg[(pk[r] >> (4 * k)) & 15u];
+    }
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        QUAD_G(a, b, c, d, mw[r][0], mw[r][1])
+        b = QUAD_ROT1(b); c = QUAD_ROT2(c); d = QUAD_ROT3(d);
+        QUAD_G(a, b, c, d, mw[r][2], mw[r][3])
+        b = QUAD_ROT3(b); c = QUAD_ROT2(c); d = QUAD_ROT1(d);
+    }
+    lo = h_lo ^ a ^ c;
+    hi = h_hi ^ b ^ d;
+}
+// Levels with more than 64 nodes use one lane per node (256 lanes already fill the 4 SIMDs of the CU: more lanes per node
+// would only add instructions); from 64 nodes down a quad per node shortens the chain.
+__global__ __launch_bounds__(256) void merkle_multi_quad_kernel(Digest* nodes, size_t m, int L) {
+    __shared__ __attribute__((aligned(16))) Digest buf[512];
+    const int tid = threadIdx.x, q = tid >> 2, j = tid & 3;
+    const size_t r = m + blockIdx.x;
+    const int nchild = 1 << L;
+    for (int i = tid; i < nchild; i += 256) buf[i] = load_digest(&nodes[(r << L) + i]);
+    uint32_t pk[10];
+#pragma unroll
+    for (int rd = 0; rd < 10; rd++)
+        pk[rd] = (uint32_t)QUAD_SIGMA[rd][2 * j] | ((uint32_t)QUAD_SIGMA[rd][2 * j + 1] << 4) | ((uint32_t)QUAD_SIGMA[rd][8 + 2 * j] << 8) |
+                 ((uint32_t)QUAD_SIGMA[rd][8 + 2 * j + 1] << 12);
+    __syncthreads();
+    uint32_t* words = reinterpret_cast<uint32_t*>(buf);
+    for (int d = L - 1; d >= 0; d--) {
+        const int w = 1 << d;
+        if (w > 64) {
+            Digest v;
+            if (tid < w) v = b2s::merge(buf[2 * tid], buf[2 * tid + 1]);
+            __syncthreads();
+            if (tid < w) { buf[tid] = v; store_digest(&nodes[(r << d) + tid], v); }
+            __syncthreads();
+        } else {
+            const bool live = q < w;
+            uint32_t lo, hi;
+            quad_merge(words + (live ? 16 * q : 0), j, pk, lo, hi);
+            __syncthreads();
+            if (live) {
+                words[8 * q + j] = lo; words[8 * q + 4 + j] = hi;
+                uint32_t* dst = reinterpret_cast<uint32_t*>(&nodes[(r << d) + q]);
+                dst[j] = lo; dst[4 + j] = hi;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Recompute unstored low nodes for openings: out[q] = digest of heap node idx[q] (height h < 3 above the leaves).
 // 8 lanes cooperate on one node: each lane hashes one leaf of the (at most 8-leaf) subtree, partners are fetched with
 // wave shuffles, so the latency is one leaf hash plus h merges instead of 2^(h+1) - 1 serial compressions.
@@ -256,7 +340,8 @@ void Context::merkle_upper(Digest* nodes, size_t c) {
         int L = 0;
         while (L < 9 && ((size_t)1 << (L + 1)) <= c) L++;
         size_t m = c >> L;
-        AERO_LAUNCH(this, "merkle_multi_kernel", c * 64, merkle_multi_kernel, dim3((unsigned)m), dim3(256), 0, nodes, m, L);
+        if (quad_tops) AERO_LAUNCH(this, "merkle_multi_kernel", c * 64, merkle_multi_quad_kernel, dim3((unsigned)m), dim3(256), 0, nodes, m, L);
+        else AERO_LAUNCH(this, "merkle_multi_kernel", c * 64, merkle_multi_kernel, dim3((unsigned)m), dim3(256), 0, nodes, m, L);
         c = m;
     }
     check_launch("merkle_upper");

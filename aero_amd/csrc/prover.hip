@@ -24,6 +24,7 @@ Context::Context(int dev) : device(dev) {
     AERO_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (const char* e = getenv("AERO_NTT_REG")) reg_passes = e[0] != '0';
     if (const char* e = getenv("AERO_NTT_NAMES")) pass_names = e[0] != '0';
+    if (const char* e = getenv("AERO_QUAD_TOPS")) quad_tops = e[0] != '0';
 }
 Context::~Context() {
     (void)hipSetDevice(device);
