@@ -824,6 +824,7 @@ static void verify_impl(const Proof& pr, const Col& pub_elements, AirKind kind, 
     }
     {   // remainder degree (winter-fri 0.4 verify_remainder): interpolate over <omega>, degree <= n / Fd^layers - 1
         size_t maxdeg_plus1 = n; for (int l = 0; l < layers; l++) maxdeg_plus1 /= Fd;
+        if (maxdeg_plus1 == 0) maxdeg_plus1 = 1;   // folded past degree 0 (large blowup, small remainder): the remainder is a constant
         if (maxdeg_plus1 >= dom) throw Err("verify: remainder degree bound not valid");
         for (int k = 0; k < F::DEG; k++) {
             Col comp(dom);
