@@ -16,7 +16,11 @@ def pytest_configure(config):
 def oracle():
     """CPU restatement of the reference path (test infrastructure, oracle/)."""
     from tests import oracle_lib
-    return oracle_lib.load()
+    orc = oracle_lib.load()
+    # the oracle's OpenMP loops stop scaling around 32 threads (bench.py picks that on a 256-CPU box); the default of one
+    # thread per logical CPU makes the many small proofs of the test-suite slower, not faster
+    orc.set_threads(min(32, os.cpu_count() or 1))
+    return orc
 
 
 @pytest.fixture(scope="session")
