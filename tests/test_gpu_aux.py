@@ -33,7 +33,7 @@ CASES = [
     (12, 2, 4, 4, {"blowup_factor": 16, "fri_folding_factor": 16, "fri_log_max_remainder": 4}),
     (12, 72, 9, 16, {"fri_folding_factor": 4, "num_queries": 16}),           # config-5 shape (72 + 9 columns, fold 4)
     (13, 4, 2, 3, {}),                                                       # more than one scan block per column
-    (14, 2, 2, 2, {"field_extension": 2}),
+    (16, 2, 2, 2, {"field_extension": 2}),
 ]
 
 
@@ -101,9 +101,9 @@ def test_aux_bad_shapes_fail_loudly(ctx):
 
 
 def test_full_size_aux_verifies(ctx, oracle):
-    """2^18 rows (fused leaf kernel, unstored low Merkle levels, 128 scan blocks per aux column), 2 main + 2 aux columns:
+    """2^20 rows (fused leaf kernel, unstored low Merkle levels, 512 scan blocks per aux column), 2 main + 2 aux columns:
     byte-identical to the oracle and verified with the OOD check."""
-    log_n, W, A, R = 18, 2, 2, 2
+    log_n, W, A, R = 20, 2, 2, 2
     dev = ctx.trace_upload(aero_amd.fib_trace(W, log_n))
     got, pub = ctx.prove_fib_aux(dev, A, R, opts())
     oracle.verify_fib_aux(got, pub, W, log_n, A, R)

@@ -205,9 +205,9 @@ CASES = [
     (11, 6, {"field_extension": 2, "fri_folding_factor": 4, "num_queries": 20}),
     (12, 72, {"num_queries": 16}),                                                     # Miden-width main segment
     (12, 2, {"blowup_factor": 16, "fri_folding_factor": 16, "fri_log_max_remainder": 4}),
-    (13, 8, {"blowup_factor": 4, "fri_folding_factor": 2, "fri_log_max_remainder": 6, "num_queries": 40}),
+    (14, 8, {"blowup_factor": 4, "fri_folding_factor": 2, "fri_log_max_remainder": 6, "num_queries": 40}),
     (16, 2, {}),
-    (15, 4, {"field_extension": 2}),
+    (17, 4, {"field_extension": 2}),
 ]
 
 

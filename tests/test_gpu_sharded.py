@@ -85,8 +85,8 @@ CASES_SMALL = [
 ]
 
 
-# world 2 runs every case; worlds 4 and 8 interleaved subsets (every case runs at two world sizes, the aux / degree-8 cases at all)
-SUBSETS = {2: range(len(CASES_SMALL)), 4: [0, 2, 4, 6, 8, 9, 10], 8: [1, 3, 5, 7, 8, 9, 11]}
+# every case runs at every world size
+SUBSETS = {2: range(len(CASES_SMALL)), 4: range(len(CASES_SMALL)), 8: range(len(CASES_SMALL))}
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
@@ -97,8 +97,10 @@ def test_sharded_proof_identical_small(oracle, world, tmp_path):
 def test_sharded_proof_identical_config2_shape(oracle, tmp_path):
     """2^16 rows with the DEFAULT sharding threshold (two sharded FRI layers at world 2, then the un-shard all-gather), base
     and quadratic field."""
-    cases = [{"width": 2, "log_n": 16, "options": DEFAULT}, {"width": 2, "log_n": 15, "options": [27, 8, 16, 4, 2, 8, 8]}]
+    cases = [{"width": 2, "log_n": 16, "options": DEFAULT}, {"width": 2, "log_n": 16, "options": [27, 8, 16, 4, 2, 8, 8]},
+             {"width": 72, "log_n": 12, "options": [27, 8, 16, 4, 1, 4, 8], "aux": [9, 16, 8]}]     # config-5 shape
     check(oracle, 2, cases, tmp_path)
+    check(oracle, 8, [cases[0], cases[2]], tmp_path)
 
 
 def test_sharded_rejects_bad_world(tmp_path):
