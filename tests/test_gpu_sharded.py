@@ -103,6 +103,11 @@ def test_sharded_proof_identical_config2_shape(oracle, tmp_path):
     check(oracle, 8, [cases[0], cases[2]], tmp_path)
 
 
+def test_sharded_proof_identical_full_size(oracle, tmp_path):
+    """BASELINE configs[1] at full size (2^20 rows) sharded 8 ways: byte-identical to the single-GPU proof and the oracle's."""
+    check(oracle, 8, [{"width": 2, "log_n": 20, "options": DEFAULT}], tmp_path)
+
+
 def test_sharded_rejects_bad_world(tmp_path):
     """world must be a power of two not larger than the blowup factor; a missing callback is refused."""
     import ctypes as C
