@@ -94,7 +94,7 @@ def aggregate_value(cells_per_proof, steps, world, dt):
 
 def cpu_thread_candidates(cores):
     """Thread counts tried for the CPU baseline: the oracle's OpenMP loops stop scaling well before 256 threads."""
-    c = sorted({max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores})
+    c = sorted({max(1, cores // 16), max(1, cores // 8), max(1, cores // 4), max(1, cores // 2), cores})
     return [t for t in c if t >= 1]
 
 
