@@ -42,6 +42,7 @@ template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
         fn();
         return AERO_OK;
     } catch (const Error& e) {
+        (void)hipGetLastError();   // leave no stale HIP error behind for the next call's launch checks
         if (ctx) { ctx->err = e.what(); if (ctx->c) ctx->c->scratch_reset(); }
         return e.code;
     } catch (const std::bad_alloc&) {

@@ -53,7 +53,10 @@ void* Context::pool_alloc(size_t bytes) {
             for (auto& kv : free_blocks) (void)hipFree(kv.second);
             free_blocks.clear();
             e = hipMalloc(&p, bytes);
-            if (e != hipSuccess) throw Error(ST_OOM, "device allocation of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+            if (e != hipSuccess) {
+                (void)hipGetLastError();   // the failed hipMalloc must not surface again at the next launch check
+                throw Error(ST_OOM, "device allocation of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+            }
         }
     }
     live_blocks[p] = bytes;

@@ -302,3 +302,16 @@ def test_non_canonical_trace_is_refused(ctx):
         ctx.prove_fib(t, opts())
     t[1, 200] = P - 1                      # largest canonical value is fine (the proof is simply not FibAir-valid)
     ctx.trace_upload(t).free()
+
+
+def test_out_of_memory_is_an_error_not_a_crash(ctx):
+    """A request that cannot fit in HBM (255 columns x 2^29 rows = 1 TiB) comes back as AERO_E_OOM before any host byte is read,
+    and the context keeps working."""
+    import ctypes as C
+    dummy = np.zeros(8, np.uint64)
+    h = C.c_void_p()
+    rc = aero_amd.lib().aero_trace_upload(ctx.h, dummy.ctypes.data_as(aero_amd.u64p), C.c_uint32(255), C.c_uint32(29), C.byref(h))
+    assert rc == -2, rc
+    assert b"allocation" in aero_amd.lib().aero_last_error(ctx.h)
+    proof, _ = ctx.prove_fib(aero_amd.fib_trace(2, 8), opts())
+    assert len(proof) > 1000
