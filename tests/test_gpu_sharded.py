@@ -123,3 +123,27 @@ def test_sharded_rejects_bad_world(tmp_path):
         assert rc == -1, (rank, world, rc)
     trace.free()
     ctx.close()
+
+
+def test_exchange_failure_is_reported_and_recoverable():
+    """A failing exchange callback surfaces as AERO_E_COMM (-4); the context proves normally afterwards."""
+    import ctypes as C
+    import aero_amd
+    from aero_amd import shard
+    ctx = aero_amd.Context(0)
+    trace = ctx.trace_upload(aero_amd.fib_trace(2, 8))
+    opts = aero_amd.ProofOptions(*DEFAULT)
+    cs = shard.CommStruct(0, 2, None, shard._A2A(lambda u, s, r, n: 1), shard._AG(lambda u, s, r, n: 1), shard._AR(lambda u, b, n: 1), 0)
+    proof, plen = aero_amd.u8p(), C.c_size_t(0)
+    rc = aero_amd.lib().aero_prove_fib_sharded(ctx.h, C.byref(cs), trace.h, C.byref(opts), C.byref(proof), C.byref(plen), None)
+    assert rc == -4, rc
+    assert b"exchange failed" in aero_amd.lib().aero_last_error(ctx.h)
+    ok, _ = ctx.prove_fib(trace, opts)
+    assert len(ok) > 1000
+    in_use_before = ctx.memory_stats()[0]
+    for _ in range(3):
+        rc = aero_amd.lib().aero_prove_fib_sharded(ctx.h, C.byref(cs), trace.h, C.byref(opts), C.byref(proof), C.byref(plen), None)
+        assert rc == -4
+    assert ctx.memory_stats()[0] == in_use_before, "a failed proof leaked pool memory"
+    trace.free()
+    ctx.close()
