@@ -415,5 +415,64 @@ class Context:
         return a.value, b.value
 
 
+class _BorrowedContext(Context):
+    """A pool slot's context: owned by the pool (never destroyed from Python)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def close(self):
+        self.h = None
+
+
+class Pool:
+    """`slots` contexts on one device, each with its own worker thread inside the library (aero_pool_*): several independent
+    proofs in flight per GPU through one call."""
+
+    def __init__(self, device=0, slots=8):
+        self.h = C.c_void_p()
+        rc = lib().aero_pool_create(C.c_int32(device), C.c_uint32(slots), C.byref(self.h))
+        if rc != 0:
+            raise AeroError(rc, lib().aero_last_error(None).decode())
+        lib().aero_pool_ctx.restype = C.c_void_p
+        self.slots = slots
+        self.ctxs = [_BorrowedContext(C.c_void_p(lib().aero_pool_ctx(self.h, C.c_uint32(i)))) for i in range(slots)]
+
+    def ctx(self, slot) -> Context:
+        return self.ctxs[slot]
+
+    def prove_fib(self, traces, options: ProofOptions, aux=(0, 0, 2), rounds=1):
+        """traces[i] = Matrix resident on slot i's context. Every slot proves its trace `rounds` times back to back; returns
+        [(proof_bytes, public_inputs)] of the last round."""
+        n = len(traces)
+        arr = (C.c_void_p * n)(*[t.h for t in traces])
+        proofs = (u8p * n)()
+        lens = (C.c_size_t * n)()
+        widths = [t.shape[0] for t in traces]
+        pubs = np.zeros(sum(w // 2 for w in widths), np.uint64)
+        air = FibAirDesc(aux[0], aux[1], aux[2])
+        rc = lib().aero_pool_prove_fib(self.h, arr, C.c_uint32(n), C.byref(air), C.byref(options), C.c_uint32(rounds), proofs, lens, _p64(pubs))
+        if rc != 0:
+            msgs = [lib().aero_last_error(c.h).decode() for c in self.ctxs[:n]]
+            for i in range(n):
+                if proofs[i]:
+                    lib().aero_free(proofs[i])
+            raise AeroError(rc, "; ".join(m for m in msgs if m))
+        out, off = [], 0
+        for i in range(n):
+            data = C.string_at(proofs[i], lens[i])
+            lib().aero_free(proofs[i])
+            out.append((data, pubs[off:off + widths[i] // 2].tolist()))
+            off += widths[i] // 2
+        return out
+
+    def close(self):
+        if self.h:
+            lib().aero_pool_destroy(self.h)
+            self.h = None
+            for c in self.ctxs:
+                c.h = None
+
+
 def device_count():
     return lib().aero_device_count()

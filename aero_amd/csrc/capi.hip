@@ -1,6 +1,9 @@
 // extern "C" boundary of libaero_stark.so (declarations + reference citations: include/aero_stark.h).
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 #include "../../include/aero_stark.h"
 #include "prover.hpp"
@@ -602,4 +605,120 @@ int32_t aero_memory_stats(const aero_ctx* ctx, uint64_t* in_use, uint64_t* peak)
     return AERO_OK;
 }
 
+}  // extern "C"
+
+// ---- pool: several proofs in flight on one device, one worker thread per context ---------------------------------------
+struct aero_pool {
+    struct Slot {
+        aero_ctx* ctx = nullptr;
+        std::thread th;
+        // job (written by the caller under `mu`, read by the worker)
+        const aero_matrix* trace = nullptr;
+        uint8_t* proof = nullptr;
+        size_t proof_len = 0;
+        std::vector<uint64_t> pub;
+        int32_t status = 0;
+        bool has_job = false;
+    };
+    std::vector<std::unique_ptr<Slot>> slots;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    uint64_t generation = 0;       // bumped per batch
+    int pending = 0;
+    bool stop = false;
+    // batch parameters
+    aero_fib_air air{0, 0, 2};
+    aero_proof_options opt{};
+    uint32_t rounds = 1;
+
+    void worker(Slot* s) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return stop || (generation != seen && s->has_job); });
+                if (stop) return;
+                seen = generation;
+            }
+            int32_t rc = AERO_OK;
+            uint8_t* out = nullptr;
+            size_t len = 0;
+            std::vector<uint64_t> pub((size_t)s->trace->m.cols / 2);
+            for (uint32_t r = 0; r < rounds && rc == AERO_OK; r++) {
+                if (out) { free(out); out = nullptr; }
+                rc = aero_prove_fib_air(s->ctx, nullptr, s->trace, &air, &opt, &out, &len, pub.data());
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                s->status = rc; s->proof = out; s->proof_len = len; s->pub = std::move(pub); s->has_job = false;
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+};
+
+extern "C" {
+int32_t aero_pool_create(int32_t device_id, uint32_t slots, aero_pool** out) {
+    if (!out || slots == 0 || slots > 64) return AERO_E_BAD_ARG;
+    *out = nullptr;
+    std::unique_ptr<aero_pool> p(new (std::nothrow) aero_pool());
+    if (!p) return AERO_E_OOM;
+    for (uint32_t i = 0; i < slots; i++) {
+        aero_ctx* c = nullptr;
+        int32_t rc = aero_ctx_create(device_id, &c);
+        if (rc != AERO_OK) {
+            for (auto& s : p->slots) aero_ctx_destroy(s->ctx);
+            return rc;
+        }
+        p->slots.emplace_back(new aero_pool::Slot());
+        p->slots.back()->ctx = c;
+    }
+    for (auto& s : p->slots) s->th = std::thread(&aero_pool::worker, p.get(), s.get());
+    *out = p.release();
+    return AERO_OK;
+}
+void aero_pool_destroy(aero_pool* pool) {
+    if (!pool) return;
+    {
+        std::lock_guard<std::mutex> lk(pool->mu);
+        pool->stop = true;
+    }
+    pool->cv_job.notify_all();
+    for (auto& s : pool->slots) if (s->th.joinable()) s->th.join();
+    for (auto& s : pool->slots) aero_ctx_destroy(s->ctx);
+    delete pool;
+}
+uint32_t aero_pool_slots(const aero_pool* pool) { return pool ? (uint32_t)pool->slots.size() : 0; }
+aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot) { return (pool && slot < pool->slots.size()) ? pool->slots[slot]->ctx : nullptr; }
+int32_t aero_pool_prove_fib(aero_pool* pool, const aero_matrix* const* traces, uint32_t count, const aero_fib_air* air,
+                            const aero_proof_options* options, uint32_t rounds, uint8_t** proofs, size_t* proof_lens, uint64_t* pubs) {
+    if (!pool || !traces || !options || !proofs || !proof_lens || count == 0 || count > pool->slots.size() || rounds == 0) return AERO_E_BAD_ARG;
+    for (uint32_t i = 0; i < count; i++)
+        if (!traces[i] || traces[i]->keep.get() != pool->slots[i]->ctx->c) return AERO_E_BAD_ARG;   // must live on slot i's context
+    {
+        std::lock_guard<std::mutex> lk(pool->mu);
+        pool->air = air ? *air : aero_fib_air{0, 0, 2};
+        pool->opt = *options;
+        pool->rounds = rounds;
+        for (uint32_t i = 0; i < count; i++) { pool->slots[i]->trace = traces[i]; pool->slots[i]->has_job = true; }
+        pool->pending = (int)count;
+        pool->generation++;
+    }
+    pool->cv_job.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(pool->mu);
+        pool->cv_done.wait(lk, [&] { return pool->pending == 0; });
+    }
+    int32_t first = AERO_OK;
+    size_t poff = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        aero_pool::Slot& s = *pool->slots[i];
+        proofs[i] = s.proof; proof_lens[i] = s.proof_len;
+        if (pubs && s.status == AERO_OK) memcpy(pubs + poff, s.pub.data(), s.pub.size() * 8);
+        poff += (size_t)traces[i]->m.cols / 2;
+        if (first == AERO_OK && s.status != AERO_OK) first = s.status;
+        s.proof = nullptr;
+    }
+    return first;
+}
 }  // extern "C"

@@ -221,6 +221,26 @@ typedef struct aero_fib_air {
 int32_t aero_prove_fib_air(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_fib_air* air,
                            const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
 
+/* ---- several proofs in flight on one GPU --------------------------------------------------------------------------------------- */
+/* A pool = `slots` contexts on one device, each driven by its own host thread inside the library. One proof alone cannot fill
+ * an MI355X (its tree tops and transcript round trips are latency-bound); with ~8 independent proofs in flight the GPU stays
+ * busy. The reference's analogue is its worker pool (aero-sdk/miden-wasm/src/pool.rs:28-45), which
+ * spreads ONE proof's row-hash / constraint batches over web workers; here whole proofs are the unit.
+ *   aero_pool_ctx ........ the context of slot i (for aero_trace_upload etc.; do not destroy it, and do not use it while a
+ *                          aero_pool_prove_fib call is running)
+ *   aero_pool_prove_fib .. `count` <= slots proofs at once: traces[i] must be resident on slot i's context; proofs[i] is
+ *                          malloc'd (aero_free), pubs receives width/2 values per proof back to back. air may be NULL (plain
+ *                          FibAir). `rounds` > 1 repeats the batch that many times back to back inside the library (every
+ *                          slot proves its trace `rounds` times; the last proof of each slot is returned) - for throughput
+ *                          measurements without host re-entry. Returns the first non-zero status of any slot. */
+typedef struct aero_pool aero_pool;
+int32_t aero_pool_create(int32_t device_id, uint32_t slots, aero_pool** out);
+void aero_pool_destroy(aero_pool* pool);
+uint32_t aero_pool_slots(const aero_pool* pool);
+aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot);
+int32_t aero_pool_prove_fib(aero_pool* pool, const aero_matrix* const* traces, uint32_t count, const aero_fib_air* air,
+                            const aero_proof_options* options, uint32_t rounds, uint8_t** proofs, size_t* proof_lens, uint64_t* pubs);
+
 /* bincode ProofData{input_bytes, proof_bytes} = u64 len || inputs || u64 len || proof
  * (miden-proof-generator/src/lib.rs:1-6, main.rs:49-51). */
 int32_t aero_proof_container(const uint8_t* inputs, size_t inputs_len, const uint8_t* proof, size_t proof_len, uint8_t** out,

@@ -315,3 +315,26 @@ def test_out_of_memory_is_an_error_not_a_crash(ctx):
     assert b"allocation" in aero_amd.lib().aero_last_error(ctx.h)
     proof, _ = ctx.prove_fib(aero_amd.fib_trace(2, 8), opts())
     assert len(proof) > 1000
+
+
+def test_pool_proves_batches_identically(oracle):
+    """aero_pool_*: several contexts + library worker threads; every slot's proof equals the single-context proof, repeated
+    rounds return the same bytes, a trace that lives on another slot is refused."""
+    pool = aero_amd.Pool(0, 4)
+    o = opts()
+    shapes = [(2, 10), (4, 9), (2, 12), (6, 8)]
+    devs = [pool.ctx(i).trace_upload(aero_amd.fib_trace(w, ln)) for i, (w, ln) in enumerate(shapes)]
+    res = pool.prove_fib(devs, o)
+    for (w, ln), (proof, pub) in zip(shapes, res):
+        want, want_pub, _ = oracle.prove_fib(w, ln, o.to_list())
+        assert proof == want and pub == want_pub
+    again = pool.prove_fib(devs, o, rounds=3)
+    assert [p for p, _ in again] == [p for p, _ in res]
+    aux = pool.prove_fib(devs[:2], o, aux=(2, 3, 8))
+    want, _, _ = oracle.prove_fib_aux(2, 10, 2, 3, o.to_list(), D=8)
+    assert aux[0][0] == want
+    with pytest.raises(aero_amd.AeroError):
+        pool.prove_fib([devs[1], devs[0]], o)          # traces on the wrong slots
+    for d in devs:
+        d.free()
+    pool.close()
