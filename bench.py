@@ -352,9 +352,12 @@ def main():
         proof, pub = pool.prove_fib(devs, opt, aux)[0]
     # one more untimed pass with every launch bracketed by HIP events: per-kernel table, picks the dominant kernel
     # (steady state: tables and code objects are already resident after the warmup)
+    TRACED = 3
+    prove_call(ctx, dev, opt, over)                   # settle after the all-streams warmup
     ctx.set_kernel_timing(True)
-    proof, pub = prove_call(ctx, dev, opt, over)
-    table = ctx.kernel_timing_report()
+    for _ in range(TRACED):
+        proof, pub = prove_call(ctx, dev, opt, over)
+    table = {k: (c / TRACED, ms / TRACED, b / TRACED) for k, (c, ms, b) in ctx.kernel_timing_report().items()}
     ctx.set_kernel_timing(False)
     proof_len = len(proof)
     dominant = max(table.items(), key=lambda kv: kv[1][1])[0]
