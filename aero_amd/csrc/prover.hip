@@ -386,6 +386,19 @@ MerkleTree Prover::commit_fri_layer(const FriSrc& src, bool keep_low_levels) {
     return t;
 }
 
+MerkleTree Prover::commit_fri_layer_async(const FriSrc& src) {
+    const size_t rows = src.rows;
+    if (rows < 2) {   // a single leaf is its own root
+        MerkleTree t(ctx_, 1);
+        ctx_->hash_fri_rows(src, t.nodes.get() + 1);
+        return t;
+    }
+    MerkleTree t(ctx_, rows, 0);
+    ctx_->hash_fri_rows(src, t.leaves());
+    ctx_->merkle_build(t.nodes.get(), rows);
+    return t;
+}
+
 // ================================================================================================
 template <class F> static void flatten(const typename F::T* v, size_t n, std::vector<uint64_t>& out) {
     for (size_t i = 0; i < n; i++) for (int d = 0; d < F::DEG; d++) out.push_back(F::comp(v[i], d));
@@ -536,25 +549,31 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
     }
     fl.vals.push_back(std::move(evals));
     const uint64_t gen_inv = gl::inv(gl::GEN);
+    // The transcript steps of the commit phase (reseed with the root, draw alpha) run on the device, so every layer is enqueued
+    // without a host round trip; the roots come back with ONE copy at the end and the host replays the coin to stay in step.
+    Digest* d_seed = (Digest*)ctx->scratch_alloc(sizeof(Digest));
+    T* d_alpha = (T*)ctx->scratch_alloc(sizeof(T) * (fl.layers + 1));
+    Digest* h_seed = (Digest*)ctx->stage_alloc(sizeof(Digest));
+    *h_seed = coin.seed;
+    AERO_HIP(hipMemcpyAsync(d_seed, h_seed, sizeof(Digest), hipMemcpyHostToDevice, ctx->stream));
+    Digest* h_roots = (Digest*)ctx->stage_alloc(sizeof(Digest) * (fl.layers + 1));
     uint64_t dom = N;
     for (int l = 0; l <= fl.layers; l++) {
         const size_t rows = dom / Fd;
         const FriSrc fsrc{fl.vals[l].get(), fl.vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd};
         Commitment c;
-        c.tree = commit_fri_layer(fsrc);
+        c.tree = commit_fri_layer_async(fsrc);
         c.n_global = rows;
-        c.root = c.tree.root();
-        if (roots) wdigest(*roots, c.root);
-        coin.reseed(c.root);
+        launch_fri_coin_step<F>(ctx, d_seed, c.tree.nodes.get() + 1, d_alpha + l);
+        AERO_HIP(hipMemcpyAsync(h_roots + l, c.tree.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
         fl.coms.push_back(std::move(c));
-        const T alpha = coin.draw<F>();
         if (l == fl.layers) break;   // alpha drawn after the remainder commitment is unused
         fl.vals.emplace_back(ctx, (size_t)F::DEG * rows);
         NttTables* td = ctx->ntt_tables(ilog2(dom));
         FoldArgs<F> a{};
         for (int d = 0; d < F::DEG; d++) { a.in[d] = fl.vals[l].get() + (size_t)d * dom; a.out[d] = fl.vals[l + 1].get() + (size_t)d * rows; }
         if (F::DEG == 1) { a.in[1] = a.in[0]; a.out[1] = a.out[0]; }
-        a.rows = rows; a.fold = (int)Fd; a.alpha = alpha;
+        a.rows = rows; a.fold = (int)Fd; a.alpha = F::zero(); a.alpha_dev = d_alpha + l;
         a.twi_lo = td->lo_inv; a.twi_hi = td->hi_inv; a.tw_h = td->h;
         a.gen_inv = gen_inv; a.fold_inv = gl::inv(Fd);
         uint64_t wFi = gl::inv(gl::root_of_unity(ilog2(Fd)));
@@ -562,6 +581,17 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
         launch_fri_fold<F>(ctx, a);
         dom = rows;
     }
+    AERO_HIP(hipMemcpyAsync(h_seed, d_seed, sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    for (int l = 0; l <= fl.layers; l++) {
+        Commitment& c = fl.coms[l];
+        c.root = h_roots[l];
+        c.tree.root_host = c.root;
+        if (roots) wdigest(*roots, c.root);
+        coin.reseed(c.root);
+        (void)coin.draw<F>();
+    }
+    if (memcmp(coin.seed.w, h_seed->w, sizeof(Digest)) != 0) fail("FRI: device and host transcripts diverged", ST_INTERNAL);
     return fl;
 }
 template FriLayers Prover::fri_build_layers<FB>(DevBuf<uint64_t>&&, uint64_t, HostCoin&, Bytes*);

@@ -328,7 +328,7 @@ template <class F> __global__ __launch_bounds__(256) void fri_fold_kernel(FoldAr
     T v[16];
     for (int j = 0; j < a.fold; j++) v[j] = F::make(a.in[0][i + (size_t)j * a.rows], F::DEG > 1 ? a.in[1][i + (size_t)j * a.rows] : 0);
     const uint64_t xinv = gl::mul(a.gen_inv, tw2(a.twi_lo, a.twi_hi, (uint32_t)i, a.tw_h));
-    const T r = F::mulb(a.alpha, xinv);
+    const T r = F::mulb(a.alpha_dev ? *a.alpha_dev : a.alpha, xinv);
     T rp = F::one(), acc = F::zero();
     for (int k = 0; k < a.fold; k++) {
         T ck = F::zero();
@@ -355,7 +355,7 @@ template <class F, int LOGF> __global__ __launch_bounds__(256) void fri_fold_fft
     dft_dif_inv<LOGF>(y0);
     if (F::DEG > 1) dft_dif_inv<LOGF>(y1);
     const uint64_t xinv = gl::mul(a.gen_inv, tw2(a.twi_lo, a.twi_hi, (uint32_t)i, a.tw_h));
-    const T r = F::mulb(a.alpha, xinv);
+    const T r = F::mulb(a.alpha_dev ? *a.alpha_dev : a.alpha, xinv);
     T acc = F::zero();
 #pragma unroll
     for (int k = FD - 1; k >= 0; k--) {
@@ -374,6 +374,23 @@ template <class F> void launch_fri_fold(Context* ctx, const FoldArgs<F>& a) {
     else AERO_LAUNCH(ctx, "fri_fold_kernel", bytes, (fri_fold_kernel<F>), grid, block, 0, a);
     ctx->check_launch("fri_fold");
 }
+template <class F> __global__ void fri_coin_step_kernel(Digest* seed_io, const Digest* root, typename F::T* alpha_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    const Digest seed = b2s::merge(*seed_io, *root);
+    *seed_io = seed;
+    for (uint64_t ctr = 1; ctr < 1000; ctr++) {
+        const Digest d = b2s::merge_with_int(seed, ctr);
+        const uint64_t v0 = (uint64_t)d.w[0] | ((uint64_t)d.w[1] << 32), v1 = (uint64_t)d.w[2] | ((uint64_t)d.w[3] << 32);
+        if (v0 < gl::P && (F::DEG == 1 || v1 < gl::P)) { *alpha_out = F::make(v0, v1); return; }
+    }
+    *alpha_out = F::zero();   // unreachable in practice (the host replay of the transcript would fail the same way)
+}
+template <class F> void launch_fri_coin_step(Context* ctx, Digest* seed_io, const Digest* root, typename F::T* alpha_out) {
+    AERO_LAUNCH(ctx, "fri_coin_step_kernel", 0, (fri_coin_step_kernel<F>), dim3(1), dim3(64), 0, seed_io, root, alpha_out);
+    ctx->check_launch("fri_coin_step");
+}
+template void launch_fri_coin_step<FB>(Context*, Digest*, const Digest*, uint64_t*);
+template void launch_fri_coin_step<FQ>(Context*, Digest*, const Digest*, gl::E2*);
 template void launch_fri_fold<FB>(Context*, const FoldArgs<FB>&);
 template void launch_fri_fold<FQ>(Context*, const FoldArgs<FQ>&);
 

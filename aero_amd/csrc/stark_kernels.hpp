@@ -84,6 +84,7 @@ template <class F> struct FoldArgs {
     size_t rows;
     int fold;
     T alpha;
+    const T* alpha_dev;                // non-null: the folding challenge is read from device memory (drawn by fri_coin_step)
     const uint64_t *twi_lo, *twi_hi;   // two-level table of w_dom^-1
     int tw_h;
     uint64_t gen_inv, fold_inv;        // inverse of the domain offset (7, or 7 w_dom^rank for a coset shard), 1/fold
@@ -99,6 +100,11 @@ template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, 
 
 // true iff every one of the `count` device values is a canonical field element (< p); synchronises the stream
 bool all_canonical(Context* ctx, const uint64_t* vals, size_t count);
+
+// One transcript step of the FRI commit phase on the device (random.cairo:108-166 mirror): seed <- BLAKE2s(seed || root),
+// then alpha = the first draw (counter 1, 2, ... until the 8-byte words are canonical). Lets the host enqueue every layer of
+// the commit phase without waiting for a root.
+template <class F> void launch_fri_coin_step(Context* ctx, Digest* seed_io, const Digest* root, typename F::T* alpha_out);
 
 uint64_t run_grind(Context* ctx, const Digest& seed, uint32_t bits);
 void launch_gather_rows(Context* ctx, const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out);
