@@ -474,5 +474,18 @@ class Pool:
                 c.h = None
 
 
+def verify_fib(proof: bytes, pub_elements, air=None):
+    """aero_verify_fib (host only, no GPU): raises AeroError(-7, reason) when the proof is rejected. air = None (unknown AIR:
+    everything except the OOD constraint check) or (aux_width, aux_rands, aux_degree) for the built-in FibAir."""
+    buf = np.frombuffer(proof, np.uint8)
+    pub = np.array(pub_elements, dtype=np.uint64, ndmin=1)
+    err = C.create_string_buffer(512)
+    desc = FibAirDesc(*air) if air is not None else None
+    rc = lib().aero_verify_fib(_p8(buf), C.c_size_t(len(proof)), _p64(pub) if pub.size else None, C.c_uint32(pub.size),
+                               C.byref(desc) if desc is not None else None, err, C.c_size_t(512))
+    if rc != 0:
+        raise AeroError(rc, err.value.decode(errors="replace"))
+
+
 def device_count():
     return lib().aero_device_count()

@@ -30,6 +30,7 @@ extern "C" {
 #define AERO_E_COMM (-4)
 #define AERO_E_UNSUPPORTED (-5)
 #define AERO_E_INTERNAL (-6)
+#define AERO_E_VERIFY (-7) /* aero_verify_fib: the proof was parsed and rejected */
 
 typedef struct aero_ctx aero_ctx;
 typedef struct aero_matrix aero_matrix; /* device, column-major u64 matrix */
@@ -240,6 +241,19 @@ uint32_t aero_pool_slots(const aero_pool* pool);
 aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot);
 int32_t aero_pool_prove_fib(aero_pool* pool, const aero_matrix* const* traces, uint32_t count, const aero_fib_air* air,
                             const aero_proof_options* options, uint32_t rounds, uint8_t** proofs, size_t* proof_lens, uint64_t* pubs);
+
+/* ---- verification (host only, no GPU) ------------------------------------------------------------------------------------------ */
+/* The counterpart of `winter_verifier::verify` for this backend's proofs, written against the reference's in-tree verifier
+ * (src/stark_verifier/stark_verifier.cairo:105-304 and the files it calls): transcript, proof of work, every Merkle opening, DEEP
+ * composition at every query, FRI layer consistency, remainder commitment and degree.
+ *   air != NULL: the built-in FibAir (pub_elements = the width/2 results; aux fields must match the proof): the out-of-domain
+ *                constraint consistency check is performed too (the Cairo code leaves it commented out: :151-159,183-187);
+ *   air == NULL: unknown AIR (e.g. the golden Miden proof proofs/fib.bin; pub_elements = the coin-seed elements, for Miden proofs
+ *                program hash || stack inputs || outputs, src/stark_verifier/crypto/random.cairo:254-280): everything except
+ *                that check, which is exactly what the Cairo verifier does.
+ * Returns AERO_OK, AERO_E_VERIFY (rejected; reason in err) or AERO_E_BAD_ARG. err may be NULL. Needs no context and no GPU. */
+int32_t aero_verify_fib(const uint8_t* proof, size_t proof_len, const uint64_t* pub_elements, uint32_t n_pub, const aero_fib_air* air,
+                        char* err, size_t err_cap);
 
 /* bincode ProofData{input_bytes, proof_bytes} = u64 len || inputs || u64 len || proof
  * (miden-proof-generator/src/lib.rs:1-6, main.rs:49-51). */

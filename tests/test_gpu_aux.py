@@ -72,6 +72,7 @@ def test_aux_degree_proof_bytes_identical_to_oracle(ctx, oracle, log_n, width, A
     assert pub == want_pub
     assert got == want, "proof bytes differ"
     oracle.verify_fib_aux(got, pub, width, log_n, A, R, D=D)
+    aero_amd.verify_fib(got, pub, (A, R, D))
     dev.free()
 
 

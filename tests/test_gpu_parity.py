@@ -221,6 +221,7 @@ def test_proof_bytes_identical_to_oracle(ctx, oracle, log_n, width, kw):
     assert pub == want_pub
     assert got == want, "proof bytes differ"
     oracle.verify(got, pub, air_kind=1, W=width, log_n=log_n)
+    aero_amd.verify_fib(got, pub, (0, 0, 2))               # the library's own host-side verifier
     # determinism + host-trace entry point
     again, _ = ctx.prove_fib(trace, o)
     assert again == got
