@@ -339,3 +339,18 @@ def test_pool_proves_batches_identically(oracle):
     for d in devs:
         d.free()
     pool.close()
+
+
+def test_command_line_prove_then_verify(tmp_path):
+    """python -m aero_amd prove ... / verify ... (the miden-proof-generator counterpart): container on disk, accepted."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "p.bin"
+    r = subprocess.run([sys.executable, "-m", "aero_amd", "prove", "--width", "4", "--log-n", "9", "--aux", "2,3,5", "--out", str(out)],
+                       capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([sys.executable, "-m", "aero_amd", "verify", str(out), "--aux", "2,3,5"], capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0 and "accepted" in r.stdout, r.stderr
+    r = subprocess.run([sys.executable, "-m", "aero_amd", "verify", str(out)], capture_output=True, text=True, cwd=root)
+    assert r.returncode != 0                     # wrong AIR parameters

@@ -79,3 +79,14 @@ def test_truncated_and_extended_proofs_are_rejected(oracle):
             aero_amd.verify_fib(proof[:cut] if cut else b"\x00", pub, (0, 0, 2))
     with pytest.raises(aero_amd.AeroError):
         aero_amd.verify_fib(proof + b"\x00", pub, (0, 0, 2))
+
+
+def test_command_line_verifies_the_golden_container(golden_dir):
+    import subprocess
+    import sys
+    root = os.path.dirname(golden_dir.rstrip("/").rsplit("/tests", 1)[0] + "/x")
+    r = subprocess.run([sys.executable, "-m", "aero_amd", "verify", os.path.join(golden_dir, "fib.bin"), "--miden"], capture_output=True,
+                       text=True, cwd=root)
+    assert r.returncode == 0 and "accepted" in r.stdout, r.stderr
+    r = subprocess.run([sys.executable, "-m", "aero_amd", "verify", os.path.join(golden_dir, "fib.bin")], capture_output=True, text=True, cwd=root)
+    assert r.returncode != 0                     # as a FibAir proof it must be rejected
