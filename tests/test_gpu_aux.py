@@ -111,3 +111,24 @@ def test_full_size_aux_verifies(ctx, oracle):
     want, _, _ = oracle.prove_fib_aux(W, log_n, A, R, opts().to_list())
     assert got == want
     dev.free()
+
+
+EXTREMES = [
+    # log_n, width, A, R, D, options
+    (5, 254, 1, 1, 2, [16, 8, 4, 4, 1, 8, 5]),            # widest trace the one-byte width fields allow (254 + 1 columns)
+    (10, 2, 0, 0, 2, [255, 8, 8, 4, 1, 8, 6]),            # most queries the one-byte count allows
+    (9, 2, 1, 255, 3, [8, 8, 20, 4, 2, 4, 5]),            # 255 aux random elements, grinding 20, F_p^2
+    (8, 4, 251, 7, 2, [8, 2, 0, 4, 1, 2, 4]),             # 251 aux columns, blowup 2 (= the number of composition columns)
+    (3, 2, 1, 1, 8, [4, 8, 0, 4, 2, 2, 3]),               # 8-row trace with 8 composition columns over F_p^2
+]
+
+
+@pytest.mark.parametrize("log_n,width,A,R,D,o", EXTREMES)
+def test_extreme_shapes(ctx, oracle, log_n, width, A, R, D, o):
+    dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
+    got, pub = ctx.prove_fib_aux(dev, A, R, aero_amd.ProofOptions(*o), aux_degree=D)
+    want, want_pub, _ = oracle.prove_fib_aux(width, log_n, A, R, o, D=D)
+    assert pub == want_pub and got == want
+    oracle.verify_fib_aux(got, pub, width, log_n, A, R, D=D)
+    aero_amd.verify_fib(got, pub, (A, R, D))
+    dev.free()
