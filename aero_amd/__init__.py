@@ -473,6 +473,12 @@ class Pool:
             for c in self.ctxs:
                 c.h = None
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def verify_fib(proof: bytes, pub_elements, air=None):
     """aero_verify_fib (host only, no GPU): raises AeroError(-7, reason) when the proof is rejected. air = None (unknown AIR:
