@@ -24,23 +24,36 @@ def _free_port():
     return p
 
 
-def run_world(world, cases, tmp_path, timeout=600):
+def _spawn_world(world, cases, tmp_path, timeout):
+    """One attempt: returns (ok, per-rank output). Worker output goes to files (a pipe can be kept open by helper processes)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world))
-    procs = []
-    for r in range(world):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), str(tmp_path), json.dumps(cases)],
-                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = []
+    logs = [open(tmp_path / f"rank{r}.log", "wb") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), str(tmp_path), json.dumps(cases)],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=logs[r], stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL)
+             for r in range(world)]
+    import time
+    t_end = time.time() + timeout
     try:
         for p in procs:
-            outs.append(p.communicate(timeout=timeout)[0].decode(errors="replace"))
+            p.wait(timeout=max(1.0, t_end - time.time()))
+    except subprocess.TimeoutExpired:
+        pass
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+                p.wait()
+        for f in logs:
+            f.close()
+    outs = [open(tmp_path / f"rank{r}.log", "rb").read().decode(errors="replace") for r in range(world)]
+    return all(p.returncode == 0 for p in procs), outs
+
+
+def run_world(world, cases, tmp_path, timeout=900):
+    ok, outs = _spawn_world(world, cases, tmp_path, timeout)
+    if not ok and any(k in o for o in outs for k in ("address already in use", "EADDRINUSE", "Connection refused", "connect() timed out")):
+        ok, outs = _spawn_world(world, cases, tmp_path, timeout)     # the rendezvous port was taken between probing and binding
+    assert ok, "sharded workers failed:\n" + "\n----\n".join(o[-2500:] for o in outs)
     res = []
     for i in range(len(cases)):
         single = open(tmp_path / f"case{i}.single.bin", "rb").read()
