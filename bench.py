@@ -250,7 +250,7 @@ def spawn_sharded_check(world, workloads, steps, warmup, timeout_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="fib_2^20x2_blowup8_blake2s_base", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
