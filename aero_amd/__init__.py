@@ -95,6 +95,31 @@ def fib_trace(width, log_n):
     return out
 
 
+class PinnedTrace:
+    """A host trace whose memory is pinned for asynchronous DMA (aero_host_register); `.array` is the (width, n) uint64 matrix.
+    The reference's traces live in host memory when `Prover::prove` is called (proving_worker.rs:140,465-467)."""
+
+    def __init__(self, trace: np.ndarray):
+        self.array = np.ascontiguousarray(trace, np.uint64)
+        self.width, n = self.array.shape
+        self.log_n = int(n).bit_length() - 1
+        rc = lib().aero_host_register(self.array.ctypes.data_as(C.c_void_p), C.c_size_t(self.array.nbytes))
+        if rc != 0:
+            raise AeroError(rc, lib().aero_last_error(None).decode())
+        self._registered = True
+
+    def release(self):
+        if getattr(self, "_registered", False):
+            lib().aero_host_unregister(self.array.ctypes.data_as(C.c_void_p))
+            self._registered = False
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 def proof_container(inputs: bytes, proof: bytes) -> bytes:
     """bincode ProofData{input_bytes, proof_bytes} (miden-proof-generator/src/lib.rs:1-6)."""
     out = u8p()
@@ -221,6 +246,9 @@ class Context:
             lib().aero_ctx_destroy(self.h)
             self.h = None
 
+    def synchronize(self):
+        self._ck(lib().aero_ctx_synchronize(self.h))
+
     # ---- matrices / stage 1
     def trace_upload(self, trace: np.ndarray) -> Matrix:
         t = np.ascontiguousarray(trace, np.uint64)
@@ -341,7 +369,7 @@ class Context:
             pub = np.zeros(w // 2, np.uint64)
             rc = lib().aero_prove_fib(self.h, trace.h, C.byref(options), C.byref(proof), C.byref(plen), _p64(pub))
         else:
-            t = np.ascontiguousarray(trace, np.uint64)
+            t = trace.array if isinstance(trace, PinnedTrace) else np.ascontiguousarray(trace, np.uint64)
             w, n = t.shape
             pub = np.zeros(w // 2, np.uint64)
             rc = lib().aero_prove_fib_host(self.h, _p64(t), C.c_uint32(w), C.c_uint32(int(n).bit_length() - 1), C.byref(options),
@@ -372,9 +400,20 @@ class Context:
         Returns (proof_bytes, public_inputs)."""
         proof = u8p()
         plen = C.c_size_t(0)
+        air = FibAirDesc(aux_width, aux_rands, aux_degree)
+        if isinstance(trace, (PinnedTrace, np.ndarray)):      # trace in host memory: the copy is part of the call
+            assert comm is None, "sharded proofs take a device-resident trace"
+            t = trace.array if isinstance(trace, PinnedTrace) else np.ascontiguousarray(trace, np.uint64)
+            w, n = t.shape
+            pub = np.zeros(w // 2, np.uint64)
+            rc = lib().aero_prove_fib_air_host(self.h, _p64(t), C.c_uint32(w), C.c_uint32(int(n).bit_length() - 1), C.byref(air), C.byref(options),
+                                               C.byref(proof), C.byref(plen), _p64(pub))
+            self._ck(rc)
+            data = C.string_at(proof, plen.value)
+            lib().aero_free(proof)
+            return data, pub.tolist()
         w, _ = trace.shape
         pub = np.zeros(w // 2, np.uint64)
-        air = FibAirDesc(aux_width, aux_rands, aux_degree)
         rc = lib().aero_prove_fib_air(self.h, C.byref(comm.struct) if comm is not None else None, trace.h, C.byref(air),
                                       C.byref(options), C.byref(proof), C.byref(plen), _p64(pub))
         if rc != 0 and getattr(comm, "last_error", None) is not None:
@@ -464,6 +503,34 @@ class Pool:
             lib().aero_free(proofs[i])
             out.append((data, pubs[off:off + widths[i] // 2].tolist()))
             off += widths[i] // 2
+        return out
+
+    def prove_fib_host(self, host_traces, options: ProofOptions, aux=(0, 0, 2), rounds=1):
+        """host_traces[i] = PinnedTrace (or a C-contiguous (width, n) uint64 ndarray) in HOST memory, all of one shape. Every slot
+        copies its trace to the device and proves it, `rounds` times back to back (aero_pool_prove_fib_host); returns
+        [(proof_bytes, public_inputs)] of the last round."""
+        arrs = [t.array if isinstance(t, PinnedTrace) else np.ascontiguousarray(t, np.uint64) for t in host_traces]
+        n = len(arrs)
+        w, rows = arrs[0].shape
+        assert all(a.shape == (w, rows) for a in arrs), "host traces of one batch must have one shape"
+        ptrs = (u64p * n)(*[_p64(a) for a in arrs])
+        proofs = (u8p * n)()
+        lens = (C.c_size_t * n)()
+        pubs = np.zeros(n * (w // 2), np.uint64)
+        air = FibAirDesc(aux[0], aux[1], aux[2])
+        rc = lib().aero_pool_prove_fib_host(self.h, ptrs, C.c_uint32(w), C.c_uint32(int(rows).bit_length() - 1), C.c_uint32(n), C.byref(air),
+                                            C.byref(options), C.c_uint32(rounds), proofs, lens, _p64(pubs))
+        if rc != 0:
+            msgs = [lib().aero_last_error(c.h).decode() for c in self.ctxs[:n]]
+            for i in range(n):
+                if proofs[i]:
+                    lib().aero_free(proofs[i])
+            raise AeroError(rc, "; ".join(m for m in msgs if m))
+        out = []
+        for i in range(n):
+            data = C.string_at(proofs[i], lens[i])
+            lib().aero_free(proofs[i])
+            out.append((data, pubs[i * (w // 2):(i + 1) * (w // 2)].tolist()))
         return out
 
     def close(self):

@@ -87,6 +87,7 @@ public:
     // until stage_reset(), which callers issue only after a stream synchronisation
     void* stage_alloc(size_t bytes);
     void stage_reset() { stage_off = 0; }
+    unsigned int* pinned_word();         // one pinned 32-bit word that outlives stage_reset() (deferred input-check verdict)
     size_t bytes_in_use = 0, bytes_peak = 0;
 
     void check_launch(const char* what);
@@ -142,6 +143,7 @@ private:
     std::map<void*, size_t> live_blocks;
     std::vector<void*> persistent, scratch;
     uint8_t* stage_base = nullptr;
+    unsigned int* pinned_flag = nullptr;
     size_t stage_cap = 0, stage_off = 0;
 };
 

@@ -38,6 +38,8 @@ struct aero_fri {
 
 static thread_local std::string g_create_err;
 
+namespace aero { Context* ctx_of(aero_ctx* c) { return c ? c->c : nullptr; } }   // for comm_rccl.hip
+
 template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
     try {
         if (!ctx || !ctx->c) { g_create_err = "null context"; return AERO_E_BAD_ARG; }
@@ -81,6 +83,9 @@ int32_t aero_ctx_create(int32_t device_id, aero_ctx** out) {
 void aero_ctx_destroy(aero_ctx* ctx) {
     if (!ctx) return;
     delete ctx;   // the Context itself dies with the last matrix / tree that still references it
+}
+int32_t aero_ctx_synchronize(aero_ctx* ctx) {
+    return guard(ctx, [&] { ctx->c->sync(); });
 }
 const char* aero_last_error(const aero_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 void aero_free(void* p) { free(p); }
@@ -495,6 +500,7 @@ static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, i
         sc.rank = comm->rank; sc.world = comm->world; sc.user = comm->user;
         sc.all_to_all = comm->all_to_all; sc.all_gather = comm->all_gather; sc.all_reduce_sum_u64 = comm->all_reduce_sum_u64;
         sc.min_peer_digests = comm->min_peer_digests ? comm->min_peer_digests : 2048;
+        sc.stream_ordered = (comm->flags & AERO_COMM_STREAM_ORDERED) != 0;
         p.set_comm(sc);
     }
     p.collect_stage_times = ctx->stage_timing;
@@ -543,17 +549,49 @@ int32_t aero_prove_fib_air(aero_ctx* ctx, const aero_comm* comm, const aero_matr
                  air->aux_rands, air->aux_width ? air->aux_degree : 2);
     });
 }
+}  // extern "C"
+// Trace in host memory -> proof: the host-to-device copy is enqueued on the context's stream, the canonical-form check runs
+// behind it WITHOUT a stream synchronisation of its own (its verdict is read after the proof, which is discarded when the
+// trace held an element >= p), then the proof. Pinned host memory (aero_host_register) makes the copy a true async DMA.
+static void prove_from_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n, const aero_fib_air* air,
+                            const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out) {
+    REQUIRE(trace_col_major, "prove_fib_host: null trace");
+    REQUIRE(width >= 2 && width <= 254 && log_n >= 3 && log_n <= 29, "prove_fib_host: bad shape");
+    Context* c = ctx->c;
+    const size_t n = (size_t)1 << log_n;
+    DevBuf<uint64_t> d(c, (size_t)width * n);
+    AERO_HIP(hipMemcpyAsync(d.get(), trace_col_major, (size_t)width * n * 8, hipMemcpyHostToDevice, c->stream));
+    unsigned int* verdict = c->pinned_word();
+    *verdict = 0;
+    canonical_check_enqueue(c, d.get(), (size_t)width * n, verdict);
+    const uint32_t A = air ? air->aux_width : 0;
+    do_prove(ctx, d.get(), width, (int)log_n, options, proof, proof_len, pub_out, nullptr, A, air ? air->aux_rands : 0, A ? air->aux_degree : 2);
+    if (*verdict != 0) {   // the proof's own synchronisations have long passed the check
+        free(*proof);
+        *proof = nullptr; *proof_len = 0;
+        fail("prove_fib_host: trace holds a non-canonical field element (>= p)");
+    }
+}
+extern "C" {
 int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n, const aero_proof_options* options,
                             uint8_t** proof, size_t* proof_len, uint64_t* pub_out) {
-    return guard(ctx, [&] {
-        REQUIRE(trace_col_major, "prove_fib_host: null trace");
-        REQUIRE(width >= 2 && width <= 254 && log_n >= 3 && log_n <= 29, "prove_fib_host: bad shape");
-        size_t n = (size_t)1 << log_n;
-        DevBuf<uint64_t> d(ctx->c, (size_t)width * n);
-        AERO_HIP(hipMemcpyAsync(d.get(), trace_col_major, (size_t)width * n * 8, hipMemcpyHostToDevice, ctx->c->stream));
-        if (!all_canonical(ctx->c, d.get(), (size_t)width * n)) fail("prove_fib_host: trace holds a non-canonical field element (>= p)");
-        do_prove(ctx, d.get(), width, (int)log_n, options, proof, proof_len, pub_out);
-    });
+    return guard(ctx, [&] { prove_from_host(ctx, trace_col_major, width, log_n, nullptr, options, proof, proof_len, pub_out); });
+}
+int32_t aero_prove_fib_air_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n, const aero_fib_air* air,
+                                const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out) {
+    return guard(ctx, [&] { prove_from_host(ctx, trace_col_major, width, log_n, air, options, proof, proof_len, pub_out); });
+}
+int32_t aero_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return AERO_E_BAD_ARG;
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); g_create_err = std::string("hipHostRegister: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? AERO_E_OOM : AERO_E_HIP; }
+    return AERO_OK;
+}
+int32_t aero_host_unregister(void* p) {
+    if (!p) return AERO_E_BAD_ARG;
+    hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); g_create_err = std::string("hipHostUnregister: ") + hipGetErrorString(e); return AERO_E_HIP; }
+    return AERO_OK;
 }
 int32_t aero_proof_container(const uint8_t* inputs, size_t inputs_len, const uint8_t* proof, size_t proof_len, uint8_t** out, size_t* out_len) {
     if (!out || !out_len || (!inputs && inputs_len) || (!proof && proof_len)) return AERO_E_BAD_ARG;
@@ -614,6 +652,7 @@ struct aero_pool {
         std::thread th;
         // job (written by the caller under `mu`, read by the worker)
         const aero_matrix* trace = nullptr;
+        const uint64_t* host_trace = nullptr;   // host-trace batch (aero_pool_prove_fib_host): copied in before every proof
         uint8_t* proof = nullptr;
         size_t proof_len = 0;
         std::vector<uint64_t> pub;
@@ -630,6 +669,7 @@ struct aero_pool {
     aero_fib_air air{0, 0, 2};
     aero_proof_options opt{};
     uint32_t rounds = 1;
+    uint32_t host_width = 0, host_log_n = 0;
 
     void worker(Slot* s) {
         uint64_t seen = 0;
@@ -643,10 +683,11 @@ struct aero_pool {
             int32_t rc = AERO_OK;
             uint8_t* out = nullptr;
             size_t len = 0;
-            std::vector<uint64_t> pub((size_t)s->trace->m.cols / 2);
+            std::vector<uint64_t> pub((size_t)(s->host_trace ? host_width : (uint32_t)s->trace->m.cols) / 2);
             for (uint32_t r = 0; r < rounds && rc == AERO_OK; r++) {
                 if (out) { free(out); out = nullptr; }
-                rc = aero_prove_fib_air(s->ctx, nullptr, s->trace, &air, &opt, &out, &len, pub.data());
+                if (s->host_trace) rc = aero_prove_fib_air_host(s->ctx, s->host_trace, host_width, host_log_n, &air, &opt, &out, &len, pub.data());
+                else rc = aero_prove_fib_air(s->ctx, nullptr, s->trace, &air, &opt, &out, &len, pub.data());
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -690,17 +731,20 @@ void aero_pool_destroy(aero_pool* pool) {
 }
 uint32_t aero_pool_slots(const aero_pool* pool) { return pool ? (uint32_t)pool->slots.size() : 0; }
 aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot) { return (pool && slot < pool->slots.size()) ? pool->slots[slot]->ctx : nullptr; }
-int32_t aero_pool_prove_fib(aero_pool* pool, const aero_matrix* const* traces, uint32_t count, const aero_fib_air* air,
-                            const aero_proof_options* options, uint32_t rounds, uint8_t** proofs, size_t* proof_lens, uint64_t* pubs) {
-    if (!pool || !traces || !options || !proofs || !proof_lens || count == 0 || count > pool->slots.size() || rounds == 0) return AERO_E_BAD_ARG;
-    for (uint32_t i = 0; i < count; i++)
-        if (!traces[i] || traces[i]->keep.get() != pool->slots[i]->ctx->c) return AERO_E_BAD_ARG;   // must live on slot i's context
+static int32_t pool_run(aero_pool* pool, const aero_matrix* const* traces, const uint64_t* const* host_traces, uint32_t width, uint32_t log_n,
+                        uint32_t count, const aero_fib_air* air, const aero_proof_options* options, uint32_t rounds, uint8_t** proofs,
+                        size_t* proof_lens, uint64_t* pubs) {
     {
         std::lock_guard<std::mutex> lk(pool->mu);
         pool->air = air ? *air : aero_fib_air{0, 0, 2};
         pool->opt = *options;
         pool->rounds = rounds;
-        for (uint32_t i = 0; i < count; i++) { pool->slots[i]->trace = traces[i]; pool->slots[i]->has_job = true; }
+        pool->host_width = width; pool->host_log_n = log_n;
+        for (uint32_t i = 0; i < count; i++) {
+            pool->slots[i]->trace = traces ? traces[i] : nullptr;
+            pool->slots[i]->host_trace = host_traces ? host_traces[i] : nullptr;
+            pool->slots[i]->has_job = true;
+        }
         pool->pending = (int)count;
         pool->generation++;
     }
@@ -715,10 +759,25 @@ int32_t aero_pool_prove_fib(aero_pool* pool, const aero_matrix* const* traces, u
         aero_pool::Slot& s = *pool->slots[i];
         proofs[i] = s.proof; proof_lens[i] = s.proof_len;
         if (pubs && s.status == AERO_OK) memcpy(pubs + poff, s.pub.data(), s.pub.size() * 8);
-        poff += (size_t)traces[i]->m.cols / 2;
+        poff += (size_t)(traces ? (uint32_t)traces[i]->m.cols : width) / 2;
         if (first == AERO_OK && s.status != AERO_OK) first = s.status;
         s.proof = nullptr;
     }
     return first;
+}
+int32_t aero_pool_prove_fib(aero_pool* pool, const aero_matrix* const* traces, uint32_t count, const aero_fib_air* air,
+                            const aero_proof_options* options, uint32_t rounds, uint8_t** proofs, size_t* proof_lens, uint64_t* pubs) {
+    if (!pool || !traces || !options || !proofs || !proof_lens || count == 0 || count > pool->slots.size() || rounds == 0) return AERO_E_BAD_ARG;
+    for (uint32_t i = 0; i < count; i++)
+        if (!traces[i] || traces[i]->keep.get() != pool->slots[i]->ctx->c) return AERO_E_BAD_ARG;   // must live on slot i's context
+    return pool_run(pool, traces, nullptr, 0, 0, count, air, options, rounds, proofs, proof_lens, pubs);
+}
+int32_t aero_pool_prove_fib_host(aero_pool* pool, const uint64_t* const* host_traces, uint32_t width, uint32_t log_n, uint32_t count,
+                                 const aero_fib_air* air, const aero_proof_options* options, uint32_t rounds, uint8_t** proofs,
+                                 size_t* proof_lens, uint64_t* pubs) {
+    if (!pool || !host_traces || !options || !proofs || !proof_lens || count == 0 || count > pool->slots.size() || rounds == 0) return AERO_E_BAD_ARG;
+    if (width < 2 || width > 254 || log_n < 3 || log_n > 29) return AERO_E_BAD_ARG;
+    for (uint32_t i = 0; i < count; i++) if (!host_traces[i]) return AERO_E_BAD_ARG;
+    return pool_run(pool, nullptr, host_traces, width, log_n, count, air, options, rounds, proofs, proof_lens, pubs);
 }
 }  // extern "C"

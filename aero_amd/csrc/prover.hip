@@ -33,6 +33,7 @@ Context::~Context() {
     for (auto& kv : live_blocks) (void)hipFree(kv.first);
     for (void* p : persistent) (void)hipFree(p);
     if (stage_base) (void)hipHostFree(stage_base);
+    if (pinned_flag) (void)hipHostFree(pinned_flag);
     for (auto& r : kt_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (hipEvent_t e : kt_pool) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
@@ -97,6 +98,10 @@ void* Context::stage_alloc(size_t bytes) {
     void* p = stage_base + stage_off;
     stage_off += bytes;
     return p;
+}
+unsigned int* Context::pinned_word() {
+    if (!pinned_flag) AERO_HIP(hipHostMalloc((void**)&pinned_flag, 64, hipHostMallocDefault));
+    return pinned_flag;
 }
 void Context::check_launch(const char* what) {
     hipError_t e = hipGetLastError();
@@ -445,15 +450,15 @@ struct StageClock {
 
 // ---- exchange helpers (sharded proof only) -----------------------------------------------------------
 void Prover::comm_all_to_all(const void* send, void* recv, size_t bytes) {
-    ctx_->sync();
+    if (!comm_.stream_ordered) ctx_->sync();
     if (!comm_.all_to_all || comm_.all_to_all(comm_.user, send, recv, bytes) != 0) fail("sharded prove: all_to_all exchange failed", ST_COMM);
 }
 void Prover::comm_all_gather(const void* send, void* recv, size_t bytes) {
-    ctx_->sync();
+    if (!comm_.stream_ordered) ctx_->sync();
     if (!comm_.all_gather || comm_.all_gather(comm_.user, send, recv, bytes) != 0) fail("sharded prove: all_gather exchange failed", ST_COMM);
 }
 void Prover::comm_all_reduce(uint64_t* buf, size_t count) {
-    ctx_->sync();
+    if (!comm_.stream_ordered) ctx_->sync();
     if (!comm_.all_reduce_sum_u64 || comm_.all_reduce_sum_u64(comm_.user, buf, count) != 0) fail("sharded prove: all_reduce exchange failed", ST_COMM);
 }
 // Leaf digests of this rank's coset (local leaf t = global leaf t*G + rank) -> every rank ends up with the digests of the

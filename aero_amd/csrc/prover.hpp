@@ -130,6 +130,7 @@ struct ShardComm {
     int32_t (*all_gather)(void*, const void*, void*, uint64_t) = nullptr;
     int32_t (*all_reduce_sum_u64)(void*, void*, uint64_t) = nullptr;
     uint32_t min_peer_digests = 2048;
+    bool stream_ordered = false;   // the callbacks enqueue on the context's stream (aero_comm flag AERO_COMM_STREAM_ORDERED)
 };
 // A commitment as the opening phase sees it: either a whole tree on this GPU, or this rank's contiguous subtree of
 // n_global / world leaves plus the top log2(world) levels (host copy, heap order: top[1] = root, top[world + r] = subtree r).

@@ -542,6 +542,18 @@ bool all_canonical(Context* ctx, const uint64_t* vals, size_t count) {
     return bad == 0;
 }
 
+// Same check without waiting for it: the verdict lands in *h_bad_pinned (pinned host memory, 0 = all canonical) once the stream
+// reaches this point; the caller reads it after its next stream synchronisation.
+void canonical_check_enqueue(Context* ctx, const uint64_t* vals, size_t count, unsigned int* h_bad_pinned) {
+    unsigned int* d_bad = (unsigned int*)ctx->scratch_alloc(4);
+    AERO_HIP(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (count) AERO_LAUNCH(ctx, "canonical_check_kernel", count * 8, canonical_check_kernel, dim3((unsigned)blocks), dim3(256), 0, vals, count, d_bad);
+    ctx->check_launch("canonical_check");
+    AERO_HIP(hipMemcpyAsync(h_bad_pinned, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Query gathers: rows of a column-major matrix at given positions; digests at given node indices.
 __global__ void gather_rows_kernel(const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out) {

@@ -100,6 +100,7 @@ template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, 
 
 // true iff every one of the `count` device values is a canonical field element (< p); synchronises the stream
 bool all_canonical(Context* ctx, const uint64_t* vals, size_t count);
+void canonical_check_enqueue(Context* ctx, const uint64_t* vals, size_t count, unsigned int* h_bad_pinned);
 
 // One transcript step of the FRI commit phase on the device (random.cairo:108-166 mirror): seed <- BLAKE2s(seed || root),
 // then alpha = the first draw (counter 1, 2, ... until the 8-byte words are canonical). Lets the host enqueue every layer of

@@ -14,7 +14,7 @@ _AR = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64)
 
 class CommStruct(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _A2A), ("all_gather", _AG),
-                ("all_reduce_sum_u64", _AR), ("min_peer_digests", C.c_uint32)]
+                ("all_reduce_sum_u64", _AR), ("min_peer_digests", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class _DevPtr:
@@ -35,6 +35,9 @@ class TorchComm:
         self.calls = {"all_to_all": 0, "all_gather": 0, "all_reduce": 0}
         self.bytes_sent = 0
         self.last_error = None
+        # one collective per exchange, chosen ONCE by backend (a fallback taken by one rank only would desynchronise the ranks):
+        # gloo has no all_gather_into_tensor for device tensors, nccl (= RCCL) has
+        self.gather_into_tensor = dist.get_backend(group) == "nccl"
         # keep the CFUNCTYPE objects alive for as long as the struct is in use
         self._a2a, self._ag, self._ar = _A2A(self._all_to_all), _AG(self._all_gather), _AR(self._all_reduce)
         self.struct = CommStruct(self.rank, self.world, None, self._a2a, self._ag, self._ar, min_peer_digests)
@@ -62,9 +65,9 @@ class TorchComm:
     def _all_gather(self, _user, send, recv, nbytes):
         def run():
             out, inp = self._t(recv, int(nbytes) * self.world), self._t(send, int(nbytes))
-            try:
+            if self.gather_into_tensor:
                 self.dist.all_gather_into_tensor(out, inp, group=self.group)
-            except (RuntimeError, NotImplementedError):
+            else:
                 self.dist.all_gather(list(out.chunk(self.world)), inp, group=self.group)
             self.calls["all_gather"] += 1
             self.bytes_sent += int(nbytes) * (self.world - 1)
@@ -77,6 +80,78 @@ class TorchComm:
             self.calls["all_reduce"] += 1
             self.bytes_sent += int(count) * 8
         return self._guard(run)
+
+
+class RcclComm:
+    """The library's NATIVE communicator (aero_rccl_*: RCCL over xGMI, exchanges enqueued on the context's stream). Python only
+    moves the 128-byte id from rank 0 to the other ranks - `share_id` is any callable(bytes_or_None) -> bytes that broadcasts
+    rank 0's value (default: torch.distributed.broadcast_object_list on the default group, any backend)."""
+
+    def __init__(self, ctx, rank, world, share_id=None, min_peer_digests=0):
+        import aero_amd
+        self.lib = aero_amd.lib()
+        self.lib.aero_rccl_last_error.restype = C.c_char_p
+        self.lib.aero_rccl_last_error.argtypes = [C.c_void_p]
+        self.rank, self.world = rank, world
+        self.h = None
+        uid = None
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            rc = self.lib.aero_rccl_unique_id(buf)
+            if rc != 0:
+                raise aero_amd.AeroError(rc, self.lib.aero_rccl_last_error(None).decode())
+            uid = bytes(buf)
+        if share_id is None:
+            share_id = _share_over_torch_dist if world > 1 else (lambda b: b)
+        uid = share_id(uid)
+        assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
+        self.h = C.c_void_p()
+        rc = self.lib.aero_rccl_create(ctx.h, C.c_int32(rank), C.c_int32(world), (C.c_uint8 * 128)(*uid), C.byref(self.h))
+        if rc != 0:
+            raise aero_amd.AeroError(rc, self.lib.aero_rccl_last_error(None).decode())
+        self.struct = CommStruct()
+        rc = self.lib.aero_rccl_comm(self.h, C.c_uint32(min_peer_digests), C.byref(self.struct))
+        assert rc == 0
+        self._base = self._stats()
+
+    def _stats(self):
+        out = (C.c_uint64 * 4)()
+        self.lib.aero_rccl_stats(self.h, out)
+        return list(out)
+
+    @property
+    def calls(self):
+        s = self._stats()
+        return {"all_to_all": s[0], "all_gather": s[1], "all_reduce": s[2]}
+
+    @property
+    def bytes_sent(self):
+        return self._stats()[3]
+
+    def error_text(self):
+        return self.lib.aero_rccl_last_error(self.h).decode() if self.h else ""
+
+    @property
+    def last_error(self):
+        return self.error_text() or None
+
+    def close(self):
+        if self.h:
+            self.lib.aero_rccl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _share_over_torch_dist(uid):
+    import torch.distributed as dist
+    box = [uid]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
 
 class LoopbackComm:

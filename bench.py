@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the MI355X proving hot path on BASELINE.json's headline workload.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic input: a batch of --concurrent (default 8) independent
-traces, each proven completely (one proof per trace, each on its own HIP stream so that the latency-bound tree tops
-and host round trips of one proof overlap the throughput-bound kernels of another). Every trace is the 2^20-row x
-2-column Fibonacci trace (BASELINE configs[1]: Goldilocks base field, blowup 8, blake2s, 27 queries,
-grinding 16, FRI fold 8) — interpolate, LDE, row hashing + Merkle, constraint evaluation, composition commit, OOD,
-DEEP, FRI, grinding, openings, proof bytes. The trace is resident in HBM before the timed region starts.
-metric = trace cells/sec = n * W * proofs / wall-clock (max over ranks); `single_proof_ms` is the wall-clock of ONE
-proof with nothing else in flight (the "proof-gen wall-clock" half of BASELINE's metric).
+A "step" is one pass of the hot path over one batch of synthetic input: a batch of independent traces (64 per GPU for the
+2^20 x 2 workload: `traces_per_step_per_gpu`), each proven completely, --concurrent (default 8) of them in flight at a time,
+each on its own HIP stream so that the latency-bound tree tops and host round trips of one proof overlap the throughput-bound
+kernels of another. Every trace is the 2^20-row x 2-column Fibonacci trace (BASELINE configs[1]: Goldilocks base field,
+blowup 8, blake2s, 27 queries, grinding 16, FRI fold 8) — interpolate, LDE, row hashing + Merkle, constraint evaluation,
+composition commit, OOD, DEEP, FRI, grinding, openings, proof bytes.
 
-Multi-GPU (N > 1): one process per GPU, each proving its own independent trace (the path shards by independent
+Hand-over: the trace is in (pinned) HOST memory and the proof bytes come back to host
+memory; the host-to-device copy of every trace is INSIDE the timed region (`config.h2d_included: true`), enqueued on the
+proving stream so that it overlaps the other streams' kernels. The same measurement with the traces already resident in HBM
+is reported next to it as `hbm_resident_value` (`--resident` swaps the two).
+metric = trace cells/sec = n * W * proofs / wall-clock (max over ranks); `single_proof_ms` is the wall-clock of ONE
+proof with nothing else in flight (the "proof-gen wall-clock" half of BASELINE's metric), host trace -> proof bytes.
+
+Multi-GPU (N > 1): one process per GPU, each proving its own independent traces (the path shards by independent
 proofs; no data-path collective) -> "scaling": "weak". torch.distributed (RCCL) is used only for the barriers and the
 max-over-ranks of the timing.
 
@@ -29,9 +34,9 @@ Extra objects on the JSON line:
                  launches / their summed duration, measured with HIP events on the launch stream inside the timed
                  region (only that kernel's launches are bracketed, so the timed region is perturbed by 2 event
                  records per launch of one kernel). traffic = PMC-measured HBM bytes per launch from
-                 profiles/pmc_traffic.json when present, else null.
-  cpu_baseline — the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample, rank 0,
-                 N == 1 only.
+                 profiles/pmc_traffic.json when present, else null. `limiter` names what actually bounds the kernel.
+  cpu_baseline — the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample (1 warm-up +
+                 median of 5 runs), rank 0, N == 1 only.
 """
 import argparse
 import json
@@ -119,17 +124,20 @@ def prove_call(ctx, dev, opt, over, comm=None):
     return ctx.prove_fib(dev, opt)
 
 
-def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch):
+def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch, comm_kind="auto"):
     """ONE proof of `workload` proven cooperatively by all ranks of the default process group: `warmup` untimed proofs, then
     exactly `steps` timed ones (barrier + synchronize on both sides, max over ranks). Every rank checks its proof bytes
     against the single-GPU proof it computes itself. Returns the result dict (same on every rank)."""
     import aero_amd
-    from aero_amd.shard import TorchComm
+    from aero_amd.shard import RcclComm, TorchComm
     log_n, width, over = WORKLOADS[workload]
     opt = make_options(aero_amd, over)
     ctx = aero_amd.Context(device)
     dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
-    comm = TorchComm(device=device)
+    # data plane: the library's native RCCL communicator when every rank has its own GPU; torch.distributed collectives on the
+    # device buffers (gloo) when the ranks share one GPU (RCCL refuses two ranks on one device)
+    native = comm_kind == "rccl" or (comm_kind == "auto" and torch.cuda.device_count() >= world)
+    comm = RcclComm(ctx, rank, world) if native else TorchComm(device=device)
 
     def barrier():
         dist.barrier()
@@ -142,9 +150,10 @@ def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch):
     identical = proof == single
     calls0, sent0 = dict(comm.calls), comm.bytes_sent
     dt = timed_steps(lambda: prove_call(ctx, dev, opt, over, comm), steps, barrier)
-    dt = max_over_ranks(dt, dist, torch.device("cuda", device))
+    ctl = torch.device("cuda", device) if dist.get_backend() == "nccl" else "cpu"     # control-plane tensors
+    dt = max_over_ranks(dt, dist, ctl)
     calls1, sent1 = dict(comm.calls), comm.bytes_sent
-    flag = torch.tensor([1 if identical else 0], dtype=torch.int32, device=torch.device("cuda", device))
+    flag = torch.tensor([1 if identical else 0], dtype=torch.int32, device=ctl)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     ctx.set_stage_timing(True)
     prove_call(ctx, dev, opt, over, comm)
@@ -155,7 +164,8 @@ def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch):
         prove_call(ctx, dev, opt, over)
     single_ms = (time.perf_counter() - t1) * 1e3 / 3
     res = {
-        "workload": workload, "world": world, "backend": dist.get_backend(), "gpus_visible": torch.cuda.device_count(),
+        "workload": workload, "world": world, "exchange": ("native RCCL (aero_rccl_*), stream-ordered" if native else f"torch.distributed {dist.get_backend()} on device buffers"),
+        "control_plane": dist.get_backend(), "gpus_visible": torch.cuda.device_count(),
         "steps": steps, "ms_per_proof": 1e3 * dt / steps, "value": (1 << log_n) * trace_cols(width, over) * steps / dt, "unit": "cells/s",
         "single_gpu_ms_same_process": single_ms, "speedup_vs_single_gpu": single_ms / (1e3 * dt / steps),
         "proof_identical_to_single_gpu_on_every_rank": bool(flag.item() == 1), "proof_bytes": len(proof),
@@ -164,6 +174,8 @@ def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch):
         "rank0_stage_ms": {k: round(v, 3) for k, v in stages.items()},
     }
     dev.free()
+    if native:
+        comm.close()
     ctx.close()
     return res
 
@@ -176,15 +188,12 @@ def shard_worker_main(args):
     ndev = torch.cuda.device_count()
     device = local_rank % max(ndev, 1)
     torch.cuda.set_device(device)
-    backend = "nccl" if ndev >= world else "gloo"      # several ranks on one GPU (1-GPU box): gloo, device tensors
-    if backend == "nccl":
-        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", device))
-    else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    # control plane (barriers, the max-reduce of the timing, the 128-byte RCCL id): gloo. The data plane is chosen in sharded_measure.
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     results = []
     for wl in args.sharded_workloads.split(","):
         try:
-            results.append(sharded_measure(wl, args.steps, args.warmup, rank, world, device, dist, torch))
+            results.append(sharded_measure(wl, args.steps, args.warmup, rank, world, device, dist, torch, args.shard_comm))
         except Exception as e:  # keep the other workloads; every rank fails the same way on a deterministic error
             results.append({"workload": wl, "error": f"{type(e).__name__}: {e}"[:400]})
             break
@@ -194,7 +203,7 @@ def shard_worker_main(args):
     dist.destroy_process_group()
 
 
-def spawn_sharded_check(world, workloads, steps, warmup, timeout_s):
+def spawn_sharded_check(world, workloads, steps, warmup, timeout_s, comm_kind="auto"):
     """Run the sharded-proof measurement in `world` fresh worker processes (one per GPU) under a hard timeout."""
     import socket
     import subprocess
@@ -205,7 +214,7 @@ def spawn_sharded_check(world, workloads, steps, warmup, timeout_s):
     base = {k: v for k, v in os.environ.items() if not k.startswith(("TORCHELASTIC", "GROUP_", "ROLE_", "LOCAL_WORLD", "TORCH_NCCL_ASYNC"))}
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
     cmd = [sys.executable, os.path.abspath(__file__), "--shard-worker", "--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup),
-           "--sharded-workloads", workloads]
+           "--sharded-workloads", workloads, "--shard-comm", comm_kind]
     import tempfile
     logdir = tempfile.mkdtemp(prefix="aero_shard_")
     logs = [open(os.path.join(logdir, f"rank{r}.log"), "wb") for r in range(world)]
@@ -247,19 +256,140 @@ def spawn_sharded_check(world, workloads, steps, warmup, timeout_s):
     return {"error": why, "rank0_log_tail": tail(0), "last_rank_log_tail": tail(world - 1)}
 
 
+def launch_ranks(n, argv, script=None, timeout_s=None):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no RANK in the environment): start the N rank processes here —
+    fresh children (never a re-exec: this process has not touched the GPU and does not after this point), one per GPU, with
+    the same RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* contract torch.distributed.run provides. Rank 0 inherits stdout (its
+    JSON line is the job's line), the other ranks log to files. Returns the exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    import tempfile
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    logdir = tempfile.mkdtemp(prefix="aero_bench_ranks_")
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
+    procs, logs = [], []
+    for r in range(n):
+        out = None if r == 0 else open(os.path.join(logdir, f"rank{r}.log"), "wb")
+        logs.append(out)
+        procs.append(subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=out,
+                                      stderr=None if r == 0 else subprocess.STDOUT, stdin=subprocess.DEVNULL))
+    t_end = None if timeout_s is None else time.time() + timeout_s
+    rc = 0
+    pending = list(range(n))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.remove(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    # one rank died: the others would wait for it in a collective for ever
+                    for q in pending:
+                        procs[q].terminate()
+        if pending:
+            if t_end is not None and time.time() > t_end:
+                for q in pending:
+                    procs[q].kill()
+                rc = rc or 124
+            time.sleep(0.05)
+    for f in logs:
+        if f is not None:
+            f.close()
+    if rc != 0:
+        for r in range(1, n):
+            try:
+                with open(os.path.join(logdir, f"rank{r}.log"), "rb") as f:
+                    tail = f.read()[-1500:].decode(errors="replace")
+                if tail.strip():
+                    print(f"---- rank {r} log tail ----\n{tail}", file=sys.stderr)
+            except OSError:
+                pass
+    return rc
+
+
+def median(xs):
+    xs = sorted(xs)
+    m = len(xs) // 2
+    return xs[m] if len(xs) % 2 else 0.5 * (xs[m - 1] + xs[m])
+
+
+def cpu_baseline_leg(args, log_n, width, over, opt, first_proof):
+    """The CPU oracle (oracle/, kind "port") on this box's host cores: thread count picked on a probe, then 1 warm-up + the
+    MEDIAN of 5 complete proofs of the sample (SURVEY 8d / BASELINE.md section 2)."""
+    from tests import oracle_lib
+    orc = oracle_lib.load()
+    ncpu = os.cpu_count() or 1
+    aux = over.get("aux") or (0, 0, 2)
+    cols = trace_cols(width, over)
+    probe_log = min(14 if width > 8 else 16, log_n)
+    best = None
+    for t in cpu_thread_candidates(ncpu):
+        orc.set_threads(t)
+        orc.prove_fib_aux(width, min(12, log_n), aux[0], aux[1], opt.to_list(), D=aux[2])
+        _, _, probe = orc.prove_fib_aux(width, probe_log, aux[0], aux[1], opt.to_list(), D=aux[2])
+        if best is None or probe["total"] < best[1]:
+            best = (t, probe["total"])
+    cores = best[0]
+    orc.set_threads(cores)
+    if args.cpu_sample_log_n:
+        s_log_n = min(args.cpu_sample_log_n, log_n)
+    else:
+        # 1 warm-up + 5 timed runs must stay within about half a minute of host time
+        projected = best[1] * (1 << max(log_n - probe_log, 0)) * 1.3
+        s_log_n = log_n
+        while s_log_n > probe_log and projected > 5.0:
+            s_log_n -= 1
+            projected /= 2
+    runs, walls = [], []
+    cproof = None
+    for i in range(6):                                # run 0 = warm-up
+        t1 = time.perf_counter()
+        cproof, _, ctimes = orc.prove_fib_aux(width, s_log_n, aux[0], aux[1], opt.to_list(), D=aux[2])
+        if i:
+            runs.append(ctimes["total"])
+            walls.append(time.perf_counter() - t1)
+    if s_log_n == log_n:
+        assert cproof == first_proof, "GPU and CPU proofs differ"
+    med = median(runs)
+    # the reference binary itself runs Winterfell single-threaded (SURVEY 2): one thread on a smaller sample
+    orc.set_threads(1)
+    st_log = min(log_n, 16 if width <= 8 else 13)
+    _, _, st = orc.prove_fib_aux(width, st_log, aux[0], aux[1], opt.to_list(), D=aux[2])
+    orc.set_threads(cores)
+    return {
+        "value": (1 << s_log_n) * cols / med, "unit": "cells/s", "cores": cores, "kind": "port",
+        "sample": f"complete proofs of a 2^{s_log_n} x {cols} trace of the same AIR with the same options: 1 warm-up + median of 5 runs "
+                  f"(prover time per run {', '.join(f'{r:.2f}' for r in runs)} s; median {med:.2f} s; wall incl. trace generation {median(walls):.2f} s); "
+                  f"OpenMP port, single-run thread sweep over {cpu_thread_candidates(ncpu)} on a 2^{probe_log} probe picked {cores}; "
+                  f"host has {ncpu} logical CPUs" + ("; proof bytes identical to the GPU's" if s_log_n == log_n else ""),
+        "runs_s": runs,
+        "single_thread": {"value": (1 << st_log) * cols / st["total"], "unit": "cells/s",
+                          "sample": f"one complete proof of a 2^{st_log} x {cols} trace, 1 thread (the reference binary runs Winterfell single-threaded)"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="fib_2^20x2_blowup8_blake2s_base", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=0,
-                    help="trace size of the bounded CPU-baseline sample (0 = the full workload if a 2^16 probe projects <= 40 s, else 2^18)")
+                    help="trace size of the bounded CPU-baseline sample (0 = the full workload if six runs of it project to <= 30 s, else smaller)")
     ap.add_argument("--concurrent", type=int, default=0,
-                    help="proofs in flight per GPU: a step proves a batch of this many independent traces, each on its own "
-                         "HIP stream (context) driven by its own host thread; 1 = strictly one proof at a time; 0 (default) = 8, "
-                         "fewer when 8 working sets would not fit comfortably in HBM (throughput plateaus at 8 on the 2^20 x 2 workload)")
+                    help="proofs IN FLIGHT per GPU: each on its own HIP stream (context) driven by its own host thread inside the library; "
+                         "1 = strictly one proof at a time; 0 (default) = 8, fewer when 8 working sets would not fit comfortably in HBM "
+                         "(throughput plateaus at 8 on the 2^20 x 2 workload)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="traces per step per GPU (a step = one batch of independent traces, each proven completely); 0 (default) = "
+                         "8 x the proofs in flight for the small workloads (so that 20 steps are > 2 s of GPU work), 1 x otherwise")
+    ap.add_argument("--resident", action="store_true",
+                    help="time the HBM-resident variant as `value` (traces uploaded before the clock) instead of the host-memory hand-over")
     ap.add_argument("--stages", action="store_true", help="also print per-stage ms and the per-kernel table to stderr")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
                     help="N > 1: replicas = every GPU proves its own traces (weak scaling, default); sharded = ONE proof per step "
@@ -273,16 +403,21 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing aid for a 1-GPU box: every rank uses cuda:0 and the ranks talk over gloo (exercises the whole "
                          "N > 1 control flow; the numbers then describe N processes sharing one GPU)")
+    ap.add_argument("--shard-comm", default="auto", choices=["auto", "rccl", "torch"],
+                    help="exchanges of a sharded proof: rccl = the library's native communicator (aero_rccl_*), torch = torch.distributed "
+                         "collectives on the device buffers, auto = rccl when every rank has its own GPU")
     ap.add_argument("--shard-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.shard_worker:
         return shard_worker_main(args)
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: be the launcher (nothing in this process has touched the GPU; torch is not even imported)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank, local_rank, world = rank_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world} (launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         "or run `python bench.py --gpus N` without RANK/WORLD_SIZE in the environment and it starts its own ranks)")
 
     import torch
     import aero_amd
@@ -311,8 +446,9 @@ def main():
 
     if args.mode == "sharded":
         if world < 2:
-            raise SystemExit("--mode sharded needs --gpus N with N > 1 (launched with torch.distributed.run)")
-        res = sharded_measure(args.workload, args.steps, args.warmup, rank, world, local_rank, dist, torch)
+            raise SystemExit("--mode sharded needs --gpus N with N > 1")
+        res = sharded_measure(args.workload, args.steps, args.warmup, rank, world, local_rank, dist, torch,
+                              "torch" if args.share_gpu else args.shard_comm)
         if rank == 0:
             E = 2
             bpc = 168 + 8 * E + (1259 + 176 * E) / width + ((162 + 176 * E) / width if opt.field_extension == 2 else 0)
@@ -331,52 +467,72 @@ def main():
         dist.destroy_process_group()
         return
 
+    cols = trace_cols(width, over)
     if args.concurrent > 0:
         S = args.concurrent
     else:
         # working set of one proof ~ 1.5 x the LDE matrices (trace + aux + composition + DEEP columns) over N = blowup * n rows
-        est = 1.5 * 8 * (opt.blowup_factor << log_n) * (trace_cols(width, over) + 4)
+        est = 1.5 * 8 * (opt.blowup_factor << log_n) * (cols + 4)
         S = int(max(1, min(8, (120 << 30) // est)))
-    # S contexts on this GPU, each driven by its own worker thread INSIDE the library (aero_pool_*): the whole batch is one C call
+    # traces per step: a multiple of the proofs in flight; small workloads take 8 rounds per step so that the driver's 20 steps are > 2 s
+    per_slot = (max(1, args.batch // S) if args.batch > 0 else (8 if (cols << log_n) <= (1 << 22) else 1))
+    batch = per_slot * S
+    # S contexts on this GPU, each driven by its own worker thread INSIDE the library (aero_pool_*): the whole timed region is one C call
     pool = aero_amd.Pool(local_rank, S)
     ctxs = [pool.ctx(i) for i in range(S)]
     trace = aero_amd.fib_trace(width, log_n)          # synthetic data, pure function of (width, log_n)
-    devs = [c.trace_upload(trace) for c in ctxs]      # resident in HBM before the timed region
+    # the hand-over the metric is defined on: trace in (pinned) HOST memory -> proof bytes in
+    # host memory; every proof starts with the host-to-device copy of its trace on its own stream. One pinned buffer per slot.
+    hosts = [aero_amd.PinnedTrace(trace.copy()) for _ in range(S)]
+    devs = [c.trace_upload(trace) for c in ctxs]      # HBM-resident copies for the secondary figure and the traced pass
     del trace
     ctx, dev = ctxs[0], devs[0]
     aux = over.get("aux") or (0, 0, 2)
+    h2d = not args.resident
 
-    # ---- warmup (untimed), every stream ----
+    def run_rounds(rounds, from_host):
+        if from_host:
+            return pool.prove_fib_host(hosts, opt, aux, rounds=rounds)
+        return pool.prove_fib(devs, opt, aux, rounds=rounds)
+
+    # ---- warmup (untimed): W steps of the timed path, every stream ----
     proof = None
-    for _ in range(args.warmup):
-        proof, pub = pool.prove_fib(devs, opt, aux)[0]
+    for _ in range(max(1, args.warmup)):
+        proof, pub = run_rounds(per_slot, h2d)[0]
     # one more untimed pass with every launch bracketed by HIP events: per-kernel table, picks the dominant kernel
     # (steady state: tables and code objects are already resident after the warmup)
     TRACED = 3
     prove_call(ctx, dev, opt, over)                   # settle after the all-streams warmup
     ctx.set_kernel_timing(True)
     for _ in range(TRACED):
-        proof, pub = prove_call(ctx, dev, opt, over)
+        first_proof, pub = prove_call(ctx, dev, opt, over)
     table = {k: (c / TRACED, ms / TRACED, b / TRACED) for k, (c, ms, b) in ctx.kernel_timing_report().items()}
     ctx.set_kernel_timing(False)
-    proof_len = len(proof)
+    assert proof == first_proof, "host-trace and resident-trace proofs differ"
+    proof_len = len(first_proof)
     dominant = max(table.items(), key=lambda kv: kv[1][1])[0]
-    first_proof = proof
 
-    # single-proof wall-clock (one stream, nothing else on the GPU): the "proof-gen wall-clock" half of the metric
+    # single-proof wall-clock (one stream, nothing else on the GPU): the "proof-gen wall-clock" half of the metric, trace in
+    # pinned host memory -> proof bytes (H2D included), and the same with the trace already resident
+    def one_proof_ms(src, reps=7):
+        ts = []
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            ctx.prove_fib_aux(src, aux[0], aux[1], opt, aux_degree=aux[2])
+            ts.append((time.perf_counter() - t1) * 1e3)
+        return median(ts)
+
     barrier()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        prove_call(ctx, dev, opt, over)
-    single_ms = (time.perf_counter() - t1) * 1e3 / 5
+    single_ms = one_proof_ms(hosts[0])
+    single_resident_ms = one_proof_ms(dev)
 
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides. One step = one batch of S independent
-    # traces; the S streams run their K proofs back to back inside the library (no artificial join between batches). ----
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides. One step = one batch of `batch` independent
+    # traces; the S streams run their K * batch / S proofs back to back inside the library (no artificial join between steps). ----
     ctx.set_kernel_timing(True, only_kernel=dominant)
     last = [None] * S
 
     def all_steps():
-        for i, (p, _) in enumerate(pool.prove_fib(devs, opt, aux, rounds=args.steps)):
+        for i, (p, _) in enumerate(run_rounds(args.steps * per_slot, h2d)):
             last[i] = p
 
     dt = timed_steps(all_steps, 1, barrier)
@@ -384,9 +540,14 @@ def main():
     ctx.set_kernel_timing(False)
     assert all(p == first_proof for p in last), "non-deterministic proof bytes"
     dt = max_over_ranks(dt, dist, "cpu" if args.share_gpu else "cuda")
+    # secondary figure: the other hand-over (HBM-resident when `value` includes H2D and vice versa), a quarter of the steps
+    other_steps = max(1, args.steps // 4)
+    dt_other = timed_steps(lambda: run_rounds(other_steps * per_slot, not h2d), 1, barrier)
+    dt_other = max_over_ranks(dt_other, dist, "cpu" if args.share_gpu else "cuda")
 
-    cells = (1 << log_n) * trace_cols(width, over) * S   # cells per step (batch of S traces)
+    cells = (1 << log_n) * cols * batch                # cells per step (one batch)
     value = aggregate_value(cells, args.steps, world, dt)
+    other_value = aggregate_value(cells, other_steps, world, dt_other)
     out = {
         "metric": "trace_cells_per_sec",
         "value": value,
@@ -406,11 +567,19 @@ def main():
                    "aux_segment": ({"columns": over["aux"][0], "random_elements": over["aux"][1], "constraint_degree": over["aux"][2],
                                     "composition_columns": 2 if over["aux"][2] <= 2 else (4 if over["aux"][2] <= 4 else 8), "air": "synthetic stand-in (prefix-product columns); the Miden AIR is not in the reference mount"}
                                    if over.get("aux") else None),
-                   "proofs_per_step_per_gpu": S, "proof_bytes": proof_len,
+                   "h2d_included": h2d,
+                   "hand_over": ("trace in pinned host memory -> proof bytes in host memory; the host-to-device copy of every trace is inside the timed region"
+                                 if h2d else "trace resident in HBM before the timed region"),
+                   "traces_per_step_per_gpu": batch, "proofs_in_flight_per_gpu": S, "proof_bytes": proof_len,
                    "parallelism": f"{world} GPU(s) x {S} independent proofs in flight per GPU (one HIP stream + one library worker thread each), no data-path collective"},
+        "timed_region_s": dt,
+        "ms_per_proof": 1e3 * dt / (args.steps * batch),
+        ("hbm_resident_value" if h2d else "h2d_inclusive_value"): other_value,
         "device_bytes_peak_per_proof_in_flight": ctx.memory_stats()[1],
-        "single_proof_ms": single_ms,
-        "single_proof_value": (1 << log_n) * trace_cols(width, over) / (single_ms * 1e-3),
+        "single_proof_ms": single_ms if h2d else single_resident_ms,
+        "single_proof_ms_hbm_resident": single_resident_ms,
+        "single_proof_ms_h2d_included": single_ms,
+        "single_proof_value": (1 << log_n) * cols / ((single_ms if h2d else single_resident_ms) * 1e-3),
     }
 
     if rank == 0:
@@ -429,12 +598,16 @@ def main():
         s_calls, s_ms, s_bytes = table[dominant]
         s_achieved = (s_bytes / (s_ms * 1e-3)) / 1e9 if s_ms > 0 else 0.0
         comp_per_launch = (1 << log_n) * opt.blowup_factor * ((width + 1) // 2 + 7 / 8)
+        is_hash = dominant.startswith("merkle_") or dominant.startswith("hash_")
         out["roofline"] = {
             # contract numbers: HIP events on the launch stream INSIDE the timed region (stream 0's launches of this kernel; with
             # several proofs in flight a launch shares the CUs with the other streams, so this duration is a property of the
             # mix, not of the kernel - the kernel alone is reported under "one_proof_in_flight")
             "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "limiter": ("valu: BLAKE2s is 32-bit integer issue-bound (about 1190 VALU ops per 64-byte block, 16 of which bytes come from HBM); "
+                        "the HBM fraction is priced as the contract asks but is not what limits this kernel - see valu_view") if is_hash
+                       else "valu (64-bit modular arithmetic on the 32-bit VALU) unless the achieved fraction says otherwise",
             "avg_launch_us": 1e3 * ms / max(calls, 1), "launches_timed": calls, "proofs_in_flight": S,
             "algorithmic_bytes_per_launch": s_bytes / max(s_calls, 1),
             "launches_per_proof": s_calls, "share_of_kernel_time": s_ms / total_ms if total_ms else None,
@@ -443,15 +616,13 @@ def main():
                                     "measured": "HIP events, 3 traced proofs with nothing else on the GPU (right before the timed region)"},
             "valu_view": ({"what": "BLAKE2s compressions/s of this kernel (8 leaves + 7 nodes per thread)",
                            "achieved_Gcomp_per_s": comp_per_launch / (1e-3 * s_ms / max(s_calls, 1)) / 1e9,
-                           "in_register_ceiling_Gcomp_per_s": 41.0, "ceiling_source": "tools/ubench_valu.hip on MI355X"}
+                           "in_register_ceiling_Gcomp_per_s": 41.0, "ceiling_source": "tools/ubench_valu.hip on MI355X; ISA histogram of one compression in profiles/"}
                           if dominant == "merkle_leaf8_kernel" else None),
             "next_kernels": [{"kernel": k, "share_of_kernel_time": v[1] / total_ms if total_ms else None,
                               "achieved": (v[2] / (v[1] * 1e-3)) / 1e9 if v[1] > 0 else 0.0,
                               "frac": (v[2] / (v[1] * 1e-3)) / 1e9 / HBM_PEAK_GBS if v[1] > 0 else 0.0,
                               "avg_launch_us": 1e3 * v[1] / max(v[0], 1)}
                              for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[1:4]],
-            "note": "field-arithmetic and BLAKE2s kernels on this path are integer-VALU bound (SQ counters: VALU issue ~95 % busy); "
-                    "their HBM fraction is low by construction (DESIGN.md section 3)",
         }
         # whole-proof view: SURVEY 8d algorithmic bytes per cell
         E = 2
@@ -465,58 +636,18 @@ def main():
             prove_call(ctx, dev, opt, over)
             print("stage ms:", json.dumps(ctx.last_stage_ms()), file=sys.stderr)
             ctx.set_stage_timing(False)
-            w = 1
             for name, (c, m, b) in sorted(table.items(), key=lambda kv: -kv[1][1]):
                 gbs = (b / (m * 1e-3)) / 1e9 if m > 0 else 0.0
-                print(f"  {name:28s} calls/step {c / w:7.1f}  ms/step {m / w:8.3f}  alg GB/s {gbs:8.1f}", file=sys.stderr)
+                print(f"  {name:28s} calls/proof {c:7.1f}  ms/proof {m:8.3f}  alg GB/s {gbs:8.1f}", file=sys.stderr)
 
         if world == 1 and not args.no_cpu_baseline:
             sys.stdout.flush()
-            from tests import oracle_lib
-            orc = oracle_lib.load()
-            ncpu = os.cpu_count() or 1
-            # pick the thread count on a 2^16 probe (also warms the thread pool), then time the sample with it
-            best = None
-            aux = over.get("aux") or (0, 0, 2)
-            probe_log = min(14 if width > 8 else 16, log_n)
-            for t in cpu_thread_candidates(ncpu):
-                orc.set_threads(t)
-                orc.prove_fib_aux(width, min(12, log_n), aux[0], aux[1], opt.to_list(), D=aux[2])
-                _, _, probe = orc.prove_fib_aux(width, probe_log, aux[0], aux[1], opt.to_list(), D=aux[2])
-                if best is None or probe["total"] < best[1]:
-                    best = (t, probe["total"])
-            cores = best[0]
-            orc.set_threads(cores)
-            if args.cpu_sample_log_n:
-                s_log_n = min(args.cpu_sample_log_n, log_n)
-            else:
-                projected = best[1] * (1 << max(log_n - probe_log, 0)) * 1.3
-                s_log_n = log_n
-                while s_log_n > probe_log and projected > 40.0:
-                    s_log_n -= 1
-                    projected /= 2
-            t1 = time.perf_counter()
-            cproof, cpub, ctimes = orc.prove_fib_aux(width, s_log_n, aux[0], aux[1], opt.to_list(), D=aux[2])
-            cdt = time.perf_counter() - t1
-            if s_log_n == log_n:
-                assert cproof == first_proof, "GPU and CPU proofs differ"
-            # the reference binary itself runs Winterfell single-threaded: one thread on a smaller sample
-            orc.set_threads(1)
-            st_log = min(log_n, 16 if width <= 8 else 13)
-            _, _, st = orc.prove_fib_aux(width, st_log, aux[0], aux[1], opt.to_list(), D=aux[2])
-            orc.set_threads(cores)
-            out["cpu_baseline"] = {
-                "value": (1 << s_log_n) * trace_cols(width, over) / ctimes["total"], "unit": "cells/s", "cores": cores, "kind": "port",
-                "sample": f"one complete proof of a 2^{s_log_n} x {trace_cols(width, over)} trace of the same AIR with the same options "
-                          f"(OpenMP, best of {cpu_thread_candidates(ncpu)} threads on a 2^{probe_log} probe = {cores}; host has {ncpu} logical CPUs; prover time {ctimes['total']:.2f} s, wall {cdt:.2f} s incl. trace generation)",
-                "single_thread": {"value": (1 << st_log) * trace_cols(width, over) / st["total"], "unit": "cells/s",
-                                  "sample": f"one complete proof of a 2^{st_log} x {trace_cols(width, over)} trace, 1 thread"},
-            }
+            out["cpu_baseline"] = cpu_baseline_leg(args, log_n, width, over, opt, first_proof)
         check_world = args.sharded_check_world if args.sharded_check_world >= 0 else (world if world > 1 else 0)
         if check_world > 1:
             sys.stdout.flush()
             try:
-                out["sharded_proof"] = spawn_sharded_check(check_world, args.sharded_workloads, 10, 2, args.sharded_timeout)
+                out["sharded_proof"] = spawn_sharded_check(check_world, args.sharded_workloads, 10, 2, args.sharded_timeout, args.shard_comm)
             except Exception as e:
                 out["sharded_proof"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)
@@ -532,6 +663,8 @@ def main():
 
     for d in devs:
         d.free()
+    for h in hosts:
+        h.release()
     pool.close()
     if dist is not None:
         dist.barrier()

@@ -58,6 +58,9 @@ typedef struct aero_proof_options {
 int32_t aero_device_count(void);
 int32_t aero_ctx_create(int32_t device_id, aero_ctx** out);
 void aero_ctx_destroy(aero_ctx* ctx);
+/* Wait until everything enqueued on the context's stream has completed (entry points that return host data do this
+ * themselves; needed after stream-ordered exchanges issued through an aero_comm outside a proof). */
+int32_t aero_ctx_synchronize(aero_ctx* ctx);
 /* Text of the last error on this context; ctx may be NULL for errors of aero_ctx_create itself. */
 const char* aero_last_error(const aero_ctx* ctx);
 void aero_free(void* p); /* releases buffers returned through uint8_t** out-parameters */
@@ -165,16 +168,26 @@ int32_t aero_grind(aero_ctx* ctx, const uint8_t seed[32], uint32_t bits, uint64_
  * malloc'd (aero_free). pub_out receives the width/2 public inputs (the asserted results). */
 int32_t aero_prove_fib(aero_ctx* ctx, const aero_matrix* trace, const aero_proof_options* options, uint8_t** proof,
                        size_t* proof_len, uint64_t* pub_out);
-/* Same with the trace in host memory (includes the host-to-device copy). */
+/* Same with the trace in HOST memory — the reference's actual hand-over: `Prover::prove(trace)` receives the ExecutionTrace
+ * the VM left in host memory (proving_worker.rs:140,465-467; miden-proof-generator/src/main.rs:31). The host-to-device copy is
+ * enqueued on the context's stream in front of the proof; the canonical-form check of the elements runs behind it without a
+ * stream synchronisation of its own (a trace with an element >= p yields AERO_E_BAD_ARG and no proof). With the buffer pinned
+ * (aero_host_register) the copy is an asynchronous DMA that overlaps other contexts' kernels. */
 int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n,
                             const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
+/* Pin / unpin a caller-owned host buffer (e.g. the Vec<Felt> behind winter's `Matrix<Felt>` columns, utils.rs:235-236) so that
+ * trace hand-overs from it are asynchronous DMA transfers. On failure the text is available from aero_last_error(NULL). */
+int32_t aero_host_register(void* p, size_t bytes);
+int32_t aero_host_unregister(void* p);
 /* ---- one proof sharded over the GPUs of a node ------------------------------------------------------------------------------ */
 /* The exchange steps of a sharded proof, supplied by the host (one process per GPU; torch.distributed over RCCL in this
  * repo's harness, `ncclSend/Recv`-style bindings from Rust). The reference has no multi-device prover; its parallel
  * decomposition is the worker pool of aero-sdk/miden-wasm/src/proving_worker.rs:276-321 (row-hash batches) and :374-437
  * (constraint fragments), whose gather step these callbacks replace. All buffers are DEVICE pointers on the context's GPU.
- * Each callback must return only when `recv` (or `buf`) is complete and safe to read from any stream of the device;
- * the library synchronises its own stream before calling. Return 0 on success.
+ * Default contract: each callback must return only when `recv` (or `buf`) is complete and safe to read from any stream of the
+ * device, and the library synchronises its own stream before calling. With AERO_COMM_STREAM_ORDERED in `flags` the callbacks
+ * instead ENQUEUE the exchange on the context's own stream (the native RCCL communicator below does): the library then neither
+ * synchronises before the call nor assumes completion after it - ordering is the stream's. Return 0 on success.
  *   all_to_all ........ send = world chunks of `bytes` (chunk r goes to rank r); recv = world chunks (chunk r came from rank r)
  *   all_gather ........ send = `bytes`; recv = world chunks of `bytes` in rank order
  *   all_reduce_sum_u64  in-place wrapping sum of `count` u64 over all ranks
@@ -187,7 +200,27 @@ typedef struct aero_comm {
     int32_t (*all_gather)(void* user, const void* send, void* recv, uint64_t bytes);
     int32_t (*all_reduce_sum_u64)(void* user, void* buf, uint64_t count);
     uint32_t min_peer_digests;
+    uint32_t flags;      /* 0, or AERO_COMM_STREAM_ORDERED */
 } aero_comm;
+#define AERO_COMM_STREAM_ORDERED 1u
+
+/* Native communicator: RCCL over xGMI, one process per GPU, created next to the context (SURVEY 8b asked for the communicator
+ * at context creation; with one context = one GPU = one process it is its own object so that single-GPU users never touch
+ * RCCL). Usage on every rank: rank 0 calls aero_rccl_unique_id and distributes the 128 bytes out of band (a file, a socket, the
+ * launcher's store); all ranks call aero_rccl_create (collective: `ncclCommInitRank`), then aero_rccl_comm to obtain the
+ * aero_comm to pass to aero_prove_fib_sharded / aero_prove_fib_air. The exchanges are `ncclSend`/`ncclRecv` groups (digest
+ * all-to-all), `ncclAllGather` (subtree roots) and one `ncclAllReduce` (openings), all enqueued on the context's stream.
+ * librccl is bound with dlopen at first use: AERO_E_COMM when it is not installed. The context must outlive the communicator.
+ * (The reference has no multi-device prover; its gather step is the worker-pool fan-in of proving_worker.rs:302-310,428-437.) */
+#define AERO_RCCL_ID_BYTES 128
+typedef struct aero_rccl aero_rccl;
+int32_t aero_rccl_unique_id(uint8_t id_out[AERO_RCCL_ID_BYTES]);
+int32_t aero_rccl_create(aero_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[AERO_RCCL_ID_BYTES], aero_rccl** out);
+int32_t aero_rccl_comm(aero_rccl* r, uint32_t min_peer_digests, aero_comm* out);
+/* out = {all_to_all calls, all_gather calls, all_reduce calls, bytes sent by this rank} since creation */
+int32_t aero_rccl_stats(const aero_rccl* r, uint64_t out[4]);
+const char* aero_rccl_last_error(const aero_rccl* r);   /* r may be NULL for errors of unique_id / create */
+void aero_rccl_destroy(aero_rccl* r);
 /* `Prover::prove` + `to_bytes` for ONE trace proven cooperatively by comm->world GPUs (BASELINE config 4). Rank k owns
  * the LDE rows j = k (mod world), i.e. the coset 7 w_N^k <w_(N/world)>: LDEs, row hashing, constraint evaluation, DEEP
  * and FRI folds are local; per commitment the ranks exchange leaf digests (all_to_all) so that each builds one
@@ -221,6 +254,9 @@ typedef struct aero_fib_air {
 } aero_fib_air;
 int32_t aero_prove_fib_air(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_fib_air* air,
                            const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
+/* aero_prove_fib_host with an AIR descriptor (air may be NULL = plain FibAir). */
+int32_t aero_prove_fib_air_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n, const aero_fib_air* air,
+                                const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
 
 /* ---- several proofs in flight on one GPU --------------------------------------------------------------------------------------- */
 /* A pool = `slots` contexts on one device, each driven by its own host thread inside the library. One proof alone cannot fill
@@ -241,6 +277,12 @@ uint32_t aero_pool_slots(const aero_pool* pool);
 aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot);
 int32_t aero_pool_prove_fib(aero_pool* pool, const aero_matrix* const* traces, uint32_t count, const aero_fib_air* air,
                             const aero_proof_options* options, uint32_t rounds, uint8_t** proofs, size_t* proof_lens, uint64_t* pubs);
+/* Same with the traces in HOST memory (host_traces[i] = column-major width x 2^log_n, ideally pinned): every proof of every
+ * round starts with the host-to-device copy of its trace on the slot's own stream, so one slot's transfer overlaps the other
+ * slots' kernels. This is the "trace in host memory -> proof bytes" job the reference's `prove` performs per call. */
+int32_t aero_pool_prove_fib_host(aero_pool* pool, const uint64_t* const* host_traces, uint32_t width, uint32_t log_n, uint32_t count,
+                                 const aero_fib_air* air, const aero_proof_options* options, uint32_t rounds, uint8_t** proofs,
+                                 size_t* proof_lens, uint64_t* pubs);
 
 /* ---- verification (host only, no GPU) ------------------------------------------------------------------------------------------ */
 /* The counterpart of `winter_verifier::verify` for this backend's proofs, written against the reference's in-tree verifier

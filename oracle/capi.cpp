@@ -13,7 +13,9 @@ static thread_local std::string g_err;
 static int fail(const std::exception& e) { g_err = e.what(); return -1; }
 static std::string hexd(const Digest& d) { char b[65]; for (int i = 0; i < 32; i++) sprintf(b + 2 * i, "%02x", d.b[i]); return b; }
 
-static ProverArtifacts<FB> g_art;   // intermediates of the last orc_prove_fib(..., keep_artifacts=1) (base field only)
+static ProverArtifacts<FB> g_art;   // intermediates of the last orc_prove_fib(..., keep_artifacts=1), base field
+static ProverArtifacts<FQ> g_art_q; // same for the quadratic extension (only the artifacts listed in orc_artifact)
+static bool g_art_is_q = false;
 
 extern "C" {
 
@@ -157,7 +159,8 @@ int orc_prove_fib(const uint64_t* trace, uint32_t W, int log_n, const uint8_t op
         else tr = fib_trace(W, log_n);
         Options o{opt7[0], opt7[1], opt7[2], opt7[3], opt7[4], opt7[5], opt7[6]};
         Col pub; StageTimes tm; Bytes pf;
-        if (keep_artifacts && o.field_ext == EXT_NONE) { g_art = ProverArtifacts<FB>(); pf = prove_fib<FB>(tr, log_n, o, &pub, &tm, &g_art); }
+        if (keep_artifacts && o.field_ext == EXT_NONE) { g_art = ProverArtifacts<FB>(); g_art_is_q = false; pf = prove_fib<FB>(tr, log_n, o, &pub, &tm, &g_art); }
+        else if (keep_artifacts && o.field_ext == EXT_QUADRATIC) { g_art_q = ProverArtifacts<FQ>(); g_art_is_q = true; pf = prove_fib<FQ>(tr, log_n, o, &pub, &tm, &g_art_q); }
         else pf = prove_fib_any(tr, log_n, o, &pub, &tm);
         *proof = (uint8_t*)malloc(pf.size()); memcpy(*proof, pf.data(), pf.size()); *proof_len = pf.size();
         if (pub_out) memcpy(pub_out, pub.data(), pub.size() * 8);
@@ -197,6 +200,19 @@ long orc_artifact(const char* name, uint64_t* out, size_t cap) {
     std::string s(name);
     Col flat;
     auto put_cols = [&](const std::vector<Col>& m) { for (auto& c : m) flat.insert(flat.end(), c.begin(), c.end()); };
+    if (g_art_is_q) {
+        // quadratic extension: E-valued columns come out as component columns, column c * 2 + d (the layout of the
+        // product's aero_eval_constraints_fib)
+        if (s == "ce_cols") { for (auto& col : g_art_q.ce_cols) for (int d = 0; d < 2; d++) for (auto& v : col) flat.push_back(FQ::comp(v, d)); }
+        else if (s == "cons_coeffs") flat = g_art_q.cons_coeffs;
+        else if (s == "trace_lde") put_cols(g_art_q.trace_lde);
+        else if (s == "comp_polys") put_cols(g_art_q.comp_polys);
+        else if (s == "comp_lde") put_cols(g_art_q.comp_lde);
+        else return -1;
+        if (flat.size() > cap) return -(long)flat.size() - 2;
+        memcpy(out, flat.data(), flat.size() * 8);
+        return (long)flat.size();
+    }
     if (s == "trace_polys") put_cols(g_art.trace_polys);
     else if (s == "trace_lde") put_cols(g_art.trace_lde);
     else if (s == "trace_leaves") { flat.resize(g_art.trace_leaves.size() * 4); memcpy(flat.data(), g_art.trace_leaves.data(), flat.size() * 8); }
@@ -208,6 +224,7 @@ long orc_artifact(const char* name, uint64_t* out, size_t cap) {
     else if (s == "ood_cur") flat = g_art.ood_cur;
     else if (s == "ood_next") flat = g_art.ood_next;
     else if (s == "ood_h") flat = g_art.ood_h;
+    else if (s == "cons_coeffs") flat = g_art.cons_coeffs;
     else return -1;
     if (flat.size() > cap) return -(long)flat.size() - 2;
     memcpy(out, flat.data(), flat.size() * 8);

@@ -38,6 +38,7 @@ template <class F> struct ProverArtifacts {
     std::vector<typename F::T> deep;                  // N
     std::vector<std::vector<typename F::T>> fri_layers;   // transposed evaluations per layer (incl. remainder layer)
     std::vector<typename F::T> ood_cur, ood_next, ood_h;
+    Col cons_coeffs;                                  // constraint composition coefficients in draw order, DEG u64 each
 };
 
 // hash every row of a column-major matrix: leaf_j = hash_elements(row j)   [a5]
@@ -400,6 +401,8 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
         art->comp_polys = cpolys; art->comp_lde = clde; art->deep = deep;
         for (auto& L : fl) art->fri_layers.push_back(L.rows);
         art->ood_cur = ood_cur; art->ood_next = ood_next; art->ood_h = ood_h;
+        for (size_t i = 0; i < cc.ta.size(); i++) { f_flatten<F>(&cc.ta[i], 1, art->cons_coeffs); f_flatten<F>(&cc.tb[i], 1, art->cons_coeffs); }
+        for (size_t i = 0; i < cc.ba.size(); i++) { f_flatten<F>(&cc.ba[i], 1, art->cons_coeffs); f_flatten<F>(&cc.bb[i], 1, art->cons_coeffs); }
     }
     return pr.to_bytes();
 }

@@ -15,18 +15,23 @@ def main():
     import torch
     import torch.distributed as dist
     import aero_amd
-    from aero_amd.shard import TorchComm
+    from aero_amd.shard import RcclComm, TorchComm
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     ndev = torch.cuda.device_count()
     dev = rank % ndev
     torch.cuda.set_device(dev)
-    backend = "nccl" if ndev >= world else "gloo"
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    # control plane over gloo; data plane: the native RCCL communicator when every rank has its own GPU, else (ranks sharing
+    # the test box's one GPU) torch.distributed collectives on the device buffers
+    backend = "rccl-native" if ndev >= world else "gloo"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = aero_amd.Context(dev)
     for i, case in enumerate(cases):
         opts = aero_amd.ProofOptions(*case["options"])
-        comm = TorchComm(device=dev, min_peer_digests=case.get("min_peer", 0))
+        if ndev >= world:
+            comm = RcclComm(ctx, rank, world, min_peer_digests=case.get("min_peer", 0))
+        else:
+            comm = TorchComm(device=dev, min_peer_digests=case.get("min_peer", 0))
         trace = ctx.trace_upload(aero_amd.fib_trace(case["width"], case["log_n"]))
         aux = (case.get("aux") or [0, 0]) + [2]
         proof, pub = ctx.prove_fib_aux(trace, aux[0], aux[1], opts, comm=comm, aux_degree=aux[2])
@@ -40,6 +45,8 @@ def main():
             with open(os.path.join(out_dir, f"case{i}.comm.json"), "w") as f:
                 json.dump({"calls": comm.calls, "bytes_sent": comm.bytes_sent, "backend": backend}, f)
         trace.free()
+        if ndev >= world:
+            comm.close()
         dist.barrier()
     ctx.close()
     dist.destroy_process_group()

@@ -71,6 +71,59 @@ def test_two_rank_gloo_timing_and_aggregate(tmp_path):
 
 
 def test_bench_refuses_mismatched_world():
+    """Under a launcher (RANK set) a WORLD_SIZE that disagrees with --gpus is an error, not a silent fallback."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
-                         env=dict(os.environ, WORLD_SIZE="1"), timeout=120)
+                         env=dict(os.environ, WORLD_SIZE="1", RANK="0"), timeout=120)
     assert out.returncode != 0 and "torch.distributed.run" in (out.stderr + out.stdout)
+
+
+CHILD = textwrap.dedent('''
+    import json, os, sys
+    r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+    if "--fail-rank" in sys.argv and r == int(sys.argv[sys.argv.index("--fail-rank") + 1]):
+        sys.exit(7)
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo", rank=r, world_size=w)          # the rendezvous the launcher set up works
+    got = [None] * w
+    dist.all_gather_object(got, r)
+    if r == 0:
+        print(json.dumps({"ranks": got, "argv": sys.argv[1:]}), flush=True)
+    else:
+        print("noise from rank", r)                                          # must not reach the job's stdout
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_self_launch_of_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts its own N ranks (bench.launch_ranks): fresh child processes with the
+    torch.distributed.run environment contract, rank 0's stdout is the job's stdout, a failing rank fails the job."""
+    sys.path.insert(0, ROOT)
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text(CHILD)
+    runner = tmp_path / "runner.py"
+    runner.write_text(f"import sys; sys.path.insert(0, {ROOT!r}); import bench; sys.exit(bench.launch_ranks(3, sys.argv[1:], script={str(child)!r}, timeout_s=120))")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(runner), "--gpus", "3", "--steps", "5"], capture_output=True, text=True, timeout=200, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]     # gloo logs its own line on rank 0
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["ranks"] == [0, 1, 2] and r["argv"] == ["--gpus", "3", "--steps", "5"]
+    out = subprocess.run([sys.executable, str(runner), "--fail-rank", "2"], capture_output=True, text=True, timeout=200, env=env)
+    assert out.returncode != 0
+
+
+def test_plain_multi_gpu_invocation_takes_the_launcher_path():
+    """bench.py --gpus 2 with no RANK in the environment must not exit with a usage error: it becomes the launcher. Here (no GPU)
+    the ranks then fail loudly because the HIP library finds no device - which proves they were started."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], capture_output=True,
+                         text=True, env=env, timeout=300)
+    text = out.stderr + out.stdout
+    assert "must be launched with torch.distributed.run" not in text
+    import torch
+    if not torch.cuda.is_available():
+        assert out.returncode != 0 and ("HIP" in text or "cuda" in text.lower() or "device" in text.lower())

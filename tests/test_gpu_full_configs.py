@@ -1,0 +1,82 @@
+"""BASELINE.json configs at FULL size on the GPU (the small shapes of the same configs are in test_gpu_parity.py,
+test_gpu_aux.py and test_gpu_sharded.py):
+
+  configs[3]  2^24-row Fibonacci trace — one GPU and sharded 8 ways (ranks share the test box's one GPU and exchange over
+              gloo; the exchange code path is the one a multi-GPU node runs over RCCL): proof bytes identical to the CPU
+              oracle's on every rank;
+  configs[4]  Miden's SHAPE (72 main + 9 auxiliary columns from 16 coin elements, degree-8 constraints => 8 composition
+              columns, FRI folding factor 4) at 2^22 rows on the stand-in AIR (the Miden AIR is absent from the reference
+              mount): prove -> verify with the OOD constraint check by the oracle's verifier and by the library's own; the
+              same shape at 2^18 rows is compared byte for byte with the oracle's prover.
+
+The reference's own counterpart is the prove-then-verify self check of miden-proof-generator/src/main.rs:31-47 and the
+`prove` vs `prove_sequential` A/B pair of aero-sdk/miden-wasm/src/proving_worker.rs:124-223 / :441-518.
+"""
+import pytest
+
+import aero_amd
+
+pytestmark = pytest.mark.gpu
+
+DEFAULT = [27, 8, 16, 4, 1, 8, 8]
+MIDEN_SHAPE = [27, 8, 16, 4, 1, 4, 8]        # FRI folding factor 4 (BASELINE configs[4])
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = aero_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def oracle_2p24(oracle):
+    """The oracle's proof of the 2^24 x 2 trace (about half a minute of host time), shared by the tests below."""
+    proof, pub, _ = oracle.prove_fib(2, 24, DEFAULT)
+    return proof, pub
+
+
+def test_config4_2p24_single_gpu_bytes_identical(ctx, oracle, oracle_2p24):
+    log_n, width = 24, 2
+    dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
+    got, pub = ctx.prove_fib(dev, aero_amd.ProofOptions(*DEFAULT))
+    dev.free()
+    want, want_pub = oracle_2p24
+    assert pub == want_pub
+    assert got == want, "2^24-row proof differs from the oracle's"
+    oracle.verify(got, pub, air_kind=1, W=width, log_n=log_n)
+    aero_amd.verify_fib(got, pub, (0, 0, 2))
+
+
+def test_config4_2p24_sharded_8_ways_bytes_identical(oracle, oracle_2p24, tmp_path):
+    from tests.test_gpu_sharded import run_world
+    case = {"width": 2, "log_n": 24, "options": DEFAULT}
+    (single, per_rank, comm), = run_world(8, [case], tmp_path, timeout=1500)
+    want, _ = oracle_2p24
+    assert single == want, "single-GPU 2^24 proof differs from the oracle's"
+    for r, p in enumerate(per_rank):
+        assert p == want, f"rank {r} of 8: sharded 2^24 proof differs from the oracle's"
+    assert comm["calls"]["all_reduce"] == 1 and comm["calls"]["all_to_all"] >= 2
+
+
+def test_config5_standin_2p22_verifies(ctx, oracle):
+    log_n, W, A, R, D = 22, 72, 9, 16, 8
+    dev = ctx.trace_upload(aero_amd.fib_trace(W, log_n))
+    got, pub = ctx.prove_fib_aux(dev, A, R, aero_amd.ProofOptions(*MIDEN_SHAPE), aux_degree=D)
+    again, _ = ctx.prove_fib_aux(dev, A, R, aero_amd.ProofOptions(*MIDEN_SHAPE), aux_degree=D)
+    dev.free()
+    assert again == got, "non-deterministic proof bytes"
+    # header: 72 main columns, 9 aux columns, 16 aux random elements, 2^22 rows; options incl. fold 4
+    assert got[:4] == bytes([W, A, R, log_n]) and got[15:22] == bytes(MIDEN_SHAPE)
+    oracle.verify_fib_aux(got, pub, W, log_n, A, R, D=D)      # every check of src/stark_verifier + the OOD constraint check
+    aero_amd.verify_fib(got, pub, (A, R, D))
+
+
+def test_config5_standin_2p18_bytes_identical(ctx, oracle):
+    log_n, W, A, R, D = 18, 72, 9, 16, 8
+    dev = ctx.trace_upload(aero_amd.fib_trace(W, log_n))
+    got, pub = ctx.prove_fib_aux(dev, A, R, aero_amd.ProofOptions(*MIDEN_SHAPE), aux_degree=D)
+    dev.free()
+    want, want_pub, _ = oracle.prove_fib_aux(W, log_n, A, R, MIDEN_SHAPE, D=D)
+    assert pub == want_pub
+    assert got == want, "config-5-shaped proof differs from the oracle's"

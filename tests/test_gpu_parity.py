@@ -134,22 +134,23 @@ def test_lde_large_properties(ctx, oracle, log_n):
 @pytest.mark.parametrize("log_n,width,ext", [(6, 2, 1), (8, 4, 1), (8, 2, 2), (10, 6, 2)])
 def test_constraint_fragments_match_oracle(ctx, oracle, log_n, width, ext):
     o = [27, 8, 16, 4, ext, 8, 5 if log_n < 8 else 8]
-    proof, pub, _ = oracle.prove_fib(width, log_n, o, keep_artifacts=(ext == 1))
+    proof, pub, _ = oracle.prove_fib(width, log_n, o, keep_artifacts=True)
     trace = aero_amd.fib_trace(width, log_n)
     lde = ctx.evaluate_columns_over(ctx.interpolate_columns(ctx.trace_upload(trace)), 3)
-    rng = np.random.default_rng(7)
     deg = 2 if ext == 2 else 1
     ncoef = 2 * deg * (width + width + width // 2)
+    # the very coefficients the oracle's prover drew (base field and F_p^2 alike): its artifact ...
+    coeffs = oracle.artifact("cons_coeffs", ncoef).tolist()
+    assert len(coeffs) == ncoef
     if ext == 1:
-        # replay the oracle transcript to obtain the very coefficients its prover drew
+        # ... which for the base field is also what replaying the transcript from the proof bytes gives
         seed = oracle.coin_new(pub)
         seed = oracle.coin_reseed(seed, proof[22 + 2:22 + 2 + 32])
-        ctr, coeffs = 0, []
+        ctr, replay = 0, []
         for _ in range(ncoef):
             v, ctr = oracle.coin_draw(seed, ctr)
-            coeffs.append(v)
-    else:
-        coeffs = rand_felts(rng, ncoef).tolist()
+            replay.append(v)
+        assert replay == coeffs
     ce_n = 2 << log_n
     full = None
     for nfrag in (1, 8):
@@ -161,14 +162,13 @@ def test_constraint_fragments_match_oracle(ctx, oracle, log_n, width, ext):
         if full is None:
             full = cols
         assert (cols == full).all()   # fragmentation does not change the table
-    if ext == 1:
-        want = oracle.artifact("ce_cols", 3 * ce_n).reshape(3, ce_n)
-        assert (full == want).all()
-    else:
-        # linearity in the coefficients: evaluating with 2*coeffs doubles every numerator
-        c2 = [(2 * c) % P for c in coeffs]
-        _, dbl = ctx.eval_constraints_fib(lde, 3, pub, c2, field_extension=ext)
-        assert (((2 * full.astype(object)) % P).astype(np.uint64) == dbl).all()
+    # numerator table of the oracle's own prover run (E-valued columns as component columns c * deg + d)
+    want = oracle.artifact("ce_cols", 3 * deg * ce_n).reshape(3 * deg, ce_n)
+    assert (full == want).all()
+    # linearity in the coefficients: evaluating with 2*coeffs doubles every numerator
+    c2 = [(2 * c) % P for c in coeffs]
+    _, dbl = ctx.eval_constraints_fib(lde, 3, pub, c2, field_extension=ext)
+    assert (((2 * full.astype(object)) % P).astype(np.uint64) == dbl).all()
     with pytest.raises(aero_amd.AeroError):
         ctx.eval_constraints_fib(lde, 3, pub, coeffs, field_extension=ext, fragment_offset=3, num_fragments=3)
 
@@ -251,13 +251,16 @@ def test_full_size_config2(ctx, oracle):
     assert got == want
 
 
-def test_full_size_config3_verifies(ctx, oracle):
-    """BASELINE config 3: 2^20 rows with the quadratic extension; checked by the oracle verifier (size-independent
-    property: prove -> verify), byte comparison is done at 2^17 above."""
+def test_full_size_config3(ctx, oracle):
+    """BASELINE config 3: 2^20 rows with the quadratic extension — bytes identical to the oracle, accepted by both verifiers."""
     log_n, width = 20, 2
     o = opts(field_extension=2)
     got, pub = ctx.prove_fib(ctx.trace_upload(aero_amd.fib_trace(width, log_n)), o)
     oracle.verify(got, pub, air_kind=1, W=width, log_n=log_n)
+    aero_amd.verify_fib(got, pub, (0, 0, 2))
+    want, want_pub, _ = oracle.prove_fib(width, log_n, o.to_list())
+    assert pub == want_pub
+    assert got == want, "config 3 proof bytes differ from the oracle"
 
 
 def test_bad_arguments_fail_loudly(ctx):
