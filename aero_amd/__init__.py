@@ -148,6 +148,12 @@ class Matrix:
         lib().aero_matrix_shape(self.h, C.byref(c), C.byref(r))
         return (c.value, r.value)
 
+    @property
+    def device_ptr(self):
+        p = u64p()
+        lib().aero_matrix_device_ptr(self.h, C.byref(p))
+        return C.cast(p, C.c_void_p).value
+
     def download(self):
         cols, rows = self.shape
         out = np.zeros((cols, rows), np.uint64)
@@ -259,6 +265,12 @@ class Context:
         h = C.c_void_p()
         self._ck(lib().aero_trace_upload(self.h, _p64(t), C.c_uint32(w), C.c_uint32(log_n), C.byref(h)))
         return Matrix(self, h)
+
+    def trace_file_load(self, path):
+        """Stream an AEROTRC file to the device (aero_trace_file_load). Returns (Matrix, air_id, (aux_width, aux_rands, aux_degree))."""
+        h, aid, air = C.c_void_p(), C.c_uint32(0), FibAirDesc()
+        self._ck(lib().aero_trace_file_load(self.h, os.fsencode(path), C.byref(h), C.byref(aid), C.byref(air)))
+        return Matrix(self, h), aid.value, (air.aux_width, air.aux_rands, air.aux_degree)
 
     def interpolate_columns(self, trace: Matrix) -> Matrix:
         h = C.c_void_p()
@@ -547,17 +559,104 @@ class Pool:
             pass
 
 
-def verify_fib(proof: bytes, pub_elements, air=None):
-    """aero_verify_fib (host only, no GPU): raises AeroError(-7, reason) when the proof is rejected. air = None (unknown AIR:
-    everything except the OOD constraint check) or (aux_width, aux_rands, aux_degree) for the built-in FibAir."""
+class VerifyPolicy(C.Structure):
+    """aero_verify_policy (include/aero_stark.h)."""
+    _fields_ = [("min_query_security_bits", C.c_uint32), ("expected_log_n", C.c_uint32), ("allow_unknown_air", C.c_uint32),
+                ("cairo_compat", C.c_uint32), ("require_options", C.c_uint32), ("options", ProofOptions)]
+
+
+def verify_fib(proof: bytes, pub_elements, air, min_query_security_bits=None, expected_log_n=0, allow_unknown_air=False, cairo_compat=False,
+               require_options=None):
+    """aero_verify_fib (host only, no GPU): raises AeroError(-7, reason) when the proof is rejected.
+    air = (aux_width, aux_rands, aux_degree) of the built-in FibAir - mandatory; None is accepted only together with
+    allow_unknown_air=True (everything except the OOD constraint check, what the reference's Cairo verifier does).
+    min_query_security_bits=None leaves the library default (96) in force."""
     buf = np.frombuffer(proof, np.uint8)
     pub = np.array(pub_elements, dtype=np.uint64, ndmin=1)
     err = C.create_string_buffer(512)
     desc = FibAirDesc(*air) if air is not None else None
+    pol = VerifyPolicy(96 if min_query_security_bits is None else min_query_security_bits, expected_log_n, 1 if allow_unknown_air else 0,
+                       1 if cairo_compat else 0, 1 if require_options is not None else 0,
+                       require_options if require_options is not None else ProofOptions())
     rc = lib().aero_verify_fib(_p8(buf), C.c_size_t(len(proof)), _p64(pub) if pub.size else None, C.c_uint32(pub.size),
-                               C.byref(desc) if desc is not None else None, err, C.c_size_t(512))
+                               C.byref(desc) if desc is not None else None, C.byref(pol), err, C.c_size_t(512))
     if rc != 0:
         raise AeroError(rc, err.value.decode(errors="replace"))
+
+
+def proof_security_bits(proof: bytes):
+    """(query_bits, field_bits) of a proof's self-declared parameters (aero_proof_security_bits)."""
+    buf = np.frombuffer(proof, np.uint8)
+    q, f = C.c_uint32(0), C.c_uint32(0)
+    rc = lib().aero_proof_security_bits(_p8(buf), C.c_size_t(len(proof)), C.byref(q), C.byref(f))
+    if rc != 0:
+        raise AeroError(rc, "proof_security_bits: malformed proof")
+    return q.value, f.value
+
+
+AIR_FIB, AIR_MIDEN_PROCESSOR = 0, 1
+
+
+def trace_file_write(path, trace: np.ndarray, air=(0, 0, 2), air_id=AIR_FIB):
+    """Write a trace in the AEROTRC hand-over format (include/aero_stark.h: aero_trace_file_write)."""
+    t = np.ascontiguousarray(trace, np.uint64)
+    w, n = t.shape
+    rc = lib().aero_trace_file_write(os.fsencode(path), _p64(t), C.c_uint32(w), C.c_uint32(int(n).bit_length() - 1), C.c_uint32(air_id),
+                                     C.byref(FibAirDesc(*air)))
+    if rc != 0:
+        raise AeroError(rc, lib().aero_last_error(None).decode())
+
+
+def trace_file_info(path):
+    """(width, log_n, air_id, (aux_width, aux_rands, aux_degree)) of an AEROTRC file."""
+    w, ln, aid, air = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), FibAirDesc()
+    rc = lib().aero_trace_file_info(os.fsencode(path), C.byref(w), C.byref(ln), C.byref(aid), C.byref(air))
+    if rc != 0:
+        raise AeroError(rc, lib().aero_last_error(None).decode())
+    return w.value, ln.value, aid.value, (air.aux_width, air.aux_rands, air.aux_degree)
+
+
+CAIRO_COMMANDS = {"proof": 0, "public-inputs": 1, "trace-queries": 2, "constraint-queries": 3, "fri-queries": 4}
+
+
+def cairo_memory(command: str, proof: bytes = b"", input_bytes: bytes = b"", indexes=()) -> str:
+    """The JSON array `stark_parser <file> <command>` prints (aero_cairo_memory); `indexes` = query positions for the three
+    *-queries commands."""
+    pb = np.frombuffer(proof, np.uint8) if proof else None
+    ib = np.frombuffer(input_bytes, np.uint8) if input_bytes else None
+    idx = np.array(list(indexes), dtype=np.uint64)
+    out, n = C.c_char_p(), C.c_size_t(0)
+    err = C.create_string_buffer(512)
+    rc = lib().aero_cairo_memory(C.c_uint32(CAIRO_COMMANDS[command]), _p8(pb) if pb is not None else None, C.c_size_t(len(proof)),
+                                 _p8(ib) if ib is not None else None, C.c_size_t(len(input_bytes)), _p64(idx) if idx.size else None,
+                                 C.c_uint32(idx.size), C.byref(out), C.byref(n), err, C.c_size_t(512))
+    if rc != 0:
+        raise AeroError(rc, err.value.decode(errors="replace"))
+    text = C.string_at(out, n.value).decode()
+    lib().aero_free(out)
+    return text
+
+
+def _pb_call(fn, data: bytes) -> bytes:
+    buf = np.frombuffer(data, np.uint8)
+    out, n = u8p(), C.c_size_t(0)
+    err = C.create_string_buffer(512)
+    rc = fn(_p8(buf), C.c_size_t(len(data)), C.byref(out), C.byref(n), err, C.c_size_t(512))
+    if rc != 0:
+        raise AeroError(rc, err.value.decode(errors="replace"))
+    res = C.string_at(out, n.value)
+    lib().aero_free(out)
+    return res
+
+
+def proof_to_protobuf(proof: bytes) -> bytes:
+    """sdk.StarkProof bytes (aero_proof_to_protobuf)."""
+    return _pb_call(lib().aero_proof_to_protobuf, proof)
+
+
+def miden_public_inputs_to_protobuf(input_bytes: bytes) -> bytes:
+    """sdk.MidenPublicInputs bytes (aero_miden_public_inputs_to_protobuf)."""
+    return _pb_call(lib().aero_miden_public_inputs_to_protobuf, input_bytes)
 
 
 def device_count():

@@ -2,8 +2,13 @@
 (miden-proof-generator/src/main.rs:23-51: build options, prove, `proof.to_bytes()`, bincode ProofData container on disk).
 
     python -m aero_amd prove  --width 2 --log-n 20 --out proofs/fib_gpu.bin [--aux 9,16,8] [--quadratic] [--fold 8] [--blowup 8]
+    python -m aero_amd prove  --trace dump.aerotrc --out proofs/p.bin    # a trace produced elsewhere (AEROTRC file: include/aero_stark.h)
+    python -m aero_amd trace  --width 2 --log-n 20 --out dump.aerotrc [--aux 9,16,8]   # write the synthetic trace in that format (no GPU)
+    python -m aero_amd cairo  proofs/p.bin proof | public-inputs | trace-queries '[5207,...]' | constraint-queries '[..]' | fri-queries '[..]'
+                                                                         # = bin/stark_parser <file> <command> (miden-to-cairo-parser/src/main.rs:42-113)
+    python -m aero_amd protobuf proofs/p.bin --out p.pb [--public-inputs]  # sdk.StarkProof / sdk.MidenPublicInputs bytes (aero-sdk/proto)
     python -m aero_amd verify proofs/fib_gpu.bin [--aux 9,16,8]        # host only, no GPU
-    python -m aero_amd verify /path/to/reference/proofs/fib.bin --miden  # unknown AIR: the Cairo verifier's checks
+    python -m aero_amd verify /path/to/reference/proofs/fib.bin --miden [--cairo-compat]   # unknown AIR: the Cairo verifier's checks
 
 The container is `u64 len || input_bytes || u64 len || proof_bytes` (miden-proof-generator/src/lib.rs:1-6); for the built-in
 AIR input_bytes = the public results as little-endian u64."""
@@ -49,19 +54,58 @@ def main():
     p.add_argument("--blowup", type=int, default=8)
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--out", required=True)
+    p.add_argument("--trace", default=None, help="AEROTRC file holding the trace (and its AIR parameters) instead of the synthetic one")
+    t = sub.add_parser("trace")
+    t.add_argument("--width", type=int, default=2)
+    t.add_argument("--log-n", type=int, default=10)
+    t.add_argument("--aux", default="0,0,2")
+    t.add_argument("--out", required=True)
+    c = sub.add_parser("cairo")
+    c.add_argument("file")
+    c.add_argument("command", choices=sorted(aero_amd.CAIRO_COMMANDS))
+    c.add_argument("indexes", nargs="?", default="[]", help="JSON array of query positions (the *-queries commands)")
+    b = sub.add_parser("protobuf")
+    b.add_argument("file")
+    b.add_argument("--out", required=True)
+    b.add_argument("--public-inputs", action="store_true", help="encode the container's Miden public inputs instead of the proof")
     v = sub.add_parser("verify")
     v.add_argument("file")
     v.add_argument("--aux", default="0,0,2")
-    v.add_argument("--miden", action="store_true", help="proof of an AIR this library does not know (e.g. the reference's proofs/fib.bin)")
+    v.add_argument("--miden", action="store_true", help="proof of an AIR this library does not know (e.g. the reference's proofs/fib.bin): "
+                   "everything except the out-of-domain constraint check, which is what the reference's Cairo verifier does")
+    v.add_argument("--min-security", type=int, default=96, help="reject proofs whose num_queries * log2(blowup) + grinding is below this")
+    v.add_argument("--log-n", type=int, default=0, help="trace length the statement is about (0 = accept the proof's own)")
+    v.add_argument("--cairo-compat", action="store_true", help="also require the shape the reference's Cairo verifier hard-codes")
     args = ap.parse_args()
+    if args.cmd == "cairo":
+        import json
+        inputs, proof = split_container(open(args.file, "rb").read())
+        print(aero_amd.cairo_memory(args.command, proof, inputs, json.loads(args.indexes)))
+        return
+    if args.cmd == "protobuf":
+        inputs, proof = split_container(open(args.file, "rb").read())
+        data = aero_amd.miden_public_inputs_to_protobuf(inputs) if args.public_inputs else aero_amd.proof_to_protobuf(proof)
+        with open(args.out, "wb") as f:
+            f.write(data)
+        print(f"{len(data)} protobuf bytes -> {args.out}")
+        return
     aux = tuple(int(x) for x in args.aux.split(","))
+    if args.cmd == "trace":
+        aero_amd.trace_file_write(args.out, aero_amd.fib_trace(args.width, args.log_n), aux)
+        print(f"{args.width} x 2^{args.log_n} trace -> {args.out}")
+        return
     if args.cmd == "prove":
         opt = aero_amd.ProofOptions.with_96_bit_security()
         opt.fri_folding_factor, opt.blowup_factor = args.fold, args.blowup
         if args.quadratic:
             opt.field_extension = 2
         ctx = aero_amd.Context(args.device)
-        dev = ctx.trace_upload(aero_amd.fib_trace(args.width, args.log_n))
+        if args.trace:
+            dev, _, aux = ctx.trace_file_load(args.trace)
+            args.width, rows = dev.shape
+            args.log_n = rows.bit_length() - 1
+        else:
+            dev = ctx.trace_upload(aero_amd.fib_trace(args.width, args.log_n))
         t0 = time.perf_counter()
         proof, pub = ctx.prove_fib_aux(dev, aux[0], aux[1], opt, aux_degree=aux[2])
         ms = (time.perf_counter() - t0) * 1e3
@@ -71,11 +115,13 @@ def main():
         print(f"proved {args.width} x 2^{args.log_n} in {ms:.2f} ms (first call includes table setup): {len(proof)} proof bytes -> {args.out}")
     else:
         inputs, proof = split_container(open(args.file, "rb").read())
+        pol = dict(min_query_security_bits=args.min_security, expected_log_n=args.log_n, cairo_compat=args.cairo_compat)
         if args.miden:
-            aero_amd.verify_fib(proof, miden_pub_elements(inputs))
+            aero_amd.verify_fib(proof, miden_pub_elements(inputs), None, allow_unknown_air=True, **pol)
         else:
-            aero_amd.verify_fib(proof, list(struct.unpack(f"<{len(inputs) // 8}Q", inputs)), aux)
-        print("proof accepted")
+            aero_amd.verify_fib(proof, list(struct.unpack(f"<{len(inputs) // 8}Q", inputs)), aux, **pol)
+        q, f = aero_amd.proof_security_bits(proof)
+        print(f"proof accepted (query security {q} bits, field-size term {f} bits)")
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
 // extern "C" boundary of libaero_stark.so (declarations + reference citations: include/aero_stark.h).
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -109,6 +110,11 @@ int32_t aero_matrix_shape(const aero_matrix* m, uint32_t* cols, uint64_t* rows) 
     if (!m) return AERO_E_BAD_ARG;
     if (cols) *cols = (uint32_t)m->m.cols;
     if (rows) *rows = m->m.rows;
+    return AERO_OK;
+}
+int32_t aero_matrix_device_ptr(const aero_matrix* m, uint64_t** dev_ptr_out) {
+    if (!m || !dev_ptr_out) return AERO_E_BAD_ARG;
+    *dev_ptr_out = m->m.data.get();
     return AERO_OK;
 }
 int32_t aero_matrix_download(aero_ctx* ctx, const aero_matrix* m, uint64_t* out) {
@@ -606,6 +612,90 @@ int32_t aero_proof_container(const uint8_t* inputs, size_t inputs_len, const uin
     if (proof_len) memcpy(b + 16 + inputs_len, proof, proof_len);
     *out = b; *out_len = total;
     return AERO_OK;
+}
+
+// ---- trace files ---------------------------------------------------------------------------------------------
+// "AEROTRC" + format version byte, u32 width, u32 log_n, u32 air_id, u32 aux_width, u32 aux_rands, u32 aux_degree (all
+// little-endian), then width * 2^log_n u64 little-endian in column-major order (include/aero_stark.h).
+namespace {
+const char TRACE_MAGIC[8] = {'A', 'E', 'R', 'O', 'T', 'R', 'C', 1};
+struct TraceHeader { uint32_t width, log_n, air_id, aux_width, aux_rands, aux_degree; };
+struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
+void read_header(FILE* f, const char* path, TraceHeader* h) {
+    char magic[8];
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, TRACE_MAGIC, 8) != 0) fail(std::string("trace file: ") + path + " is not an AEROTRC version-1 file");
+    uint32_t w[6];
+    if (fread(w, 4, 6, f) != 6) fail("trace file: truncated header");
+    *h = TraceHeader{w[0], w[1], w[2], w[3], w[4], w[5]};
+    if (h->width < 1 || h->width > 255 || h->log_n < 3 || h->log_n > 29) fail("trace file: width must be in [1,255] and log_n in [3,29]");
+}
+}  // namespace
+
+int32_t aero_trace_file_write(const char* path, const uint64_t* col_major, uint32_t width, uint32_t log_n, uint32_t air_id, const aero_fib_air* air) {
+    if (!path || !col_major || width < 1 || width > 255 || log_n < 3 || log_n > 29) return AERO_E_BAD_ARG;
+    FileCloser fc{fopen(path, "wb")};
+    if (!fc.f) { g_create_err = std::string("trace file: cannot create ") + path; return AERO_E_BAD_ARG; }
+    const uint32_t w[6] = {width, log_n, air_id, air ? air->aux_width : 0, air ? air->aux_rands : 0, air ? air->aux_degree : 2};
+    const size_t count = (size_t)width << log_n;
+    if (fwrite(TRACE_MAGIC, 1, 8, fc.f) != 8 || fwrite(w, 4, 6, fc.f) != 6 || fwrite(col_major, 8, count, fc.f) != count) {
+        g_create_err = std::string("trace file: short write to ") + path;
+        return AERO_E_INTERNAL;
+    }
+    return AERO_OK;
+}
+int32_t aero_trace_file_info(const char* path, uint32_t* width, uint32_t* log_n, uint32_t* air_id, aero_fib_air* air) {
+    if (!path) return AERO_E_BAD_ARG;
+    try {
+        FileCloser fc{fopen(path, "rb")};
+        if (!fc.f) fail(std::string("trace file: cannot open ") + path);
+        TraceHeader h;
+        read_header(fc.f, path, &h);
+        if (width) *width = h.width;
+        if (log_n) *log_n = h.log_n;
+        if (air_id) *air_id = h.air_id;
+        if (air) *air = aero_fib_air{h.aux_width, h.aux_rands, h.aux_degree};
+        return AERO_OK;
+    } catch (const Error& e) { g_create_err = e.what(); return e.code; }
+}
+// The file is streamed through two pinned buffers: while chunk i travels to the device, chunk i + 1 is read from disk.
+int32_t aero_trace_file_load(aero_ctx* ctx, const char* path, aero_matrix** trace_out, uint32_t* air_id, aero_fib_air* air) {
+    return guard(ctx, [&] {
+        REQUIRE(path && trace_out, "trace_file_load: null argument");
+        *trace_out = nullptr;
+        Context* c = ctx->c;
+        FileCloser fc{fopen(path, "rb")};
+        if (!fc.f) fail(std::string("trace file: cannot open ") + path);
+        TraceHeader h;
+        read_header(fc.f, path, &h);
+        if (h.air_id != AERO_AIR_FIB)
+            fail("trace file: AIR id " + std::to_string(h.air_id) + " is not built into this library (0 = FibAir; Miden's ProcessorAir, id 1, needs the "
+                 "constraint set of the miden-air crate, which the reference mount does not contain)", ST_UNSUPPORTED);
+        const size_t count = (size_t)h.width << h.log_n;
+        std::unique_ptr<aero_matrix> m(new aero_matrix(ctx));
+        m->m = Matrix(c, (int)h.width, (size_t)1 << h.log_n);
+        const size_t chunk = (size_t)4 << 20;   // elements per chunk (32 MiB)
+        uint64_t* pin[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        auto cleanup = [&] { for (int i = 0; i < 2; i++) { if (pin[i]) (void)hipHostFree(pin[i]); if (done[i]) (void)hipEventDestroy(done[i]); } };
+        try {
+            for (int i = 0; i < 2; i++) { AERO_HIP(hipHostMalloc((void**)&pin[i], std::min(chunk, count) * 8, hipHostMallocDefault)); AERO_HIP(hipEventCreate(&done[i])); }
+            size_t off = 0;
+            for (int k = 0; off < count; k ^= 1) {
+                const size_t n = std::min(chunk, count - off);
+                AERO_HIP(hipEventSynchronize(done[k]));                   // the previous copy out of this buffer has finished
+                if (fread(pin[k], 8, n, fc.f) != n) fail("trace file: fewer elements than width * 2^log_n");
+                AERO_HIP(hipMemcpyAsync(m->m.data.get() + off, pin[k], n * 8, hipMemcpyHostToDevice, c->stream));
+                AERO_HIP(hipEventRecord(done[k], c->stream));
+                off += n;
+            }
+            if (fgetc(fc.f) != EOF) fail("trace file: trailing bytes after the trace");
+            if (!all_canonical(c, m->m.data.get(), count)) fail("trace file: the trace holds a non-canonical field element (>= p)");
+        } catch (...) { (void)hipStreamSynchronize(c->stream); cleanup(); throw; }
+        cleanup();
+        if (air_id) *air_id = h.air_id;
+        if (air) *air = aero_fib_air{h.aux_width, h.aux_rands, h.aux_degree};
+        *trace_out = m.release();
+    });
 }
 
 // ---- instrumentation ------------------------------------------------------------------------------------

@@ -10,14 +10,15 @@
 // xGMI is point-to-point: the all-to-all uses all 7 links of a GPU at once, none of the exchanges is a ring all-reduce of
 // bulk data (the one all-reduce carries a few hundred KiB).
 //
-// librccl is bound at run time (dlopen), not at link time: a process that already carries an RCCL (PyTorch bundles its own
-// librccl.so with the same soname) keeps exactly one copy, and libaero_stark.so loads on a box without RCCL as long as no
-// sharded proof is requested.
+// librccl is bound at run time (dlopen), not at link time: libaero_stark.so loads on a box without RCCL as long as no sharded
+// proof is requested, and the copy that is bound is the one living next to the HIP runtime this library itself uses (see rccl_api).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <cstring>
 #include <mutex>
+#include <string>
+#include <vector>
 
 #include "../../include/aero_stark.h"
 #include "aero_internal.hpp"
@@ -55,10 +56,27 @@ RcclApi* rccl_api() {
     std::lock_guard<std::mutex> lk(g_api_mu);
     if (g_api.handle) return &g_api;
     if (!g_api.err.empty()) { g_rccl_err = g_api.err; return nullptr; }
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // The RCCL to bind is the one that runs on the HIP runtime THIS library runs on. A process can hold two runtimes (PyTorch
+    // bundles libamdhip64 + librccl in torch/lib; imported after this library it brings a second, separate runtime): binding
+    // "whatever librccl is loaded" could pick the copy of the other runtime, whose ncclCommInitRank then fails. So: look next
+    // to our own libamdhip64 first (torch/lib when torch came first and we share its runtime, /opt/rocm/lib otherwise).
+    std::vector<std::string> names;
+    {
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                names.push_back(dir + "librccl.so.1");
+                names.push_back(dir + "librccl.so");
+            }
+        }
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+    }
     void* h = nullptr;
-    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   // the copy the process already has
-    if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    for (const std::string& n : names) if ((h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
     if (!h) { g_api.err = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"); g_rccl_err = g_api.err; return nullptr; }
     RcclApi a;
     const bool ok = bind(h, "ncclGetUniqueId", a.GetUniqueId) && bind(h, "ncclCommInitRank", a.CommInitRank) && bind(h, "ncclCommDestroy", a.CommDestroy) &&

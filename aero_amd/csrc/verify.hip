@@ -13,6 +13,7 @@
 
 #include "../../include/aero_stark.h"
 #include "prover.hpp"
+#include "proof_format.hpp"
 
 namespace aero {
 namespace {
@@ -22,63 +23,11 @@ using gl::FQ;
 
 [[noreturn]] void reject(const std::string& why) { throw Error(AERO_E_VERIFY, "verify: " + why); }
 
-struct Reader {
-    const uint8_t* p;
-    size_t n, off = 0;
-    void need(size_t k) const { if (off + k > n) reject("proof is truncated"); }
-    uint8_t u8() { need(1); return p[off++]; }
-    uint64_t le(int bytes) { need(bytes); uint64_t v = 0; for (int i = 0; i < bytes; i++) v |= (uint64_t)p[off + i] << (8 * i); off += bytes; return v; }
-    Bytes bytes(size_t k) { need(k); Bytes b(p + off, p + off + k); off += k; return b; }
-};
-struct Parsed {
-    uint32_t W = 0, A = 0, R = 0;
-    int log_n = 0;
-    ProofOptions opt{};
-    Bytes commitments;
-    std::vector<QueriesBytes> trace_queries;
-    QueriesBytes constraint_queries;
-    Bytes ood_trace_states, ood_evaluations;
-    std::vector<QueriesBytes> fri_layers;
-    Bytes fri_remainder;
-    uint64_t nonce = 0;
-};
-Parsed parse(const uint8_t* data, size_t len) {
-    Reader r{data, len};
-    Parsed q;
-    q.W = r.u8(); q.A = r.u8(); q.R = r.u8(); q.log_n = r.u8();
-    r.bytes(r.le(2));                                          // trace meta
-    if (r.u8() != 8 || r.le(8) != gl::P) reject("wrong field modulus");
-    uint8_t o[7];
-    for (auto& b : o) b = r.u8();
-    q.opt = ProofOptions::from_bytes(o);
-    q.commitments = r.bytes(r.le(2));
-    for (int s = 0; s < (q.A ? 2 : 1); s++) {
-        QueriesBytes t;
-        t.values = r.bytes(r.le(4)); t.paths = r.bytes(r.le(4));
-        q.trace_queries.push_back(t);
-    }
-    q.constraint_queries.values = r.bytes(r.le(4)); q.constraint_queries.paths = r.bytes(r.le(4));
-    q.ood_trace_states = r.bytes(r.le(2));
-    q.ood_evaluations = r.bytes(r.le(2));
-    const int layers = r.u8();
-    for (int l = 0; l < layers; l++) {
-        QueriesBytes t;
-        t.values = r.bytes(r.le(4)); t.paths = r.bytes(r.le(4));
-        q.fri_layers.push_back(t);
-    }
-    q.fri_remainder = r.bytes(r.le(2));
-    if (r.u8() != 0) reject("partitioned FRI proofs are not supported");
-    q.nonce = r.le(8);
-    if (r.off != len) reject("trailing bytes after the proof");
-    return q;
-}
+using fmt::Parsed;
+using fmt::parse;
+using fmt::rd64;
+using fmt::batch_root;
 
-uint64_t rd64(const Bytes& b, size_t word) {
-    uint64_t v = 0;
-    for (int i = 0; i < 8; i++) v |= (uint64_t)b[word * 8 + i] << (8 * i);
-    if (v >= gl::P) reject("non-canonical field element");
-    return v;
-}
 template <class F> typename F::T rd_elem(const Bytes& b, size_t idx) {
     return F::make(rd64(b, idx * F::DEG), F::DEG > 1 ? rd64(b, idx * F::DEG + 1) : 0);
 }
@@ -103,49 +52,6 @@ int leading_zero_bits(const Digest& d) {      // MSB-first from digest byte 0 (r
     return z;
 }
 
-// Root implied by a BatchMerkleProof (channel.cairo:136-175; node selection: prover.hip batch_proof_indices).
-Digest batch_root(size_t n_leaves, const std::vector<uint64_t>& positions, const std::vector<Digest>& leaves, const Bytes& paths) {
-    if (n_leaves == 1) {
-        if (positions.size() != 1 || positions[0] != 0) reject("bad opening of a single-leaf tree");
-        return leaves[0];
-    }
-    const auto plan = batch_proof_indices(n_leaves, positions);
-    std::map<uint64_t, Digest> known;
-    size_t off = 0;
-    if (paths.empty() || paths[off++] != plan.size()) reject("batch proof: wrong number of paths");
-    for (auto& v : plan) {
-        if (off >= paths.size() || paths[off++] != v.size()) reject("batch proof: wrong path length");
-        for (uint64_t idx : v) {
-            if (off + 32 > paths.size()) reject("batch proof is truncated");
-            Digest d;
-            memcpy(d.w, paths.data() + off, 32);
-            off += 32;
-            known[idx] = d;
-        }
-    }
-    if (off != paths.size()) reject("batch proof: trailing bytes");
-    std::vector<uint64_t> level;
-    for (size_t i = 0; i < positions.size(); i++) { known[n_leaves + positions[i]] = leaves[i]; level.push_back(n_leaves + positions[i]); }
-    while (!level.empty() && level[0] > 1) {
-        std::sort(level.begin(), level.end());
-        level.erase(std::unique(level.begin(), level.end()), level.end());
-        std::vector<uint64_t> next;
-        for (uint64_t idx : level) {
-            const uint64_t parent = idx >> 1;
-            if (known.count(parent)) continue;
-            auto l = known.find(idx & ~1ull), r = known.find(idx | 1ull);
-            if (l == known.end() || r == known.end()) reject("batch proof: missing sibling");
-            known[parent] = b2s::merge(l->second, r->second);
-            next.push_back(parent);
-        }
-        level.swap(next);
-        if (level.empty()) break;
-    }
-    auto it = known.find(1);
-    if (it == known.end()) reject("batch proof: root not reached");
-    return it->second;
-}
-
 // in-place inverse transform over <w_n> (values in natural order -> coefficients in natural order), n <= 2^16
 void intt_host(std::vector<uint64_t>& a) {
     const size_t n = a.size();
@@ -168,12 +74,42 @@ void intt_host(std::vector<uint64_t>& a) {
     for (auto& v : a) v = gl::mul(v, ninv);
 }
 
-template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t>& pub, const aero_fib_air* air_desc) {
+template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t>& pub, const aero_fib_air* air_desc, const aero_verify_policy& policy) {
     typedef typename F::T T;
     const size_t n = (size_t)1 << pr.log_n, B = pr.opt.blowup_factor, N = n * B, Fd = pr.opt.fri_folding_factor;
     const uint32_t W = pr.W, A = pr.A, TW = W + A;
     const size_t EB = 8 * F::DEG;
     if (pr.log_n < 1 || pr.log_n > 28 || N > ((size_t)1 << gl::TWO_ADICITY)) reject("unsupported trace length");
+    // ---- acceptance policy: what the CALLER requires of the proof's self-declared parameters. Without it a forger picks
+    // num_queries = 1, grinding = 0, blowup = 2 and an arbitrary trace length, and "verification" means ~1 bit of soundness
+    // (Winterfell 0.4 had the same gap; upstream later added AcceptableOptions).
+    {
+        int log_b = 0;
+        while ((1u << log_b) < B) log_b++;
+        const uint32_t query_bits = (uint32_t)pr.opt.num_queries * (uint32_t)log_b + pr.opt.grinding_factor;
+        if (query_bits < policy.min_query_security_bits)
+            reject("proof options give " + std::to_string(query_bits) + " query-security bits (num_queries * log2(blowup) + grinding), the policy requires " +
+                   std::to_string(policy.min_query_security_bits));
+        if (policy.expected_log_n && (int)policy.expected_log_n != pr.log_n)
+            reject("trace length 2^" + std::to_string(pr.log_n) + " is not the expected 2^" + std::to_string(policy.expected_log_n));
+        if (policy.require_options) {
+            const aero_proof_options& q = policy.options;
+            const ProofOptions& o = pr.opt;
+            if (q.num_queries != o.num_queries || q.blowup_factor != o.blowup_factor || q.grinding_factor != o.grinding_factor || q.hash_fn != o.hash_fn ||
+                q.field_extension != o.field_extension || q.fri_folding_factor != o.fri_folding_factor || q.fri_log_max_remainder != o.fri_log_max_remainder)
+                reject("proof options differ from the options the policy requires");
+        }
+        if (policy.cairo_compat) {
+            // the shape src/stark_verifier hard-codes (fri_verifier.cairo:22-25, channel.cairo:28,360-370, composer.cairo:24,159-311,
+            // air_instance.cairo:96-104): only such proofs can be accepted by the reference's Cairo verifier
+            if (W != 72 || A != 9) reject("cairo-compat: the Cairo verifier hard-codes 72 main and 9 auxiliary columns");
+            if (pr.ood_evaluations.size() != 8 * 8) reject("cairo-compat: the Cairo verifier hard-codes 8 composition columns");
+            if (pr.opt.num_queries != 27) reject("cairo-compat: the Cairo verifier hard-codes 27 queries");
+            if (Fd != 8) reject("cairo-compat: the Cairo verifier hard-codes FRI folding factor 8");
+            if (pr.opt.field_extension != EXT_NONE) reject("cairo-compat: the Cairo verifier has no extension field");
+            if (B != 8) reject("cairo-compat: the Cairo verifier hard-codes blowup 8 (log_blowup 3)");
+        }
+    }
     if (pr.ood_evaluations.size() % EB || pr.ood_evaluations.empty()) reject("bad OOD evaluations length");
     const size_t C = pr.ood_evaluations.size() / EB;
     const int layers = num_fri_layers(N, Fd, 1ull << pr.opt.fri_log_max_remainder);
@@ -396,18 +332,25 @@ template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t
 }  // namespace aero
 
 extern "C" int32_t aero_verify_fib(const uint8_t* proof, size_t proof_len, const uint64_t* pub_elements, uint32_t n_pub, const aero_fib_air* air,
-                                   char* err, size_t err_cap) {
+                                   const aero_verify_policy* policy, char* err, size_t err_cap) {
     using namespace aero;
     auto put = [&](const std::string& s) { if (err && err_cap) { size_t k = std::min(err_cap - 1, s.size()); memcpy(err, s.data(), k); err[k] = 0; } };
     try {
         if (!proof || (!pub_elements && n_pub)) { put("verify: null argument"); return AERO_E_BAD_ARG; }
+        aero_verify_policy pol{};
+        if (policy) pol = *policy; else pol.min_query_security_bits = 96;
+        if (!air && !pol.allow_unknown_air) {
+            put("verify: the AIR descriptor is mandatory (without it the out-of-domain constraint check cannot run and any low-degree "
+                "commitment would be accepted); set policy.allow_unknown_air to verify everything but that check");
+            return AERO_E_BAD_ARG;
+        }
         put("");
         const Parsed pr = parse(proof, proof_len);
         try { pr.opt.validate(); } catch (const Error& e) { reject(e.what()); }
         std::vector<uint64_t> pub(pub_elements, pub_elements + n_pub);
         for (uint64_t v : pub) if (v >= gl::P) reject("non-canonical public input");
-        if (pr.opt.field_extension == EXT_NONE) verify_impl<gl::FB>(pr, pub, air);
-        else verify_impl<gl::FQ>(pr, pub, air);
+        if (pr.opt.field_extension == EXT_NONE) verify_impl<gl::FB>(pr, pub, air, pol);
+        else verify_impl<gl::FQ>(pr, pub, air, pol);
         return AERO_OK;
     } catch (const Error& e) {
         put(e.what());
@@ -416,4 +359,22 @@ extern "C" int32_t aero_verify_fib(const uint8_t* proof, size_t proof_len, const
         put(std::string("verify: ") + e.what());
         return AERO_E_INTERNAL;
     }
+}
+
+// num_queries * log2(blowup) + grinding, and the field-size term 64 * extension degree - log2(LDE domain) that caps any
+// security claim over this field (Winterfell's conjectured-security formula takes the minimum of the two, minus one).
+extern "C" int32_t aero_proof_security_bits(const uint8_t* proof, size_t proof_len, uint32_t* query_bits, uint32_t* field_bits) {
+    using namespace aero;
+    try {
+        if (!proof) return AERO_E_BAD_ARG;
+        const Parsed pr = parse(proof, proof_len);
+        pr.opt.validate();
+        int log_b = 0;
+        while ((1u << log_b) < pr.opt.blowup_factor) log_b++;
+        if (query_bits) *query_bits = (uint32_t)pr.opt.num_queries * (uint32_t)log_b + pr.opt.grinding_factor;
+        if (field_bits) *field_bits = 64u * (uint32_t)pr.deg() - (uint32_t)(pr.log_n + log_b);
+        return AERO_OK;
+    } catch (const Error& e) {
+        return e.code == AERO_E_VERIFY ? AERO_E_VERIFY : AERO_E_BAD_ARG;
+    } catch (...) { return AERO_E_INTERNAL; }
 }

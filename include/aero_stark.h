@@ -52,6 +52,13 @@ typedef struct aero_proof_options {
     uint8_t fri_log_max_remainder;
 } aero_proof_options;
 
+/* Parameters of the built-in AIR's optional auxiliary segment (described at aero_prove_fib_air below). */
+typedef struct aero_fib_air {
+    uint32_t aux_width;   /* 0 = no auxiliary segment */
+    uint32_t aux_rands;
+    uint32_t aux_degree;  /* ignored when aux_width = 0 */
+} aero_fib_air;
+
 /* ---- context --------------------------------------------------------------------------------------------------- */
 /* One context = one GPU + one HIP stream + a device memory pool. (Reference has no analogue: its workers are
  * web workers, aero-sdk/miden-wasm/src/pool.rs:28-45.) */
@@ -70,10 +77,30 @@ void aero_free(void* p); /* releases buffers returned through uint8_t** out-para
 int32_t aero_trace_upload(aero_ctx* ctx, const uint64_t* col_major, uint32_t width, uint32_t log_n, aero_matrix** out);
 int32_t aero_matrix_shape(const aero_matrix* m, uint32_t* cols, uint64_t* rows);
 int32_t aero_matrix_download(aero_ctx* ctx, const aero_matrix* m, uint64_t* col_major_out);
+/* Device address of the matrix's column-major storage (for a caller's own kernels or collectives on the context's GPU; work the
+ * caller enqueues elsewhere must be ordered against the context's stream, e.g. with aero_ctx_synchronize). */
+int32_t aero_matrix_device_ptr(const aero_matrix* m, uint64_t** dev_ptr_out);
 void aero_matrix_free(aero_ctx* ctx, aero_matrix* m);
 /* Synthetic Fibonacci trace (host buffer, column-major width x 2^log_n): pair k = columns (2k, 2k+1) = (a, b),
  * a' = a + b, b' = b + a', seeds (1 + 2k, 2 + 2k). Pure function of (width, log_n). */
 int32_t aero_fib_trace(uint32_t width, uint32_t log_n, uint64_t* col_major_out);
+
+/* ---- trace files: how a trace produced elsewhere reaches this library ------------------------------------------------------------- */
+/* The reference obtains its trace from the VM in the same process (`processor::execute`: miden-proof-generator/src/main.rs:20-31,
+ * proving_worker.rs:239-259 `build_execution_trace`). For a trace dumped by another program the hand-over is a file:
+ *   bytes 0..7   "AEROTRC" followed by the format version byte 1
+ *   u32 x 6      width, log_n, air_id, aux_width, aux_rands, aux_degree   (little-endian)
+ *   u64 x width * 2^log_n   the main segment, COLUMN-MAJOR (column c = elements [c * 2^log_n, (c + 1) * 2^log_n)), canonical (< p)
+ * air_id names the constraint set the trace is to be proven against: AERO_AIR_FIB = 0 is the built-in FibAir (aux_* = its
+ * optional auxiliary segment, see aero_fib_air); 1 is reserved for Miden's ProcessorAir, whose constraints are not part of the
+ * reference mount - loading such a file yields AERO_E_UNSUPPORTED, not a proof against the wrong AIR.
+ * aero_trace_file_load streams the file to the device through pinned double buffers (disk reads overlap the copies). */
+#define AERO_AIR_FIB 0u
+#define AERO_AIR_MIDEN_PROCESSOR 1u
+int32_t aero_trace_file_write(const char* path, const uint64_t* col_major, uint32_t width, uint32_t log_n, uint32_t air_id,
+                              const aero_fib_air* air);
+int32_t aero_trace_file_info(const char* path, uint32_t* width, uint32_t* log_n, uint32_t* air_id, aero_fib_air* air);
+int32_t aero_trace_file_load(aero_ctx* ctx, const char* path, aero_matrix** trace_out, uint32_t* air_id, aero_fib_air* air);
 
 /* ---- stage 1: interpolation and low-degree extension ----------------------------------------------------------------- */
 /* Replaces `main_trace.interpolate_columns()` (proving_worker.rs:273). Output polynomials are kept in the backend's
@@ -247,11 +274,6 @@ int32_t aero_prove_fib_aux(aero_ctx* ctx, const aero_comm* comm, const aero_matr
  * aux_degree in [2, 8]. The constraint-evaluation blowup and the number of composition columns follow Winterfell's rule
  * max(next_pow2(max constraint degree), 2): 2 / 4 / 8 for degree 2 / 3-4 / 5-8 — 8 is the shape of the reference's golden
  * Miden proof (proofs/fib.bin carries 8 composition columns; stark_verifier.cairo:166-176). blowup_factor must be >= that. */
-typedef struct aero_fib_air {
-    uint32_t aux_width;   /* 0 = no auxiliary segment */
-    uint32_t aux_rands;
-    uint32_t aux_degree;  /* ignored when aux_width = 0 */
-} aero_fib_air;
 int32_t aero_prove_fib_air(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_fib_air* air,
                            const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
 /* aero_prove_fib_host with an AIR descriptor (air may be NULL = plain FibAir). */
@@ -287,20 +309,67 @@ int32_t aero_pool_prove_fib_host(aero_pool* pool, const uint64_t* const* host_tr
 /* ---- verification (host only, no GPU) ------------------------------------------------------------------------------------------ */
 /* The counterpart of `winter_verifier::verify` for this backend's proofs, written against the reference's in-tree verifier
  * (src/stark_verifier/stark_verifier.cairo:105-304 and the files it calls): transcript, proof of work, every Merkle opening, DEEP
- * composition at every query, FRI layer consistency, remainder commitment and degree.
- *   air != NULL: the built-in FibAir (pub_elements = the width/2 results; aux fields must match the proof): the out-of-domain
- *                constraint consistency check is performed too (the Cairo code leaves it commented out: :151-159,183-187);
- *   air == NULL: unknown AIR (e.g. the golden Miden proof proofs/fib.bin; pub_elements = the coin-seed elements, for Miden proofs
- *                program hash || stack inputs || outputs, src/stark_verifier/crypto/random.cairo:254-280): everything except
- *                that check, which is exactly what the Cairo verifier does.
- * Returns AERO_OK, AERO_E_VERIFY (rejected; reason in err) or AERO_E_BAD_ARG. err may be NULL. Needs no context and no GPU. */
+ * composition at every query, FRI layer consistency, remainder commitment and degree, and - which the Cairo code leaves commented
+ * out (:151-159,183-187) - the out-of-domain constraint consistency check for the built-in FibAir.
+ *
+ * A proof declares its own options and trace length; what the CALLER accepts is the policy (NULL = {96, 0, 0, 0, 0}):
+ *   min_query_security_bits  reject when num_queries * log2(blowup) + grinding is below this (with_96_bit_security() = 97)
+ *   expected_log_n           the trace length the statement is about (FibAir: "the 2^k-th term is pub"); 0 = take the proof's
+ *   allow_unknown_air        non-zero: `air` may be NULL - everything except the OOD constraint check, exactly what the Cairo
+ *                            verifier does (e.g. the golden Miden proof proofs/fib.bin; pub_elements = the coin-seed elements,
+ *                            for Miden proofs program hash || stack inputs || outputs, crypto/random.cairo:254-280). Never use
+ *                            this to accept FibAir proofs: any low-degree commitment passes without that check.
+ *   cairo_compat             non-zero: additionally require the shape src/stark_verifier hard-codes (72 + 9 columns, 8
+ *                            composition columns, 27 queries, blowup 8, FRI folding factor 8, no extension field)
+ *   require_options/options  non-zero: the proof's 7 option bytes must equal `options`
+ * air: the built-in FibAir descriptor (aux fields must match the proof); pub_elements = the width/2 results.
+ * Returns AERO_OK, AERO_E_VERIFY (rejected; reason in err) or AERO_E_BAD_ARG (incl. air == NULL without allow_unknown_air). */
+typedef struct aero_verify_policy {
+    uint32_t min_query_security_bits;
+    uint32_t expected_log_n;
+    uint32_t allow_unknown_air;
+    uint32_t cairo_compat;
+    uint32_t require_options;
+    aero_proof_options options;
+} aero_verify_policy;
 int32_t aero_verify_fib(const uint8_t* proof, size_t proof_len, const uint64_t* pub_elements, uint32_t n_pub, const aero_fib_air* air,
-                        char* err, size_t err_cap);
+                        const aero_verify_policy* policy, char* err, size_t err_cap);
+/* The two terms of Winterfell's conjectured-security estimate for a proof's self-declared parameters: query_bits =
+ * num_queries * log2(blowup) + grinding; field_bits = 64 * extension degree - log2(LDE domain size). */
+int32_t aero_proof_security_bits(const uint8_t* proof, size_t proof_len, uint32_t* query_bits, uint32_t* field_bits);
 
 /* bincode ProofData{input_bytes, proof_bytes} = u64 len || inputs || u64 len || proof
  * (miden-proof-generator/src/lib.rs:1-6, main.rs:49-51). */
 int32_t aero_proof_container(const uint8_t* inputs, size_t inputs_len, const uint8_t* proof, size_t proof_len, uint8_t** out,
                              size_t* out_len);
+
+/* ---- re-encoding a proof for the reference's downstream consumers (host only, no GPU) ------------------------------------------ */
+/* Cairo-memory image: the JSON array `stark_parser <file> <sub-command>` prints (miden-to-cairo-parser/src/main.rs:42-113) and
+ * src/stark_verifier/utils.py:10-23 loads into the Cairo VM - values as hex strings (`0x...`), pointers as decimal offsets into the
+ * same array (segment model and formats: memory.rs:31-150; field order: lib.rs:41-260,395-470).
+ *   AERO_CAIRO_PROOF               the parsed StarkProof (context, commitments, OOD frame, pow nonce, queried states, remainder)
+ *   AERO_CAIRO_PUBLIC_INPUTS       Miden `PublicInputs` from the container's input bytes (proof may be NULL)
+ *   AERO_CAIRO_TRACE_QUERIES       per trace segment, per index: the Merkle authentication path (`indexes` = the query positions
+ *   AERO_CAIRO_CONSTRAINT_QUERIES  the proof was opened at, in draw order; the paths are checked against the commitments)
+ *   AERO_CAIRO_FRI_QUERIES         per FRI layer, per folded index: path + the row's folding_factor values
+ * Like the reference's encoder this needs a proof WITH an auxiliary trace segment over the base field (lib.rs:138,147 unwrap the
+ * auxiliary frame / states): otherwise AERO_E_UNSUPPORTED. *json_out is malloc'd (aero_free), NUL-terminated, without the
+ * trailing newline `println!` adds. Errors: AERO_E_VERIFY (malformed / inconsistent proof), text in err. */
+#define AERO_CAIRO_PROOF 0u
+#define AERO_CAIRO_PUBLIC_INPUTS 1u
+#define AERO_CAIRO_TRACE_QUERIES 2u
+#define AERO_CAIRO_CONSTRAINT_QUERIES 3u
+#define AERO_CAIRO_FRI_QUERIES 4u
+int32_t aero_cairo_memory(uint32_t what, const uint8_t* proof, size_t proof_len, const uint8_t* input_bytes, size_t input_len,
+                          const uint64_t* indexes, uint32_t n_indexes, char** json_out, size_t* json_len, char* err, size_t err_cap);
+/* protobuf `sdk.StarkProof` (aero-sdk/proto/stark_proof.proto:13-30 and the files it imports; contents after
+ * `StarkProof::into_sdk`, aero-sdk/miden-wasm/src/convert/convert_proof.rs:13-307: parsed tables, per-segment and per-layer
+ * BatchMerkleProofs with explicit leaves and depth) and `sdk.MidenPublicInputs` (proto/miden_vm.proto:14-18) - the bytes the
+ * reference's browser prover hands to the SDK (proving_worker.rs:210-222). proto3 wire format as prost 0.11 writes it. Base
+ * field + Blake2s only (the reference has no enum values for anything else): otherwise AERO_E_UNSUPPORTED. */
+int32_t aero_proof_to_protobuf(const uint8_t* proof, size_t proof_len, uint8_t** out, size_t* out_len, char* err, size_t err_cap);
+int32_t aero_miden_public_inputs_to_protobuf(const uint8_t* input_bytes, size_t input_len, uint8_t** out, size_t* out_len, char* err,
+                                             size_t err_cap);
 
 /* ---- instrumentation --------------------------------------------------------------------------------------------------------- */
 /* Per-stage wall-clock of the last aero_prove_* (ms; adds one stream sync per stage when enabled). Order:

@@ -45,7 +45,7 @@ def test_config4_2p24_single_gpu_bytes_identical(ctx, oracle, oracle_2p24):
     assert pub == want_pub
     assert got == want, "2^24-row proof differs from the oracle's"
     oracle.verify(got, pub, air_kind=1, W=width, log_n=log_n)
-    aero_amd.verify_fib(got, pub, (0, 0, 2))
+    aero_amd.verify_fib(got, pub, (0, 0, 2), expected_log_n=log_n, require_options=aero_amd.ProofOptions(*DEFAULT))
 
 
 def test_config4_2p24_sharded_8_ways_bytes_identical(oracle, oracle_2p24, tmp_path):
@@ -69,7 +69,7 @@ def test_config5_standin_2p22_verifies(ctx, oracle):
     # header: 72 main columns, 9 aux columns, 16 aux random elements, 2^22 rows; options incl. fold 4
     assert got[:4] == bytes([W, A, R, log_n]) and got[15:22] == bytes(MIDEN_SHAPE)
     oracle.verify_fib_aux(got, pub, W, log_n, A, R, D=D)      # every check of src/stark_verifier + the OOD constraint check
-    aero_amd.verify_fib(got, pub, (A, R, D))
+    aero_amd.verify_fib(got, pub, (A, R, D), expected_log_n=log_n)
 
 
 def test_config5_standin_2p18_bytes_identical(ctx, oracle):

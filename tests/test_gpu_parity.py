@@ -221,7 +221,7 @@ def test_proof_bytes_identical_to_oracle(ctx, oracle, log_n, width, kw):
     assert pub == want_pub
     assert got == want, "proof bytes differ"
     oracle.verify(got, pub, air_kind=1, W=width, log_n=log_n)
-    aero_amd.verify_fib(got, pub, (0, 0, 2))               # the library's own host-side verifier
+    aero_amd.verify_fib(got, pub, (0, 0, 2), min_query_security_bits=0, expected_log_n=log_n)   # the library's own host-side verifier (these shapes use weak options on purpose)
     # determinism + host-trace entry point
     again, _ = ctx.prove_fib(trace, o)
     assert again == got
@@ -257,7 +257,7 @@ def test_full_size_config3(ctx, oracle):
     o = opts(field_extension=2)
     got, pub = ctx.prove_fib(ctx.trace_upload(aero_amd.fib_trace(width, log_n)), o)
     oracle.verify(got, pub, air_kind=1, W=width, log_n=log_n)
-    aero_amd.verify_fib(got, pub, (0, 0, 2))
+    aero_amd.verify_fib(got, pub, (0, 0, 2), expected_log_n=log_n)
     want, want_pub, _ = oracle.prove_fib(width, log_n, o.to_list())
     assert pub == want_pub
     assert got == want, "config 3 proof bytes differ from the oracle"

@@ -1,55 +1,53 @@
 """The library's native RCCL communicator (aero_rccl_*, include/aero_stark.h) on the one GPU of the test box: a world of ONE
 rank runs the real `ncclCommInitRank`, `ncclSend`/`ncclRecv` group, `ncclAllGather` and `ncclAllReduce` calls, enqueued on
 the context's stream (RCCL refuses two ranks on one device, so world > 1 needs a multi-GPU node: bench.py measures that
-there; tests/test_gpu_sharded.py checks the sharding itself at world 2/4/8 over gloo)."""
+there; tests/test_gpu_sharded.py checks the sharding itself at world 2/4/8 over gloo). No torch in this file: the
+communicator must work in a process that holds only this library and its HIP runtime."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
+import aero_amd
+from aero_amd.shard import RcclComm
+
 pytestmark = pytest.mark.gpu
+P = aero_amd.P
 
 
 @pytest.fixture(scope="module")
 def env():
-    import torch                      # torch first: its HIP runtime and its RCCL are the copies the process keeps
-    import aero_amd
-    from aero_amd.shard import RcclComm
     ctx = aero_amd.Context(0)
     comm = RcclComm(ctx, 0, 1)
-    yield torch, aero_amd, ctx, comm
+    yield ctx, comm
     comm.close()
     ctx.close()
 
 
 def test_exchanges_run_on_the_context_stream(env):
-    torch, aero_amd, ctx, comm = env
+    ctx, comm = env
     cs = comm.struct
     assert cs.rank == 0 and cs.world == 1 and cs.flags == 1          # AERO_COMM_STREAM_ORDERED
-    n = 1 << 20
-    src = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda")
-    dst = torch.zeros_like(src)
-    torch.cuda.synchronize()
-    assert cs.all_to_all(cs.user, src.data_ptr(), dst.data_ptr(), n) == 0, comm.error_text()
+    rng = np.random.default_rng(5)
+    n = 1 << 17
+    data = rng.integers(0, P, size=(1, n), dtype=np.uint64)
+    src, dst = ctx.trace_upload(data), ctx.trace_upload(np.zeros((1, n), np.uint64))
+    assert cs.all_to_all(cs.user, src.device_ptr, dst.device_ptr, 8 * n) == 0, comm.error_text()
+    assert (dst.download() == data).all()                               # download waits on the same stream: ordering is the stream's
+    dst2 = ctx.trace_upload(np.zeros((1, n), np.uint64))
+    assert cs.all_gather(cs.user, src.device_ptr, dst2.device_ptr, 8 * n) == 0, comm.error_text()
     ctx.synchronize()
-    assert torch.equal(src, dst)
-    dst.zero_()
-    torch.cuda.synchronize()
-    assert cs.all_gather(cs.user, src.data_ptr(), dst.data_ptr(), n) == 0, comm.error_text()
-    ctx.synchronize()
-    assert torch.equal(src, dst)
-    vals = torch.arange(1, 1001, dtype=torch.int64, device="cuda") * (1 << 53)      # wraps in u64 when summed over > 1 rank
-    want = vals.clone()
-    torch.cuda.synchronize()
-    assert cs.all_reduce_sum_u64(cs.user, vals.data_ptr(), vals.numel()) == 0, comm.error_text()
-    ctx.synchronize()
-    assert torch.equal(vals, want)                                     # world of one: the sum is the value itself
+    assert (dst2.download() == data).all()
+    assert cs.all_reduce_sum_u64(cs.user, dst2.device_ptr, n) == 0, comm.error_text()
+    assert (dst2.download() == data).all()                              # world of one: the sum is the value itself
     assert comm.calls == {"all_to_all": 1, "all_gather": 1, "all_reduce": 1}
-    assert comm.bytes_sent == 8 * 1000                                 # nothing leaves a world of one except the all-reduce count
+    assert comm.bytes_sent == 8 * n                                     # nothing leaves a world of one except the all-reduce count
+    for m in (src, dst, dst2):
+        m.free()
 
 
 def test_world_of_one_proof_is_the_single_gpu_proof(env, oracle):
-    torch, aero_amd, ctx, comm = env
+    ctx, comm = env
     opt = aero_amd.ProofOptions.with_96_bit_security()
     dev = ctx.trace_upload(aero_amd.fib_trace(2, 12))
     got, pub = ctx.prove_fib_aux(dev, 0, 0, opt, comm=comm)
@@ -59,7 +57,7 @@ def test_world_of_one_proof_is_the_single_gpu_proof(env, oracle):
 
 
 def test_bad_arguments(env):
-    torch, aero_amd, ctx, comm = env
+    ctx, comm = env
     L = aero_amd.lib()
     h = C.c_void_p()
     uid = (C.c_uint8 * 128)()

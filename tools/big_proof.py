@@ -12,7 +12,7 @@ t0 = time.perf_counter()
 proof, pub = ctx.prove_fib(dev, opt)
 ms = (time.perf_counter() - t0) * 1e3
 t0 = time.perf_counter()
-aero_amd.verify_fib(proof, pub, (0, 0, 2))
+aero_amd.verify_fib(proof, pub, (0, 0, 2), expected_log_n=log_n)
 vms = (time.perf_counter() - t0) * 1e3
 print(f"2^{log_n} x {width}: {ms:.1f} ms ({(width << log_n) / ms / 1e3:.0f} M cells/s), {len(proof)} proof bytes, verified on the host in {vms:.1f} ms, "
       f"device memory peak {ctx.memory_stats()[1] / 2**30:.1f} GiB")
