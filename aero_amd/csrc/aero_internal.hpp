@@ -49,7 +49,7 @@ struct NttTables {
 struct NttPass {
     int log_s, log_r, log_tl;
 };
-std::vector<NttPass> plan_passes(int log_n, bool reg_passes);
+std::vector<NttPass> plan_passes(int log_n, bool reg_passes, int first_bits = 12);
 
 typedef b2s::Digest Digest;   // 8 x u32, byte order = digest byte order (little-endian words)
 
@@ -65,6 +65,14 @@ struct FriSrc {   // FRI layer rows: row i = (v[i + j*rows])_{j < fold}, each va
     int deg;
     size_t rows;
     int fold;
+};
+
+// Transcript step appended to a Merkle tree build (FRI commit phase): once the root is known the same thread reseeds the coin
+// with it and draws the layer's folding challenge (random.cairo:108-114,159-166) - no separate launch, no host round trip.
+struct CoinStep {
+    Digest* seed_io = nullptr;   // coin seed: reseeded in place with the root
+    uint64_t* alpha_out = nullptr;   // `deg` u64: the drawn element
+    int deg = 1;
 };
 
 // One context = one device + one stream. Not thread-safe: one host thread drives it (SURVEY 8b "Threading").
@@ -108,7 +116,9 @@ public:
     const uint64_t* pass_twiddles(int log_n, int log_s, int log_r, bool inverse);
     bool quad_tops = true;     // latency-bound tree tops: four lanes per BLAKE2s compression (AERO_QUAD_TOPS=0: one lane)
     bool pass_names = false;   // AERO_NTT_NAMES=1: forward passes are timed under per-variant names (diagnosis)
+    bool two_phase = true;     // contiguous pass of the blowup-8 LDE as two register transforms around one LDS exchange (AERO_NTT_2PHASE=0: LDS rounds)
     bool reg_passes = true;    // strided passes of radix 16..64 run entirely in registers (AERO_NTT_REG=0: LDS passes only)
+    bool fwd_two_phase(int log_out, int log_pad) const;
     void ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad);
     void ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift);
 
@@ -119,11 +129,11 @@ public:
     // component columns comp[k] (k < deg): leaf i = hash_elements(flattened row)
     void hash_fri_rows(const FriSrc& src, Digest* leaves);
     // nodes[n + i] already hold the leaves; fills nodes[1 .. n-1]
-    void merkle_build(Digest* nodes, size_t n);
+    void merkle_build(Digest* nodes, size_t n, const CoinStep* coin = nullptr);
     // same when the leaf level holds 2^log_parts pieces in arrival order (leaf u in slot n + (u mod parts)*(n/parts) + u/parts)
     void merkle_build_parts(Digest* nodes, size_t n, int log_parts);
     // levels above a stored level of c nodes (heap indices [c, 2c)) up to the root
-    void merkle_upper(Digest* nodes, size_t c);
+    void merkle_upper(Digest* nodes, size_t c, const CoinStep* coin = nullptr);
     // fused leaf hashing + whole tree; the lowest `skip` (0 or 3) levels are not stored (nodes holds 2n >> skip slots)
     template <class Src> void merkle_commit(const Src& src, size_t n, Digest* nodes, int skip);
     // digests of unstored low nodes (heap indices >= 2n >> skip), recomputed from the leaf source
@@ -132,7 +142,9 @@ public:
     // internal state
     std::map<int, NttTables> ntt_tabs;
     std::map<uint64_t, uint64_t*> pass_tabs;
+    std::map<std::vector<uint64_t>, uint64_t*> ktab_cache;   // final-pass scale tables of ntt_inverse, keyed by their parameters
     uint64_t *tw4096_fwd = nullptr, *tw4096_inv = nullptr;
+    uint64_t *twmt_fwd = nullptr, *twmt_inv = nullptr;   // [r * 64 + k] = w_2048^(+-r k), r < 32
 
 private:
     struct KtRec { const char* name; size_t abytes; hipEvent_t start, stop; };

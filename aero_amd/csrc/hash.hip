@@ -188,7 +188,19 @@ template <class Src> __global__ __launch_bounds__(256) void hash_rows_kernel(Src
 // levels below (heap indices (r << L) + j), staged through LDS. Lane utilisation is poor (2^L - 1 compressions on
 // L * 2^(L-1) lane slots), so this is used only where a level has too few nodes to fill the chip anyway: there the cost
 // is the serial latency of one compression per level (~2.4 us with one wave per SIMD) and one launch instead of L.
-__global__ __launch_bounds__(256) void merkle_multi_kernel(Digest* nodes, size_t m, int L) {
+// reseed with the root, then draw one element of E (deg components); same retry rule as the host coin (prover.hip HostCoin)
+__device__ __forceinline__ void coin_step(const CoinStep& cs, const Digest& root) {
+    const Digest seed = b2s::merge(*cs.seed_io, root);
+    *cs.seed_io = seed;
+    for (uint64_t ctr = 1; ctr < 1000; ctr++) {
+        const Digest d = b2s::merge_with_int(seed, ctr);
+        const uint64_t v0 = (uint64_t)d.w[0] | ((uint64_t)d.w[1] << 32), v1 = (uint64_t)d.w[2] | ((uint64_t)d.w[3] << 32);
+        if (v0 < gl::P && (cs.deg == 1 || v1 < gl::P)) { cs.alpha_out[0] = v0; if (cs.deg > 1) cs.alpha_out[1] = v1; return; }
+    }
+    cs.alpha_out[0] = 0;
+    if (cs.deg > 1) cs.alpha_out[1] = 0;   // unreachable in practice (the host replay of the transcript would fail the same way)
+}
+__global__ __launch_bounds__(256) void merkle_multi_kernel(Digest* nodes, size_t m, int L, CoinStep cs) {
     __shared__ Digest buf[512];
     const int tid = threadIdx.x;
     const size_t r = m + blockIdx.x;
@@ -203,6 +215,7 @@ __global__ __launch_bounds__(256) void merkle_multi_kernel(Digest* nodes, size_t
         if (tid < w) { buf[tid] = v; store_digest(&nodes[(r << d) + tid], v); }
         __syncthreads();
     }
+    if (cs.seed_io && m == 1 && tid == 0) coin_step(cs, buf[0]);
 }
 
 // Same subtree build with FOUR lanes per compression (a quad holds one column of the 4 x 4 BLAKE2s state each: lane j has
@@ -253,7 +266,7 @@ __device__ __forceinline__ void quad_merge(const uint32_t* msg, int j, const uin
 }
 // Levels with more than 64 nodes use one lane per node (256 lanes already fill the 4 SIMDs of the CU: more lanes per node
 // would only add instructions); from 64 nodes down a quad per node shortens the chain.
-__global__ __launch_bounds__(256) void merkle_multi_quad_kernel(Digest* nodes, size_t m, int L) {
+__global__ __launch_bounds__(256) void merkle_multi_quad_kernel(Digest* nodes, size_t m, int L, CoinStep cs) {
     __shared__ __attribute__((aligned(16))) Digest buf[512];
     const int tid = threadIdx.x, q = tid >> 2, j = tid & 3;
     const size_t r = m + blockIdx.x;
@@ -287,6 +300,7 @@ __global__ __launch_bounds__(256) void merkle_multi_quad_kernel(Digest* nodes, s
             __syncthreads();
         }
     }
+    if (cs.seed_io && m == 1 && tid == 0) coin_step(cs, buf[0]);
 }
 
 // Recompute unstored low nodes for openings: out[q] = digest of heap node idx[q] (height h < 3 above the leaves).
@@ -328,7 +342,7 @@ void Context::hash_fri_rows(const FriSrc& src, Digest* leaves) {
 }
 
 // levels above a stored level of `c` nodes (heap indices [c, 2c)) up to the root
-void Context::merkle_upper(Digest* nodes, size_t c) {
+void Context::merkle_upper(Digest* nodes, size_t c, const CoinStep* coin) {
     // throughput regime: 3 levels per launch, one thread per subtree of 8
     while (c > ((size_t)1 << 17)) {
         size_t m = c / 8;
@@ -340,16 +354,17 @@ void Context::merkle_upper(Digest* nodes, size_t c) {
         int L = 0;
         while (L < 9 && ((size_t)1 << (L + 1)) <= c) L++;
         size_t m = c >> L;
-        if (quad_tops) AERO_LAUNCH(this, "merkle_multi_kernel", c * 64, merkle_multi_quad_kernel, dim3((unsigned)m), dim3(256), 0, nodes, m, L);
-        else AERO_LAUNCH(this, "merkle_multi_kernel", c * 64, merkle_multi_kernel, dim3((unsigned)m), dim3(256), 0, nodes, m, L);
+        const CoinStep cs = (coin && m == 1) ? *coin : CoinStep{};     // the launch that produces the root also steps the coin
+        if (quad_tops) AERO_LAUNCH(this, "merkle_multi_kernel", c * 64, merkle_multi_quad_kernel, dim3((unsigned)m), dim3(256), 0, nodes, m, L, cs);
+        else AERO_LAUNCH(this, "merkle_multi_kernel", c * 64, merkle_multi_kernel, dim3((unsigned)m), dim3(256), 0, nodes, m, L, cs);
         c = m;
     }
     check_launch("merkle_upper");
 }
 
-void Context::merkle_build(Digest* nodes, size_t n) {
+void Context::merkle_build(Digest* nodes, size_t n, const CoinStep* coin) {
     if (n < 2 || (n & (n - 1))) fail("merkle_build: leaf count must be a power of two >= 2");
-    merkle_upper(nodes, n);
+    merkle_upper(nodes, n, coin);
 }
 
 void Context::merkle_build_parts(Digest* nodes, size_t n, int log_parts) {

@@ -52,6 +52,7 @@ struct PassArgs {
     const uint64_t* tw_hi;
     int tw_h;
     const uint64_t* tw_pass;  // register passes only: pass-boundary twiddles, row b * R + k
+    const uint64_t* tw_mt;    // two-phase contiguous pass only: [r * 64 + k] = w_4096^(r k)
     // inverse contiguous pass only: out[p] *= ktab[k] * blockfac(block)
     const uint64_t* ktab;     // R entries: c0 * (a^(2^(L-r)) * b^(2^(L-r-shift)))^rev_r(k)
     uint64_t sc_a, sc_b;      // per-block factor = a^rev(block) * b^(rev(block) >> shift)
@@ -221,6 +222,106 @@ __global__ __launch_bounds__(256) void ntt_fwd_first_pass(PassArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Contiguous first pass of the blowup-8 LDE (log_r = 11, log_pad = 3: 8 butterfly stages on 2048-point tiles) as TWO register
+// transforms around ONE exchange, one wavefront per tile, 32 values per lane:
+//   A  bits 3..5: the three skipped stages broadcast 8 coefficients over the positions [64h, 64h + 64) of the tile. Lane
+//      (h, half) loads them and computes, for the 4 values klow = 4 half + klow' of (position mod 8), the twiddled 8-point
+//      transform. Every twiddle is a power of w_64 = 2^39, i.e. a compile-time shift (dft_small.cuh): no multiplication, no
+//      table. The two halves run the same code: the factor w_64^(4 rev(i)) that separates klow from klow + 4 is applied to
+//      the inputs of the upper half with a select.
+//   -- the 32 x 64 transpose through LDS (XOR-swizzled columns: conflict-free writes and reads, no padding) --
+//   B  bits 6..10: lane k holds positions k + 64 i. One table multiplication per element (w_2048^(k rev(i)), read from a
+//      [rev(i)][k] table so that a wavefront's load is one contiguous 512-byte segment), then the 32-point transform whose
+//      internal twiddles are shifts again; the pass-boundary twiddle w_N^(rev(tile) p) runs as a geometric progression in i
+//      (one lookup per lane + one per tile instead of one lookup per element); stores are contiguous 512-byte segments.
+// Against the LDS-round formulation (ntt_fwd_first_pass) this removes a third of the full multiplications, one of two LDS
+// exchanges and both workgroup barriers (the waves of a workgroup never synchronise with each other). A first attempt with
+// 4096-point tiles and 64 values per lane left one wavefront per SIMD (285 VGPRs, 33 KiB of LDS per wave) and ran 1.8x SLOWER
+// than the LDS rounds: the carry chains of the field arithmetic need a second wave to hide their dependent-issue latency.
+template <int E> __device__ __forceinline__ uint64_t mul_w64(uint64_t x) {      // x * w_64^E
+    constexpr int K = (39 * E) % 192;
+    if constexpr (K == 0) return x;
+    else if constexpr (K < 96) return mul_pow2<K>(x);
+    else if constexpr (K == 96) return gl::neg(x);
+    else return gl::neg(mul_pow2<K - 96>(x));
+}
+template <int KLOW> __device__ __forceinline__ void first8_group(const uint64_t (&c)[8], uint64_t (&v)[32]) {
+    // members in position order i carry the sub-transform values in bit-reversed order: twiddle T^rev3(i), T = w_64^KLOW
+    uint64_t y[8] = {c[0], mul_w64<KLOW * 4>(c[1]), mul_w64<KLOW * 2>(c[2]), mul_w64<KLOW * 6>(c[3]),
+                     mul_w64<KLOW * 1>(c[4]), mul_w64<KLOW * 5>(c[5]), mul_w64<KLOW * 3>(c[6]), mul_w64<KLOW * 7>(c[7])};
+    dft_dit<3>(y);
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[KLOW + 4 * i] = y[i];
+}
+constexpr int F8_TILE_LDS = 32 * 64;             // elements per tile: element (row, col) of the 32 x 64 exchange lives at
+                                                 // row * 64 + (col ^ (2 row & 63)) - conflict-free for the row-wise writes of
+                                                 // phase A and the column-wise reads of phase B without any padding
+constexpr int F8_WAVES = 4;                      // tiles per workgroup
+__global__ __launch_bounds__(64 * F8_WAVES, 2) void ntt_fwd_first_pass_8(PassArgs a) {
+    __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t* lds = f8_lds + wave * F8_TILE_LDS;
+    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * F8_WAVES + wave;          // tile
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    const size_t base = (size_t)b << 11, cbase = base >> 3;
+    const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
+    uint64_t y[32];
+    {
+        // A: 8 coefficients -> 32 of the 64 positions [64 h, 64 h + 64): (position mod 8) in [4 half, 4 half + 4)
+        const int h = lane & 31;
+        const bool upper = lane >= 32;
+        uint64_t c[8];
+        const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(in + cbase + 8 * h);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const ulonglong2 t = cp[q]; c[2 * q] = t.x; c[2 * q + 1] = t.y; }
+        // upper half: klow = klow' + 4, i.e. member i carries the extra factor w_64^(4 rev3(i))
+        { uint64_t t;
+          t = mul_w64<16>(c[1]); c[1] = upper ? t : c[1];   t = mul_w64<8>(c[2]);  c[2] = upper ? t : c[2];
+          t = mul_w64<24>(c[3]); c[3] = upper ? t : c[3];   t = mul_w64<4>(c[4]);  c[4] = upper ? t : c[4];
+          t = mul_w64<20>(c[5]); c[5] = upper ? t : c[5];   t = mul_w64<12>(c[6]); c[6] = upper ? t : c[6];
+          t = mul_w64<28>(c[7]); c[7] = upper ? t : c[7]; }
+        first8_group<0>(c, y); first8_group<1>(c, y); first8_group<2>(c, y); first8_group<3>(c, y);
+        // y[klow' + 4 i] sits at tile position (klow' + 4 half) + 8 i + 64 h: row h, column klow' + 4 half + 8 i
+        uint64_t* row = lds + h * 64;
+        const int sw = (2 * h) & 63, c0 = upper ? 4 : 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) row[(c0 + k + 8 * i) ^ sw] = y[k + 4 * i];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // B: lane k <- positions k + 64 i
+#pragma unroll
+    for (int i = 0; i < 32; i++) y[i] = lds[i * 64 + (lane ^ ((2 * i) & 63))];
+#pragma unroll
+    for (int i = 1; i < 32; i++) y[i] = mul(y[i], a.tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane]);
+    dft_dit_reg<5>(y);
+    if (!a.first && rbk) {
+        const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
+        uint64_t cur = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)lane) & nmask), a.tw_h);
+        const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            out[base + lane + 64 * i] = mul(y[i], cur);
+            cur = mul(cur, step);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = y[i];
+    }
+}
+// tab[r * 64 + k] = root^(r * k), r < rows
+__global__ void fill_mul_table64(uint64_t* tab, uint32_t rows, uint64_t root) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 64) return;
+    tab[i] = gl::pow(root, (uint64_t)((i >> 6) * (i & 63)));
+}
+
 // Inverse: exact mirror (decimation in frequency with inverse roots), natural input -> bit-reversed output.
 __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
@@ -378,6 +479,12 @@ void Context::ensure_small_twiddles() {
     uint64_t w = gl::root_of_unity(12);
     AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3(16), dim3(256), 0, tw4096_fwd, 4096u, w, 1ull);
     AERO_LAUNCH(this, "fill_pow_linear", 0, fill_pow_linear, dim3(16), dim3(256), 0, tw4096_inv, 4096u, gl::inv(w), 1ull);
+    // two-phase contiguous pass: [r * 64 + k] = w_2048^(r k), r < 32
+    twmt_fwd = (uint64_t*)dev_alloc(2048 * 8);
+    twmt_inv = (uint64_t*)dev_alloc(2048 * 8);
+    const uint64_t w2048 = gl::mul(w, w);
+    AERO_LAUNCH(this, "fill_mul_table64", 0, fill_mul_table64, dim3(8), dim3(256), 0, twmt_fwd, 32u, w2048);
+    AERO_LAUNCH(this, "fill_mul_table64", 0, fill_mul_table64, dim3(8), dim3(256), 0, twmt_inv, 32u, gl::inv(w2048));
     check_launch("small twiddles");
 }
 
@@ -385,9 +492,9 @@ void Context::ensure_small_twiddles() {
 // passes every strided pass has radix <= 64 (one more pass over HBM beats a radix-128/256 pass through LDS: measured 2^25
 // points, 4 columns: 1162 us for the LDS radix-128 pass against 550 us for a register radix-64 pass); without them the
 // strided passes take up to 8 bits each through LDS tiles of R x TL = 4096 elements.
-std::vector<NttPass> plan_passes(int L, bool reg) {
+std::vector<NttPass> plan_passes(int L, bool reg, int first_bits) {
     std::vector<NttPass> p;
-    int r1 = L < 12 ? L : 12;
+    int r1 = L < first_bits ? L : first_bits;
     p.push_back(NttPass{0, r1, 0});
     int rem = L - r1, s = r1;
     if (rem == 0) return p;
@@ -404,10 +511,15 @@ std::vector<NttPass> plan_passes(int L, bool reg) {
 
 // coefficients (bit-reversed, pre-scaled by offset^i), n_in = 2^(log_out - log_pad) per column
 //   -> evaluations in natural order over offset * <w_(2^log_out)>
+// The two-phase contiguous pass covers 11 bits instead of 12: it is used where that does not cost an extra strided pass.
+bool Context::fwd_two_phase(int log_out, int log_pad) const {
+    if (!reg_passes || !two_phase || log_pad != 3 || log_out < 13) return false;
+    return (log_out - 11 + 5) / 6 == (log_out - 12 + 5) / 6 || log_out - 12 <= 0;
+}
 void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad) {
     ensure_small_twiddles();
     NttTables* t = ntt_tables(log_out);
-    std::vector<NttPass> plan = plan_passes(log_out, reg_passes);
+    std::vector<NttPass> plan = plan_passes(log_out, reg_passes, fwd_two_phase(log_out, log_pad) ? 11 : 12);
     if (plan[0].log_r < log_pad) fail("ntt_forward: transform too small for the requested padding");
     for (size_t q = 0; q < plan.size(); q++) {
         PassArgs a{};
@@ -436,6 +548,12 @@ void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
         dim3 grid((unsigned)(((size_t)1 << log_out) / E), ncols);
+        if (q == 0 && a.log_r == 11 && a.log_pad == 3 && fwd_two_phase(log_out, log_pad)) {
+            a.tw_mt = twmt_fwd;
+            const dim3 g8((unsigned)((((size_t)1 << log_out) >> 11) / F8_WAVES), ncols);
+            AERO_LAUNCH(this, pass_names ? "ntt_fwd_first8" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass_8, g8, dim3(64 * F8_WAVES), 0, a);
+            continue;
+        }
         if (q == 0 && reg_passes && a.log_r > a.log_pad) {
             AERO_LAUNCH(this, pass_names ? "ntt_fwd_first" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass, grid, dim3(256), 0, a);
             continue;
@@ -450,7 +568,7 @@ void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
 void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift) {
     ensure_small_twiddles();
     NttTables* t = ntt_tables(log_n);
-    std::vector<NttPass> plan = plan_passes(log_n, reg_passes);
+    std::vector<NttPass> plan = plan_passes(log_n, reg_passes, 12);
     const int r1 = plan[0].log_r;
     // per-k table for the final (contiguous) pass
     uint64_t ninv = gl::inv((uint64_t)1 << log_n);
@@ -465,8 +583,20 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
     } else {
         abase = gl::pow(sa, 1ull << q); bbase = sb; bshift = shift - q;
     }
-    uint64_t* ktab = (uint64_t*)scratch_alloc(((size_t)1 << r1) * 8);
-    AERO_LAUNCH(this, "fill_pow_bitrev", 0, fill_pow_bitrev, dim3(((1u << r1) + 255) / 256), dim3(256), 0, ktab, r1, abase, bbase, bshift, gl::mul(c0, ninv));
+    // the table depends on (size, scale parameters) only: a prover asks for the same two or three tables proof after proof, so
+    // they are built once per context and kept (a bounded number; anything beyond that is built per call)
+    uint64_t* ktab = nullptr;
+    {
+        const std::vector<uint64_t> key{(uint64_t)r1, abase, bbase, (uint64_t)bshift, gl::mul(c0, ninv)};
+        auto it = ktab_cache.find(key);
+        if (it != ktab_cache.end()) ktab = it->second;
+        else {
+            const bool keep = ktab_cache.size() < 64;
+            ktab = keep ? (uint64_t*)dev_alloc(((size_t)1 << r1) * 8) : (uint64_t*)scratch_alloc(((size_t)1 << r1) * 8);
+            AERO_LAUNCH(this, "fill_pow_bitrev", 0, fill_pow_bitrev, dim3(((1u << r1) + 255) / 256), dim3(256), 0, ktab, r1, abase, bbase, bshift, key[4]);
+            if (keep) ktab_cache[key] = ktab;
+        }
+    }
     for (size_t qi = plan.size(); qi-- > 0;) {
         PassArgs a{};
         a.in = data; a.out = data; a.in_col_stride = stride; a.out_col_stride = stride;

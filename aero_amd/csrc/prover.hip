@@ -24,6 +24,7 @@ Context::Context(int dev) : device(dev) {
     AERO_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (const char* e = getenv("AERO_NTT_REG")) reg_passes = e[0] != '0';
     if (const char* e = getenv("AERO_NTT_NAMES")) pass_names = e[0] != '0';
+    if (const char* e = getenv("AERO_NTT_2PHASE")) two_phase = e[0] != '0';
     if (const char* e = getenv("AERO_QUAD_TOPS")) quad_tops = e[0] != '0';
 }
 Context::~Context() {
@@ -391,16 +392,20 @@ MerkleTree Prover::commit_fri_layer(const FriSrc& src, bool keep_low_levels) {
     return t;
 }
 
-MerkleTree Prover::commit_fri_layer_async(const FriSrc& src) {
+MerkleTree Prover::commit_fri_layer_async(const FriSrc& src, const CoinStep* coin) {
     const size_t rows = src.rows;
     if (rows < 2) {   // a single leaf is its own root
         MerkleTree t(ctx_, 1);
         ctx_->hash_fri_rows(src, t.nodes.get() + 1);
+        if (coin) {
+            if (coin->deg == 1) launch_fri_coin_step<FB>(ctx_, coin->seed_io, t.nodes.get() + 1, coin->alpha_out);
+            else launch_fri_coin_step<FQ>(ctx_, coin->seed_io, t.nodes.get() + 1, reinterpret_cast<gl::E2*>(coin->alpha_out));
+        }
         return t;
     }
     MerkleTree t(ctx_, rows, 0);
     ctx_->hash_fri_rows(src, t.leaves());
-    ctx_->merkle_build(t.nodes.get(), rows);
+    ctx_->merkle_build(t.nodes.get(), rows, coin);
     return t;
 }
 
@@ -567,9 +572,9 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
         const size_t rows = dom / Fd;
         const FriSrc fsrc{fl.vals[l].get(), fl.vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd};
         Commitment c;
-        c.tree = commit_fri_layer_async(fsrc);
+        const CoinStep cs{d_seed, reinterpret_cast<uint64_t*>(d_alpha + l), F::DEG};
+        c.tree = commit_fri_layer_async(fsrc, &cs);
         c.n_global = rows;
-        launch_fri_coin_step<F>(ctx, d_seed, c.tree.nodes.get() + 1, d_alpha + l);
         AERO_HIP(hipMemcpyAsync(h_roots + l, c.tree.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
         fl.coms.push_back(std::move(c));
         if (l == fl.layers) break;   // alpha drawn after the remainder commitment is unused
@@ -682,21 +687,20 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     StageClock clk(ctx, collect_stage_times);
     auto t_start = std::chrono::steady_clock::now();
 
-    // 0. AIR, public inputs, channel [proving_worker.rs:248-268]
+    // 0. AIR, public inputs, channel [proving_worker.rs:248-268]. The public inputs (results[k] = trace[2k+1][n-1]) seed the coin, but
+    //    nothing before the first commitment depends on the coin: their read-back is only enqueued here and consumed after the
+    //    stream synchronisation the trace commitment performs anyway (one host round trip less per proof).
     air.results.resize(W / 2);
+    uint64_t* h_last_row = (uint64_t*)ctx->stage_alloc((size_t)W * 8);
     {
-        // results[k] = trace[2k+1][n-1]
-        DevBuf<uint64_t> d_pos(ctx, 1), d_row(ctx, W);
-        uint64_t last = n - 1;
-        AERO_HIP(hipMemcpyAsync(d_pos.get(), &last, 8, hipMemcpyHostToDevice, ctx->stream));
-        launch_gather_rows(ctx, trace_dev, n, (int)W, d_pos.get(), 1, d_row.get());
-        std::vector<uint64_t> row(W);
-        AERO_HIP(hipMemcpyAsync(row.data(), d_row.get(), W * 8, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->sync();
-        for (uint32_t k = 0; k < W / 2; k++) air.results[k] = row[2 * k + 1];
+        uint64_t* h_pos = (uint64_t*)ctx->stage_alloc(8);
+        *h_pos = n - 1;
+        uint64_t* d_pos = (uint64_t*)ctx->scratch_alloc(8);
+        uint64_t* d_row = (uint64_t*)ctx->scratch_alloc((size_t)W * 8);
+        AERO_HIP(hipMemcpyAsync(d_pos, h_pos, 8, hipMemcpyHostToDevice, ctx->stream));
+        launch_gather_rows(ctx, trace_dev, n, (int)W, d_pos, 1, d_row);
+        AERO_HIP(hipMemcpyAsync(h_last_row, d_row, (size_t)W * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (pub_out) *pub_out = air.results;
-    HostCoin coin = HostCoin::from_elements(air.results.data(), (uint32_t)air.results.size());
     StarkProof proof;
     proof.main_width = (uint8_t)W; proof.aux_width = (uint8_t)A; proof.aux_rands = (uint8_t)R; proof.log_n = (uint8_t)log_n; proof.options = opt_;
     const uint64_t g = gl::root_of_unity(log_n);
@@ -726,7 +730,10 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     ctx->ntt_forward(polys.data.get(), n, tlde.data.get(), M, (int)W, log_M, log_Bl);
     ms.lde = clk.lap();
     // 3. row hashes, Merkle tree, commit [a5, a6, a8]
-    Commitment tcom = commit_matrix(tlde);
+    Commitment tcom = commit_matrix(tlde);          // synchronises the stream: the last trace row has arrived as well
+    for (uint32_t k = 0; k < W / 2; k++) air.results[k] = h_last_row[2 * k + 1];
+    if (pub_out) *pub_out = air.results;
+    HostCoin coin = HostCoin::from_elements(air.results.data(), (uint32_t)air.results.size());
     wdigest(proof.commitments, tcom.root);
     coin.reseed(tcom.root);
     // 3b. auxiliary segment [a8; stark_verifier.cairo:266-294]: draw the random elements, build the columns (prefix products
@@ -997,30 +1004,9 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
                 return L + (u & ((1ull << c.leaf_parts_log) - 1)) * (L >> c.leaf_parts_log) + (u >> c.leaf_parts_log);
             return L + u;
         };
-        // index block (u64): [pos | fpos_0.. | per tree: stored node indices, then unstored (recomputed) node indices]
-        std::vector<uint64_t> idx;
-        for (uint64_t p : pos) idx.push_back(local_row(p, G > 1));
-        std::vector<size_t> fpos_off(layers), plan_off(coms.size()), plan_cnt(coms.size()), plan_hi(coms.size());
-        std::vector<std::vector<size_t>> plan_slot(coms.size());   // item k of the plan (in plan order) -> slot in the tree's block
-        for (int l = 0; l < layers; l++) { fpos_off[l] = idx.size(); for (uint64_t p : fpos[l]) idx.push_back(local_row(p, fri_sharded[l])); }
-        for (size_t t = 0; t < coms.size(); t++) {
-            plan_off[t] = idx.size();
-            const MerkleTree& tree = coms[t]->tree;
-            if (G > 1 && tree.skip) fail("sharded prove: tree with unstored levels", ST_INTERNAL);
-            std::vector<uint64_t> hi, lo;
-            for (auto& v : plans[t]) for (uint64_t i : v) {
-                const bool stored = G > 1 || i < tree.stored_limit();
-                (stored ? hi : lo).push_back(G > 1 ? local_node(i, *coms[t]) : i);
-            }
-            size_t nh = 0, nl = 0;
-            for (auto& v : plans[t]) for (uint64_t i : v) plan_slot[t].push_back((G > 1 || i < tree.stored_limit()) ? nh++ : hi.size() + nl++);
-            if (!lo.empty() && tree.src_kind == 0) fail("batch opening: tree has unstored levels but no leaf source", ST_INTERNAL);
-            idx.insert(idx.end(), hi.begin(), hi.end());
-            idx.insert(idx.end(), lo.begin(), lo.end());
-            plan_hi[t] = hi.size();
-            plan_cnt[t] = hi.size() + lo.size();
-        }
-        // value block (u64): [trace rows | comp rows | fri rows per layer | remainder | digests (4 u64 each) per tree]
+        // Openings: every source address is known on the host, so ONE address list goes up, ONE kernel gathers every value and
+        // digest, and the (few) unstored low tree nodes are recomputed behind it. Value block (u64):
+        //   [trace rows | comp rows | aux rows | fri rows per layer | remainder | digests (4 u64 each) per tree]
         size_t voff = 0;
         const size_t off_trows = voff; voff += Q * tw;
         const size_t off_crows = voff; voff += Q * cw;
@@ -1028,67 +1014,117 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         std::vector<size_t> off_frows(layers);
         for (int l = 0; l < layers; l++) { off_frows[l] = voff; voff += fpos[l].size() * Fd * F::DEG; }
         const size_t off_rem = voff; voff += (size_t)F::DEG * rem_dom;
-        std::vector<size_t> off_dig(coms.size());
-        for (size_t t = 0; t < coms.size(); t++) { off_dig[t] = voff; voff += plan_cnt[t] * 4; }
-        uint64_t* h_idx = (uint64_t*)ctx->stage_alloc(idx.size() * 8);
-        memcpy(h_idx, idx.data(), idx.size() * 8);
-        uint64_t* h_val = (uint64_t*)ctx->stage_alloc(voff * 8);
-        DevBuf<uint64_t> d_idx(ctx, idx.size()), d_val(ctx, voff);
-        AERO_HIP(hipMemcpyAsync(d_idx.get(), h_idx, idx.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        launch_gather_rows(ctx, tlde.data.get(), M, (int)tw, d_idx.get(), (int)Q, d_val.get() + off_trows);
-        launch_gather_rows(ctx, clde.data.get(), M, (int)cw, d_idx.get(), (int)Q, d_val.get() + off_crows);
-        if (A) launch_gather_rows(ctx, alde.data.get(), M, (int)aw, d_idx.get(), (int)Q, d_val.get() + off_arows);
+        const size_t n_u64 = voff;
+        auto A64 = [](const void* p) { return (uint64_t)(uintptr_t)p; };
+        std::vector<uint64_t> addr(n_u64, 0);
+        for (size_t q = 0; q < Q; q++) {
+            const uint64_t r = local_row(pos[q], G > 1);
+            if (r == GATHER_SKIP) continue;
+            for (size_t c = 0; c < tw; c++) addr[off_trows + q * tw + c] = A64(tlde.data.get() + c * M + r);
+            for (size_t c = 0; c < cw; c++) addr[off_crows + q * cw + c] = A64(clde.data.get() + c * M + r);
+            for (size_t c = 0; c < aw; c++) addr[off_arows + q * aw + c] = A64(alde.data.get() + c * M + r);
+        }
         {
             uint64_t Dom = N;
             for (int l = 0; l < layers; l++) {
                 const size_t dom = Dom / (fri_sharded[l] ? G : 1), rows = dom / Fd;
-                launch_gather_fri_rows(ctx, fri_vals[l].get(), fri_vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd,
-                                       d_idx.get() + fpos_off[l], (int)fpos[l].size(), d_val.get() + off_frows[l]);
+                const uint64_t* comp[2] = {fri_vals[l].get(), fri_vals[l].get() + (F::DEG > 1 ? dom : 0)};
+                for (size_t q = 0; q < fpos[l].size(); q++) {
+                    const uint64_t r = local_row(fpos[l][q], fri_sharded[l]);
+                    if (r == GATHER_SKIP) continue;
+                    for (size_t j = 0; j < Fd; j++) for (int d = 0; d < F::DEG; d++)
+                        addr[off_frows[l] + (q * Fd + j) * F::DEG + d] = A64(comp[d] + r + j * rows);
+                }
                 Dom /= Fd;
             }
         }
-        if (G == 1 || rank == 0)
-            AERO_HIP(hipMemcpyAsync(d_val.get() + off_rem, fri_vals[layers].get(), (size_t)F::DEG * rem_dom * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        else
-            AERO_HIP(hipMemsetAsync(d_val.get() + off_rem, 0, (size_t)F::DEG * rem_dom * 8, ctx->stream));
+        if (G == 1 || rank == 0) for (size_t i = 0; i < (size_t)F::DEG * rem_dom; i++) addr[off_rem + i] = A64(fri_vals[layers].get() + i);
+        // digests: per tree the plan's items in plan order; unstored low nodes (address 0 here) are recomputed into their slots
+        std::vector<size_t> off_dig(coms.size());
+        std::vector<std::vector<uint64_t>> low_idx(coms.size());       // heap indices of the unstored nodes a plan needs
+        std::vector<std::vector<uint32_t>> low_slot(coms.size());      // their item numbers within the tree's digest block
+        size_t n_dig = 0;
         for (size_t t = 0; t < coms.size(); t++) {
+            off_dig[t] = n_u64 + 4 * n_dig;
             const MerkleTree& tree = coms[t]->tree;
-            Digest* dout = reinterpret_cast<Digest*>(d_val.get() + off_dig[t]);
-            const int nh = (int)plan_hi[t], nl = (int)(plan_cnt[t] - plan_hi[t]);
-            if (nh) launch_gather_digests(ctx, tree.nodes.get(), d_idx.get() + plan_off[t], nh, dout);
-            if (nl) {
-                if (tree.src_kind == 1) ctx->merkle_recompute(tree.row_src, tree.n, d_idx.get() + plan_off[t] + nh, nl, dout + nh);
-                else ctx->merkle_recompute(tree.fri_src, tree.n, d_idx.get() + plan_off[t] + nh, nl, dout + nh);
+            if (G > 1 && tree.skip) fail("sharded prove: tree with unstored levels", ST_INTERNAL);
+            uint32_t k = 0;
+            for (auto& v : plans[t]) for (uint64_t i : v) {
+                uint64_t a = 0;
+                if (G > 1) { const uint64_t li = local_node(i, *coms[t]); if (li != GATHER_SKIP) a = A64(tree.nodes.get() + li); }
+                else if (i < tree.stored_limit()) a = A64(tree.nodes.get() + i);
+                else { low_idx[t].push_back(i); low_slot[t].push_back(k); }
+                addr.push_back(a);
+                k++;
+            }
+            if (!low_idx[t].empty() && tree.src_kind == 0) fail("batch opening: tree has unstored levels but no leaf source", ST_INTERNAL);
+            n_dig += k;
+        }
+        voff = n_u64 + 4 * n_dig;
+        size_t n_low = 0;
+        for (auto& v : low_idx) n_low += v.size();
+        uint64_t* h_addr = (uint64_t*)ctx->stage_alloc((addr.size() + n_low) * 8);
+        memcpy(h_addr, addr.data(), addr.size() * 8);
+        {
+            size_t o = addr.size();
+            for (auto& v : low_idx) { memcpy(h_addr + o, v.data(), v.size() * 8); o += v.size(); }
+        }
+        uint64_t* h_val = (uint64_t*)ctx->stage_alloc((voff + 4 * n_low) * 8);
+        DevBuf<uint64_t> d_addr(ctx, addr.size() + n_low), d_val(ctx, voff + 4 * n_low);
+        AERO_HIP(hipMemcpyAsync(d_addr.get(), h_addr, (addr.size() + n_low) * 8, hipMemcpyHostToDevice, ctx->stream));
+        launch_gather_addr(ctx, d_addr.get(), (uint32_t)n_u64, (uint32_t)n_dig, d_val.get());
+        {
+            // recomputed low nodes land behind the value block (one compact run per tree) and are patched in on the host
+            size_t o = 0;
+            for (size_t t = 0; t < coms.size(); t++) {
+                const int nl = (int)low_idx[t].size();
+                if (!nl) continue;
+                const MerkleTree& tree = coms[t]->tree;
+                Digest* dout = reinterpret_cast<Digest*>(d_val.get() + voff) + o;
+                if (tree.src_kind == 1) ctx->merkle_recompute(tree.row_src, tree.n, d_addr.get() + addr.size() + o, nl, dout);
+                else ctx->merkle_recompute(tree.fri_src, tree.n, d_addr.get() + addr.size() + o, nl, dout);
+                o += nl;
             }
         }
         if (G > 1) comm_all_reduce(d_val.get(), voff);
-        AERO_HIP(hipMemcpyAsync(h_val, d_val.get(), voff * 8, hipMemcpyDeviceToHost, ctx->stream));
+        AERO_HIP(hipMemcpyAsync(h_val, d_val.get(), (voff + 4 * n_low) * 8, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
+        {
+            size_t o = 0;
+            for (size_t t = 0; t < coms.size(); t++)
+                for (size_t k = 0; k < low_slot[t].size(); k++, o++) memcpy(h_val + off_dig[t] + 4 * (size_t)low_slot[t][k], h_val + voff + 4 * o, 32);
+        }
         auto paths = [&](size_t t) {
             const Digest* raw = reinterpret_cast<const Digest*>(h_val + off_dig[t]);
-            std::vector<Digest> ordered(plan_slot[t].size());
+            size_t cnt = 0;
+            for (auto& v : plans[t]) cnt += v.size();
+            std::vector<Digest> ordered(cnt);
             size_t k = 0;
             for (auto& v : plans[t]) for (uint64_t i : v) {
-                ordered[k] = (coms[t]->sharded && i < 2 * (uint64_t)G) ? coms[t]->top[i] : raw[plan_slot[t][k]];
+                ordered[k] = (coms[t]->sharded && i < 2 * (uint64_t)G) ? coms[t]->top[i] : raw[k];
                 k++;
             }
             return serialize_batch(plans[t], ordered.data());
         };
+        auto put = [&](Bytes& b, size_t off, size_t count) {      // `count` little-endian u64 from the value block
+            const uint8_t* p8 = reinterpret_cast<const uint8_t*>(h_val + off);
+            b.insert(b.end(), p8, p8 + 8 * count);
+        };
         QueriesBytes tq;
-        for (size_t i = 0; i < Q * tw; i++) w64(tq.values, h_val[off_trows + i]);
+        put(tq.values, off_trows, Q * tw);
         tq.paths = paths(0);
         proof.trace_queries.push_back(tq);
         if (A) {
             QueriesBytes aq;
-            for (size_t i = 0; i < Q * aw; i++) w64(aq.values, h_val[off_arows + i]);
+            put(aq.values, off_arows, Q * aw);
             aq.paths = paths(2);
             proof.trace_queries.push_back(aq);
         }
-        for (size_t i = 0; i < Q * cw; i++) w64(proof.constraint_queries.values, h_val[off_crows + i]);
+        put(proof.constraint_queries.values, off_crows, Q * cw);
         proof.constraint_queries.paths = paths(1);
         for (int l = 0; l < layers; l++) {
             QueriesBytes q;
-            for (size_t i = 0; i < fpos[l].size() * Fd * F::DEG; i++) w64(q.values, h_val[off_frows[l] + i]);
+            put(q.values, off_frows[l], fpos[l].size() * Fd * F::DEG);
             q.paths = paths(fri_tree0 + l);
             proof.fri_layers.push_back(q);
         }

@@ -184,7 +184,8 @@ public:
     MerkleTree commit_to_rows(const Matrix& lde, bool keep_low_levels = true);
     MerkleTree commit_fri_layer(const FriSrc& src, bool keep_low_levels = false);
     // same without waiting for the root: root_host is NOT set; the root sits in nodes[1] on the device
-    MerkleTree commit_fri_layer_async(const FriSrc& src);
+    // `coin` (optional): the tree build's last launch also reseeds the device coin with the root and draws the folding challenge
+    MerkleTree commit_fri_layer_async(const FriSrc& src, const CoinStep* coin = nullptr);
 
     // H on the constraint domain (components [DEG][ce_n], evaluations on h<w_ce>) -> coefficients of the C column
     // polynomials, in place: chunk c of component d = column c (internal form, pre-scaled by h^i)   [a11]

@@ -579,6 +579,29 @@ __global__ void gather_digests_kernel(const Digest* nodes, const uint64_t* idx, 
     Digest z{};
     out[t] = i == GATHER_SKIP ? z : nodes[i];
 }
+// All openings of a proof in ONE launch: item t < n_u64 copies the u64 at device address addr[t]; the following n_dig items copy
+// the 32-byte digest at addr[n_u64 + i] to out + n_u64 + 4 i. Address 0 yields zeros (item owned by another shard, or a low tree
+// node that merkle_recompute fills in afterwards).
+__global__ __launch_bounds__(256) void gather_addr_kernel(const uint64_t* __restrict__ addr, uint32_t n_u64, uint32_t n_dig, uint64_t* __restrict__ out) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n_u64) {
+        const uint64_t* p = reinterpret_cast<const uint64_t*>(addr[t]);
+        out[t] = p ? *p : 0;
+    } else if (t < n_u64 + n_dig) {
+        const uint32_t i = t - n_u64;
+        const ulonglong2* p = reinterpret_cast<const ulonglong2*>(addr[t]);
+        ulonglong2 a = make_ulonglong2(0, 0), b = a;
+        if (p) { a = p[0]; b = p[1]; }
+        uint64_t* o = out + n_u64 + 4 * (size_t)i;
+        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+    }
+}
+void launch_gather_addr(Context* ctx, const uint64_t* addr, uint32_t n_u64, uint32_t n_dig, uint64_t* out) {
+    const uint32_t n = n_u64 + n_dig;
+    if (!n) return;
+    AERO_LAUNCH(ctx, "gather_addr_kernel", 0, gather_addr_kernel, dim3((n + 255) / 256), dim3(256), 0, addr, n_u64, n_dig, out);
+    ctx->check_launch("gather_addr");
+}
 void launch_gather_rows(Context* ctx, const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out) {
     int n = npos * ncols;
     AERO_LAUNCH(ctx, "gather_rows_kernel", 0, gather_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, cols, col_stride, ncols, pos, npos, out);

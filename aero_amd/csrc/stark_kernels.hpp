@@ -113,6 +113,7 @@ void launch_gather_fri_rows(Context* ctx, const uint64_t* c0, const uint64_t* c1
 void launch_gather_digests(Context* ctx, const Digest* nodes, const uint64_t* idx, int n, Digest* out);
 // In all three gathers an index of GATHER_SKIP yields zeros (the item belongs to another shard).
 constexpr uint64_t GATHER_SKIP = ~0ull;
+void launch_gather_addr(Context* ctx, const uint64_t* addr, uint32_t n_u64, uint32_t n_dig, uint64_t* out);
 // out[u * parts + k] = in[k * src_stride + u], u < len: merges `parts` equally long pieces into their interleaved order
 void launch_interleave_digests(Context* ctx, const Digest* in, size_t src_stride, Digest* out, int parts, size_t len);
 void launch_interleave_u64(Context* ctx, const uint64_t* in, size_t src_stride, uint64_t* out, int parts, size_t len);
