@@ -75,6 +75,25 @@ struct CoinStep {
     int deg = 1;
 };
 
+// The small end of the FRI commit phase in ONE launch (hash.hip: fri_tail_kernel): every layer whose domain has at most
+// FRI_TAIL_MAX_DOM points - leaf hashing, tree, transcript step and fold, layer after layer, by a single workgroup working out of
+// LDS. These layers are pure latency (a 2^11-point layer cannot fill one CU, let alone 256), and as separate launches each of
+// them costs four kernel boundaries.
+constexpr int FRI_TAIL_MAX_DOM = 4096;
+constexpr int FRI_TAIL_MAX_ROWS = 512;      // rows (= leaves) of the first tail layer: one per thread of the workgroup
+constexpr int FRI_TAIL_MAX_LAYERS = 13;
+struct FriTailArgs {
+    int deg, n_layers;                          // n_layers commitments (the last one has no fold behind it)
+    uint32_t dom0;                              // domain size of the first tail layer
+    const uint64_t* vals0;                      // its evaluations: [deg][dom0]
+    uint64_t* vals_out[FRI_TAIL_MAX_LAYERS];    // evaluations of tail layer i + 1: [deg][dom_(i+1)], i < n_layers - 1
+    Digest* nodes[FRI_TAIL_MAX_LAYERS];         // tree of tail layer i: 2 * rows_i slots (rows_i = 1: the root in slot 1)
+    Digest* roots_out;                          // n_layers roots
+    Digest* seed_io;                            // coin seed, reseeded with every root
+    uint64_t* alphas_out;                       // deg u64 per layer
+    uint64_t gen_inv, fold_inv, w_inv0;         // 1 / domain offset, 1 / fold, w_dom0^-1
+};
+
 // One context = one device + one stream. Not thread-safe: one host thread drives it (SURVEY 8b "Threading").
 class Context {
 public:
@@ -132,6 +151,8 @@ public:
     void merkle_build(Digest* nodes, size_t n, const CoinStep* coin = nullptr);
     // same when the leaf level holds 2^log_parts pieces in arrival order (leaf u in slot n + (u mod parts)*(n/parts) + u/parts)
     void merkle_build_parts(Digest* nodes, size_t n, int log_parts);
+    // fold = 2, 4 or 8; see FriTailArgs
+    void fri_tail(const FriTailArgs& a, int fold);
     // levels above a stored level of c nodes (heap indices [c, 2c)) up to the root
     void merkle_upper(Digest* nodes, size_t c, const CoinStep* coin = nullptr);
     // fused leaf hashing + whole tree; the lowest `skip` (0 or 3) levels are not stored (nodes holds 2n >> skip slots)

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "aero_internal.hpp"
+#include "dft_small.cuh"
 
 namespace aero {
 
@@ -134,18 +135,37 @@ template <class Src> __global__ __launch_bounds__(256) void merkle_leaf8_kernel(
 // The 8 leaf hashes of a thread as straight-line code by construction: with two compressions per leaf (3 or 4 columns) the
 // compiler declines `#pragma unroll` on the leaf loop (23 compression bodies) and the digest array goes to scratch.
 template <int NC, int I> struct LeafUnroll {
-    static __device__ __forceinline__ void run(const RowSrc& src, size_t first, Digest (&d)[8], Digest* nodes, size_t n, int skip) {
-        d[I] = leaf_digest_fixed<NC>(src, first + I);
+    static __device__ __forceinline__ void run(const uint64_t (&e)[NC][8], Digest (&d)[8], Digest* nodes, size_t n, size_t first, int skip) {
+        b2s::State st;
+        b2s::init(st);
+#pragma unroll
+        for (int c = 0; c < NC; c += 2) {
+            const bool two = c + 1 < NC;
+            const uint32_t t = (uint32_t)(two ? c + 2 : c + 1) * 32;
+            b2s::compress_elems(st, e[c][I], two ? e[c + 1 < NC ? c + 1 : c][I] : 0, two, t, t == (uint32_t)NC * 32);
+        }
+        d[I] = state_digest(st);
         if (skip == 0) store_digest(&nodes[n + first + I], d[I]);
-        if constexpr (I + 1 < 8) LeafUnroll<NC, I + 1>::run(src, first, d, nodes, n, skip);
+        if constexpr (I + 1 < 8) LeafUnroll<NC, I + 1>::run(e, d, nodes, n, first, skip);
     }
 };
+// A thread's 8 rows are 64 contiguous bytes per column: they are fetched up front with four 16-byte loads per column, so every
+// sector that comes in from HBM is consumed at once. (With the loads left next to the compression that uses them the PMC
+// counters showed 229 MB fetched per 2^23-row tree for 134 MB of data: by the time a lane came back for the next element of a
+// line - one 960-instruction compression later - the line had often left the L2.)
 template <int NC> __global__ __launch_bounds__(256) void merkle_leaf8_rows_kernel(RowSrc src, Digest* nodes, size_t n, int skip) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n / 8) return;
     const size_t first = t * 8;
+    uint64_t e[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const ulonglong2* p = reinterpret_cast<const ulonglong2*>(src.cols + (size_t)c * src.stride + first);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const ulonglong2 v = p[k]; e[c][2 * k] = v.x; e[c][2 * k + 1] = v.y; }
+    }
     Digest d[8];
-    LeafUnroll<NC, 0>::run(src, first, d, nodes, n, skip);
+    LeafUnroll<NC, 0>::run(e, d, nodes, n, first, skip);
     build3(d, nodes, n + first, skip > 1 ? skip : 1);
 }
 
@@ -301,6 +321,142 @@ __global__ __launch_bounds__(256) void merkle_multi_quad_kernel(Digest* nodes, s
         }
     }
     if (cs.seed_io && m == 1 && tid == 0) coin_step(cs, buf[0]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FRI tail (FriTailArgs): one workgroup of 512 threads, the current layer's evaluations and the tree level under construction
+// live in LDS; global memory only receives what the opening phase reads later (evaluations, tree nodes, roots).
+template <int LOGF> __global__ __launch_bounds__(512) void fri_tail_kernel(FriTailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t tail_lds[];
+    constexpr int FD = 1 << LOGF;
+    const int tid = threadIdx.x, q = tid >> 2, j = tid & 3;
+    const int deg = a.deg;
+    uint64_t* v0 = tail_lds;
+    uint64_t* v1 = tail_lds + (deg > 1 ? a.dom0 : 0);
+    Digest* dig = reinterpret_cast<Digest*>(tail_lds + (size_t)deg * a.dom0);     // up to 512 digests (+ 1 spare for single-leaf layers)
+    __shared__ uint64_t s_alpha[2];
+    for (uint32_t i = tid; i < a.dom0 * (uint32_t)deg; i += 512) tail_lds[i] = a.vals0[i];
+    uint32_t pk[10];
+#pragma unroll
+    for (int rd = 0; rd < 10; rd++)
+        pk[rd] = (uint32_t)QUAD_SIGMA[rd][2 * j] | ((uint32_t)QUAD_SIGMA[rd][2 * j + 1] << 4) | ((uint32_t)QUAD_SIGMA[rd][8 + 2 * j] << 8) |
+                 ((uint32_t)QUAD_SIGMA[rd][8 + 2 * j + 1] << 12);
+    __syncthreads();
+    uint32_t dom = a.dom0;
+    uint64_t w_inv = a.w_inv0;
+    uint32_t* words = reinterpret_cast<uint32_t*>(dig);
+    for (int L = 0; L < a.n_layers; L++) {
+        const uint32_t rows = dom >> LOGF;
+        Digest* nodes = a.nodes[L];
+        // leaves: row t = (v[t + j rows])_j, each value deg components
+        const FriSrc src{v0, v1, deg, rows, FD};
+        for (uint32_t t = tid; t < rows; t += 512) {
+            const Digest d = leaf_digest(src, t);
+            dig[t] = d;
+            store_digest(&nodes[rows > 1 ? rows + t : 1], d);
+        }
+        __syncthreads();
+        // tree: one lane per node while a level has more than 64 nodes, a quad per node below that (merkle_multi_quad_kernel)
+        for (uint32_t w = rows >> 1; w >= 1; w >>= 1) {
+            if (w > 64) {
+                Digest v;
+                if ((uint32_t)tid < w) v = b2s::merge(dig[2 * tid], dig[2 * tid + 1]);
+                __syncthreads();
+                if ((uint32_t)tid < w) { dig[tid] = v; store_digest(&nodes[w + tid], v); }
+                __syncthreads();
+            } else {
+                const bool live = (uint32_t)q < w;
+                uint32_t lo, hi;
+                quad_merge(words + (live ? 16 * q : 0), j, pk, lo, hi);
+                __syncthreads();
+                if (live) {
+                    words[8 * q + j] = lo; words[8 * q + 4 + j] = hi;
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(&nodes[w + q]);
+                    dst[j] = lo; dst[4 + j] = hi;
+                }
+                __syncthreads();
+            }
+        }
+        // transcript: reseed with the root, draw the folding challenge
+        if (tid == 0) {
+            const Digest root = dig[0];
+            store_digest(&a.roots_out[L], root);
+            const Digest seed = b2s::merge(*a.seed_io, root);
+            *a.seed_io = seed;
+            uint64_t a0 = 0, a1 = 0;
+            for (uint64_t ctr = 1; ctr < 1000; ctr++) {
+                const Digest d = b2s::merge_with_int(seed, ctr);
+                const uint64_t x0 = (uint64_t)d.w[0] | ((uint64_t)d.w[1] << 32), x1 = (uint64_t)d.w[2] | ((uint64_t)d.w[3] << 32);
+                if (x0 < gl::P && (deg == 1 || x1 < gl::P)) { a0 = x0; a1 = deg > 1 ? x1 : 0; break; }
+            }
+            s_alpha[0] = a0; s_alpha[1] = a1;
+            a.alphas_out[(size_t)L * deg] = a0;
+            if (deg > 1) a.alphas_out[(size_t)L * deg + 1] = a1;
+        }
+        __syncthreads();
+        if (L + 1 == a.n_layers) break;
+        // fold (stark.hip fri_fold_fft_kernel): inverse DFT of the row in registers, Horner in alpha / x_t, x_t = offset * w_dom^t
+        uint64_t r0 = 0, r1 = 0;
+        const bool act = (uint32_t)tid < rows;
+        if (act) {
+            uint64_t y0[FD], y1[FD];
+#pragma unroll
+            for (int k = 0; k < FD; k++) { y0[k] = v0[tid + k * rows]; y1[k] = deg > 1 ? v1[tid + k * rows] : 0; }
+            dft_dif_inv<LOGF>(y0);
+            if (deg > 1) dft_dif_inv<LOGF>(y1);
+            const uint64_t xinv = gl::mul(a.gen_inv, gl::pow(w_inv, (uint64_t)tid));
+            if (deg == 1) {
+                const uint64_t r = gl::mul(s_alpha[0], xinv);
+                uint64_t acc = 0;
+#pragma unroll
+                for (int k = FD - 1; k >= 0; k--) acc = gl::add(gl::mul(acc, r), y0[(int)gl::bitrev((uint32_t)k, LOGF)]);
+                r0 = gl::mul(acc, a.fold_inv);
+            } else {
+                const gl::E2 r = gl::mulb(gl::E2{s_alpha[0], s_alpha[1]}, xinv);
+                gl::E2 acc{0, 0};
+#pragma unroll
+                for (int k = FD - 1; k >= 0; k--) {
+                    const int p = (int)gl::bitrev((uint32_t)k, LOGF);
+                    acc = gl::add(gl::mul(acc, r), gl::E2{y0[p], y1[p]});
+                }
+                acc = gl::mulb(acc, a.fold_inv);
+                r0 = acc.a0; r1 = acc.a1;
+            }
+        }
+        __syncthreads();          // every row has been read: the next layer may overwrite the buffer
+        // layout [deg][dom] for every layer: the next layer's second component sits right behind its first
+        uint64_t* nv1 = v0 + rows;
+        if (act) {
+            v0[tid] = r0;
+            a.vals_out[L][tid] = r0;
+            if (deg > 1) { nv1[tid] = r1; a.vals_out[L][rows + tid] = r1; }
+        }
+        v1 = deg > 1 ? nv1 : v0;
+        __syncthreads();
+        dom = rows;
+        uint64_t wn = w_inv;
+#pragma unroll
+        for (int k = 0; k < LOGF; k++) wn = gl::sqr(wn);
+        w_inv = wn;
+    }
+}
+void Context::fri_tail(const FriTailArgs& a, int fold) {
+    if (a.dom0 > (uint32_t)FRI_TAIL_MAX_DOM || a.dom0 / (uint32_t)fold > (uint32_t)FRI_TAIL_MAX_ROWS || a.n_layers < 1 || a.n_layers > FRI_TAIL_MAX_LAYERS)
+        fail("fri_tail: bad shape", ST_INTERNAL);
+    const size_t lds = (size_t)a.deg * a.dom0 * 8 + 513 * sizeof(Digest);
+    static bool attr_set = false;
+    if (!attr_set) {   // up to 2 x 4096 evaluations + 513 digests: above the 64 KiB default limit of dynamic LDS
+        const int cap = 2 * FRI_TAIL_MAX_DOM * 8 + 513 * (int)sizeof(Digest);
+        AERO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fri_tail_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        AERO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fri_tail_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        AERO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fri_tail_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        attr_set = true;
+    }
+    if (fold == 8) AERO_LAUNCH(this, "fri_tail_kernel", 0, fri_tail_kernel<3>, dim3(1), dim3(512), lds, a);
+    else if (fold == 4) AERO_LAUNCH(this, "fri_tail_kernel", 0, fri_tail_kernel<2>, dim3(1), dim3(512), lds, a);
+    else if (fold == 2) AERO_LAUNCH(this, "fri_tail_kernel", 0, fri_tail_kernel<1>, dim3(1), dim3(512), lds, a);
+    else fail("fri_tail: folding factor must be 2, 4 or 8", ST_INTERNAL);
+    check_launch("fri_tail");
 }
 
 // Recompute unstored low nodes for openings: out[q] = digest of heap node idx[q] (height h < 3 above the leaves).

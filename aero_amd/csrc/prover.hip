@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <set>
 
@@ -243,25 +244,29 @@ int num_fri_layers(uint64_t domain, uint64_t fold, uint64_t max_remainder) {
 }
 
 std::vector<std::vector<uint64_t>> batch_proof_indices(size_t n, const std::vector<uint64_t>& positions) {
-    std::set<uint64_t> qs(positions.begin(), positions.end());
-    if (qs.size() != positions.size()) fail("batch opening: duplicate positions");
-    std::set<uint64_t> norm;
-    for (uint64_t p : positions) {
-        if (p >= n) fail("batch opening: position out of range");
-        norm.insert(p - (p & 1));
-    }
+    // sorted copies instead of tree sets: this runs on the critical path of every proof (once per committed tree)
+    std::vector<uint64_t> qs(positions);
+    std::sort(qs.begin(), qs.end());
+    if (std::adjacent_find(qs.begin(), qs.end()) != qs.end()) fail("batch opening: duplicate positions");
+    if (!qs.empty() && qs.back() >= n) fail("batch opening: position out of range");
+    std::vector<uint64_t> norm;                       // even partners, sorted, unique
+    norm.reserve(qs.size());
+    for (uint64_t p : qs) { const uint64_t e = p - (p & 1); if (norm.empty() || norm.back() != e) norm.push_back(e); }
     int depth = 0;
     while (((size_t)1 << depth) < n) depth++;
-    std::vector<std::vector<uint64_t>> nodes;
+    std::vector<std::vector<uint64_t>> nodes(norm.size());
     std::vector<uint64_t> next;
-    for (uint64_t e : norm) {
-        std::vector<uint64_t> miss;
-        for (uint64_t i = e; i < e + 2; i++) if (!qs.count(i)) miss.push_back(n + i);
-        nodes.push_back(miss);
+    next.reserve(norm.size());
+    for (size_t v = 0; v < norm.size(); v++) {
+        const uint64_t e = norm[v];
+        nodes[v].reserve(depth + 1);
+        for (uint64_t i = e; i < e + 2; i++) if (!std::binary_search(qs.begin(), qs.end(), i)) nodes[v].push_back(n + i);
         next.push_back((e + n) >> 1);
     }
+    std::vector<uint64_t> idx;
+    idx.reserve(norm.size());
     for (int lvl = 1; lvl < depth; lvl++) {
-        std::vector<uint64_t> idx = next;
+        idx.swap(next);
         next.clear();
         size_t i = 0;
         while (i < idx.size()) {
@@ -536,6 +541,12 @@ DevBuf<uint64_t> Prover::deep_compose(const uint64_t* tlde, const uint64_t* clde
     pp.commit();
     a.ood_cur = pp.ptr<T>(i0); a.ood_next = pp.ptr<T>(i1); a.ood_h = pp.ptr<T>(i2);
     a.da = pp.ptr<T>(i3); a.db = pp.ptr<T>(i4); a.dg = pp.ptr<T>(i5); a.dc = pp.ptr<T>(i6);
+    if (log_bl == 0) {
+        // a shard of exactly n rows (world = blowup): the n-point coset IS the local domain - no interpolation, no extension
+        for (int d = 0; d < F::DEG; d++) a.out[d] = out.get() + (size_t)d * n;
+        launch_deep<F>(ctx, a);
+        return out;
+    }
     for (int d = 0; d < F::DEG; d++) a.out[d] = dsm.get() + (size_t)d * n;
     launch_deep<F>(ctx, a);
     ctx->ntt_inverse(dsm.get(), n, F::DEG, log_n, 1, 1, 1, 0);
@@ -568,7 +579,14 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
     AERO_HIP(hipMemcpyAsync(d_seed, h_seed, sizeof(Digest), hipMemcpyHostToDevice, ctx->stream));
     Digest* h_roots = (Digest*)ctx->stage_alloc(sizeof(Digest) * (fl.layers + 1));
     uint64_t dom = N;
-    for (int l = 0; l <= fl.layers; l++) {
+    // layers of at most FRI_TAIL_MAX_DOM points are pure latency: they all go into ONE single-workgroup launch (Context::fri_tail)
+    int tail0 = fl.layers + 1;
+    if (fri_tail && (Fd == 2 || Fd == 4 || Fd == 8)) {
+        uint64_t d = N;
+        for (int l = 0; l <= fl.layers; l++, d /= Fd)
+            if (d <= (uint64_t)FRI_TAIL_MAX_DOM && d / Fd <= (uint64_t)FRI_TAIL_MAX_ROWS && fl.layers + 1 - l <= FRI_TAIL_MAX_LAYERS) { tail0 = l; break; }
+    }
+    for (int l = 0; l < tail0; l++) {
         const size_t rows = dom / Fd;
         const FriSrc fsrc{fl.vals[l].get(), fl.vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd};
         Commitment c;
@@ -590,6 +608,29 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
         for (size_t m = 0; m < Fd; m++) a.dft[m] = gl::pow(wFi, m);
         launch_fri_fold<F>(ctx, a);
         dom = rows;
+    }
+    if (tail0 <= fl.layers) {
+        FriTailArgs t{};
+        t.deg = F::DEG; t.n_layers = fl.layers + 1 - tail0; t.dom0 = (uint32_t)dom; t.vals0 = fl.vals[tail0].get();
+        Digest* d_roots = (Digest*)ctx->scratch_alloc(sizeof(Digest) * t.n_layers);
+        uint64_t dd = dom;
+        for (int i = 0; i < t.n_layers; i++) {
+            const size_t rows = dd / Fd;
+            Commitment c;
+            c.tree = MerkleTree(ctx, rows < 2 ? 1 : rows, 0);
+            c.n_global = rows;
+            t.nodes[i] = c.tree.nodes.get();
+            fl.coms.push_back(std::move(c));
+            if (i + 1 < t.n_layers) {
+                fl.vals.emplace_back(ctx, (size_t)F::DEG * rows);
+                t.vals_out[i] = fl.vals.back().get();
+            }
+            dd = rows;
+        }
+        t.roots_out = d_roots; t.seed_io = d_seed; t.alphas_out = reinterpret_cast<uint64_t*>(d_alpha + tail0);
+        t.gen_inv = gen_inv; t.fold_inv = gl::inv(Fd); t.w_inv0 = gl::inv(gl::root_of_unity(ilog2(dom)));
+        ctx->fri_tail(t, (int)Fd);
+        AERO_HIP(hipMemcpyAsync(h_roots + tail0, d_roots, sizeof(Digest) * t.n_layers, hipMemcpyDeviceToHost, ctx->stream));
     }
     AERO_HIP(hipMemcpyAsync(h_seed, d_seed, sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
@@ -972,7 +1013,16 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     // 11. queries [a17]: every position / node index is known up front, so all gathers are issued behind ONE upload and
     //     read back with ONE download (one stream synchronisation for the whole opening phase). Sharded: every rank lays
     //     out the same value block, fills the items it owns (zeros elsewhere) and ONE all-reduce completes it everywhere.
+    static const bool q_timing = getenv("AERO_QUERY_TIMING") != nullptr;
+    auto q_t0 = std::chrono::steady_clock::now();
+    auto q_lap = [&](const char* what) {
+        if (!q_timing) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "  queries/%s: %.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - q_t0).count());
+        q_t0 = t1;
+    };
     std::vector<uint64_t> pos = coin.draw_integers(opt_.num_queries, N);
+    q_lap("draw_positions");
     {
         const size_t Q = pos.size(), tw = W, aw = (size_t)A * F::DEG, cw = C * F::DEG;
         std::vector<std::vector<uint64_t>> fpos(layers);
@@ -984,9 +1034,10 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         const uint64_t rem_dom = N / [&] { uint64_t d = 1; for (int l = 0; l < layers; l++) d *= Fd; return d; }();
         // node index plans per tree (global heap indices): trace, composition, FRI layers
         std::vector<const Commitment*> coms{&tcom, &ccom};
-        std::vector<std::vector<std::vector<uint64_t>>> plans{batch_proof_indices(N, pos), batch_proof_indices(N, pos)};
+        std::vector<std::vector<std::vector<uint64_t>>> plans{batch_proof_indices(N, pos)};
+        plans.push_back(plans[0]);                     // same positions, same tree shape: trace and composition share the plan
         const size_t fri_tree0 = A ? 3 : 2;          // tree order: trace, composition, [aux], FRI layers
-        if (A) { coms.push_back(&acom); auto aux_plan = plans[0]; plans.push_back(std::move(aux_plan)); }
+        if (A) { coms.push_back(&acom); plans.push_back(plans[0]); }
         for (int l = 0; l < layers; l++) { coms.push_back(&fri_coms[l]); plans.push_back(batch_proof_indices(fri_coms[l].n_global, fpos[l])); }
         // position of a row / node in this rank's arrays, GATHER_SKIP when another rank owns it
         auto local_row = [&](uint64_t p, bool sharded) -> uint64_t {
@@ -1004,6 +1055,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
                 return L + (u & ((1ull << c.leaf_parts_log) - 1)) * (L >> c.leaf_parts_log) + (u >> c.leaf_parts_log);
             return L + u;
         };
+        q_lap("plans");
         // Openings: every source address is known on the host, so ONE address list goes up, ONE kernel gathers every value and
         // digest, and the (few) unstored low tree nodes are recomputed behind it. Value block (u64):
         //   [trace rows | comp rows | aux rows | fri rows per layer | remainder | digests (4 u64 each) per tree]
@@ -1063,6 +1115,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         voff = n_u64 + 4 * n_dig;
         size_t n_low = 0;
         for (auto& v : low_idx) n_low += v.size();
+        q_lap("addresses");
         uint64_t* h_addr = (uint64_t*)ctx->stage_alloc((addr.size() + n_low) * 8);
         memcpy(h_addr, addr.data(), addr.size() * 8);
         {
@@ -1086,9 +1139,11 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
                 o += nl;
             }
         }
+        q_lap("enqueue");
         if (G > 1) comm_all_reduce(d_val.get(), voff);
         AERO_HIP(hipMemcpyAsync(h_val, d_val.get(), (voff + 4 * n_low) * 8, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
+        q_lap("device_round_trip");
         {
             size_t o = 0;
             for (size_t t = 0; t < coms.size(); t++)
@@ -1131,6 +1186,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         // remainder = last layer's evaluations in natural order
         for (size_t i = 0; i < rem_dom; i++) for (int d = 0; d < F::DEG; d++) w64(proof.fri_remainder, h_val[off_rem + (size_t)d * rem_dom + i]);
     }
+    q_lap("serialise");
     ms.queries = clk.lap();
     ctx->scratch_reset();
     ms.total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();

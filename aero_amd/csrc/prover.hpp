@@ -14,6 +14,7 @@
 //   StarkProof::to_bytes .......... miden-proof-generator/src/main.rs:38 (layout: SURVEY a18)
 // The transcript (random coin) lives on the host and is the only serialisation point between device stages.
 #pragma once
+#include <cstdlib>
 #include <memory>
 
 #include "aero_internal.hpp"
@@ -172,6 +173,7 @@ public:
     Bytes prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_inputs_out);
     StageMs last_stage_ms;
     bool collect_stage_times = false;   // adds a stream sync per stage
+    bool fri_tail = getenv("AERO_FRI_TAIL") ? getenv("AERO_FRI_TAIL")[0] != '0' : true;   // small FRI layers in one launch (Context::fri_tail)
     bool low_level_skip = true;         // large trees: the 3 lowest Merkle levels are not stored but recomputed by the openings
 
     // ---- stage-level entry points (the reference's split API; also what the C ABI exposes) ----

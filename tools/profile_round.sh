@@ -12,9 +12,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c4" -- python3 "$R
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c1" -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --concurrent 1 > "$OUT/c1.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pf" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --concurrent 1 > "$OUT/pf.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pw" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --concurrent 1 > "$OUT/pw.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ps" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --concurrent 1 > "$OUT/ps.log" 2>&1
 cd "$ROOT"
 for d in c4 c1; do f=$(find "$OUT/$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${d}_kernel_stats.csv"; done
-for d in pf pw; do f=$(find "$OUT/$d" -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${d}_counter_collection.csv"; done
-rm -rf "$OUT/c4" "$OUT/c1" "$OUT/pf" "$OUT/pw"
+for d in pf pw ps; do f=$(find "$OUT/$d" -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${d}_counter_collection.csv"; done
+rm -rf "$OUT/c4" "$OUT/c1" "$OUT/pf" "$OUT/pw" "$OUT/ps"
 ls -la "$OUT"
 tail -c 600 "$OUT/bench.json"
