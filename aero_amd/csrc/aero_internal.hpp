@@ -49,6 +49,12 @@ struct NttTables {
 struct NttPass {
     int log_s, log_r, log_tl;
 };
+// Optional second output of an LDE: rows = 0 mod 2^log_step, stored densely (row r at r >> log_step), column stride col_stride.
+struct CompactOut {
+    uint64_t* ptr = nullptr;
+    size_t col_stride = 0;
+    int log_step = 0;
+};
 std::vector<NttPass> plan_passes(int log_n, bool reg_passes, int first_bits = 12);
 
 typedef b2s::Digest Digest;   // 8 x u32, byte order = digest byte order (little-endian words)
@@ -138,7 +144,10 @@ public:
     bool two_phase = true;     // contiguous pass of the blowup-8 LDE as two register transforms around one LDS exchange (AERO_NTT_2PHASE=0: LDS rounds)
     bool reg_passes = true;    // strided passes of radix 16..64 run entirely in registers (AERO_NTT_REG=0: LDS passes only)
     bool fwd_two_phase(int log_out, int log_pad) const;
-    void ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad);
+    // returns true when `compact` was requested AND written (the last pass must be a strided register pass: transforms that fit the
+    // contiguous pass alone do not produce it and the caller falls back to strided reads of the full matrix)
+    bool ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad,
+                     const CompactOut* compact = nullptr);
     void ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift);
 
     // ---- hashing (hash.hip) ----

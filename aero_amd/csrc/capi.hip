@@ -494,11 +494,12 @@ int32_t aero_grind(aero_ctx* ctx, const uint8_t seed[32], uint32_t bits, uint64_
 // ---- whole proof ----------------------------------------------------------------------------------------
 static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, int log_n, const aero_proof_options* o, uint8_t** proof,
                      size_t* proof_len, uint64_t* pub_out, const aero_comm* comm = nullptr, uint32_t aux_width = 0, uint32_t aux_rands = 0,
-                     uint32_t aux_degree = 2) {
+                     uint32_t aux_degree = 2, const uint64_t* trace_host = nullptr, unsigned int* verdict = nullptr) {
     REQUIRE(o && proof && proof_len, "prove: null argument");
     ProofOptions po{o->num_queries, o->blowup_factor, o->grinding_factor, o->hash_fn, o->field_extension, o->fri_folding_factor, o->fri_log_max_remainder};
     Prover p(ctx->c, po);
     p.set_aux_segment(aux_width, aux_rands, aux_degree);
+    if (trace_host) p.set_host_trace(trace_host, verdict);
     if (comm) {
         REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "prove_fib_sharded: bad rank / world");
         REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "prove_fib_sharded: missing exchange callback");
@@ -565,13 +566,18 @@ static void prove_from_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint
     REQUIRE(width >= 2 && width <= 254 && log_n >= 3 && log_n <= 29, "prove_fib_host: bad shape");
     Context* c = ctx->c;
     const size_t n = (size_t)1 << log_n;
-    DevBuf<uint64_t> d(c, (size_t)width * n);
-    AERO_HIP(hipMemcpyAsync(d.get(), trace_col_major, (size_t)width * n * 8, hipMemcpyHostToDevice, c->stream));
     unsigned int* verdict = c->pinned_word();
     *verdict = 0;
-    canonical_check_enqueue(c, d.get(), (size_t)width * n, verdict);
     const uint32_t A = air ? air->aux_width : 0;
-    do_prove(ctx, d.get(), width, (int)log_n, options, proof, proof_len, pub_out, nullptr, A, air ? air->aux_rands : 0, A ? air->aux_degree : 2);
+    if (A == 0) {
+        // no device copy of the trace at all: the columns go straight into the interpolation buffer (Prover::set_host_trace)
+        do_prove(ctx, nullptr, width, (int)log_n, options, proof, proof_len, pub_out, nullptr, 0, 0, 2, trace_col_major, verdict);
+    } else {
+        DevBuf<uint64_t> d(c, (size_t)width * n);
+        AERO_HIP(hipMemcpyAsync(d.get(), trace_col_major, (size_t)width * n * 8, hipMemcpyHostToDevice, c->stream));
+        canonical_check_enqueue(c, d.get(), (size_t)width * n, verdict);
+        do_prove(ctx, d.get(), width, (int)log_n, options, proof, proof_len, pub_out, nullptr, A, air->aux_rands, air->aux_degree);
+    }
     if (*verdict != 0) {   // the proof's own synchronisations have long passed the check
         free(*proof);
         *proof = nullptr; *proof_len = 0;

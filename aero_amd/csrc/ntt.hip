@@ -52,7 +52,11 @@ struct PassArgs {
     const uint64_t* tw_hi;
     int tw_h;
     const uint64_t* tw_pass;  // register passes only: pass-boundary twiddles, row b * R + k
-    const uint64_t* tw_mt;    // two-phase contiguous pass only: [r * 64 + k] = w_4096^(r k)
+    const uint64_t* tw_mt;    // two-phase contiguous pass only: [r * 64 + k] = w_2048^(r k)
+    // last pass only (optional): rows = 0 mod 2^compact_log are also written, densely, to compact[row >> compact_log]
+    uint64_t* compact;
+    size_t compact_col_stride;
+    int compact_log;
     // inverse contiguous pass only: out[p] *= ktab[k] * blockfac(block)
     const uint64_t* ktab;     // R entries: c0 * (a^(2^(L-r)) * b^(2^(L-r-shift)))^rev_r(k)
     uint64_t sc_a, sc_b;      // per-block factor = a^rev(block) * b^(rev(block) >> shift)
@@ -391,6 +395,13 @@ template <int LOGR> __global__ __launch_bounds__(256) void ntt_fwd_strided_reg(P
     }
 #pragma unroll
     for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
+    if (a.compact && (lo & (((size_t)1 << a.compact_log) - 1)) == 0) {
+        // every 2^compact_log-th row once more, densely: what the per-row kernels that walk the LDE with that stride read
+        // (constraint evaluation, DEEP) - a strided walk over the full matrix drags in a whole 64-byte sector per 8 useful bytes
+        uint64_t* co = a.compact + (size_t)blockIdx.y * a.compact_col_stride;
+#pragma unroll
+        for (int k = 0; k < R; k++) co[(base + ((size_t)k << a.log_s)) >> a.compact_log] = y[k];
+    }
 }
 template <int LOGR> __global__ __launch_bounds__(256) void ntt_inv_strided_reg(PassArgs a) {
     constexpr int R = 1 << LOGR;
@@ -516,8 +527,10 @@ bool Context::fwd_two_phase(int log_out, int log_pad) const {
     if (!reg_passes || !two_phase || log_pad != 3 || log_out < 13) return false;
     return (log_out - 11 + 5) / 6 == (log_out - 12 + 5) / 6 || log_out - 12 <= 0;
 }
-void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad) {
+bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad,
+                          const CompactOut* compact) {
     ensure_small_twiddles();
+    bool compact_written = false;
     NttTables* t = ntt_tables(log_out);
     std::vector<NttPass> plan = plan_passes(log_out, reg_passes, fwd_two_phase(log_out, log_pad) ? 11 : 12);
     if (plan[0].log_r < log_pad) fail("ntt_forward: transform too small for the requested padding");
@@ -534,6 +547,10 @@ void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         const size_t abytes = (size_t)ncols * 8 * ((((size_t)1 << log_out) >> a.log_pad) + ((size_t)1 << log_out));
         if (q > 0 && reg_passes) {
             if (!a.first) a.tw_pass = pass_twiddles(log_out, a.log_s, a.log_r, false);
+            if (a.first && compact && compact->ptr && compact->log_step >= 1 && compact->log_step <= a.log_s) {
+                a.compact = compact->ptr; a.compact_col_stride = compact->col_stride; a.compact_log = compact->log_step;
+                compact_written = true;
+            }
             dim3 rgrid((unsigned)((((size_t)1 << log_out) >> a.log_r) / 256), ncols);
             const char* nm = pass_names ? (a.log_r == 6 ? "ntt_fwd_reg6" : a.log_r == 5 ? "ntt_fwd_reg5" : a.log_r == 4 ? "ntt_fwd_reg4" : "ntt_fwd_reg123") : "ntt_fwd_pass";
             switch (a.log_r) {
@@ -561,6 +578,7 @@ void Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         AERO_LAUNCH(this, pass_names ? (a.log_r == 7 ? "ntt_fwd_lds7" : a.log_r == 8 ? "ntt_fwd_lds8" : "ntt_fwd_ldsX") : "ntt_fwd_pass", abytes, ntt_fwd_pass, grid, dim3(256), 0, a);
     }
     check_launch("ntt_forward");
+    return compact_written;
 }
 
 // evaluations in natural order over <w_n> (n = 2^log_n) -> coefficients in bit-reversed order, where coefficient

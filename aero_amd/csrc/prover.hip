@@ -518,7 +518,7 @@ void Prover::composition_from_evaluations(uint64_t* hbuf, int deg, int log_ce, i
 
 template <class F>
 DevBuf<uint64_t> Prover::deep_compose(const uint64_t* tlde, const uint64_t* clde, const uint64_t* alde, uint32_t W, uint32_t A, uint32_t C,
-                                      int log_n, int log_bl, uint64_t h, const DeepInputs<F>& in) {
+                                      int log_n, int log_bl, uint64_t h, const DeepInputs<F>& in, const DeepCompact* compact) {
     typedef typename F::T T;
     Context* ctx = ctx_;
     const size_t n = (size_t)1 << log_n, M = n << log_bl;
@@ -533,6 +533,14 @@ DevBuf<uint64_t> Prover::deep_compose(const uint64_t* tlde, const uint64_t* clde
     DevBuf<uint64_t> dsm(ctx, (size_t)F::DEG * n);
     DeepArgs<F> a{};
     a.tlde = tlde; a.clde = clde; a.alde = alde; a.A = A; a.N = M; a.count = n; a.row_step = (uint32_t)1 << log_bl; a.W = W; a.C = C;
+    a.t_stride = a.c_stride = a.a_stride = M;
+    a.t_step = a.c_step = a.a_step = a.row_step;
+    if (compact) {
+        // a compact copy holds every 2^k-th row (k <= log_bl): stride M >> k, step row_step >> k
+        if (compact->t && compact->t_log <= log_bl) { a.tlde = compact->t; a.t_stride = M >> compact->t_log; a.t_step = a.row_step >> compact->t_log; }
+        if (compact->c && compact->c_log <= log_bl) { a.clde = compact->c; a.c_stride = M >> compact->c_log; a.c_step = a.row_step >> compact->c_log; }
+        if (A && compact->a && compact->a_log <= log_bl) { a.alde = compact->a; a.a_stride = M >> compact->a_log; a.a_step = a.row_step >> compact->a_log; }
+    }
     a.tw_lo = tM->lo_fwd; a.tw_hi = tM->hi_fwd; a.tw_h = tM->h; a.offset = h;
     a.z = in.z; a.z_next = F::mulb(in.z, gl::root_of_unity(log_n)); a.z_c = gl::fpow<F>(in.z, C); a.z_conj = F::conj(in.z);
     a.lambda = in.lambda; a.mu = in.mu;
@@ -553,8 +561,8 @@ DevBuf<uint64_t> Prover::deep_compose(const uint64_t* tlde, const uint64_t* clde
     ctx->ntt_forward(dsm.get(), n, out.get(), M, F::DEG, log_M, log_bl);
     return out;
 }
-template DevBuf<uint64_t> Prover::deep_compose<FB>(const uint64_t*, const uint64_t*, const uint64_t*, uint32_t, uint32_t, uint32_t, int, int, uint64_t, const DeepInputs<FB>&);
-template DevBuf<uint64_t> Prover::deep_compose<FQ>(const uint64_t*, const uint64_t*, const uint64_t*, uint32_t, uint32_t, uint32_t, int, int, uint64_t, const DeepInputs<FQ>&);
+template DevBuf<uint64_t> Prover::deep_compose<FB>(const uint64_t*, const uint64_t*, const uint64_t*, uint32_t, uint32_t, uint32_t, int, int, uint64_t, const DeepInputs<FB>&, const Prover::DeepCompact*);
+template DevBuf<uint64_t> Prover::deep_compose<FQ>(const uint64_t*, const uint64_t*, const uint64_t*, uint32_t, uint32_t, uint32_t, int, int, uint64_t, const DeepInputs<FQ>&, const Prover::DeepCompact*);
 
 template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, uint64_t N, HostCoin& coin, Bytes* roots) {
     typedef typename F::T T;
@@ -732,8 +740,11 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     //    nothing before the first commitment depends on the coin: their read-back is only enqueued here and consumed after the
     //    stream synchronisation the trace commitment performs anyway (one host round trip less per proof).
     air.results.resize(W / 2);
+    const uint64_t* const host_trace = host_trace_;     // trace still in HOST memory (pipelined hand-over below), or nullptr
     uint64_t* h_last_row = (uint64_t*)ctx->stage_alloc((size_t)W * 8);
-    {
+    if (host_trace) {
+        for (uint32_t c = 0; c < W; c++) h_last_row[c] = host_trace[(size_t)c * n + (n - 1)];
+    } else {
         uint64_t* h_pos = (uint64_t*)ctx->stage_alloc(8);
         *h_pos = n - 1;
         uint64_t* d_pos = (uint64_t*)ctx->scratch_alloc(8);
@@ -763,12 +774,38 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
 
     // 1. interpolate_columns [a3]: coefficient i scaled by h^i, so the coset LDE below needs no shift pass
     Matrix polys(ctx, (int)W, n);
-    AERO_HIP(hipMemcpyAsync(polys.data.get(), trace_dev, (size_t)W * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0);
+    if (host_trace) {
+        // Direct hand-over: the columns are copied straight into the buffer the interpolation works in (no device-side copy of
+        // the trace is kept, no device-to-device pass), canonical-form check and inverse transform follow on the same stream.
+        // (Measured and dropped: copying column groups on a SECOND stream so that group g + 1 travels while group g is being
+        // transformed. One proof gained 40 us of 2.93 ms; with 8 proofs in flight the 16 streams and their cross-stream waits
+        // cost 9 % of the throughput. Other proofs' kernels are what a transfer should overlap with, and they already do.)
+        if (A) fail("prove: the direct host hand-over does not cover the auxiliary segment", ST_INTERNAL);
+        unsigned int* d_bad = (unsigned int*)ctx->scratch_alloc(4);
+        AERO_HIP(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+        AERO_HIP(hipMemcpyAsync(polys.data.get(), host_trace, (size_t)W * n * 8, hipMemcpyHostToDevice, ctx->stream));
+        canonical_check_accumulate(ctx, polys.data.get(), (size_t)W * n, d_bad);
+        ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0);
+        AERO_HIP(hipMemcpyAsync(host_verdict_, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        AERO_HIP(hipMemcpyAsync(polys.data.get(), trace_dev, (size_t)W * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0);
+    }
     ms.interpolate = clk.lap();
     // 2. evaluate_columns_over [a4] (this rank's coset: M rows)
-    Matrix tlde(ctx, (int)W, M);
-    ctx->ntt_forward(polys.data.get(), n, tlde.data.get(), M, (int)W, log_M, log_Bl);
+    // Compact copies for the per-row kernels that walk an LDE with a stride (one GPU only): the trace / aux LDE's last pass also
+    // writes every ce_step-th row densely (what constraint evaluation reads; DEEP reads every (B / ce_step)-th row of that), or
+    // every B-th row when the constraint domain is the whole LDE domain; the composition LDE every B-th row (DEEP only).
+    const int log_ce_step = log_B - ilog2(C);
+    const int tc_log = (G == 1 && compact_rows) ? (log_ce_step > 0 ? log_ce_step : log_B) : 0;
+    const int cc_log = (G == 1 && compact_rows) ? log_B : 0;
+    Matrix tlde(ctx, (int)W, M), tlde_c, alde_c, clde_c;
+    bool have_tc = false, have_ac = false, have_cc = false;
+    {
+        CompactOut co;
+        if (tc_log > 0 && log_M >= 14) { tlde_c = Matrix(ctx, (int)W, M >> tc_log); co.ptr = tlde_c.data.get(); co.col_stride = M >> tc_log; co.log_step = tc_log; }
+        have_tc = ctx->ntt_forward(polys.data.get(), n, tlde.data.get(), M, (int)W, log_M, log_Bl, &co);
+    }
     ms.lde = clk.lap();
     // 3. row hashes, Merkle tree, commit [a5, a6, a8]
     Commitment tcom = commit_matrix(tlde);          // synchronises the stream: the last trace row has arrived as well
@@ -793,7 +830,11 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         launch_aux_columns<F>(ctx, trace_dev, n, W, A, R, D, d_rands, apolys.data.get());
         ctx->ntt_inverse(apolys.data.get(), n, (int)(A * F::DEG), log_n, 1, h, 1, 0);
         alde = Matrix(ctx, (int)(A * F::DEG), M);
-        ctx->ntt_forward(apolys.data.get(), n, alde.data.get(), M, (int)(A * F::DEG), log_M, log_Bl);
+        {
+            CompactOut co;
+            if (have_tc) { alde_c = Matrix(ctx, (int)(A * F::DEG), M >> tc_log); co.ptr = alde_c.data.get(); co.col_stride = M >> tc_log; co.log_step = tc_log; }
+            have_ac = ctx->ntt_forward(apolys.data.get(), n, alde.data.get(), M, (int)(A * F::DEG), log_M, log_Bl, &co);
+        }
         acom = commit_matrix(alde);
         wdigest(proof.commitments, acom.root);
         coin.reseed(acom.root);
@@ -833,6 +874,12 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         const size_t rows_eval = gather_h ? M : ceN;
         const size_t xcount = gather_h ? M / n : C;             // distinct values of x^n over those rows
         NttTables* tce = ctx->ntt_tables(ilog2(rows_eval));
+        // one GPU: the rows the constraint domain consists of were also written densely by the LDE (every ce_step-th row)
+        if (have_tc && (!A || have_ac) && log_ce_step > 0 && frame_src == tlde.data.get()) {
+            frame_src = tlde_c.data.get();
+            if (A) aux_src = alde_c.data.get();
+            frame_rows = M >> tc_log;
+        }
         FibConsArgs<F> a{};
         a.lde = frame_src; a.N = frame_rows; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)(frame_rows / n); a.ce_step = (uint32_t)(frame_rows / rows_eval);
         a.xmask = (uint32_t)xcount - 1;
@@ -880,16 +927,23 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     ms.composition = clk.lap();
     // 6. composition commitment [a12]: column c*DEG + d <- chunk c of component d
     Matrix clde(ctx, (int)(C * F::DEG), M);
+    if (cc_log > 0 && log_M >= 14) { clde_c = Matrix(ctx, (int)(C * F::DEG), M >> cc_log); have_cc = true; }
     // In bit-reversed coefficient order the low log2(C) bits of the coefficient index (= the column) are the HIGH bits of the
     // position: column c is chunk bitrev(c). For C = 2 that is the identity and all columns of a component go in one launch.
     const int log_C = ilog2(C);
     for (int d = 0; d < F::DEG; d++) {
         if (C == 2) {
-            ctx->ntt_forward(hbuf.get() + (size_t)d * ceN, n, clde.data.get() + (size_t)d * M, (size_t)F::DEG * M, (int)C, log_M, log_Bl);
+            CompactOut co;
+            if (have_cc) { co.ptr = clde_c.data.get() + (size_t)d * (M >> cc_log); co.col_stride = (size_t)F::DEG * (M >> cc_log); co.log_step = cc_log; }
+            if (!ctx->ntt_forward(hbuf.get() + (size_t)d * ceN, n, clde.data.get() + (size_t)d * M, (size_t)F::DEG * M, (int)C, log_M, log_Bl, &co)) have_cc = false;
         } else {
             for (size_t c = 0; c < C; c++)
-                ctx->ntt_forward(hbuf.get() + (size_t)d * ceN + (size_t)gl::bitrev((uint32_t)c, log_C) * n, n,
-                                 clde.data.get() + ((size_t)c * F::DEG + d) * M, M, 1, log_M, log_Bl);
+            {
+                CompactOut co;
+                if (have_cc) { co.ptr = clde_c.data.get() + ((size_t)c * F::DEG + d) * (M >> cc_log); co.col_stride = M >> cc_log; co.log_step = cc_log; }
+                if (!ctx->ntt_forward(hbuf.get() + (size_t)d * ceN + (size_t)gl::bitrev((uint32_t)c, log_C) * n, n,
+                                      clde.data.get() + ((size_t)c * F::DEG + d) * M, M, 1, log_M, log_Bl, &co)) have_cc = false;
+            }
         }
     }
     Commitment ccom = commit_matrix(clde);
@@ -937,7 +991,10 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         DeepInputs<F> in;
         in.z = z; in.ood_cur = ood_cur; in.ood_next = ood_next; in.ood_h = ood_h;
         in.da = da; in.db = db; in.dg = dg; in.dc = dc; in.lambda = lambda; in.mu = mu;
-        fri_vals.push_back(deep_compose<F>(tlde.data.get(), clde.data.get(), A ? alde.data.get() : nullptr, W, A, (uint32_t)C, log_n, log_Bl, h, in));
+        DeepCompact dc_src;
+        if (have_tc && (!A || have_ac)) { dc_src.t = tlde_c.data.get(); dc_src.t_log = tc_log; if (A) { dc_src.a = alde_c.data.get(); dc_src.a_log = tc_log; } }
+        if (have_cc) { dc_src.c = clde_c.data.get(); dc_src.c_log = cc_log; }
+        fri_vals.push_back(deep_compose<F>(tlde.data.get(), clde.data.get(), A ? alde.data.get() : nullptr, W, A, (uint32_t)C, log_n, log_Bl, h, in, &dc_src));
     }
     ms.deep = clk.lap();
 

@@ -168,12 +168,16 @@ public:
     void set_aux_segment(uint32_t aux_width, uint32_t aux_rands, uint32_t aux_degree = 2) {
         aux_width_ = aux_width; aux_rands_ = aux_width ? aux_rands : 0; aux_degree_ = aux_degree;
     }
+    // The next prove() takes its trace from HOST memory (column-major width x 2^log_n; `trace_dev` is then ignored): it is copied
+    // straight into the interpolation buffer. *verdict (pinned) receives 0 when every element was canonical. FibAir without aux segment.
+    void set_host_trace(const uint64_t* trace_host, unsigned int* verdict) { host_trace_ = trace_host; host_verdict_ = verdict; }
     const ProofOptions& options() const { return opt_; }
     // trace: device, column-major W x 2^log_n (not modified). Returns StarkProof::to_bytes().
     Bytes prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_inputs_out);
     StageMs last_stage_ms;
     bool collect_stage_times = false;   // adds a stream sync per stage
     bool fri_tail = getenv("AERO_FRI_TAIL") ? getenv("AERO_FRI_TAIL")[0] != '0' : true;   // small FRI layers in one launch (Context::fri_tail)
+    bool compact_rows = getenv("AERO_COMPACT_ROWS") ? getenv("AERO_COMPACT_ROWS")[0] != '0' : true;   // compact every-k-th-row LDE copies for constraints / DEEP
     bool low_level_skip = true;         // large trees: the 3 lowest Merkle levels are not stored but recomputed by the openings
 
     // ---- stage-level entry points (the reference's split API; also what the C ABI exposes) ----
@@ -194,9 +198,11 @@ public:
     void composition_from_evaluations(uint64_t* hbuf, int deg, int log_ce, int log_c, uint64_t h);
     // DEEP composition over the coset h<w_M>, M = n << log_bl: evaluates on every (M/n)-th row, interpolates, extends.
     // tlde: W x M, clde: (C*DEG) x M (column c*DEG + d), alde: (A*DEG) x M or nullptr. Returns [DEG][M].   [a14]
+    // Optional compact copies (every 2^log_step-th row, written by the LDE's last pass): nullptr = walk the full matrix.
+    struct DeepCompact { const uint64_t* t = nullptr; int t_log = 0; const uint64_t* c = nullptr; int c_log = 0; const uint64_t* a = nullptr; int a_log = 0; };
     template <class F>
     DevBuf<uint64_t> deep_compose(const uint64_t* tlde, const uint64_t* clde, const uint64_t* alde, uint32_t W, uint32_t A, uint32_t C, int log_n,
-                                  int log_bl, uint64_t h, const DeepInputs<F>& in);
+                                  int log_bl, uint64_t h, const DeepInputs<F>& in, const DeepCompact* compact = nullptr);
     // FRI commit phase on one GPU: per layer transpose-hash-commit, reseed, draw alpha, fold; `roots` receives every
     // commitment (layers + remainder) in order.   [a15]
     template <class F> FriLayers fri_build_layers(DevBuf<uint64_t>&& evals, uint64_t N, HostCoin& coin, Bytes* roots);
@@ -214,6 +220,8 @@ private:
     ProofOptions opt_;
     ShardComm comm_;
     uint32_t aux_width_ = 0, aux_rands_ = 0, aux_degree_ = 2;
+    const uint64_t* host_trace_ = nullptr;
+    unsigned int* host_verdict_ = nullptr;
 };
 
 // BatchMerkleProof node selection (winter-crypto 0.4 MerkleTree::prove_batch restated):

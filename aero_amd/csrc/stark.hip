@@ -275,17 +275,18 @@ template <class F, int K> __global__ __launch_bounds__(256) void deep_kernel(Dee
     for (int i = ND * K - 1; i >= 0; i--) { T v = F::mul(ia, pre[i]); ia = F::mul(ia, den[i]); den[i] = v; }
 #pragma unroll
     for (int q = 0; q < K; q++) {
-        const size_t m = t + (size_t)q * nthreads, r = m * a.row_step;
+        const size_t m = t + (size_t)q * nthreads;
+        const size_t rt = m * a.t_step, rc = m * a.c_step, ra = m * a.a_step;
         T s1 = F::zero(), s2 = F::zero(), s3 = F::zero();
         for (uint32_t c = 0; c < a.W; c++) {
-            const T v = F::from(a.tlde[(size_t)c * a.N + r]);
+            const T v = F::from(a.tlde[(size_t)c * a.t_stride + rt]);
             s1 = F::add(s1, F::mul(F::sub(v, a.ood_cur[c]), a.da[c]));
             s2 = F::add(s2, F::mul(F::sub(v, a.ood_next[c]), a.db[c]));
             if (F::DEG > 1) s3 = F::add(s3, F::mul(F::sub(v, F::conj(a.ood_cur[c])), a.dg[c]));
         }
         for (uint32_t c = 0; c < a.A; c++) {   // aux columns are E-valued: no conjugate term
-            const size_t o = (size_t)(c * F::DEG) * a.N;
-            const T v = F::make(a.alde[o + r], F::DEG > 1 ? a.alde[o + a.N + r] : 0);
+            const size_t o = (size_t)(c * F::DEG) * a.a_stride;
+            const T v = F::make(a.alde[o + ra], F::DEG > 1 ? a.alde[o + a.a_stride + ra] : 0);
             s1 = F::add(s1, F::mul(F::sub(v, a.ood_cur[a.W + c]), a.da[a.W + c]));
             s2 = F::add(s2, F::mul(F::sub(v, a.ood_next[a.W + c]), a.db[a.W + c]));
         }
@@ -293,7 +294,7 @@ template <class F, int K> __global__ __launch_bounds__(256) void deep_kernel(Dee
         if (F::DEG > 1) acc = F::add(acc, F::mul(s3, den[ND * q + 3]));
         T sc = F::zero();
         for (uint32_t c = 0; c < a.C; c++) {
-            const T v = F::make(a.clde[(size_t)(c * F::DEG) * a.N + r], F::DEG > 1 ? a.clde[(size_t)(c * F::DEG + F::DEG - 1) * a.N + r] : 0);
+            const T v = F::make(a.clde[(size_t)(c * F::DEG) * a.c_stride + rc], F::DEG > 1 ? a.clde[(size_t)(c * F::DEG + F::DEG - 1) * a.c_stride + rc] : 0);
             sc = F::add(sc, F::mul(F::sub(v, a.ood_h[c]), a.dc[c]));
         }
         acc = F::add(acc, F::mul(sc, den[ND * q + 2]));
@@ -542,6 +543,14 @@ bool all_canonical(Context* ctx, const uint64_t* vals, size_t count) {
     return bad == 0;
 }
 
+// kernel only: ORs a 1 into *d_bad (device) when a value is not canonical
+void canonical_check_accumulate(Context* ctx, const uint64_t* vals, size_t count, unsigned int* d_bad) {
+    if (!count) return;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    AERO_LAUNCH(ctx, "canonical_check_kernel", count * 8, canonical_check_kernel, dim3((unsigned)blocks), dim3(256), 0, vals, count, d_bad);
+    ctx->check_launch("canonical_check");
+}
 // Same check without waiting for it: the verdict lands in *h_bad_pinned (pinned host memory, 0 = all canonical) once the stream
 // reaches this point; the caller reads it after its next stream synchronisation.
 void canonical_check_enqueue(Context* ctx, const uint64_t* vals, size_t count, unsigned int* h_bad_pinned) {

@@ -64,9 +64,13 @@ template <class F> struct DeepArgs {
     const uint64_t* clde;   // (C*DEG) x N
     const uint64_t* alde;   // (A*DEG) x N auxiliary segment columns (E-valued, component columns), or nullptr
     uint32_t A;
-    size_t N;                        // LDE rows (column stride of tlde / clde)
-    size_t count;                    // points evaluated: LDE rows m * row_step, m < count (output index m)
+    size_t N;                        // LDE rows: point m sits at LDE row m * row_step, x = h w_N^(m row_step)
+    size_t count;                    // points evaluated (output index m < count)
     uint32_t row_step;
+    // where point m lives in each matrix: column stride and row step (the full LDE: N / row_step; a compact every-k-th-row
+    // copy written by the LDE's last pass: N / k and row_step / k)
+    size_t t_stride, c_stride, a_stride;
+    uint32_t t_step, c_step, a_step;
     uint32_t W, C;
     const uint64_t *tw_lo, *tw_hi;   // two-level table of w_N
     int tw_h;
@@ -100,6 +104,7 @@ template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, 
 
 // true iff every one of the `count` device values is a canonical field element (< p); synchronises the stream
 bool all_canonical(Context* ctx, const uint64_t* vals, size_t count);
+void canonical_check_accumulate(Context* ctx, const uint64_t* vals, size_t count, unsigned int* d_bad);
 void canonical_check_enqueue(Context* ctx, const uint64_t* vals, size_t count, unsigned int* h_bad_pinned);
 
 // One transcript step of the FRI commit phase on the device (random.cairo:108-166 mirror): seed <- BLAKE2s(seed || root),
