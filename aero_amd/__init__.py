@@ -252,6 +252,10 @@ class Context:
             lib().aero_ctx_destroy(self.h)
             self.h = None
 
+    def selftest(self, samples=1 << 16, seed=1):
+        """aero_selftest: device field arithmetic against a 128-bit host reference."""
+        self._ck(lib().aero_selftest(self.h, C.c_uint32(samples), C.c_uint64(seed)))
+
     def synchronize(self):
         self._ck(lib().aero_ctx_synchronize(self.h))
 

@@ -5,6 +5,8 @@
 #include <stdint.h>
 
 #include <map>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -172,7 +174,8 @@ public:
     // internal state
     std::map<int, NttTables> ntt_tabs;
     std::map<uint64_t, uint64_t*> pass_tabs;
-    std::map<std::vector<uint64_t>, uint64_t*> ktab_cache;   // final-pass scale tables of ntt_inverse, keyed by their parameters
+    std::map<std::vector<uint64_t>, uint64_t*> ktab_cache;
+   // final-pass scale tables of ntt_inverse, keyed by their parameters
     uint64_t *tw4096_fwd = nullptr, *tw4096_inv = nullptr;
     uint64_t *twmt_fwd = nullptr, *twmt_inv = nullptr;   // [r * 64 + k] = w_2048^(+-r k), r < 32
 

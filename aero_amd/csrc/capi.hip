@@ -85,6 +85,12 @@ void aero_ctx_destroy(aero_ctx* ctx) {
     if (!ctx) return;
     delete ctx;   // the Context itself dies with the last matrix / tree that still references it
 }
+int32_t aero_selftest(aero_ctx* ctx, uint32_t samples, uint64_t seed) {
+    return guard(ctx, [&] {
+        REQUIRE(samples >= 64 && samples <= (1u << 22), "selftest: samples must be in [64, 2^22]");
+        field_selftest(ctx->c, samples, seed);
+    });
+}
 int32_t aero_ctx_synchronize(aero_ctx* ctx) {
     return guard(ctx, [&] { ctx->c->sync(); });
 }

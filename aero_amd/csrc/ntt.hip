@@ -262,61 +262,84 @@ constexpr int F8_TILE_LDS = 32 * 64;             // elements per tile: element (
                                                  // row * 64 + (col ^ (2 row & 63)) - conflict-free for the row-wise writes of
                                                  // phase A and the column-wise reads of phase B without any padding
 constexpr int F8_WAVES = 4;                      // tiles per workgroup
-__global__ __launch_bounds__(64 * F8_WAVES, 2) void ntt_fwd_first_pass_8(PassArgs a) {
+// Each wave walks TPW consecutive tiles: the 31 table twiddles of phase B (they depend on the lane and the row only, not on the
+// tile) are loaded ONCE into registers, and the 8 coefficients of the next tile are requested before the current one is
+// transformed. (Reading a twiddle per ELEMENT - a 64 MiB table of all pass-boundary twiddles, one multiplication instead of the
+// progression's two - was measured and dropped: 362 us against 252 us per proof. This kernel has no memory slack to give.)
+template <int TPW> __global__ __launch_bounds__(64 * F8_WAVES, 2) void ntt_fwd_first_pass_8(PassArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t* lds = f8_lds + wave * F8_TILE_LDS;
-    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * F8_WAVES + wave;          // tile
+    const uint32_t tile0 = (xcd_tile(blockIdx.x, gridDim.x) * F8_WAVES + wave) * TPW;
     const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
     uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
-    const size_t base = (size_t)b << 11, cbase = base >> 3;
-    const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
-    uint64_t y[32];
+    const int h = lane & 31;
+    const bool upper = lane >= 32;
+    const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
+    uint64_t tw[32];
+#pragma unroll
+    for (int i = 1; i < 32; i++) tw[i] = a.tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane];
+    ulonglong2 nx[4];
     {
-        // A: 8 coefficients -> 32 of the 64 positions [64 h, 64 h + 64): (position mod 8) in [4 half, 4 half + 4)
-        const int h = lane & 31;
-        const bool upper = lane >= 32;
-        uint64_t c[8];
-        const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(in + cbase + 8 * h);
+        const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(in + ((size_t)tile0 << 8) + 8 * h);
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const ulonglong2 t = cp[q]; c[2 * q] = t.x; c[2 * q + 1] = t.y; }
-        // upper half: klow = klow' + 4, i.e. member i carries the extra factor w_64^(4 rev3(i))
-        { uint64_t t;
-          t = mul_w64<16>(c[1]); c[1] = upper ? t : c[1];   t = mul_w64<8>(c[2]);  c[2] = upper ? t : c[2];
-          t = mul_w64<24>(c[3]); c[3] = upper ? t : c[3];   t = mul_w64<4>(c[4]);  c[4] = upper ? t : c[4];
-          t = mul_w64<20>(c[5]); c[5] = upper ? t : c[5];   t = mul_w64<12>(c[6]); c[6] = upper ? t : c[6];
-          t = mul_w64<28>(c[7]); c[7] = upper ? t : c[7]; }
-        first8_group<0>(c, y); first8_group<1>(c, y); first8_group<2>(c, y); first8_group<3>(c, y);
-        // y[klow' + 4 i] sits at tile position (klow' + 4 half) + 8 i + 64 h: row h, column klow' + 4 half + 8 i
-        uint64_t* row = lds + h * 64;
-        const int sw = (2 * h) & 63, c0 = upper ? 4 : 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) row[(c0 + k + 8 * i) ^ sw] = y[k + 4 * i];
-        }
+        for (int q = 0; q < 4; q++) nx[q] = cp[q];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // B: lane k <- positions k + 64 i
+#pragma unroll 1
+    for (int it = 0; it < TPW; it++) {
+        const uint32_t b = tile0 + it;
+        const size_t base = (size_t)b << 11;
+        const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
+        uint64_t y[32];
+        {
+            // A: 8 coefficients -> 32 of the 64 positions [64 h, 64 h + 64): (position mod 8) in [4 half, 4 half + 4)
+            uint64_t c[8];
 #pragma unroll
-    for (int i = 0; i < 32; i++) y[i] = lds[i * 64 + (lane ^ ((2 * i) & 63))];
+            for (int q = 0; q < 4; q++) { c[2 * q] = nx[q].x; c[2 * q + 1] = nx[q].y; }
+            if (it + 1 < TPW) {
+                const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(in + ((size_t)(b + 1) << 8) + 8 * h);
 #pragma unroll
-    for (int i = 1; i < 32; i++) y[i] = mul(y[i], a.tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane]);
-    dft_dit_reg<5>(y);
-    if (!a.first && rbk) {
-        const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
-        uint64_t cur = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)lane) & nmask), a.tw_h);
-        const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
+                for (int q = 0; q < 4; q++) nx[q] = cp[q];
+            }
+            // upper half: klow = klow' + 4, i.e. member i carries the extra factor w_64^(4 rev3(i))
+            { uint64_t t;
+              t = mul_w64<16>(c[1]); c[1] = upper ? t : c[1];   t = mul_w64<8>(c[2]);  c[2] = upper ? t : c[2];
+              t = mul_w64<24>(c[3]); c[3] = upper ? t : c[3];   t = mul_w64<4>(c[4]);  c[4] = upper ? t : c[4];
+              t = mul_w64<20>(c[5]); c[5] = upper ? t : c[5];   t = mul_w64<12>(c[6]); c[6] = upper ? t : c[6];
+              t = mul_w64<28>(c[7]); c[7] = upper ? t : c[7]; }
+            first8_group<0>(c, y); first8_group<1>(c, y); first8_group<2>(c, y); first8_group<3>(c, y);
+            // y[klow' + 4 i] sits at tile position (klow' + 4 half) + 8 i + 64 h: row h, column klow' + 4 half + 8 i
+            uint64_t* row = lds + h * 64;
+            const int sw = (2 * h) & 63, c0 = upper ? 4 : 0;
 #pragma unroll
-        for (int i = 0; i < 32; i++) {
-            out[base + lane + 64 * i] = mul(y[i], cur);
-            cur = mul(cur, step);
+            for (int i = 0; i < 8; i++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) row[(c0 + k + 8 * i) ^ sw] = y[k + 4 * i];
+            }
         }
-    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // B: lane k <- positions k + 64 i
 #pragma unroll
-        for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = y[i];
+        for (int i = 0; i < 32; i++) y[i] = lds[i * 64 + (lane ^ ((2 * i) & 63))];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next tile's phase A overwrites the exchange buffer
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 1; i < 32; i++) y[i] = mul(y[i], tw[i]);
+        dft_dit_reg<5>(y);
+        if (!a.first && rbk) {
+            uint64_t cur = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)lane) & nmask), a.tw_h);
+            const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                out[base + lane + 64 * i] = mul(y[i], cur);
+                cur = mul(cur, step);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = y[i];
+        }
     }
 }
 // tab[r * 64 + k] = root^(r * k), r < rows
@@ -567,8 +590,11 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         dim3 grid((unsigned)(((size_t)1 << log_out) / E), ncols);
         if (q == 0 && a.log_r == 11 && a.log_pad == 3 && fwd_two_phase(log_out, log_pad)) {
             a.tw_mt = twmt_fwd;
-            const dim3 g8((unsigned)((((size_t)1 << log_out) >> 11) / F8_WAVES), ncols);
-            AERO_LAUNCH(this, pass_names ? "ntt_fwd_first8" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass_8, g8, dim3(64 * F8_WAVES), 0, a);
+            const size_t tiles = ((size_t)1 << log_out) >> 11;
+            const char* nm = pass_names ? "ntt_fwd_first8" : "ntt_fwd_pass";
+            // one tile per wave: walking 4 tiles per wave (twiddles loaded once, next tile prefetched) measured 6 % SLOWER - 256 VGPRs
+            // with spills, and a single-column launch no longer fills the chip
+            AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8<1>, dim3((unsigned)(tiles / F8_WAVES), ncols), dim3(64 * F8_WAVES), 0, a);
             continue;
         }
         if (q == 0 && reg_passes && a.log_r > a.log_pad) {

@@ -564,6 +564,87 @@ void canonical_check_enqueue(Context* ctx, const uint64_t* vals, size_t count, u
 }
 
 // ------------------------------------------------------------------------------------------------
+// Field-arithmetic self test. The device formulations of add / mul (32-bit carry chains, gl.cuh), the shift multiplications of
+// the NTT butterflies (dft_small.cuh) and the F_p^2 operations are compared, on the device they run on and inside a kernel
+// that mixes them the way the real kernels do, with results the host computed with plain 128-bit arithmetic. A carry-chain
+// `sub` combined with the carry-chain `mul` once miscompiled inside deep_kernel (ROCm 7.2; each alone was exact): this test
+// exists so that a compiler or driver change that breaks a formulation is reported by name instead of as a wrong proof.
+template <int K> __device__ __forceinline__ uint64_t selftest_pow2(uint64_t x) { return mul_pow2<K>(x); }
+__global__ __launch_bounds__(256) void field_selftest_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, size_t n, uint64_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t x = a[i], y = b[i];
+    uint64_t* o = out + i * 16;
+    o[0] = gl::add(x, y);
+    o[1] = gl::sub(x, y);
+    o[2] = gl::mul(x, y);
+    o[3] = gl::sqr(x);
+    o[4] = gl::neg(x);
+    // the mix of deep_kernel / the butterflies: differences and sums feeding multiplications
+    o[5] = gl::mul(gl::sub(x, y), gl::add(x, y));
+    o[6] = gl::sub(gl::mul(x, y), gl::mul(y, y));
+    o[7] = mul_2_24(x);
+    o[8] = mul_w4(x);
+    o[9] = mul_2_72(x);
+    o[10] = gl::add(selftest_pow2<39>(x), selftest_pow2<78>(y));       // w_64, w_32
+    o[11] = gl::sub(selftest_pow2<60>(x), selftest_pow2<7>(y));
+    o[12] = selftest_pow2<95>(x);
+    const gl::E2 e = gl::mul(gl::E2{x, y}, gl::E2{y, gl::add(x, 1)});
+    o[13] = e.a0; o[14] = e.a1;
+    o[15] = (i & 63) == 0 ? gl::mul(gl::inv(x), x) : 1;              // inversion on a sample (x != 0 by construction)
+}
+static uint64_t ref_mulmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % gl::P); }
+static uint64_t ref_addmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + b) % gl::P); }
+static uint64_t ref_submod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + gl::P - b) % gl::P); }
+static uint64_t ref_pow2(uint64_t a, int k) { uint64_t r = a; for (int i = 0; i < k; i++) r = ref_addmod(r, r); return r; }
+void field_selftest(Context* ctx, size_t n, uint64_t seed) {
+    std::vector<uint64_t> a(n), b(n);
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto next = [&] { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (size_t i = 0; i < n; i++) {
+        a[i] = next() % gl::P; b[i] = next() % gl::P;
+        if (a[i] == 0) a[i] = 1;
+    }
+    // edge values: 0 / 1 / p - 1 / 2^32 - 1 / 2^32 / 2^63 around the carry boundaries of the limb arithmetic
+    const uint64_t edge[] = {1, gl::P - 1, 0xFFFFFFFFull, 0x100000000ull, 0xFFFFFFFF00000000ull, 1ull << 63, gl::P - 0xFFFFFFFFull, 2};
+    for (size_t i = 0; i < 64 && i < n; i++) { a[i] = edge[i & 7]; b[i] = i < 8 ? 0 : edge[(i >> 3) & 7]; }
+    DevBuf<uint64_t> da(ctx, n), db(ctx, n), dout(ctx, n * 16);
+    AERO_HIP(hipMemcpyAsync(da.get(), a.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    AERO_HIP(hipMemcpyAsync(db.get(), b.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    AERO_LAUNCH(ctx, "field_selftest_kernel", 0, field_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, da.get(), db.get(), n, dout.get());
+    ctx->check_launch("field_selftest");
+    std::vector<uint64_t> out(n * 16);
+    AERO_HIP(hipMemcpyAsync(out.data(), dout.get(), n * 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    static const char* names[16] = {"add", "sub", "mul", "sqr", "neg", "mul(sub, add)", "sub(mul, mul)", "mul_2_24", "mul_w4 (2^48)", "mul_2_72",
+                                    "add(pow2<39>, pow2<78>)", "sub(pow2<60>, pow2<7>)", "pow2<95>", "E2 mul (component 0)", "E2 mul (component 1)", "inv"};
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t x = a[i], y = b[i];
+        uint64_t want[16];
+        want[0] = ref_addmod(x, y); want[1] = ref_submod(x, y); want[2] = ref_mulmod(x, y); want[3] = ref_mulmod(x, x); want[4] = ref_submod(0, x);
+        want[5] = ref_mulmod(ref_submod(x, y), ref_addmod(x, y));
+        want[6] = ref_submod(ref_mulmod(x, y), ref_mulmod(y, y));
+        want[7] = ref_pow2(x, 24); want[8] = ref_pow2(x, 48); want[9] = ref_pow2(x, 72);
+        want[10] = ref_addmod(ref_pow2(x, 39), ref_pow2(y, 78));
+        want[11] = ref_submod(ref_pow2(x, 60), ref_pow2(y, 7));
+        want[12] = ref_pow2(x, 95);
+        {   // (x + y phi)(y + (x + 1) phi), phi^2 = phi - 2
+            const uint64_t b1 = ref_addmod(x, 1), a0b0 = ref_mulmod(x, y), a1b1 = ref_mulmod(y, b1);
+            want[13] = ref_submod(a0b0, ref_addmod(a1b1, a1b1));
+            want[14] = ref_submod(ref_mulmod(ref_addmod(x, y), ref_addmod(y, b1)), a0b0);
+        }
+        want[15] = 1;
+        for (int k = 0; k < 16; k++)
+            if (out[i * 16 + k] != want[k]) {
+                char msg[256];
+                snprintf(msg, sizeof msg, "field self-test: device %s is wrong for x = %llu, y = %llu: got %llu, expected %llu", names[k],
+                         (unsigned long long)x, (unsigned long long)y, (unsigned long long)out[i * 16 + k], (unsigned long long)want[k]);
+                fail(msg, ST_INTERNAL);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Query gathers: rows of a column-major matrix at given positions; digests at given node indices.
 __global__ void gather_rows_kernel(const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;

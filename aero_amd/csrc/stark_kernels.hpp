@@ -112,6 +112,9 @@ void canonical_check_enqueue(Context* ctx, const uint64_t* vals, size_t count, u
 // the commit phase without waiting for a root.
 template <class F> void launch_fri_coin_step(Context* ctx, Digest* seed_io, const Digest* root, typename F::T* alpha_out);
 
+// device field arithmetic against a host reference on n random + edge-case operand pairs; throws ST_INTERNAL naming the operation
+void field_selftest(Context* ctx, size_t n, uint64_t seed);
+
 uint64_t run_grind(Context* ctx, const Digest& seed, uint32_t bits);
 void launch_gather_rows(Context* ctx, const uint64_t* cols, size_t col_stride, int ncols, const uint64_t* pos, int npos, uint64_t* out);
 void launch_gather_fri_rows(Context* ctx, const uint64_t* c0, const uint64_t* c1, int deg, size_t rows, int fold, const uint64_t* pos, int npos, uint64_t* out);

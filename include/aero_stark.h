@@ -65,6 +65,12 @@ typedef struct aero_fib_air {
 int32_t aero_device_count(void);
 int32_t aero_ctx_create(int32_t device_id, aero_ctx** out);
 void aero_ctx_destroy(aero_ctx* ctx);
+/* Field-arithmetic self test on the context's GPU: the device formulations of Goldilocks add / sub / mul / inverse, the
+ * power-of-two multiplications of the NTT butterflies and the F_p^2 product, run inside one kernel on `samples` random operand
+ * pairs plus the carry-boundary edge cases, against host results computed with 128-bit integers. AERO_OK, or AERO_E_INTERNAL with
+ * the failing operation and operands in aero_last_error - a deployment can run it once per driver / compiler update. (The
+ * reference relies on Rust's u128 arithmetic in winter-math and needs no such check.) */
+int32_t aero_selftest(aero_ctx* ctx, uint32_t samples, uint64_t seed);
 /* Wait until everything enqueued on the context's stream has completed (entry points that return host data do this
  * themselves; needed after stream-ordered exchanges issued through an aero_comm outside a proof). */
 int32_t aero_ctx_synchronize(aero_ctx* ctx);

@@ -263,6 +263,15 @@ def test_full_size_config3(ctx, oracle):
     assert got == want, "config 3 proof bytes differ from the oracle"
 
 
+def test_device_field_arithmetic_selftest(ctx):
+    """G4 (tests/unit/test_math_g.cairo:5-75 pins add / sub / mul / inv / pow on a handful of values) at scale and ON THE DEVICE:
+    every formulation the kernels use, on random and carry-boundary operands, against 128-bit host arithmetic."""
+    for seed in (1, 2, 3):
+        ctx.selftest(1 << 16, seed)
+    with pytest.raises(aero_amd.AeroError):
+        ctx.selftest(1, 1)
+
+
 def test_bad_arguments_fail_loudly(ctx):
     t = aero_amd.fib_trace(2, 6)
     with pytest.raises(aero_amd.AeroError) as e:
