@@ -52,10 +52,14 @@ struct NttPass {
     int log_s, log_r, log_tl;
 };
 // Optional second output of an LDE: rows = 0 mod 2^log_step, stored densely (row r at r >> log_step), column stride col_stride.
+// With log_split = k > 0 the compact rows are de-interleaved into 2^k parts: compact row j sits at (j mod 2^k) * (rows / 2^k) +
+// j / 2^k, so that a reader of every 2^k-th compact row (DEEP) finds its rows contiguous in part 0 while a reader of all
+// compact rows (constraint evaluation) still reads whole sectors (a wavefront touches 2^k contiguous runs).
 struct CompactOut {
     uint64_t* ptr = nullptr;
     size_t col_stride = 0;
     int log_step = 0;
+    int log_split = 0;
 };
 std::vector<NttPass> plan_passes(int log_n, bool reg_passes, int first_bits = 12);
 

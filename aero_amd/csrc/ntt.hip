@@ -56,7 +56,7 @@ struct PassArgs {
     // last pass only (optional): rows = 0 mod 2^compact_log are also written, densely, to compact[row >> compact_log]
     uint64_t* compact;
     size_t compact_col_stride;
-    int compact_log;
+    int compact_log, compact_split;
     // inverse contiguous pass only: out[p] *= ktab[k] * blockfac(block)
     const uint64_t* ktab;     // R entries: c0 * (a^(2^(L-r)) * b^(2^(L-r-shift)))^rev_r(k)
     uint64_t sc_a, sc_b;      // per-block factor = a^rev(block) * b^(rev(block) >> shift)
@@ -422,8 +422,12 @@ template <int LOGR> __global__ __launch_bounds__(256) void ntt_fwd_strided_reg(P
         // every 2^compact_log-th row once more, densely: what the per-row kernels that walk the LDE with that stride read
         // (constraint evaluation, DEEP) - a strided walk over the full matrix drags in a whole 64-byte sector per 8 useful bytes
         uint64_t* co = a.compact + (size_t)blockIdx.y * a.compact_col_stride;
+        const size_t part_len = (((size_t)1 << a.log_n) >> a.compact_log) >> a.compact_split, pmask = ((size_t)1 << a.compact_split) - 1;
 #pragma unroll
-        for (int k = 0; k < R; k++) co[(base + ((size_t)k << a.log_s)) >> a.compact_log] = y[k];
+        for (int k = 0; k < R; k++) {
+            const size_t j = (base + ((size_t)k << a.log_s)) >> a.compact_log;
+            co[(j & pmask) * part_len + (j >> a.compact_split)] = y[k];
+        }
     }
 }
 template <int LOGR> __global__ __launch_bounds__(256) void ntt_inv_strided_reg(PassArgs a) {
@@ -571,7 +575,7 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         if (q > 0 && reg_passes) {
             if (!a.first) a.tw_pass = pass_twiddles(log_out, a.log_s, a.log_r, false);
             if (a.first && compact && compact->ptr && compact->log_step >= 1 && compact->log_step <= a.log_s) {
-                a.compact = compact->ptr; a.compact_col_stride = compact->col_stride; a.compact_log = compact->log_step;
+                a.compact = compact->ptr; a.compact_col_stride = compact->col_stride; a.compact_log = compact->log_step; a.compact_split = compact->log_split;
                 compact_written = true;
             }
             dim3 rgrid((unsigned)((((size_t)1 << log_out) >> a.log_r) / 256), ncols);

@@ -537,9 +537,10 @@ DevBuf<uint64_t> Prover::deep_compose(const uint64_t* tlde, const uint64_t* clde
     a.t_step = a.c_step = a.a_step = a.row_step;
     if (compact) {
         // a compact copy holds every 2^k-th row (k <= log_bl): stride M >> k, step row_step >> k
-        if (compact->t && compact->t_log <= log_bl) { a.tlde = compact->t; a.t_stride = M >> compact->t_log; a.t_step = a.row_step >> compact->t_log; }
+        // (a column stride given explicitly = the copy is de-interleaved and its part 0 is what is read)
+        if (compact->t && compact->t_log <= log_bl) { a.tlde = compact->t; a.t_stride = compact->t_stride ? compact->t_stride : M >> compact->t_log; a.t_step = a.row_step >> compact->t_log; }
         if (compact->c && compact->c_log <= log_bl) { a.clde = compact->c; a.c_stride = M >> compact->c_log; a.c_step = a.row_step >> compact->c_log; }
-        if (A && compact->a && compact->a_log <= log_bl) { a.alde = compact->a; a.a_stride = M >> compact->a_log; a.a_step = a.row_step >> compact->a_log; }
+        if (A && compact->a && compact->a_log <= log_bl) { a.alde = compact->a; a.a_stride = compact->a_stride ? compact->a_stride : M >> compact->a_log; a.a_step = a.row_step >> compact->a_log; }
     }
     a.tw_lo = tM->lo_fwd; a.tw_hi = tM->hi_fwd; a.tw_h = tM->h; a.offset = h;
     a.z = in.z; a.z_next = F::mulb(in.z, gl::root_of_unity(log_n)); a.z_c = gl::fpow<F>(in.z, C); a.z_conj = F::conj(in.z);
@@ -798,12 +799,14 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     // every B-th row when the constraint domain is the whole LDE domain; the composition LDE every B-th row (DEEP only).
     const int log_ce_step = log_B - ilog2(C);
     const int tc_log = (G == 1 && compact_rows) ? (log_ce_step > 0 ? log_ce_step : log_B) : 0;
+    // every (B / ce_step)-th compact row is a DEEP row: de-interleave so that DEEP reads part 0 contiguously
+    const int tc_split = log_ce_step > 0 ? log_B - log_ce_step : 0;
     const int cc_log = (G == 1 && compact_rows) ? log_B : 0;
     Matrix tlde(ctx, (int)W, M), tlde_c, alde_c, clde_c;
     bool have_tc = false, have_ac = false, have_cc = false;
     {
         CompactOut co;
-        if (tc_log > 0 && log_M >= 14) { tlde_c = Matrix(ctx, (int)W, M >> tc_log); co.ptr = tlde_c.data.get(); co.col_stride = M >> tc_log; co.log_step = tc_log; }
+        if (tc_log > 0 && log_M >= 14) { tlde_c = Matrix(ctx, (int)W, M >> tc_log); co.ptr = tlde_c.data.get(); co.col_stride = M >> tc_log; co.log_step = tc_log; co.log_split = tc_split; }
         have_tc = ctx->ntt_forward(polys.data.get(), n, tlde.data.get(), M, (int)W, log_M, log_Bl, &co);
     }
     ms.lde = clk.lap();
@@ -832,7 +835,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         alde = Matrix(ctx, (int)(A * F::DEG), M);
         {
             CompactOut co;
-            if (have_tc) { alde_c = Matrix(ctx, (int)(A * F::DEG), M >> tc_log); co.ptr = alde_c.data.get(); co.col_stride = M >> tc_log; co.log_step = tc_log; }
+            if (have_tc) { alde_c = Matrix(ctx, (int)(A * F::DEG), M >> tc_log); co.ptr = alde_c.data.get(); co.col_stride = M >> tc_log; co.log_step = tc_log; co.log_split = tc_split; }
             have_ac = ctx->ntt_forward(apolys.data.get(), n, alde.data.get(), M, (int)(A * F::DEG), log_M, log_Bl, &co);
         }
         acom = commit_matrix(alde);
@@ -874,13 +877,16 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         const size_t rows_eval = gather_h ? M : ceN;
         const size_t xcount = gather_h ? M / n : C;             // distinct values of x^n over those rows
         NttTables* tce = ctx->ntt_tables(ilog2(rows_eval));
+        int cons_split = 0;
         // one GPU: the rows the constraint domain consists of were also written densely by the LDE (every ce_step-th row)
         if (have_tc && (!A || have_ac) && log_ce_step > 0 && frame_src == tlde.data.get()) {
             frame_src = tlde_c.data.get();
             if (A) aux_src = alde_c.data.get();
             frame_rows = M >> tc_log;
+            cons_split = tc_split;
         }
         FibConsArgs<F> a{};
+        a.split_log = (uint32_t)cons_split;
         a.lde = frame_src; a.N = frame_rows; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)(frame_rows / n); a.ce_step = (uint32_t)(frame_rows / rows_eval);
         a.xmask = (uint32_t)xcount - 1;
         a.first = 0; a.count = rows_eval;
@@ -992,7 +998,10 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         in.z = z; in.ood_cur = ood_cur; in.ood_next = ood_next; in.ood_h = ood_h;
         in.da = da; in.db = db; in.dg = dg; in.dc = dc; in.lambda = lambda; in.mu = mu;
         DeepCompact dc_src;
-        if (have_tc && (!A || have_ac)) { dc_src.t = tlde_c.data.get(); dc_src.t_log = tc_log; if (A) { dc_src.a = alde_c.data.get(); dc_src.a_log = tc_log; } }
+        // with the de-interleaved layout the DEEP rows (every B-th LDE row) are part 0 of the compact copy: contiguous, i.e. the
+        // copy looks like an every-B-th-row copy to the DEEP kernel
+        if (have_tc && (!A || have_ac)) { dc_src.t = tlde_c.data.get(); dc_src.t_log = tc_log + tc_split; dc_src.t_stride = M >> tc_log;
+                                          if (A) { dc_src.a = alde_c.data.get(); dc_src.a_log = tc_log + tc_split; dc_src.a_stride = M >> tc_log; } }
         if (have_cc) { dc_src.c = clde_c.data.get(); dc_src.c_log = cc_log; }
         fri_vals.push_back(deep_compose<F>(tlde.data.get(), clde.data.get(), A ? alde.data.get() : nullptr, W, A, (uint32_t)C, log_n, log_Bl, h, in, &dc_src));
     }

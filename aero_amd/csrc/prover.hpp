@@ -199,7 +199,8 @@ public:
     // DEEP composition over the coset h<w_M>, M = n << log_bl: evaluates on every (M/n)-th row, interpolates, extends.
     // tlde: W x M, clde: (C*DEG) x M (column c*DEG + d), alde: (A*DEG) x M or nullptr. Returns [DEG][M].   [a14]
     // Optional compact copies (every 2^log_step-th row, written by the LDE's last pass): nullptr = walk the full matrix.
-    struct DeepCompact { const uint64_t* t = nullptr; int t_log = 0; const uint64_t* c = nullptr; int c_log = 0; const uint64_t* a = nullptr; int a_log = 0; };
+    struct DeepCompact { const uint64_t* t = nullptr; int t_log = 0; size_t t_stride = 0; const uint64_t* c = nullptr; int c_log = 0;
+                         const uint64_t* a = nullptr; int a_log = 0; size_t a_stride = 0; };
     template <class F>
     DevBuf<uint64_t> deep_compose(const uint64_t* tlde, const uint64_t* clde, const uint64_t* alde, uint32_t W, uint32_t A, uint32_t C, int log_n,
                                   int log_bl, uint64_t h, const DeepInputs<F>& in, const DeepCompact* compact = nullptr);

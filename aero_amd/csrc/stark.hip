@@ -42,8 +42,13 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
 #pragma unroll
     for (int q = 0; q < K; q++) {
         const size_t s = a.first + t + (size_t)q * nthreads;   // ce step
-        const size_t r = s * a.ce_step;
-        const size_t rn = (r + a.blowup) & (a.N - 1);
+        size_t r = s * a.ce_step;
+        size_t rn = (r + a.blowup) & (a.N - 1);
+        if (a.split_log) {      // physical position of (compact) row j: part j mod 2^k, index j / 2^k
+            const size_t part_len = a.N >> a.split_log, pm = ((size_t)1 << a.split_log) - 1;
+            r = (r & pm) * part_len + (r >> a.split_log);
+            rn = (rn & pm) * part_len + (rn >> a.split_log);
+        }
         const uint64_t w = tw2(a.tw_lo, a.tw_hi, (uint32_t)s, a.tw_h);       // w_ce^s
         const uint64_t wi = tw2(a.twi_lo, a.twi_hi, (uint32_t)s, a.tw_h);    // w_ce^-s
         const uint64_t x = gl::mul(a.offset, w);

@@ -9,6 +9,7 @@ template <class F> struct FibConsArgs {
     const uint64_t* lde;       // trace LDE, column-major W x N
     size_t N;
     uint32_t W, C, blowup, ce_step;
+    uint32_t split_log;        // rows of `lde` / `aux` are de-interleaved into 2^split_log parts (CompactOut); 0 = plain row order
     uint32_t xmask;            // x^n = h^n w^(s & xmask): C - 1 on the constraint domain; (rows / n) - 1 when the rows are a coset shard
     size_t first, count;       // ce rows [first, first + count)
     const T *ta, *tb, *ba, *bb;   // composition coefficient pairs (device): transition[W + A], boundary[W + W/2 + A]
