@@ -280,6 +280,55 @@ std::vector<std::vector<uint64_t>> batch_proof_indices(size_t n, const std::vect
     return nodes;
 }
 
+BatchPlan batch_proof_plan(size_t n, const std::vector<uint64_t>& positions) {
+    std::vector<uint64_t> qs(positions);
+    std::sort(qs.begin(), qs.end());
+    if (std::adjacent_find(qs.begin(), qs.end()) != qs.end()) fail("batch opening: duplicate positions");
+    if (!qs.empty() && qs.back() >= n) fail("batch opening: position out of range");
+    int depth = 0;
+    while (((size_t)1 << depth) < n) depth++;
+    BatchPlan pl;
+    pl.cap = (size_t)depth + 2;
+    std::vector<uint64_t> cur, next;
+    cur.reserve(qs.size()); next.reserve(qs.size());
+    for (uint64_t p : qs) { const uint64_t e = p - (p & 1); if (cur.empty() || cur.back() != e) cur.push_back(e); }   // even partners
+    const size_t P = cur.size();
+    if (P > 255) fail("batch opening: too many paths", ST_UNSUPPORTED);
+    pl.count.assign(P, 0);
+    pl.idx.resize(P * pl.cap);
+    for (size_t v = 0; v < P; v++) {
+        const uint64_t e = cur[v];
+        for (uint64_t i = e; i < e + 2; i++) if (!std::binary_search(qs.begin(), qs.end(), i)) pl.idx[v * pl.cap + pl.count[v]++] = n + i;
+        cur[v] = (e + n) >> 1;
+    }
+    for (int lvl = 1; lvl < depth; lvl++) {
+        next.clear();
+        size_t i = 0;
+        while (i < cur.size()) {
+            const uint64_t sib = cur[i] ^ 1;
+            if (i + 1 < cur.size() && cur[i + 1] == sib) i += 1;
+            else pl.idx[i * pl.cap + pl.count[i]++] = sib;       // the quirk of the reference format: indexed by position in THIS level's list
+            next.push_back(sib >> 1);
+            i += 1;
+        }
+        cur.swap(next);
+    }
+    return pl;
+}
+static Bytes serialize_plan(const BatchPlan& pl, const Digest* digests) {
+    Bytes out;
+    out.reserve(1 + pl.paths() + 32 * pl.total());
+    out.push_back((uint8_t)pl.paths());
+    size_t k = 0;
+    for (size_t p = 0; p < pl.paths(); p++) {
+        out.push_back(pl.count[p]);
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(digests + k);
+        out.insert(out.end(), src, src + 32 * (size_t)pl.count[p]);
+        k += pl.count[p];
+    }
+    return out;
+}
+
 // digests for a batch opening gathered from the device tree -> serialised BatchMerkleProof nodes
 static Bytes serialize_batch(const std::vector<std::vector<uint64_t>>& idx, const Digest* digests) {
     Bytes out;
@@ -1100,11 +1149,13 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         const uint64_t rem_dom = N / [&] { uint64_t d = 1; for (int l = 0; l < layers; l++) d *= Fd; return d; }();
         // node index plans per tree (global heap indices): trace, composition, FRI layers
         std::vector<const Commitment*> coms{&tcom, &ccom};
-        std::vector<std::vector<std::vector<uint64_t>>> plans{batch_proof_indices(N, pos)};
-        plans.push_back(plans[0]);                     // same positions, same tree shape: trace and composition share the plan
+        std::vector<BatchPlan> plan_store;
+        plan_store.reserve(layers + 1);
+        plan_store.push_back(batch_proof_plan(N, pos));
+        std::vector<const BatchPlan*> plans{&plan_store[0], &plan_store[0]};   // same positions, same tree shape: trace and composition share the plan
         const size_t fri_tree0 = A ? 3 : 2;          // tree order: trace, composition, [aux], FRI layers
-        if (A) { coms.push_back(&acom); plans.push_back(plans[0]); }
-        for (int l = 0; l < layers; l++) { coms.push_back(&fri_coms[l]); plans.push_back(batch_proof_indices(fri_coms[l].n_global, fpos[l])); }
+        if (A) { coms.push_back(&acom); plans.push_back(&plan_store[0]); }
+        for (int l = 0; l < layers; l++) { coms.push_back(&fri_coms[l]); plan_store.push_back(batch_proof_plan(fri_coms[l].n_global, fpos[l])); plans.push_back(&plan_store.back()); }
         // position of a row / node in this rank's arrays, GATHER_SKIP when another rank owns it
         auto local_row = [&](uint64_t p, bool sharded) -> uint64_t {
             if (!sharded) return (G == 1 || rank == 0) ? p : GATHER_SKIP;
@@ -1167,14 +1218,14 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             const MerkleTree& tree = coms[t]->tree;
             if (G > 1 && tree.skip) fail("sharded prove: tree with unstored levels", ST_INTERNAL);
             uint32_t k = 0;
-            for (auto& v : plans[t]) for (uint64_t i : v) {
+            plans[t]->for_each([&](uint64_t i) {
                 uint64_t a = 0;
                 if (G > 1) { const uint64_t li = local_node(i, *coms[t]); if (li != GATHER_SKIP) a = A64(tree.nodes.get() + li); }
                 else if (i < tree.stored_limit()) a = A64(tree.nodes.get() + i);
                 else { low_idx[t].push_back(i); low_slot[t].push_back(k); }
                 addr.push_back(a);
                 k++;
-            }
+            });
             if (!low_idx[t].empty() && tree.src_kind == 0) fail("batch opening: tree has unstored levels but no leaf source", ST_INTERNAL);
             n_dig += k;
         }
@@ -1217,15 +1268,14 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         }
         auto paths = [&](size_t t) {
             const Digest* raw = reinterpret_cast<const Digest*>(h_val + off_dig[t]);
-            size_t cnt = 0;
-            for (auto& v : plans[t]) cnt += v.size();
-            std::vector<Digest> ordered(cnt);
+            if (!coms[t]->sharded) return serialize_plan(*plans[t], raw);       // items are already in plan order
+            std::vector<Digest> ordered(plans[t]->total());
             size_t k = 0;
-            for (auto& v : plans[t]) for (uint64_t i : v) {
-                ordered[k] = (coms[t]->sharded && i < 2 * (uint64_t)G) ? coms[t]->top[i] : raw[k];
+            plans[t]->for_each([&](uint64_t i) {
+                ordered[k] = i < 2 * (uint64_t)G ? coms[t]->top[i] : raw[k];
                 k++;
-            }
-            return serialize_batch(plans[t], ordered.data());
+            });
+            return serialize_plan(*plans[t], ordered.data());
         };
         auto put = [&](Bytes& b, size_t off, size_t count) {      // `count` little-endian u64 from the value block
             const uint8_t* p8 = reinterpret_cast<const uint8_t*>(h_val + off);

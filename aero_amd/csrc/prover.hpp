@@ -228,6 +228,17 @@ private:
 // BatchMerkleProof node selection (winter-crypto 0.4 MerkleTree::prove_batch restated):
 // returns, per vector, the node indices (into the 2n-slot node array) whose digests are serialised.
 std::vector<std::vector<uint64_t>> batch_proof_indices(size_t n_leaves, const std::vector<uint64_t>& positions);
+// The same plan in flat form (two allocations instead of one per path: the prover builds 6-8 of them on the critical path of every
+// proof): path p holds count[p] node indices at idx[p * cap ...].
+struct BatchPlan {
+    size_t cap = 0;
+    std::vector<uint8_t> count;
+    std::vector<uint64_t> idx;
+    size_t paths() const { return count.size(); }
+    size_t total() const { size_t t = 0; for (uint8_t c : count) t += c; return t; }
+    template <class Fn> void for_each(Fn&& fn) const { for (size_t p = 0; p < count.size(); p++) for (uint8_t k = 0; k < count[p]; k++) fn(idx[p * cap + k]); }
+};
+BatchPlan batch_proof_plan(size_t n_leaves, const std::vector<uint64_t>& positions);
 // serialised BatchMerkleProof nodes for `positions` (u8 #vectors, per vector u8 len + digests)
 Bytes open_batch(Context* ctx, const MerkleTree& tree, const std::vector<uint64_t>& positions);
 std::vector<uint64_t> fold_positions(const std::vector<uint64_t>& positions, uint64_t source_domain, uint64_t folding_factor);
