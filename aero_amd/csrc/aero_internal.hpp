@@ -11,8 +11,8 @@
 #include <string>
 #include <vector>
 
-#include "blake2s.cuh"
-#include "gl.cuh"
+#include "blake2s_hash.hpp"
+#include "gl_field.hpp"
 
 namespace aero {
 

@@ -1,6 +1,6 @@
 // Small in-register DFTs over Goldilocks (shared by the NTT rounds and the FRI fold).
 #pragma once
-#include "gl.cuh"
+#include "gl_field.hpp"
 
 namespace aero {
 using gl::add;

@@ -25,7 +25,7 @@
 #include <type_traits>
 
 #include "aero_internal.hpp"
-#include "dft_small.cuh"
+#include "dft_small.hpp"
 
 namespace aero {
 

@@ -22,7 +22,7 @@
 // Algorithmic HBM bytes per element and pass: 16 (8 read + 8 written); interpolate(2^20) = 2 passes, lde(2^20 -> 2^23)
 // = 3 passes of which the first reads 1/8 of what it writes.
 #include "aero_internal.hpp"
-#include "dft_small.cuh"
+#include "dft_small.hpp"
 
 namespace aero {
 
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_first_pass(PassArgs a) {
 // transforms around ONE exchange, one wavefront per tile, 32 values per lane:
 //   A  bits 3..5: the three skipped stages broadcast 8 coefficients over the positions [64h, 64h + 64) of the tile. Lane
 //      (h, half) loads them and computes, for the 4 values klow = 4 half + klow' of (position mod 8), the twiddled 8-point
-//      transform. Every twiddle is a power of w_64 = 2^39, i.e. a compile-time shift (dft_small.cuh): no multiplication, no
+//      transform. Every twiddle is a power of w_64 = 2^39, i.e. a compile-time shift (dft_small.hpp): no multiplication, no
 //      table. The two halves run the same code: the factor w_64^(4 rev(i)) that separates klow from klow + 4 is applied to
 //      the inputs of the upper half with a select.
 //   -- the 32 x 64 transpose through LDS (XOR-swizzled columns: conflict-free writes and reads, no padding) --
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Strided passes of radix <= 64 entirely in registers: a thread owns one column position `lo` of a block and the R = 2^LOGR
 // values at stride S; the R-point transform needs no LDS because every twiddle of a transform of up to 64 points is a power of
-// two in this field (dft_small.cuh). Consecutive threads own consecutive addresses, so each of the R loads / stores of a
+// two in this field (dft_small.hpp). Consecutive threads own consecutive addresses, so each of the R loads / stores of a
 // wavefront is one contiguous 512-byte segment. The pass-boundary twiddle depends on (block, row) only: it comes from a small
 // per-pass table (2^(log_n - log_s) entries, row b * R + k = w^(S * rev(b) * k)) that every lane of a workgroup reads at the
 // same address.

@@ -12,7 +12,7 @@
 // Field inversions are batched per thread (Montgomery trick over the thread's K rows).
 #include "aero_internal.hpp"
 #include "stark_kernels.hpp"
-#include "dft_small.cuh"
+#include "dft_small.hpp"
 
 namespace aero {
 
@@ -346,7 +346,7 @@ template <class F> __global__ __launch_bounds__(256) void fri_fold_kernel(FoldAr
     for (int d = 0; d < F::DEG; d++) a.out[d][i] = F::comp(acc, d);
 }
 // Same fold with the inverse DFT done as radix-2 butterflies in registers (fold = 2, 4, 8): the inverse DFT leaves
-// F * c_k at position bitrev(k); constant twiddles are powers of two (dft_small.cuh).
+// F * c_k at position bitrev(k); constant twiddles are powers of two (dft_small.hpp).
 template <class F, int LOGF> __global__ __launch_bounds__(256) void fri_fold_fft_kernel(FoldArgs<F> a) {
     typedef typename F::T T;
     constexpr int FD = 1 << LOGF;
@@ -569,8 +569,8 @@ void canonical_check_enqueue(Context* ctx, const uint64_t* vals, size_t count, u
 }
 
 // ------------------------------------------------------------------------------------------------
-// Field-arithmetic self test. The device formulations of add / mul (32-bit carry chains, gl.cuh), the shift multiplications of
-// the NTT butterflies (dft_small.cuh) and the F_p^2 operations are compared, on the device they run on and inside a kernel
+// Field-arithmetic self test. The device formulations of add / mul (32-bit carry chains, gl_field.hpp), the shift multiplications of
+// the NTT butterflies (dft_small.hpp) and the F_p^2 operations are compared, on the device they run on and inside a kernel
 // that mixes them the way the real kernels do, with results the host computed with plain 128-bit arithmetic. A carry-chain
 // `sub` combined with the carry-chain `mul` once miscompiled inside deep_kernel (ROCm 7.2; each alone was exact): this test
 // exists so that a compiler or driver change that breaks a formulation is reported by name instead of as a wrong proof.

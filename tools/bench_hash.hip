@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
-#include "../aero_amd/csrc/blake2s.cuh"
+#include "../aero_amd/csrc/blake2s_hash.hpp"
 using b2s::Digest;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 

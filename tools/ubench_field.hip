@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-#include "../aero_amd/csrc/gl.cuh"
+#include "../aero_amd/csrc/gl_field.hpp"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 typedef uint32_t u32; typedef uint64_t u64;
 static constexpr u32 EPS32 = 0xFFFFFFFFu;

@@ -4,8 +4,8 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
-#include "../aero_amd/csrc/blake2s.cuh"
-#include "../aero_amd/csrc/gl.cuh"
+#include "../aero_amd/csrc/blake2s_hash.hpp"
+#include "../aero_amd/csrc/gl_field.hpp"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 
