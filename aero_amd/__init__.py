@@ -336,6 +336,39 @@ class Context:
                                                  C.c_uint32(fragment_offset), C.c_uint32(num_fragments), _p64(out), C.byref(fi)))
         return fi.value, out
 
+    def aux_columns_fib(self, trace: Matrix, air, rands, field_extension=1) -> Matrix:
+        """The stand-in AIR's auxiliary columns from the main trace and the drawn elements (aero_aux_columns_fib)."""
+        r = np.array(rands, dtype=np.uint64, ndmin=1)
+        h = C.c_void_p()
+        desc = FibAirDesc(*air)
+        self._ck(lib().aero_aux_columns_fib(self.h, trace.h, C.byref(desc), _p64(r), C.c_uint8(field_extension), C.byref(h)))
+        return Matrix(self, h)
+
+    def eval_constraints_air(self, lde: Matrix, aux_lde, air, log_blowup, results, rands, coeffs, field_extension=1, fragment_offset=0, num_fragments=1):
+        """ConstraintComputeWorkItem -> ConstraintComputeResult for FibAir with its auxiliary segment. Returns (frag_index, cols)."""
+        w, N = lde.shape
+        deg = 2 if field_extension == 2 else 1
+        A, R, D = air
+        Cc = 2 if (not A or D <= 2) else (4 if D <= 4 else 8)
+        n = N >> log_blowup
+        rows = Cc * n // num_fragments
+        res = np.array(results, dtype=np.uint64, ndmin=1)
+        co = np.array(coeffs, dtype=np.uint64, ndmin=1)
+        rd = np.array(rands, dtype=np.uint64, ndmin=1) if A else None
+        out = np.zeros((3 * deg, rows), np.uint64)
+        fi = C.c_uint64(0)
+        desc = FibAirDesc(A, R, D)
+        self._ck(lib().aero_eval_constraints_air(self.h, lde.h, aux_lde.h if aux_lde is not None else None, C.byref(desc), C.c_uint32(log_blowup),
+                                                 _p64(res), _p64(rd) if rd is not None else None, _p64(co), C.c_uint8(field_extension),
+                                                 C.c_uint32(fragment_offset), C.c_uint32(num_fragments), _p64(out), C.byref(fi)))
+        return fi.value, out
+
+    def composition_poly_air(self, numer_cols: np.ndarray, log_n: int, num_columns: int, field_extension=1) -> Matrix:
+        a = np.ascontiguousarray(numer_cols, np.uint64)
+        h = C.c_void_p()
+        self._ck(lib().aero_composition_poly_air(self.h, _p64(a), C.c_uint32(log_n), C.c_uint32(num_columns), C.c_uint8(field_extension), C.byref(h)))
+        return Matrix(self, h)
+
     def fri_fold(self, values: np.ndarray, fold: int, alpha: int) -> np.ndarray:
         v = np.ascontiguousarray(values, np.uint64)
         out = np.zeros(max(v.size // fold, 1), np.uint64)

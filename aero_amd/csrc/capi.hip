@@ -268,22 +268,32 @@ void aero_tree_free(aero_ctx* ctx, aero_tree* tree) {
 }  // extern "C"
 
 // ---- constraint evaluation -----------------------------------------------------------------------
+// FibAir with its optional auxiliary segment (air == nullptr or aux_width == 0: the plain AIR). `aux_lde` = (A * DEG) x N component
+// columns, `rands` = R elements of E; C = the AIR's constraint-evaluation blowup (2 / 4 / 8).
 template <class F>
-static void eval_constraints_fib(Context* c, const Matrix& lde, uint32_t log_blowup, const uint64_t* results, const uint64_t* coeffs,
-                                 uint32_t frag, uint32_t nfrags, uint64_t* out_cols, uint64_t* frag_index_out) {
+static void eval_constraints_air(Context* c, const Matrix& lde, const Matrix* aux_lde, const aero_fib_air* air, uint32_t log_blowup,
+                                 const uint64_t* results, const uint64_t* rands_in, const uint64_t* coeffs, uint32_t frag, uint32_t nfrags,
+                                 uint64_t* out_cols, uint64_t* frag_index_out) {
     typedef typename F::T T;
     const uint32_t W = (uint32_t)lde.cols;
-    const size_t N = lde.rows, B = (size_t)1 << log_blowup, n = N / B, C = FibAir::plain_ce_blowup_factor(), ceN = C * n;
-    REQUIRE(W >= 2 && !(W & 1), "eval_constraints_fib: FibAir needs an even width");
-    REQUIRE(B >= C && n >= 8, "eval_constraints_fib: bad blowup / trace length");
-    REQUIRE(nfrags >= 1 && (nfrags & (nfrags - 1)) == 0 && ceN / nfrags >= 1 && frag < nfrags, "eval_constraints_fib: bad fragment spec");
+    const uint32_t A = air ? air->aux_width : 0, R = A ? air->aux_rands : 0, D = A ? air->aux_degree : 2;
+    FibAir shape;
+    shape.width = W; shape.aux_width = A; shape.aux_rands = R; shape.aux_degree = D;
+    const size_t N = lde.rows, B = (size_t)1 << log_blowup, n = N / B, C = shape.ce_blowup_factor(), ceN = C * n;
+    REQUIRE(W >= 2 && !(W & 1), "eval_constraints: FibAir needs an even width");
+    REQUIRE(!A || (D >= 2 && D <= 8 && R >= 1 && R <= 255 && A <= 255 - W), "eval_constraints: bad auxiliary segment shape");
+    REQUIRE(!A || (aux_lde && rands_in && aux_lde->rows == N && (uint32_t)aux_lde->cols == A * F::DEG), "eval_constraints: auxiliary LDE / random elements missing or of the wrong shape");
+    REQUIRE(B >= C && n >= 8, "eval_constraints: blowup smaller than the constraint-evaluation blowup, or trace too short");
+    REQUIRE(nfrags >= 1 && (nfrags & (nfrags - 1)) == 0 && ceN / nfrags >= 1 && frag < nfrags, "eval_constraints: bad fragment spec");
     const size_t rows = ceN / nfrags, first = (size_t)frag * rows;
-    const size_t nt = W, na = W + W / 2;
-    std::vector<T> ta(nt), tb(nt), ba(na), bb(na);
+    const size_t nt = shape.num_transition_constraints(), na = shape.num_assertions();
+    std::vector<T> ta(nt), tb(nt), ba(na), bb(na), rands(R);
     const uint64_t* p = coeffs;
-    auto rd = [&]() { uint64_t c0 = *p++; uint64_t c1 = F::DEG > 1 ? *p++ : 0; REQUIRE(c0 < gl::P && c1 < gl::P, "eval_constraints_fib: non-canonical coefficient"); return F::make(c0, c1); };
+    auto rd = [&]() { uint64_t c0 = *p++; uint64_t c1 = F::DEG > 1 ? *p++ : 0; REQUIRE(c0 < gl::P && c1 < gl::P, "eval_constraints: non-canonical coefficient"); return F::make(c0, c1); };
     for (size_t i = 0; i < nt; i++) { ta[i] = rd(); tb[i] = rd(); }
     for (size_t i = 0; i < na; i++) { ba[i] = rd(); bb[i] = rd(); }
+    p = rands_in;
+    for (uint32_t i = 0; i < R; i++) rands[i] = rd();
     std::vector<uint64_t> res(results, results + W / 2);
     auto up = [&](const void* src, size_t bytes) { void* d = c->scratch_alloc(bytes + 8); AERO_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, c->stream)); return d; };
     const int log_ce = ilog2u(ceN);
@@ -296,10 +306,16 @@ static void eval_constraints_fib(Context* c, const Matrix& lde, uint32_t log_blo
     a.results = (const uint64_t*)up(res.data(), res.size() * 8);
     a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.twi_lo = tce->lo_inv; a.twi_hi = tce->hi_inv; a.tw_h = tce->h;
     a.offset = gl::GEN; a.gen_inv = gl::inv(gl::GEN); a.k7 = gl::pow(gl::GEN, ceN);
-    std::vector<uint64_t> xn(C), zn(C);
+    std::vector<uint64_t> xn(C), zn(C), xnp(C);
     uint64_t g7n = gl::pow(gl::GEN, n), wC = gl::root_of_unity(ilog2u(C));
-    for (size_t k = 0; k < C; k++) { uint64_t xnk = gl::mul(g7n, gl::pow(wC, k)); xn[k] = gl::inv(xnk); zn[k] = gl::inv(gl::sub(xnk, 1)); }
-    a.xn_inv = (const uint64_t*)up(xn.data(), C * 8); a.zn_inv = (const uint64_t*)up(zn.data(), C * 8);
+    for (size_t k = 0; k < C; k++) {
+        const uint64_t xnk = gl::mul(g7n, gl::pow(wC, k));
+        xnp[k] = gl::pow(xnk, C + 1 - D);                  // aux degree adjustment x^((C + 1 - D) n + (D - 2)): its x^n part
+        xn[k] = gl::inv(xnk); zn[k] = gl::inv(gl::sub(xnk, 1));
+    }
+    a.xn_inv = (const uint64_t*)up(xn.data(), C * 8); a.zn_inv = (const uint64_t*)up(zn.data(), C * 8); a.xn = (const uint64_t*)up(xnp.data(), C * 8);
+    a.aux = A ? aux_lde->data.get() : nullptr; a.A = A; a.R = R; a.D = D;
+    a.rands = A ? (const T*)up(rands.data(), R * sizeof(T)) : nullptr;
     a.w_last = gl::pow(gl::root_of_unity(ilog2u(n)), n - 1);
     DevBuf<uint64_t> d_out(c, 3 * F::DEG * rows);
     a.out_cols = d_out.get();
@@ -309,26 +325,65 @@ static void eval_constraints_fib(Context* c, const Matrix& lde, uint32_t log_blo
     c->scratch_reset();
     if (frag_index_out) *frag_index_out = first;
 }
+// auxiliary columns of the stand-in AIR from the main trace and the drawn elements: (A * DEG) x n component columns
+template <class F> static void aux_columns_abi(aero_ctx* ctx, const Matrix& trace, const aero_fib_air* air, const uint64_t* rands_in, aero_matrix** out) {
+    typedef typename F::T T;
+    Context* c = ctx->c;
+    const uint32_t W = (uint32_t)trace.cols, A = air->aux_width, R = air->aux_rands, D = air->aux_degree;
+    REQUIRE(A >= 1 && A <= 255 - W && R >= 1 && R <= 255 && D >= 2 && D <= 8, "aux_columns: bad auxiliary segment shape");
+    std::vector<T> rands(R);
+    const uint64_t* p = rands_in;
+    for (uint32_t i = 0; i < R; i++) {
+        const uint64_t c0 = *p++, c1 = F::DEG > 1 ? *p++ : 0;
+        REQUIRE(c0 < gl::P && c1 < gl::P, "aux_columns: non-canonical random element");
+        rands[i] = F::make(c0, c1);
+    }
+    T* d_r = (T*)c->scratch_alloc(R * sizeof(T) + 8);
+    AERO_HIP(hipMemcpyAsync(d_r, rands.data(), R * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    std::unique_ptr<aero_matrix> m(new aero_matrix(ctx));
+    m->m = Matrix(c, (int)(A * F::DEG), trace.rows);
+    launch_aux_columns<F>(c, trace.data.get(), trace.rows, W, A, R, D, d_r, m->m.data.get());
+    c->sync();
+    c->scratch_reset();
+    *out = m.release();
+}
 extern "C" {
 
 int32_t aero_eval_constraints_fib(aero_ctx* ctx, const aero_matrix* trace_lde, uint32_t log_blowup, const uint64_t* results,
                                   const uint64_t* coeffs, uint8_t field_extension, uint32_t fragment_offset, uint32_t num_fragments,
                                   uint64_t* out_cols, uint64_t* frag_index_out) {
+    return aero_eval_constraints_air(ctx, trace_lde, nullptr, nullptr, log_blowup, results, nullptr, coeffs, field_extension, fragment_offset,
+                                     num_fragments, out_cols, frag_index_out);
+}
+int32_t aero_eval_constraints_air(aero_ctx* ctx, const aero_matrix* trace_lde, const aero_matrix* aux_lde, const aero_fib_air* air,
+                                  uint32_t log_blowup, const uint64_t* results, const uint64_t* rands, const uint64_t* coeffs,
+                                  uint8_t field_extension, uint32_t fragment_offset, uint32_t num_fragments, uint64_t* out_cols,
+                                  uint64_t* frag_index_out) {
     return guard(ctx, [&] {
-        REQUIRE(trace_lde && results && coeffs && out_cols, "eval_constraints_fib: null argument");
-        REQUIRE(log_blowup >= 1 && log_blowup <= 7, "eval_constraints_fib: log_blowup must be in [1,7]");
-        if (field_extension == EXT_NONE) eval_constraints_fib<gl::FB>(ctx->c, trace_lde->m, log_blowup, results, coeffs, fragment_offset, num_fragments, out_cols, frag_index_out);
-        else if (field_extension == EXT_QUADRATIC) eval_constraints_fib<gl::FQ>(ctx->c, trace_lde->m, log_blowup, results, coeffs, fragment_offset, num_fragments, out_cols, frag_index_out);
-        else fail("eval_constraints_fib: field extension must be 1 (None) or 2 (Quadratic)", ST_UNSUPPORTED);
+        REQUIRE(trace_lde && results && coeffs && out_cols, "eval_constraints: null argument");
+        REQUIRE(log_blowup >= 1 && log_blowup <= 7, "eval_constraints: log_blowup must be in [1,7]");
+        const Matrix* aux = aux_lde ? &aux_lde->m : nullptr;
+        if (field_extension == EXT_NONE) eval_constraints_air<gl::FB>(ctx->c, trace_lde->m, aux, air, log_blowup, results, rands, coeffs, fragment_offset, num_fragments, out_cols, frag_index_out);
+        else if (field_extension == EXT_QUADRATIC) eval_constraints_air<gl::FQ>(ctx->c, trace_lde->m, aux, air, log_blowup, results, rands, coeffs, fragment_offset, num_fragments, out_cols, frag_index_out);
+        else fail("eval_constraints: field extension must be 1 (None) or 2 (Quadratic)", ST_UNSUPPORTED);
+    });
+}
+int32_t aero_aux_columns_fib(aero_ctx* ctx, const aero_matrix* trace, const aero_fib_air* air, const uint64_t* rands, uint8_t field_extension,
+                             aero_matrix** aux_out) {
+    return guard(ctx, [&] {
+        REQUIRE(trace && air && rands && aux_out, "aux_columns: null argument");
+        if (field_extension == EXT_NONE) aux_columns_abi<gl::FB>(ctx, trace->m, air, rands, aux_out);
+        else if (field_extension == EXT_QUADRATIC) aux_columns_abi<gl::FQ>(ctx, trace->m, air, rands, aux_out);
+        else fail("aux_columns: field extension must be 1 (None) or 2 (Quadratic)", ST_UNSUPPORTED);
     });
 }
 
 }  // extern "C"
 
 // ---- composition polynomial / DEEP / FRI layers ------------------------------------------------------------------
-template <class F> static void composition_poly_fib(aero_ctx* ctx, const uint64_t* numer_cols, uint32_t log_n, aero_matrix** out) {
+template <class F> static void composition_poly_fib(aero_ctx* ctx, const uint64_t* numer_cols, uint32_t log_n, aero_matrix** out, size_t C = FibAir::plain_ce_blowup_factor()) {
     Context* c = ctx->c;
-    const size_t n = (size_t)1 << log_n, C = FibAir::plain_ce_blowup_factor(), ceN = C * n;
+    const size_t n = (size_t)1 << log_n, ceN = C * n;
     const int log_ce = ilog2u(ceN);
     for (size_t i = 0; i < 3 * F::DEG * ceN; i++) REQUIRE(numer_cols[i] < gl::P, "composition_poly_fib: non-canonical element");
     DevBuf<uint64_t> d_cols(c, 3 * F::DEG * ceN);
@@ -398,6 +453,17 @@ int32_t aero_composition_poly_fib(aero_ctx* ctx, const uint64_t* numer_cols, uin
         if (field_extension == EXT_NONE) composition_poly_fib<gl::FB>(ctx, numer_cols, log_n, comp_polys);
         else if (field_extension == EXT_QUADRATIC) composition_poly_fib<gl::FQ>(ctx, numer_cols, log_n, comp_polys);
         else fail("composition_poly_fib: field extension must be 1 (None) or 2 (Quadratic)", ST_UNSUPPORTED);
+    });
+}
+int32_t aero_composition_poly_air(aero_ctx* ctx, const uint64_t* numer_cols, uint32_t log_n, uint32_t num_columns, uint8_t field_extension,
+                                  aero_matrix** comp_polys) {
+    return guard(ctx, [&] {
+        REQUIRE(numer_cols && comp_polys, "composition_poly_air: null argument");
+        REQUIRE(log_n >= 3 && log_n <= 28, "composition_poly_air: log_n out of range");
+        REQUIRE(num_columns == 2 || num_columns == 4 || num_columns == 8, "composition_poly_air: 2, 4 or 8 composition columns");
+        if (field_extension == EXT_NONE) composition_poly_fib<gl::FB>(ctx, numer_cols, log_n, comp_polys, num_columns);
+        else if (field_extension == EXT_QUADRATIC) composition_poly_fib<gl::FQ>(ctx, numer_cols, log_n, comp_polys, num_columns);
+        else fail("composition_poly_air: field extension must be 1 (None) or 2 (Quadratic)", ST_UNSUPPORTED);
     });
 }
 int32_t aero_deep_compose(aero_ctx* ctx, const aero_matrix* trace_lde, const aero_matrix* comp_lde, uint32_t log_blowup, uint8_t field_extension,

@@ -154,6 +154,23 @@ int32_t aero_eval_constraints_fib(aero_ctx* ctx, const aero_matrix* trace_lde, u
                                   const uint64_t* coeffs, uint8_t field_extension, uint32_t fragment_offset,
                                   uint32_t num_fragments, uint64_t* out_cols, uint64_t* frag_index_out);
 
+/* The same seam for the built-in AIR WITH its auxiliary segment (aero_fib_air; air == NULL or aux_width == 0 is exactly
+ * aero_eval_constraints_fib): `aux_lde` = the auxiliary segment's LDE as (aux_width * deg) component columns over the same rows
+ * (column c * deg + d), `rands` = the aux_rands drawn elements (deg u64 each) - what the reference ships as
+ * `ConstraintComputeWorkItem.aux_rand_elements` (utils.rs:302-347). The constraint domain has C * trace_len points, C = 2 / 4 / 8 for
+ * aux_degree 2 / 3-4 / 5-8; coeffs = (alpha, beta) per transition constraint (width main, then aux_width aux), then per assertion
+ * (width + width/2 main, then aux_width aux). Columns as above: [transition, boundary(step 0), boundary(step n-1)] x deg. */
+int32_t aero_eval_constraints_air(aero_ctx* ctx, const aero_matrix* trace_lde, const aero_matrix* aux_lde, const aero_fib_air* air,
+                                  uint32_t log_blowup, const uint64_t* results, const uint64_t* rands, const uint64_t* coeffs,
+                                  uint8_t field_extension, uint32_t fragment_offset, uint32_t num_fragments, uint64_t* out_cols,
+                                  uint64_t* frag_index_out);
+/* The AIR-specific half of the fork's `commit_to_trace_and_validate` (proving_worker.rs:323-332): the auxiliary columns of the built-in
+ * stand-in AIR from the main trace and the drawn elements (p_c(0) = 1, p_c(i+1) = p_c(i) * (r_(c mod R) + main_(c mod W)(i))^(D-1)),
+ * as an (aux_width * deg) x trace_len matrix of component columns - input to aero_interpolate_columns / aero_evaluate_columns_over
+ * / aero_merkle_commit_rows like the main segment. */
+int32_t aero_aux_columns_fib(aero_ctx* ctx, const aero_matrix* trace, const aero_fib_air* air, const uint64_t* rands, uint8_t field_extension,
+                             aero_matrix** aux_out);
+
 /* ---- composition polynomial, DEEP composition (the stages inside the fork's `prove_after_constraint_eval`,
  *      proving_worker.rs:344-352; bodies in winter-prover 0.4) --------------------------------------------------------------- */
 /* `ConstraintEvaluationTable::into_poly` -> `CompositionPoly` for FibAir: numer_cols = the 3*deg numerator columns of
@@ -162,6 +179,11 @@ int32_t aero_eval_constraints_fib(aero_ctx* ctx, const aero_matrix* trace_lde, u
  * split into the 2 column polynomials H(x) = H_0(x^2) + x H_1(x^2). Output: matrix of 2*deg columns x 2^log_n rows in the
  * backend's internal polynomial form (input to aero_evaluate_columns_over / aero_poly_eval); column order [component][c]. */
 int32_t aero_composition_poly_fib(aero_ctx* ctx, const uint64_t* numer_cols, uint32_t log_n, uint8_t field_extension,
+                                  aero_matrix** comp_polys);
+/* Same for C = 2, 4 or 8 composition columns (the AIR with an auxiliary constraint of degree up to 8): numer_cols over the
+ * C * 2^log_n-point constraint domain. Column order of the result: column d * C + q = component d of composition column
+ * bitrev(q) (the identity for C = 2) - the order aero_evaluate_columns_over / aero_poly_eval hand back as well. */
+int32_t aero_composition_poly_air(aero_ctx* ctx, const uint64_t* numer_cols, uint32_t log_n, uint32_t num_columns, uint8_t field_extension,
                                   aero_matrix** comp_polys);
 /* DEEP composition over the LDE domain (winter-prover `DeepCompositionPoly`; verifier-side mirror
  * src/stark_verifier/composer.cairo:48-316). trace_lde: W columns; comp_lde: C*deg columns, column c*deg + d = component d of

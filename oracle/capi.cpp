@@ -170,7 +170,7 @@ int orc_prove_fib(const uint64_t* trace, uint32_t W, int log_n, const uint8_t op
 }
 // FibAir with an auxiliary segment of A columns built from R coin elements (oracle/stark.hpp: FibAir::A, R).
 int orc_prove_fib_aux(const uint64_t* trace, uint32_t W, int log_n, uint32_t A, uint32_t R, uint32_t D, const uint8_t opt7[7], uint8_t** proof,
-                      size_t* proof_len, uint64_t* pub_out, double* times) {
+                      size_t* proof_len, uint64_t* pub_out, double* times, int keep_artifacts) {
     try {
         size_t n = (size_t)1 << log_n;
         std::vector<Col> tr;
@@ -178,7 +178,10 @@ int orc_prove_fib_aux(const uint64_t* trace, uint32_t W, int log_n, uint32_t A, 
         else tr = fib_trace(W, log_n);
         Options o{opt7[0], opt7[1], opt7[2], opt7[3], opt7[4], opt7[5], opt7[6]};
         Col pub; StageTimes tm;
-        Bytes pf = prove_fib_any(tr, log_n, o, &pub, &tm, A, R, D);
+        Bytes pf;
+        if (keep_artifacts && o.field_ext == EXT_NONE) { g_art = ProverArtifacts<FB>(); g_art_is_q = false; pf = prove_fib<FB>(tr, log_n, o, &pub, &tm, &g_art, A, R, D); }
+        else if (keep_artifacts && o.field_ext == EXT_QUADRATIC) { g_art_q = ProverArtifacts<FQ>(); g_art_is_q = true; pf = prove_fib<FQ>(tr, log_n, o, &pub, &tm, &g_art_q, A, R, D); }
+        else pf = prove_fib_any(tr, log_n, o, &pub, &tm, A, R, D);
         *proof = (uint8_t*)malloc(pf.size()); memcpy(*proof, pf.data(), pf.size()); *proof_len = pf.size();
         if (pub_out) memcpy(pub_out, pub.data(), pub.size() * 8);
         if (times) { double t[12] = {tm.interpolate, tm.lde, tm.trace_commit, tm.constraints, tm.composition, tm.comp_commit, tm.ood, tm.deep, tm.fri, tm.grind, tm.queries, tm.total}; memcpy(times, t, sizeof t); }
@@ -205,6 +208,9 @@ long orc_artifact(const char* name, uint64_t* out, size_t cap) {
         // product's aero_eval_constraints_fib)
         if (s == "ce_cols") { for (auto& col : g_art_q.ce_cols) for (int d = 0; d < 2; d++) for (auto& v : col) flat.push_back(FQ::comp(v, d)); }
         else if (s == "cons_coeffs") flat = g_art_q.cons_coeffs;
+        else if (s == "aux_rands") flat = g_art_q.aux_rands;
+        else if (s == "aux_cols") put_cols(g_art_q.aux_cols);
+        else if (s == "aux_lde") put_cols(g_art_q.aux_lde);
         else if (s == "trace_lde") put_cols(g_art_q.trace_lde);
         else if (s == "comp_polys") put_cols(g_art_q.comp_polys);
         else if (s == "comp_lde") put_cols(g_art_q.comp_lde);
@@ -225,6 +231,9 @@ long orc_artifact(const char* name, uint64_t* out, size_t cap) {
     else if (s == "ood_next") flat = g_art.ood_next;
     else if (s == "ood_h") flat = g_art.ood_h;
     else if (s == "cons_coeffs") flat = g_art.cons_coeffs;
+    else if (s == "aux_rands") flat = g_art.aux_rands;
+    else if (s == "aux_cols") put_cols(g_art.aux_cols);
+    else if (s == "aux_lde") put_cols(g_art.aux_lde);
     else return -1;
     if (flat.size() > cap) return -(long)flat.size() - 2;
     memcpy(out, flat.data(), flat.size() * 8);

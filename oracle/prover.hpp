@@ -39,6 +39,8 @@ template <class F> struct ProverArtifacts {
     std::vector<std::vector<typename F::T>> fri_layers;   // transposed evaluations per layer (incl. remainder layer)
     std::vector<typename F::T> ood_cur, ood_next, ood_h;
     Col cons_coeffs;                                  // constraint composition coefficients in draw order, DEG u64 each
+    std::vector<Col> aux_cols, aux_lde;               // auxiliary segment: (A*DEG) x n trace columns, (A*DEG) x N
+    Col aux_rands;                                    // the R drawn elements, DEG u64 each
 };
 
 // hash every row of a column-major matrix: leaf_j = hash_elements(row j)   [a5]
@@ -112,7 +114,9 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
                 p = F::mul(p, f_pow<F>(F::add(rands[c % R], F::from(trace[c % W][i])), D - 1));
             }
         }
+        if (art) { art->aux_cols = apolys; f_flatten<F>(rands.data(), rands.size(), art->aux_rands); }
         for (size_t c = 0; c < A * F::DEG; c++) { intt(apolys[c].data(), n, true); alde[c] = lde(apolys[c].data(), n, B, GEN); }
+        if (art) art->aux_lde = alde;
         aleaves = hash_rows(alde, N);
         atree = MerkleTree(aleaves);
         wbytes(pr.commitments, Bytes(atree.root().b, atree.root().b + 32));

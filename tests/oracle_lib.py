@@ -225,7 +225,7 @@ class Oracle:
                  "grind", "queries", "total"]
         return data, pub.tolist(), dict(zip(names, times.tolist()))
 
-    def prove_fib_aux(self, W, log_n, A, R, opt7, trace=None, D=2):
+    def prove_fib_aux(self, W, log_n, A, R, opt7, trace=None, D=2, keep_artifacts=False):
         """FibAir(W) with an auxiliary segment of A columns built from R coin elements, aux constraint degree D.
         Returns (proof, pub, times)."""
         o = (C.c_uint8 * 7)(*opt7)
@@ -237,7 +237,7 @@ class Oracle:
             assert tr.shape == (W, 1 << log_n)
         self._ck(self.lib.orc_prove_fib_aux(_p64(tr) if tr is not None else None, C.c_uint32(W), C.c_int(log_n), C.c_uint32(A),
                                             C.c_uint32(R), C.c_uint32(D), o, C.byref(proof), C.byref(plen), _p64(pub),
-                                            times.ctypes.data_as(C.POINTER(C.c_double))))
+                                            times.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(1 if keep_artifacts else 0)))
         data = C.string_at(proof, plen.value)
         self.lib.orc_free(proof)
         names = ["interpolate", "lde", "trace_commit", "constraints", "composition", "comp_commit", "ood", "deep", "fri",

@@ -80,6 +80,57 @@ def test_composition_deep_fri_stages_match_oracle(ctx, oracle, log_n, width, opt
     fri.free()
 
 
+def bitrev(x, bits):
+    return int(format(x, f"0{bits}b")[::-1], 2) if bits else 0
+
+
+@pytest.mark.parametrize("log_n,width,A,R,D,ext", [(8, 2, 2, 3, 2, 1), (9, 4, 3, 2, 5, 1), (8, 2, 2, 2, 8, 2), (7, 72, 9, 16, 8, 1), (8, 4, 1, 1, 3, 2)])
+def test_aux_segment_stage_entry_points_match_oracle(ctx, oracle, log_n, width, A, R, D, ext):
+    """The AIR-specific stages with the auxiliary segment, one by one against the intermediates of the oracle's own prover run:
+    aux columns (the step of commit_to_trace_and_validate, proving_worker.rs:323-332), their LDE, the constraint seam with
+    aux_rand_elements (ConstraintComputeWorkItem, utils.rs:302-347; 1 and 4 fragments) and the composition polynomial with 2 / 4 / 8
+    columns."""
+    opt = [27, 8, 16, 4, ext, 8, 5]
+    deg = 2 if ext == 2 else 1
+    n, N = 1 << log_n, 8 << log_n
+    Cc = 2 if D <= 2 else (4 if D <= 4 else 8)
+    proof, pub, _ = oracle.prove_fib_aux(width, log_n, A, R, opt, D=D, keep_artifacts=True)
+    rands = oracle.artifact("aux_rands", R * deg)
+    assert rands.size == R * deg
+    dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
+    aux = ctx.aux_columns_fib(dev, (A, R, D), rands, ext)
+    assert (aux.download() == oracle.artifact("aux_cols", A * deg * n).reshape(A * deg, n)).all()
+    aux_lde = ctx.evaluate_columns_over(ctx.interpolate_columns(aux), 3)
+    assert (aux_lde.download() == oracle.artifact("aux_lde", A * deg * N).reshape(A * deg, N)).all()
+    lde = ctx.evaluate_columns_over(ctx.interpolate_columns(dev), 3)
+    ncoef = 2 * deg * ((width + A) + (width + width // 2 + A))
+    coeffs = oracle.artifact("cons_coeffs", ncoef)
+    assert coeffs.size == ncoef
+    ce_n = Cc * n
+    want = oracle.artifact("ce_cols", 3 * deg * ce_n).reshape(3 * deg, ce_n)
+    fi, cols = ctx.eval_constraints_air(lde, aux_lde, (A, R, D), 3, pub, rands, coeffs, field_extension=ext)
+    assert fi == 0 and (cols == want).all()
+    parts = np.zeros_like(cols)
+    for k in range(4):
+        fi, part = ctx.eval_constraints_air(lde, aux_lde, (A, R, D), 3, pub, rands, coeffs, field_extension=ext, fragment_offset=k, num_fragments=4)
+        assert fi == k * (ce_n // 4)
+        parts[:, fi:fi + part.shape[1]] = part
+    assert (parts == want).all()
+    comp = ctx.composition_poly_air(cols, log_n, Cc, ext)
+    assert comp.shape == (Cc * deg, n)
+    got = ctx.evaluate_columns_over(comp, 3).download()
+    want_clde = oracle.artifact("comp_lde", Cc * deg * N).reshape(Cc * deg, N)          # oracle: column c * deg + d
+    lc = Cc.bit_length() - 1
+    for q in range(Cc):
+        for d in range(deg):
+            assert (got[d * Cc + q] == want_clde[bitrev(q, lc) * deg + d]).all(), (q, d)
+    # without an aux segment the generalised entry points are the plain ones
+    with pytest.raises(aero_amd.AeroError):
+        ctx.eval_constraints_air(lde, None, (A, R, D), 3, pub, rands, coeffs, field_extension=ext)     # aux LDE missing
+    with pytest.raises(aero_amd.AeroError):
+        ctx.composition_poly_air(cols, log_n, 3, ext)
+
+
 def test_stage_argument_checks(ctx):
     with pytest.raises(aero_amd.AeroError):
         ctx.composition_poly_fib(np.full((3, 16), P, np.uint64), 3)            # non-canonical element
