@@ -56,3 +56,18 @@ def test_sharded_mode_two_ranks():
     out = _run(["--mode", "sharded"])
     assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["value"] > 0
     assert out["sharded_proof"]["proof_identical_to_single_gpu_on_every_rank"] is True
+
+
+def test_plain_invocation_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (how the driver starts N = 1): bench.py becomes the launcher, starts 2 rank
+    processes, and rank 0's JSON line is the only line on stdout."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--share-gpu", "--workload", SMALL,
+           "--concurrent", "2", "--sharded-check-world", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, stdin=subprocess.DEVNULL, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["h2d_included"] is True
+    assert "sharded_proof" not in out
