@@ -85,6 +85,7 @@ struct CoinStep {
     Digest* seed_io = nullptr;   // coin seed: reseeded in place with the root
     uint64_t* alpha_out = nullptr;   // `deg` u64: the drawn element
     int deg = 1;
+    Digest* root_out = nullptr;  // the root once more, in the block the host reads after the last layer
 };
 
 // The small end of the FRI commit phase in ONE launch (hash.hip: fri_tail_kernel): every layer whose domain has at most
@@ -131,6 +132,11 @@ public:
 
     void check_launch(const char* what);
     void sync();
+    // Small device -> host read on the critical path of the transcript: copy into pinned staging + ONE stream synchronisation.
+    // (Measured and dropped: a one-workgroup kernel that stores into mapped pinned memory followed by a sequence word the host
+    // spins on. With the producing kernel storing directly that saves 10 us per round trip - tools/ubench_roundtrip.hip - but as
+    // a separate launch it is 1 % SLOWER per proof than the runtime's own copy + synchronise, which already spins on a signal.)
+    void fetch(void* dst, const void* dev_src, size_t bytes);
 
     // ---- per-kernel HIP-event timing on this context's stream (off by default) ----
     bool kernel_timing = false;

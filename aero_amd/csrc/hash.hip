@@ -210,6 +210,7 @@ template <class Src> __global__ __launch_bounds__(256) void hash_rows_kernel(Src
 // is the serial latency of one compression per level (~2.4 us with one wave per SIMD) and one launch instead of L.
 // reseed with the root, then draw one element of E (deg components); same retry rule as the host coin (prover.hip HostCoin)
 __device__ __forceinline__ void coin_step(const CoinStep& cs, const Digest& root) {
+    if (cs.root_out) *cs.root_out = root;
     const Digest seed = b2s::merge(*cs.seed_io, root);
     *cs.seed_io = seed;
     for (uint64_t ctr = 1; ctr < 1000; ctr++) {
@@ -259,13 +260,13 @@ __constant__ uint8_t QUAD_SIGMA[10][16] = {
     c = c + d;       b = b2s::rotr(b ^ c, 7);
 // BLAKE2s(left || right) of the 16 message words at msg[0..16) (LDS), computed by the 4 lanes of a quad; lane j returns words
 // j (lo) and 4 + j (hi) of the digest. Every lane of the quad must call it (DPP moves), idle quads may pass any valid msg.
-__device__ __forceinline__ void quad_merge(const uint32_t* msg, int j, const uint32_t (&pk)[10], uint32_t& lo, uint32_t& hi) {
+__device__ __forceinline__ void quad_merge(const uint32_t* msg, int j, const uint32_t (&pk)[10], uint32_t& lo, uint32_t& hi, uint32_t tlen = 64u) {
     const uint32_t iv_lo[4] = {b2s::IV0, b2s::IV1, b2s::IV2, b2s::IV3}, iv_hi[4] = {b2s::IV4, b2s::IV5, b2s::IV6, b2s::IV7};
     const uint32_t h_lo = (j == 0 ? b2s::IV0 ^ b2s::PARAM0 : j == 1 ? iv_lo[1] : j == 2 ? iv_lo[2] : iv_lo[3]);
     const uint32_t h_hi = (j == 0 ? iv_hi[0] : j == 1 ? iv_hi[1] : j == 2 ? iv_hi[2] : iv_hi[3]);
     uint32_t a = h_lo, b = h_hi;
     uint32_t c = (j == 0 ? iv_lo[0] : j == 1 ? iv_lo[1] : j == 2 ? iv_lo[2] : iv_lo[3]);
-    uint32_t d = (j == 0 ? iv_hi[0] ^ 64u : j == 1 ? iv_hi[1] : j == 2 ? ~iv_hi[2] : iv_hi[3]);   // t = 64 bytes, last block
+    uint32_t d = (j == 0 ? iv_hi[0] ^ tlen : j == 1 ? iv_hi[1] : j == 2 ? ~iv_hi[2] : iv_hi[3]);   // t = tlen bytes (one block), last block
     // the 4 message words of each round come from LDS through this lane's packed index table; none of the 40 reads depends
     // on the G chain, so they are all in flight before it starts
     uint32_t mw[10][4];
@@ -283,6 +284,36 @@ __device__ __forceinline__ void quad_merge(const uint32_t* msg, int j, const uin
     }
     lo = h_lo ^ a ^ c;
     hi = h_hi ^ b ^ d;
+}
+// The transcript step of a FRI commitment (reseed with the root, draw the folding challenge) with quad compressions: every thread
+// of the workgroup runs it in lockstep on the same 24 LDS words (the quads all compute the same digests, thread 0..3 store) - a
+// lone lane needs 2.4 us per compression and the step is 2 of them on the critical path of every layer.
+// scratch: 24 words of LDS, words [0, 8) = the root on entry. Returns the challenge (both components) to every thread.
+__device__ __forceinline__ void coin_step_quad(Digest* seed_io, int deg, uint32_t* scratch, int tid, int j, const uint32_t (&pk)[10],
+                                               uint64_t& a0, uint64_t& a1) {
+    const uint32_t r_lo = scratch[j], r_hi = scratch[4 + j];
+    const uint32_t s_lo = seed_io->w[j], s_hi = seed_io->w[4 + j];
+    __syncthreads();
+    if (tid < 4) { scratch[j] = s_lo; scratch[4 + j] = s_hi; scratch[8 + j] = r_lo; scratch[12 + j] = r_hi; }
+    __syncthreads();
+    uint32_t lo, hi;
+    quad_merge(scratch, j, pk, lo, hi);                       // seed <- BLAKE2s(seed || root)
+    __syncthreads();
+    if (tid < 4) {
+        scratch[j] = lo; scratch[4 + j] = hi; scratch[8 + j] = 0; scratch[12 + j] = 0;
+        seed_io->w[j] = lo; seed_io->w[4 + j] = hi;
+    }
+    a0 = a1 = 0;
+    for (uint32_t ctr = 1; ctr < 1000; ctr++) {               // draw: first 8 (16) bytes of BLAKE2s(seed || LE64(ctr)), retried while >= p
+        if (tid == 0) scratch[8] = ctr;
+        __syncthreads();
+        quad_merge(scratch, j, pk, lo, hi, 40u);
+        if (tid < 4) scratch[16 + j] = lo;
+        __syncthreads();
+        const uint64_t v0 = (uint64_t)scratch[16] | ((uint64_t)scratch[17] << 32), v1 = (uint64_t)scratch[18] | ((uint64_t)scratch[19] << 32);
+        if (v0 < gl::P && (deg == 1 || v1 < gl::P)) { a0 = v0; a1 = deg > 1 ? v1 : 0; break; }
+        __syncthreads();
+    }
 }
 // Levels with more than 64 nodes use one lane per node (256 lanes already fill the 4 SIMDs of the CU: more lanes per node
 // would only add instructions); from 64 nodes down a quad per node shortens the chain.
@@ -320,7 +351,12 @@ __global__ __launch_bounds__(256) void merkle_multi_quad_kernel(Digest* nodes, s
             __syncthreads();
         }
     }
-    if (cs.seed_io && m == 1 && tid == 0) coin_step(cs, buf[0]);
+    if (cs.seed_io && m == 1) {       // uniform over the (single) workgroup
+        uint64_t a0, a1;
+        if (tid == 0 && cs.root_out) store_digest(cs.root_out, buf[0]);
+        coin_step_quad(cs.seed_io, cs.deg, words, tid, j, pk, a0, a1);
+        if (tid == 0) { cs.alpha_out[0] = a0; if (cs.deg > 1) cs.alpha_out[1] = a1; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,20 +414,15 @@ template <int LOGF> __global__ __launch_bounds__(512) void fri_tail_kernel(FriTa
             }
         }
         // transcript: reseed with the root, draw the folding challenge
-        if (tid == 0) {
-            const Digest root = dig[0];
-            store_digest(&a.roots_out[L], root);
-            const Digest seed = b2s::merge(*a.seed_io, root);
-            *a.seed_io = seed;
-            uint64_t a0 = 0, a1 = 0;
-            for (uint64_t ctr = 1; ctr < 1000; ctr++) {
-                const Digest d = b2s::merge_with_int(seed, ctr);
-                const uint64_t x0 = (uint64_t)d.w[0] | ((uint64_t)d.w[1] << 32), x1 = (uint64_t)d.w[2] | ((uint64_t)d.w[3] << 32);
-                if (x0 < gl::P && (deg == 1 || x1 < gl::P)) { a0 = x0; a1 = deg > 1 ? x1 : 0; break; }
+        {
+            if (tid == 0) store_digest(&a.roots_out[L], dig[0]);
+            uint64_t a0, a1;
+            coin_step_quad(a.seed_io, deg, words, tid, j, pk, a0, a1);     // words [0, 8) = the root; the level buffer is free again
+            if (tid == 0) {
+                s_alpha[0] = a0; s_alpha[1] = a1;
+                a.alphas_out[(size_t)L * deg] = a0;
+                if (deg > 1) a.alphas_out[(size_t)L * deg + 1] = a1;
             }
-            s_alpha[0] = a0; s_alpha[1] = a1;
-            a.alphas_out[(size_t)L * deg] = a0;
-            if (deg > 1) a.alphas_out[(size_t)L * deg + 1] = a1;
         }
         __syncthreads();
         if (L + 1 == a.n_layers) break;

@@ -262,84 +262,71 @@ constexpr int F8_TILE_LDS = 32 * 64;             // elements per tile: element (
                                                  // row * 64 + (col ^ (2 row & 63)) - conflict-free for the row-wise writes of
                                                  // phase A and the column-wise reads of phase B without any padding
 constexpr int F8_WAVES = 4;                      // tiles per workgroup
-// Each wave walks TPW consecutive tiles: the 31 table twiddles of phase B (they depend on the lane and the row only, not on the
-// tile) are loaded ONCE into registers, and the 8 coefficients of the next tile are requested before the current one is
-// transformed. (Reading a twiddle per ELEMENT - a 64 MiB table of all pass-boundary twiddles, one multiplication instead of the
-// progression's two - was measured and dropped: 362 us against 252 us per proof. This kernel has no memory slack to give.)
-template <int TPW> __global__ __launch_bounds__(64 * F8_WAVES, 2) void ntt_fwd_first_pass_8(PassArgs a) {
-    __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS];
+// The exchange is made in TWO rounds of 16 rows (8 KiB of LDS per wave): with the whole 16 KiB tile per wave the LDS capped the
+// kernel at two waves per SIMD (4 waves x 16 KiB = 64 KiB per workgroup, two workgroups per CU); now the 158 VGPRs allow three,
+// which the carry chains of the field arithmetic need to hide their dependent-issue latency (107 -> 96 us per 2 columns 2^20 -> 2^23;
+// a fourth wave per SIMD costs spills and gains nothing). The 31 table twiddles of phase B are read where they are used (they
+// depend on the lane and the row only). Dropped after measuring: a per-ELEMENT table of all pass-boundary twiddles (64 MiB, one
+// multiplication instead of the progression's two: 362 us against 252 us per proof) and walking 4 tiles per wave (6 % slower).
+__global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArgs a) {
+    __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS / 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t* lds = f8_lds + wave * F8_TILE_LDS;
-    const uint32_t tile0 = (xcd_tile(blockIdx.x, gridDim.x) * F8_WAVES + wave) * TPW;
+    uint64_t* lds = f8_lds + wave * (F8_TILE_LDS / 2);
+    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * F8_WAVES + wave;
     const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
     uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
     const int h = lane & 31;
     const bool upper = lane >= 32;
     const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
-    uint64_t tw[32];
-#pragma unroll
-    for (int i = 1; i < 32; i++) tw[i] = a.tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane];
-    ulonglong2 nx[4];
+    const size_t base = (size_t)b << 11;
+    const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
+    uint64_t y[32];
     {
-        const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(in + ((size_t)tile0 << 8) + 8 * h);
+        uint64_t c[8];
+        const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(in + ((size_t)b << 8) + 8 * h);
 #pragma unroll
-        for (int q = 0; q < 4; q++) nx[q] = cp[q];
+        for (int q = 0; q < 4; q++) { const ulonglong2 t = cp[q]; c[2 * q] = t.x; c[2 * q + 1] = t.y; }
+        { uint64_t t;
+          t = mul_w64<16>(c[1]); c[1] = upper ? t : c[1];   t = mul_w64<8>(c[2]);  c[2] = upper ? t : c[2];
+          t = mul_w64<24>(c[3]); c[3] = upper ? t : c[3];   t = mul_w64<4>(c[4]);  c[4] = upper ? t : c[4];
+          t = mul_w64<20>(c[5]); c[5] = upper ? t : c[5];   t = mul_w64<12>(c[6]); c[6] = upper ? t : c[6];
+          t = mul_w64<28>(c[7]); c[7] = upper ? t : c[7]; }
+        uint64_t v[32];
+        first8_group<0>(c, v); first8_group<1>(c, v); first8_group<2>(c, v); first8_group<3>(c, v);
+        uint64_t* row = lds + (h & 15) * 64;
+        const int sw = (2 * h) & 63, c0 = upper ? 4 : 0;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            if ((h >> 4) == r) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) row[(c0 + k + 8 * i) ^ sw] = v[k + 4 * i];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int i = 0; i < 16; i++) y[16 * r + i] = lds[i * 64 + (lane ^ ((2 * (16 * r + i)) & 63))];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-#pragma unroll 1
-    for (int it = 0; it < TPW; it++) {
-        const uint32_t b = tile0 + it;
-        const size_t base = (size_t)b << 11;
-        const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
-        uint64_t y[32];
-        {
-            // A: 8 coefficients -> 32 of the 64 positions [64 h, 64 h + 64): (position mod 8) in [4 half, 4 half + 4)
-            uint64_t c[8];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { c[2 * q] = nx[q].x; c[2 * q + 1] = nx[q].y; }
-            if (it + 1 < TPW) {
-                const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(in + ((size_t)(b + 1) << 8) + 8 * h);
+    for (int i = 1; i < 32; i++) y[i] = mul(y[i], a.tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane]);
+    dft_dit_reg<5>(y);
+    if (!a.first && rbk) {
+        uint64_t cur = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)lane) & nmask), a.tw_h);
+        const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
 #pragma unroll
-                for (int q = 0; q < 4; q++) nx[q] = cp[q];
-            }
-            // upper half: klow = klow' + 4, i.e. member i carries the extra factor w_64^(4 rev3(i))
-            { uint64_t t;
-              t = mul_w64<16>(c[1]); c[1] = upper ? t : c[1];   t = mul_w64<8>(c[2]);  c[2] = upper ? t : c[2];
-              t = mul_w64<24>(c[3]); c[3] = upper ? t : c[3];   t = mul_w64<4>(c[4]);  c[4] = upper ? t : c[4];
-              t = mul_w64<20>(c[5]); c[5] = upper ? t : c[5];   t = mul_w64<12>(c[6]); c[6] = upper ? t : c[6];
-              t = mul_w64<28>(c[7]); c[7] = upper ? t : c[7]; }
-            first8_group<0>(c, y); first8_group<1>(c, y); first8_group<2>(c, y); first8_group<3>(c, y);
-            // y[klow' + 4 i] sits at tile position (klow' + 4 half) + 8 i + 64 h: row h, column klow' + 4 half + 8 i
-            uint64_t* row = lds + h * 64;
-            const int sw = (2 * h) & 63, c0 = upper ? 4 : 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) row[(c0 + k + 8 * i) ^ sw] = y[k + 4 * i];
-            }
+        for (int i = 0; i < 32; i++) {
+            out[base + lane + 64 * i] = mul(y[i], cur);
+            cur = mul(cur, step);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // B: lane k <- positions k + 64 i
+    } else {
 #pragma unroll
-        for (int i = 0; i < 32; i++) y[i] = lds[i * 64 + (lane ^ ((2 * i) & 63))];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next tile's phase A overwrites the exchange buffer
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 1; i < 32; i++) y[i] = mul(y[i], tw[i]);
-        dft_dit_reg<5>(y);
-        if (!a.first && rbk) {
-            uint64_t cur = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)lane) & nmask), a.tw_h);
-            const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
-#pragma unroll
-            for (int i = 0; i < 32; i++) {
-                out[base + lane + 64 * i] = mul(y[i], cur);
-                cur = mul(cur, step);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = y[i];
-        }
+        for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = y[i];
     }
 }
 // tab[r * 64 + k] = root^(r * k), r < rows
@@ -399,7 +386,7 @@ __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
 // wavefront is one contiguous 512-byte segment. The pass-boundary twiddle depends on (block, row) only: it comes from a small
 // per-pass table (2^(log_n - log_s) entries, row b * R + k = w^(S * rev(b) * k)) that every lane of a workgroup reads at the
 // same address.
-template <int LOGR> __global__ __launch_bounds__(256) void ntt_fwd_strided_reg(PassArgs a) {
+template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_fwd_strided_reg(PassArgs a) {
     constexpr int R = 1 << LOGR;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;            // over 2^(log_n - LOGR) threads per column
     const size_t lo = t & (((size_t)1 << a.log_s) - 1);
@@ -410,6 +397,7 @@ template <int LOGR> __global__ __launch_bounds__(256) void ntt_fwd_strided_reg(P
     uint64_t y[R];
 #pragma unroll
     for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
+    if (LOGR == 6) __builtin_amdgcn_sched_barrier(0);   // all 64 loads in flight before the first butterfly (the scheduler otherwise sinks half of them)
     dft_dit_reg<LOGR>(y);
     if (!a.first && b) {
         const uint64_t* tw = a.tw_pass + ((size_t)b << LOGR);
@@ -430,7 +418,62 @@ template <int LOGR> __global__ __launch_bounds__(256) void ntt_fwd_strided_reg(P
         }
     }
 }
-template <int LOGR> __global__ __launch_bounds__(256) void ntt_inv_strided_reg(PassArgs a) {
+// The radix-64 pass with each 64-point transform shared by TWO lanes (lane l and l + 32 of a wavefront): 32 values per lane, the
+// register footprint and occupancy of the radix-32 pass (which streams at the HBM rate where the one-lane radix-64 pass sits at
+// 2-3 waves per SIMD and 60-70 % of it). Lane half h holds the rows 32 h + i: the first five stages are the 32-point transform of
+// each half (same shift twiddles in both), the last stage pairs row j with row j + 32 across the halves: one V_PERMLANE32_SWAP per
+// register pair hands each lane 16 complete (u, v) pairs - rows (i, i + 32) in the lower half, (16 + i, 48 + i) in the upper -
+// and the factor w_64^16 = 2^48 that separates the two sets of twiddles is applied to v in the upper half with a select.
+__device__ __forceinline__ void swap_halves(uint64_t& x, uint64_t& y) {       // x of lanes 32..63 <-> y of lanes 0..31
+    const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)y, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(x >> 32), (uint32_t)(y >> 32), false, false);
+    x = gl::mk64(lo[0], hi[0]); y = gl::mk64(lo[1], hi[1]);
+}
+template <int I> __device__ __forceinline__ void last_stage_pairs(uint64_t (&y)[32]) {
+    bfly_w64<I>(y[I], y[16 + I]);
+    if constexpr (I + 1 < 16) last_stage_pairs<I + 1>(y);
+}
+__global__ __launch_bounds__(256) void ntt_fwd_strided_reg6x2(PassArgs a) {
+    const uint32_t lane = threadIdx.x & 63, half = lane >> 5;
+    const size_t p = (((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) << 5) + (lane & 31);    // over 2^(log_n - 6) positions per column
+    const size_t lo = p & (((size_t)1 << a.log_s) - 1);
+    const uint32_t b = (uint32_t)(((size_t)blockIdx.x * 128) >> a.log_s);                  // S >= 128: uniform over the workgroup
+    const size_t base = lo + (((size_t)b << 6) << a.log_s);
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    uint64_t y[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) y[i] = in[base + ((size_t)(32 * half + i) << a.log_s)];
+    dft_dit_reg<5>(y);
+#pragma unroll
+    for (int i = 0; i < 16; i++) swap_halves(y[i], y[16 + i]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { const uint64_t t = mul_w4(y[16 + i]); y[16 + i] = half ? t : y[16 + i]; }
+    last_stage_pairs<0>(y);
+    // y[i] is row r0 + i, y[16 + i] row r0 + 32 + i, r0 = 16 half
+    const uint32_t r0 = 16 * half;
+    if (!a.first && b) {
+        const uint64_t* tw = a.tw_pass + ((size_t)b << 6) + r0;      // two distinct addresses per wavefront
+#pragma unroll
+        for (int i = 0; i < 16; i++) { y[i] = mul(y[i], tw[i]); y[16 + i] = mul(y[16 + i], tw[32 + i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        out[base + ((size_t)(r0 + i) << a.log_s)] = y[i];
+        out[base + ((size_t)(r0 + 32 + i) << a.log_s)] = y[16 + i];
+    }
+    if (a.compact && (lo & (((size_t)1 << a.compact_log) - 1)) == 0) {
+        uint64_t* co = a.compact + (size_t)blockIdx.y * a.compact_col_stride;
+        const size_t part_len = (((size_t)1 << a.log_n) >> a.compact_log) >> a.compact_split, pmask = ((size_t)1 << a.compact_split) - 1;
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const uint32_t row = r0 + (i & 15) + 2 * (i & 16);
+            const size_t j = (base + ((size_t)row << a.log_s)) >> a.compact_log;
+            co[(j & pmask) * part_len + (j >> a.compact_split)] = y[i];
+        }
+    }
+}
+template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_inv_strided_reg(PassArgs a) {
     constexpr int R = 1 << LOGR;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t lo = t & (((size_t)1 << a.log_s) - 1);
@@ -441,6 +484,7 @@ template <int LOGR> __global__ __launch_bounds__(256) void ntt_inv_strided_reg(P
     uint64_t y[R];
 #pragma unroll
     for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
+    if (LOGR == 6) __builtin_amdgcn_sched_barrier(0);
     if (!a.first && b) {
         const uint64_t* tw = a.tw_pass + ((size_t)b << LOGR);
 #pragma unroll
@@ -579,9 +623,13 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
                 compact_written = true;
             }
             dim3 rgrid((unsigned)((((size_t)1 << log_out) >> a.log_r) / 256), ncols);
-            const char* nm = pass_names ? (a.log_r == 6 ? "ntt_fwd_reg6" : a.log_r == 5 ? "ntt_fwd_reg5" : a.log_r == 4 ? "ntt_fwd_reg4" : "ntt_fwd_reg123") : "ntt_fwd_pass";
+            const char* nm = pass_names ? (a.log_r == 6 ? (a.first ? "ntt_fwd_reg6_last" : "ntt_fwd_reg6_mid") : a.log_r == 5 ? "ntt_fwd_reg5" : a.log_r == 4 ? "ntt_fwd_reg4" : "ntt_fwd_reg123") : "ntt_fwd_pass";
             switch (a.log_r) {
-                case 6: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<6>, rgrid, dim3(256), 0, a); break;
+                case 6:
+                    if (a.log_s >= 7)    // two lanes per transform: 32 values per lane (the block index stays uniform over a workgroup)
+                        AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg6x2, dim3((unsigned)((((size_t)1 << log_out) >> 5) / 256), ncols), dim3(256), 0, a);
+                    else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<6>, rgrid, dim3(256), 0, a);
+                    break;
                 case 5: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<5>, rgrid, dim3(256), 0, a); break;
                 case 4: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<4>, rgrid, dim3(256), 0, a); break;
                 case 3: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<3>, rgrid, dim3(256), 0, a); break;
@@ -596,9 +644,7 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
             a.tw_mt = twmt_fwd;
             const size_t tiles = ((size_t)1 << log_out) >> 11;
             const char* nm = pass_names ? "ntt_fwd_first8" : "ntt_fwd_pass";
-            // one tile per wave: walking 4 tiles per wave (twiddles loaded once, next tile prefetched) measured 6 % SLOWER - 256 VGPRs
-            // with spills, and a single-column launch no longer fills the chip
-            AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8<1>, dim3((unsigned)(tiles / F8_WAVES), ncols), dim3(64 * F8_WAVES), 0, a);
+            AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8, dim3((unsigned)(tiles / F8_WAVES), ncols), dim3(64 * F8_WAVES), 0, a);
             continue;
         }
         if (q == 0 && reg_passes && a.log_r > a.log_pad) {

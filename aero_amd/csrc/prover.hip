@@ -114,6 +114,14 @@ void Context::sync() {
     if (e != hipSuccess) throw Error(ST_HIP, std::string("stream synchronize: ") + hipGetErrorString(e));
 }
 
+void Context::fetch(void* dst, const void* dev_src, size_t bytes) {
+    if (bytes == 0) { sync(); return; }
+    void* h = stage_alloc(bytes);
+    AERO_HIP(hipMemcpyAsync(h, dev_src, bytes, hipMemcpyDeviceToHost, stream));
+    sync();
+    memcpy(dst, h, bytes);
+}
+
 hipEvent_t Context::kt_event() {
     if (!kt_pool.empty()) { hipEvent_t e = kt_pool.back(); kt_pool.pop_back(); return e; }
     hipEvent_t e;
@@ -413,10 +421,7 @@ MerkleTree Prover::commit_to_rows(const Matrix& lde, bool keep_low_levels) {
         ctx_->hash_rows(lde.data.get(), lde.rows, lde.cols, lde.rows, t.leaves());
         ctx_->merkle_build(t.nodes.get(), t.n);
     }
-    Digest* h = (Digest*)ctx_->stage_alloc(sizeof(Digest));
-    AERO_HIP(hipMemcpyAsync(h, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx_->stream));
-    ctx_->sync();
-    t.root_host = *h;
+    ctx_->fetch(&t.root_host, t.nodes.get() + 1, sizeof(Digest));
     return t;
 }
 MerkleTree Prover::commit_fri_layer(const FriSrc& src, bool keep_low_levels) {
@@ -439,10 +444,7 @@ MerkleTree Prover::commit_fri_layer(const FriSrc& src, bool keep_low_levels) {
         ctx_->hash_fri_rows(src, t.leaves());
         ctx_->merkle_build(t.nodes.get(), rows);
     }
-    Digest* h = (Digest*)ctx_->stage_alloc(sizeof(Digest));
-    AERO_HIP(hipMemcpyAsync(h, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx_->stream));
-    ctx_->sync();
-    t.root_host = *h;
+    ctx_->fetch(&t.root_host, t.nodes.get() + 1, sizeof(Digest));
     return t;
 }
 
@@ -454,6 +456,7 @@ MerkleTree Prover::commit_fri_layer_async(const FriSrc& src, const CoinStep* coi
         if (coin) {
             if (coin->deg == 1) launch_fri_coin_step<FB>(ctx_, coin->seed_io, t.nodes.get() + 1, coin->alpha_out);
             else launch_fri_coin_step<FQ>(ctx_, coin->seed_io, t.nodes.get() + 1, reinterpret_cast<gl::E2*>(coin->alpha_out));
+            if (coin->root_out) AERO_HIP(hipMemcpyAsync(coin->root_out, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToDevice, ctx_->stream));
         }
         return t;
     }
@@ -630,12 +633,13 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
     const uint64_t gen_inv = gl::inv(gl::GEN);
     // The transcript steps of the commit phase (reseed with the root, draw alpha) run on the device, so every layer is enqueued
     // without a host round trip; the roots come back with ONE copy at the end and the host replays the coin to stay in step.
-    Digest* d_seed = (Digest*)ctx->scratch_alloc(sizeof(Digest));
+    Digest* d_roots = (Digest*)ctx->scratch_alloc(sizeof(Digest) * (fl.layers + 2));   // roots of all layers, then the final seed
+    Digest* d_seed = d_roots + fl.layers + 1;
     T* d_alpha = (T*)ctx->scratch_alloc(sizeof(T) * (fl.layers + 1));
     Digest* h_seed = (Digest*)ctx->stage_alloc(sizeof(Digest));
     *h_seed = coin.seed;
     AERO_HIP(hipMemcpyAsync(d_seed, h_seed, sizeof(Digest), hipMemcpyHostToDevice, ctx->stream));
-    Digest* h_roots = (Digest*)ctx->stage_alloc(sizeof(Digest) * (fl.layers + 1));
+    std::vector<Digest> h_roots(fl.layers + 2);
     uint64_t dom = N;
     // layers of at most FRI_TAIL_MAX_DOM points are pure latency: they all go into ONE single-workgroup launch (Context::fri_tail)
     int tail0 = fl.layers + 1;
@@ -648,10 +652,9 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
         const size_t rows = dom / Fd;
         const FriSrc fsrc{fl.vals[l].get(), fl.vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd};
         Commitment c;
-        const CoinStep cs{d_seed, reinterpret_cast<uint64_t*>(d_alpha + l), F::DEG};
+        const CoinStep cs{d_seed, reinterpret_cast<uint64_t*>(d_alpha + l), F::DEG, d_roots + l};
         c.tree = commit_fri_layer_async(fsrc, &cs);
         c.n_global = rows;
-        AERO_HIP(hipMemcpyAsync(h_roots + l, c.tree.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
         fl.coms.push_back(std::move(c));
         if (l == fl.layers) break;   // alpha drawn after the remainder commitment is unused
         fl.vals.emplace_back(ctx, (size_t)F::DEG * rows);
@@ -670,7 +673,6 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
     if (tail0 <= fl.layers) {
         FriTailArgs t{};
         t.deg = F::DEG; t.n_layers = fl.layers + 1 - tail0; t.dom0 = (uint32_t)dom; t.vals0 = fl.vals[tail0].get();
-        Digest* d_roots = (Digest*)ctx->scratch_alloc(sizeof(Digest) * t.n_layers);
         uint64_t dd = dom;
         for (int i = 0; i < t.n_layers; i++) {
             const size_t rows = dd / Fd;
@@ -685,13 +687,12 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
             }
             dd = rows;
         }
-        t.roots_out = d_roots; t.seed_io = d_seed; t.alphas_out = reinterpret_cast<uint64_t*>(d_alpha + tail0);
+        t.roots_out = d_roots + tail0; t.seed_io = d_seed; t.alphas_out = reinterpret_cast<uint64_t*>(d_alpha + tail0);
         t.gen_inv = gen_inv; t.fold_inv = gl::inv(Fd); t.w_inv0 = gl::inv(gl::root_of_unity(ilog2(dom)));
         ctx->fri_tail(t, (int)Fd);
-        AERO_HIP(hipMemcpyAsync(h_roots + tail0, d_roots, sizeof(Digest) * t.n_layers, hipMemcpyDeviceToHost, ctx->stream));
     }
-    AERO_HIP(hipMemcpyAsync(h_seed, d_seed, sizeof(Digest), hipMemcpyDeviceToHost, ctx->stream));
-    ctx->sync();
+    ctx->fetch(h_roots.data(), d_roots, sizeof(Digest) * (fl.layers + 2));
+    *h_seed = h_roots[fl.layers + 1];
     for (int l = 0; l <= fl.layers; l++) {
         Commitment& c = fl.coms[l];
         c.root = h_roots[l];
@@ -1015,8 +1016,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         if (A) launch_eval_bitrev<F>(ctx, apolys.data.get(), (size_t)F::DEG * n, n, (int)A, F::DEG, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get() + 2 * W + C);
         launch_eval_bitrev<F>(ctx, polys.data.get(), n, 0, (int)W, 1, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get());
         launch_eval_bitrev<F>(ctx, hbuf.get(), n, ceN, (int)C, F::DEG, log_n, F::mulb(z_c, h_inv), F::zero(), 1, d_out.get() + 2 * W);
-        AERO_HIP(hipMemcpyAsync(ood.data(), d_out.get(), ood.size() * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-        ctx->sync();
+        ctx->fetch(ood.data(), d_out.get(), ood.size() * sizeof(T));
     }
     std::vector<T> ood_cur(TW), ood_next(TW), ood_h(C);
     for (uint32_t c = 0; c < W; c++) { ood_cur[c] = ood[2 * c]; ood_next[c] = ood[2 * c + 1]; }
@@ -1258,8 +1258,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         }
         q_lap("enqueue");
         if (G > 1) comm_all_reduce(d_val.get(), voff);
-        AERO_HIP(hipMemcpyAsync(h_val, d_val.get(), (voff + 4 * n_low) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->sync();
+        ctx->fetch(h_val, d_val.get(), (voff + 4 * n_low) * 8);
         q_lap("device_round_trip");
         {
             size_t o = 0;

@@ -517,8 +517,7 @@ uint64_t run_grind(Context* ctx, const Digest& seed, uint32_t bits) {
         AERO_LAUNCH(ctx, "grind_kernel", 0, grind_kernel, dim3((unsigned)(batch / 256)), dim3(256), 0, seed, bits, first, d_best.get());
         ctx->check_launch("grind");
         unsigned long long best = 0;
-        AERO_HIP(hipMemcpyAsync(&best, d_best.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->sync();
+        ctx->fetch(&best, d_best.get(), 8);
         if (best != ~0ull) return best;
         if (first > (1ull << 40)) fail("grind: no nonce found", ST_INTERNAL);
     }
