@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaero_stark.so")
+LIB_PATH = os.environ.get("AERO_LIB_PATH") or os.path.join(_HERE, "libaero_stark.so")   # override: A/B runs of another build
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "aero_stark.h")
 
