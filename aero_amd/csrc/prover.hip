@@ -898,31 +898,19 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     std::vector<T> ta, tb, ba, bb;
     for (size_t i = 0; i < air.num_transition_constraints(); i++) { ta.push_back(coin.draw<F>()); tb.push_back(coin.draw<F>()); }
     for (size_t i = 0; i < air.num_assertions(); i++) { ba.push_back(coin.draw<F>()); bb.push_back(coin.draw<F>()); }
-    DevBuf<uint64_t> hbuf(ctx, (size_t)F::DEG * ceN);   // H evaluations, then coefficients: [DEG][ceN]
-    bool h_on_global_coset = false;                     // evaluations are over 7<w_N> (all-gathered) instead of h<w_ce>
+    DevBuf<uint64_t> hbuf(ctx, (size_t)F::DEG * ceN);   // H evaluations over h<w_ce>, then coefficients: [DEG][ceN]
     {
-        // H (degree < C*n) is interpolated from its values on a coset of <w_ce>:
-        //  * one GPU, or a shard at least as large as the constraint domain: every (M/ce_n)-th row of this rank's LDE (h<w_ce>);
-        //  * sharded with constraint domain = LDE domain (C = blowup): every rank evaluates the rows of its own coset and the H
-        //    evaluations are all-gathered into natural order over 7<w_N> (8 N bytes per component in total);
-        //  * otherwise (shard smaller than a constraint domain that is itself smaller than the LDE domain): a dedicated
-        //    extension of the trace polynomials onto h<w_ce> (cheap: ce_n = C n <= N / 2).
-        const bool gather_h = G > 1 && ceN == N;
-        Matrix celde, acelde;
+        // H (degree < C*n) is interpolated from its values on the coset h<w_ce> of the constraint domain:
+        //  * one GPU, or a shard at least as large as the constraint domain: every (M/ce_n)-th row of this rank's LDE;
+        //  * a shard smaller than the constraint domain (ce_n = q M): h<w_ce> is the union of the cosets of q ranks - the point
+        //    h w_ce^t is the global LDE row rank + t N / ce_n, owned by rank (row mod G). Every rank evaluates the constraints on
+        //    the rows of its OWN coset (no extra extension of the trace, 1/q of the evaluations), the H values are all-gathered
+        //    (8 M bytes per component to each peer) and the q cosets that make up h<w_ce> are picked out of the gathered block.
+        //    (Before: a dedicated extension of every trace column onto h<w_ce> and the evaluation of all ce_n rows on every rank.)
+        const bool gather_h = G > 1 && M < ceN;
         const uint64_t* frame_src = tlde.data.get();
         const uint64_t* aux_src = A ? alde.data.get() : nullptr;
         size_t frame_rows = M;
-        if (M < ceN && !gather_h) {
-            celde = Matrix(ctx, (int)W, ceN);
-            ctx->ntt_forward(polys.data.get(), n, celde.data.get(), ceN, (int)W, log_ce, log_ce - log_n);
-            frame_src = celde.data.get();
-            frame_rows = ceN;
-            if (A) {
-                acelde = Matrix(ctx, (int)(A * F::DEG), ceN);
-                ctx->ntt_forward(apolys.data.get(), n, acelde.data.get(), ceN, (int)(A * F::DEG), log_ce, log_ce - log_n);
-                aux_src = acelde.data.get();
-            }
-        }
         // rows evaluated by this launch: the ce_n points of h<w_ce>, or (gather_h) the M rows of the coset h<w_M>
         const size_t rows_eval = gather_h ? M : ceN;
         const size_t xcount = gather_h ? M / n : C;             // distinct values of x^n over those rows
@@ -969,17 +957,16 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             launch_fib_constraints<F>(ctx, a, 1);
             comm_all_gather(hloc.get(), hall.get(), (size_t)F::DEG * M * 8);          // [rank][component][t]
             for (int d = 0; d < F::DEG; d++)
-                launch_interleave_u64(ctx, hall.get() + (size_t)d * M, (size_t)F::DEG * M, hbuf.get() + (size_t)d * N, G, M);
+                launch_select_coset_u64(ctx, hall.get() + (size_t)d * M, (size_t)F::DEG * M, hbuf.get() + (size_t)d * ceN, ceN, (uint32_t)rank,
+                                        N / ceN, N, (uint32_t)G);
         }
-        h_on_global_coset = gather_h;
     }
     ms.constraints = clk.lap();
     // 5. composition polynomial: interpolate over the coset; coefficient I gets h^-I (coset) * h^(I >> log C)
     //    (pre-scaling of column coefficient i = I >> log C for the column LDE). In bit-reversed order the C column
     //    polynomials are the C contiguous chunks of the buffer (chunk q = column bitrev(q)): no split pass
     //    (H(x) = sum_c x^c H_c(x^C)).
-    if (!h_on_global_coset) composition_from_evaluations(hbuf.get(), F::DEG, log_ce, ilog2(C), h);
-    else ctx->ntt_inverse(hbuf.get(), ceN, F::DEG, log_ce, 1, gen_inv, h, ilog2(C));   // coset 7<w_N>, columns pre-scaled by h^i
+    composition_from_evaluations(hbuf.get(), F::DEG, log_ce, ilog2(C), h);
     ms.composition = clk.lap();
     // 6. composition commitment [a12]: column c*DEG + d <- chunk c of component d
     Matrix clde(ctx, (int)(C * F::DEG), M);
@@ -1014,7 +1001,16 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     {
         DevBuf<T> d_out(ctx, 2 * W + C + 2 * A);
         if (A) launch_eval_bitrev<F>(ctx, apolys.data.get(), (size_t)F::DEG * n, n, (int)A, F::DEG, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get() + 2 * W + C);
-        launch_eval_bitrev<F>(ctx, polys.data.get(), n, 0, (int)W, 1, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get());
+        if (G > 1 && W >= (uint32_t)G && W % (uint32_t)G == 0) {
+            // the value of a column polynomial at z does not depend on the coset a rank holds its coefficients for: every rank
+            // evaluates W / G columns, one small all-gather (2 W / G elements per rank) completes the frame everywhere
+            const uint32_t cpr = W / (uint32_t)G;
+            DevBuf<T> part(ctx, 2 * cpr);
+            launch_eval_bitrev<F>(ctx, polys.data.get() + (size_t)rank * cpr * n, n, 0, (int)cpr, 1, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, part.get());
+            comm_all_gather(part.get(), d_out.get(), 2 * cpr * sizeof(T));
+        } else {
+            launch_eval_bitrev<F>(ctx, polys.data.get(), n, 0, (int)W, 1, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get());
+        }
         launch_eval_bitrev<F>(ctx, hbuf.get(), n, ceN, (int)C, F::DEG, log_n, F::mulb(z_c, h_inv), F::zero(), 1, d_out.get() + 2 * W);
         ctx->fetch(ood.data(), d_out.get(), ood.size() * sizeof(T));
     }

@@ -724,6 +724,21 @@ void launch_interleave_digests(Context* ctx, const Digest* in, size_t src_stride
     AERO_LAUNCH(ctx, "interleave_kernel", 2 * len * parts * sizeof(Digest), (interleave_kernel<Digest>), dim3((unsigned)((len + 255) / 256)), dim3(256), 0, in, src_stride, out, parts, len);
     ctx->check_launch("interleave_digests");
 }
+// out[t] = the value at global LDE row J = (first + t * step) mod rows_total, taken from the all-gathered block in[owner][local]
+// (owner = J mod parts, local = J / parts): the points of one coset of the constraint domain out of the shards of `parts` ranks.
+__global__ void select_coset_kernel(const uint64_t* __restrict__ in, size_t src_stride, uint64_t* __restrict__ out, size_t count, uint32_t first,
+                                    size_t step, size_t rows_total, uint32_t parts) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const size_t J = (first + t * step) & (rows_total - 1);
+    out[t] = in[(J % parts) * src_stride + J / parts];
+}
+void launch_select_coset_u64(Context* ctx, const uint64_t* in, size_t src_stride, uint64_t* out, size_t count, uint32_t first, size_t step,
+                             size_t rows_total, uint32_t parts) {
+    AERO_LAUNCH(ctx, "select_coset_kernel", 16 * count, select_coset_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, in, src_stride, out, count,
+                first, step, rows_total, parts);
+    ctx->check_launch("select_coset");
+}
 void launch_interleave_u64(Context* ctx, const uint64_t* in, size_t src_stride, uint64_t* out, int parts, size_t len) {
     AERO_LAUNCH(ctx, "interleave_kernel", 2 * len * parts * 8, (interleave_kernel<uint64_t>), dim3((unsigned)((len + 255) / 256)), dim3(256), 0, in, src_stride, out, parts, len);
     ctx->check_launch("interleave_u64");
