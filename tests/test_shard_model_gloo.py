@@ -3,7 +3,8 @@ checked on CPU with world_size-2 and -4 `gloo` processes and the oracle's primit
   * rank k's LDE shard (rows j = k mod G) is the plain LDE, with blowup B/G, of the coefficients scaled by (w_N^k)^i;
   * all-to-all of leaf digests + arrival-order interleave + one subtree per rank + all-gather of the subtree roots + log2 G
     host levels reproduce the root of the tree over ALL rows;
-  * FRI fold groups stay inside a coset: folding a shard with the coset's offset gives the shard of the folded layer.
+  * FRI fold groups stay inside a coset: folding a shard with the coset's offset gives the shard of the folded layer;
+  * a coset of a constraint domain larger than one shard is picked out of the all-gathered shards by global LDE row index.
 The product code cannot run without a GPU (tests/test_gpu_sharded.py covers it there); this pins the algebra it relies on and
 the collectives' data layout under a real process group."""
 import json
@@ -68,8 +69,28 @@ WORKER = textwrap.dedent('''
     mine = orc.fri_fold(np.ascontiguousarray(layer[rank::G]), fold, orc.mul(alpha, orc.inv(orc.pow(wN, rank))))
     ok_fold = bool((mine == folded[rank::G]).all())
 
+    # ---- 4. constraint domain larger than a shard (ce_n = 2 M): every rank evaluates H on its own coset, the shards are
+    #         all-gathered and point t of the coset h_r <w_ce> (h_r = 7 w_N^rank) is global LDE row J = rank + t N / ce_n, found
+    #         at [J mod G][J div G] of the gathered block
+    ceN = 2 * M
+    hc = rng.integers(0, P, size=ceN, dtype=np.uint64)                      # H, degree < ce_n
+    h_all = orc.lde(hc, N // ceN)                                           # H over the whole LDE domain 7 <w_N>
+    mine_h = torch.from_numpy(np.ascontiguousarray(h_all[rank::G]).view(np.int64).copy())
+    shards = [torch.empty_like(mine_h) for _ in range(G)]
+    dist.all_gather(shards, mine_h)
+    shards = [t.numpy().view(np.uint64) for t in shards]
+    w_ce = orc.root_of_unity(ceN.bit_length() - 1)
+    h_r = orc.mul(7, orc.pow(wN, rank))
+    ok_sel = True
+    for t in [0, 1, 2, 3, ceN // 2 - 1, ceN // 2, ceN - 2, ceN - 1] + [int(v) for v in rng.integers(0, ceN, size=8)]:
+        J = (rank + t * (N // ceN)) %% N
+        x = orc.mul(h_r, orc.pow(w_ce, t))
+        acc = 0
+        for c in hc[::-1]:
+            acc = (acc * x + int(c)) %% P
+        ok_sel = ok_sel and int(shards[J %% G][J // G]) == acc
     res = [None] * world
-    dist.all_gather_object(res, (ok_lde, ok_root, ok_sub, ok_fold))
+    dist.all_gather_object(res, (ok_lde, ok_root, ok_sub, ok_fold, ok_sel))
     if rank == 0:
         print(json.dumps({"world": world, "checks": res}))
     dist.barrier()
@@ -97,4 +118,4 @@ def test_shard_identities_under_gloo(tmp_path, world):
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["world"] == world
     for rank, checks in enumerate(r["checks"]):
-        assert all(checks), f"rank {rank}: (coset LDE, root, subtree, fold locality) = {checks}"
+        assert all(checks), f"rank {rank}: (coset LDE, root, subtree, fold locality, constraint-coset selection) = {checks}"
