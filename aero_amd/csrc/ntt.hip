@@ -267,7 +267,8 @@ constexpr int F8_WAVES = 4;                      // tiles per workgroup
 // which the carry chains of the field arithmetic need to hide their dependent-issue latency (107 -> 96 us per 2 columns 2^20 -> 2^23;
 // a fourth wave per SIMD costs spills and gains nothing). The 31 table twiddles of phase B are read where they are used (they
 // depend on the lane and the row only). Dropped after measuring: a per-ELEMENT table of all pass-boundary twiddles (64 MiB, one
-// multiplication instead of the progression's two: 362 us against 252 us per proof) and walking 4 tiles per wave (6 % slower).
+// multiplication instead of the progression's two: 362 us against 252 us per proof), walking 4 tiles per wave (6 % slower), and
+// replacing the progression's serial chain by a per-tile table of the 32 step powers read through scalar loads (2 - 5 % slower).
 __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS / 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
