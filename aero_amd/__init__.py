@@ -363,6 +363,24 @@ class Context:
                                                  C.c_uint32(fragment_offset), C.c_uint32(num_fragments), _p64(out), C.byref(fi)))
         return fi.value, out
 
+    def _msg_call(self, fn, data: bytes, *extra) -> bytes:
+        buf = np.frombuffer(data, np.uint8)
+        out, n = u8p(), C.c_size_t(0)
+        self._ck(fn(self.h, _p8(buf), C.c_size_t(len(data)), *extra, C.byref(out), C.byref(n)))
+        res = C.string_at(out, n.value)
+        lib().aero_free(out)
+        return res
+
+    def worker_hash_rows(self, work_item: bytes) -> bytes:
+        """bincode HashingWorkItem -> bincode HashingResult (aero_worker_hash_rows; messages: aero_amd.messages)."""
+        return self._msg_call(lib().aero_worker_hash_rows, work_item)
+
+    def worker_eval_constraints(self, work_item: bytes, air=None) -> bytes:
+        """bincode ConstraintComputeWorkItem -> bincode ConstraintComputeResult for the built-in FibAir (aero_worker_eval_constraints);
+        air = (aux_width, aux_rands, aux_degree) when the message's layout has auxiliary columns."""
+        desc = FibAirDesc(*air) if air and air[0] else None
+        return self._msg_call(lib().aero_worker_eval_constraints, work_item, C.byref(desc) if desc is not None else None)
+
     def composition_poly_air(self, numer_cols: np.ndarray, log_n: int, num_columns: int, field_extension=1) -> Matrix:
         a = np.ascontiguousarray(numer_cols, np.uint64)
         h = C.c_void_p()
@@ -694,6 +712,19 @@ def proof_to_protobuf(proof: bytes) -> bytes:
 def miden_public_inputs_to_protobuf(input_bytes: bytes) -> bytes:
     """sdk.MidenPublicInputs bytes (aero_miden_public_inputs_to_protobuf)."""
     return _pb_call(lib().aero_miden_public_inputs_to_protobuf, input_bytes)
+
+
+def prover_output(proof: bytes, input_bytes: bytes) -> bytes:
+    """bincode ProverOutput { proof, program_outputs, public_inputs } with the three protobuf payloads (aero_prover_output)."""
+    pb, ib = np.frombuffer(proof, np.uint8), np.frombuffer(input_bytes, np.uint8)
+    out, n = u8p(), C.c_size_t(0)
+    err = C.create_string_buffer(512)
+    rc = lib().aero_prover_output(_p8(pb), C.c_size_t(len(proof)), _p8(ib), C.c_size_t(len(input_bytes)), C.byref(out), C.byref(n), err, C.c_size_t(512))
+    if rc != 0:
+        raise AeroError(rc, err.value.decode(errors="replace"))
+    res = C.string_at(out, n.value)
+    lib().aero_free(out)
+    return res
 
 
 def device_count():

@@ -3,12 +3,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <thread>
 
 #include "../../include/aero_stark.h"
 #include "prover.hpp"
+#include "proof_format.hpp"
 #include "stark_kernels.hpp"
+#include "worker_messages.hpp"
 
 using namespace aero;
 
@@ -947,5 +950,105 @@ int32_t aero_pool_prove_fib_host(aero_pool* pool, const uint64_t* const* host_tr
     if (width < 2 || width > 254 || log_n < 3 || log_n > 29) return AERO_E_BAD_ARG;
     for (uint32_t i = 0; i < count; i++) if (!host_traces[i]) return AERO_E_BAD_ARG;
     return pool_run(pool, nullptr, host_traces, width, log_n, count, air, options, rounds, proofs, proof_lens, pubs);
+}
+// ---- the reference's worker seam at the message level (worker_messages.hpp) ------------------------------------------------------
+// hashing_worker.rs:12-26: every row of the work item -> Blake2s_256::hash_elements, answered in row order with the batch index.
+int32_t aero_worker_hash_rows(aero_ctx* ctx, const uint8_t* work_item, size_t work_item_len, uint8_t** result, size_t* result_len) {
+    return guard(ctx, [&] {
+        REQUIRE(work_item && result && result_len, "worker_hash_rows: null argument");
+        *result = nullptr; *result_len = 0;
+        const wm::HashingWorkItem w = wm::parse_hashing_work_item(work_item, work_item_len);
+        const size_t k = w.rows.size();
+        // rows of one width form one column-major matrix: one upload and one launch per distinct width (the reference's pool
+        // always posts rows of one width, pool.rs:84-99; a ragged item is still answered row by row like the worker would)
+        std::map<size_t, std::vector<size_t>> by_width;
+        for (size_t i = 0; i < k; i++) {
+            REQUIRE(!w.rows[i].empty(), "worker_hash_rows: a row without elements");
+            REQUIRE(w.rows[i].size() <= 4096, "worker_hash_rows: a row of more than 4096 elements");
+            by_width[w.rows[i].size()].push_back(i);
+        }
+        std::vector<uint8_t> digests(32 * k);
+        Context* c = ctx->c;
+        for (const auto& g : by_width) {
+            const size_t wd = g.first, m = g.second.size();
+            std::vector<uint64_t> cols(wd * m);
+            for (size_t r = 0; r < m; r++) {
+                const std::vector<uint64_t>& row = w.rows[g.second[r]];
+                for (size_t col = 0; col < wd; col++) cols[col * m + r] = row[col];
+            }
+            DevBuf<uint64_t> d(c, wd * m);
+            DevBuf<Digest> out(c, m);
+            AERO_HIP(hipMemcpyAsync(d.get(), cols.data(), cols.size() * 8, hipMemcpyHostToDevice, c->stream));
+            c->hash_rows(d.get(), m, (int)wd, m, out.get());
+            std::vector<Digest> hd(m);
+            AERO_HIP(hipMemcpyAsync(hd.data(), out.get(), m * sizeof(Digest), hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+            for (size_t r = 0; r < m; r++) memcpy(digests.data() + 32 * g.second[r], &hd[r], 32);
+        }
+        const std::vector<uint8_t> msg = wm::emit_hashing_result(w.batch_idx, digests.data(), k);
+        uint8_t* buf = (uint8_t*)malloc(msg.size() ? msg.size() : 1);
+        if (!buf) throw std::bad_alloc();
+        memcpy(buf, msg.data(), msg.size());
+        *result = buf; *result_len = msg.size();
+    });
+}
+// constraints_worker.rs:14-79 for the built-in FibAir: the work item's trace LDE (main columns + one auxiliary segment), composition
+// coefficients, auxiliary random elements and fragment -> the fragment's merged numerator columns. The message carries Miden's
+// PublicInputs; the built-in AIR takes its width/2 asserted results from `outputs.stack`. `air` names the auxiliary segment's
+// constraint degree (the message has no AIR identity: the reference's worker hard-wires ProcessorAir) and must agree with the
+// layout in the message; NULL when the layout has no auxiliary columns.
+int32_t aero_worker_eval_constraints(aero_ctx* ctx, const uint8_t* work_item, size_t work_item_len, const aero_fib_air* air, uint8_t** result,
+                                     size_t* result_len) {
+    return guard(ctx, [&] {
+        REQUIRE(work_item && result && result_len, "worker_eval_constraints: null argument");
+        *result = nullptr; *result_len = 0;
+        const wm::ConstraintWorkItem w = wm::parse_constraint_work_item(work_item, work_item_len);
+        const uint32_t W = w.main_width, A = w.aux_width;
+        REQUIRE(W >= 2 && !(W & 1) && w.main_cols.size() == W, "worker_eval_constraints: the main segment does not have the width the layout names (even, >= 2)");
+        REQUIRE(w.trace_len >= 8 && (w.trace_len & (w.trace_len - 1)) == 0 && w.trace_len <= ((uint64_t)1 << 29), "worker_eval_constraints: trace length must be a power of two in [8, 2^29]");
+        REQUIRE(w.blowup >= 2 && w.blowup <= 128 && (w.blowup & (w.blowup - 1)) == 0 && w.blowup == w.options[1], "worker_eval_constraints: blowup of the LDE and of the proof options disagree");
+        if (w.options[4] != EXT_NONE) fail("worker_eval_constraints: the message carries base-field coefficients (field extension must be None)", ST_UNSUPPORTED);
+        const size_t N = (size_t)w.trace_len * w.blowup;
+        for (const auto& col : w.main_cols) REQUIRE(col.size() == N, "worker_eval_constraints: an LDE column is not trace_length * blowup long");
+        aero_fib_air shape{};
+        if (A) {
+            REQUIRE(air && air->aux_width == A && air->aux_rands == w.aux_rands, "worker_eval_constraints: the air descriptor does not match the auxiliary layout of the message");
+            REQUIRE(w.aux_segments.size() == 1 && w.aux_segments[0].size() == A, "worker_eval_constraints: expected one auxiliary segment of the layout's width");
+            REQUIRE(w.aux_rand_elements.size() == 1 && w.aux_rand_elements[0].size() == w.aux_rands, "worker_eval_constraints: auxiliary random elements do not match the layout");
+            for (const auto& col : w.aux_segments[0]) REQUIRE(col.size() == N, "worker_eval_constraints: an auxiliary LDE column is not trace_length * blowup long");
+            shape = *air;
+        } else {
+            for (const auto& seg : w.aux_segments) REQUIRE(seg.empty(), "worker_eval_constraints: auxiliary columns without an auxiliary layout");
+        }
+        REQUIRE(w.n_transition == (size_t)W + A && w.n_boundary == (size_t)W + W / 2 + A, "worker_eval_constraints: coefficient counts do not match the AIR (width transition constraints, width + width/2 assertions, one of each per auxiliary column)");
+        const fmt::MidenInputs pub = fmt::parse_miden_inputs(w.public_inputs.data(), w.public_inputs.size());
+        REQUIRE(pub.out_stack.size() == W / 2, "worker_eval_constraints: outputs.stack must hold the width/2 asserted results");
+        for (uint64_t v : pub.out_stack) REQUIRE(v < gl::P, "worker_eval_constraints: non-canonical asserted result");
+        REQUIRE(w.num_fragments >= 1 && w.num_fragments <= ((uint64_t)1 << 30) && w.fragment_offset < w.num_fragments, "worker_eval_constraints: bad fragment");
+        Context* c = ctx->c;
+        Matrix lde(c, (int)W, N), aux;
+        for (uint32_t col = 0; col < W; col++)
+            AERO_HIP(hipMemcpyAsync(lde.data.get() + (size_t)col * N, w.main_cols[col].data(), N * 8, hipMemcpyHostToDevice, c->stream));
+        if (A) {
+            aux = Matrix(c, (int)A, N);
+            for (uint32_t col = 0; col < A; col++)
+                AERO_HIP(hipMemcpyAsync(aux.data.get() + (size_t)col * N, w.aux_segments[0][col].data(), N * 8, hipMemcpyHostToDevice, c->stream));
+        }
+        FibAir fa;
+        fa.width = W; fa.aux_width = A; fa.aux_rands = A ? shape.aux_rands : 0; fa.aux_degree = A ? shape.aux_degree : 2;
+        const size_t ceN = fa.ce_blowup_factor() * (size_t)w.trace_len;
+        REQUIRE(ceN % w.num_fragments == 0, "worker_eval_constraints: the fragments do not divide the constraint domain");
+        const size_t rows = ceN / (size_t)w.num_fragments;
+        std::vector<uint64_t> cols(3 * rows);
+        uint64_t first = 0;
+        eval_constraints_air<gl::FB>(c, lde, A ? &aux : nullptr, A ? &shape : nullptr, (uint32_t)ilog2u(w.blowup), pub.out_stack.data(),
+                                     A ? w.aux_rand_elements[0].data() : nullptr, w.coeffs.data(), (uint32_t)w.fragment_offset, (uint32_t)w.num_fragments,
+                                     cols.data(), &first);
+        const std::vector<uint8_t> msg = wm::emit_constraint_result(first, w.num_fragments, cols.data(), 3, rows);
+        uint8_t* buf = (uint8_t*)malloc(msg.size() ? msg.size() : 1);
+        if (!buf) throw std::bad_alloc();
+        memcpy(buf, msg.data(), msg.size());
+        *result = buf; *result_len = msg.size();
+    });
 }
 }  // extern "C"

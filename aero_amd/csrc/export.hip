@@ -20,6 +20,7 @@
 
 #include "../../include/aero_stark.h"
 #include "proof_format.hpp"
+#include "worker_messages.hpp"
 
 namespace aero {
 namespace {
@@ -202,24 +203,8 @@ std::string cairo_proof(const Parsed& pr) {
 // ---- `stark_parser <file> public-inputs` (lib.rs:41-57): Miden `PublicInputs` bytes = program hash (4 elements) || u64 count ||
 // stack inputs || u64 count || outputs.stack || u64 count || overflow addresses. Program hash and stack inputs
 // are `Felt`s (16-digit hex), the outputs are plain u64 (aero-sdk/miden-wasm/src/utils.rs:485-486,535).
-struct MidenInputs { std::vector<uint64_t> hash, stack_inputs, out_stack, overflow; };
-MidenInputs parse_miden_inputs(const uint8_t* b, size_t len) {
-    fmt::Reader r{b, len};
-    MidenInputs m;
-    for (int i = 0; i < 4; i++) m.hash.push_back(r.le(8));
-    std::vector<uint64_t>* parts[3] = {&m.stack_inputs, &m.out_stack, &m.overflow};
-    for (auto* v : parts) {
-        const uint64_t cnt = r.le(8);
-        if (cnt > (len - r.off) / 8) fmt::bad("public inputs are truncated");
-        for (uint64_t i = 0; i < cnt; i++) v->push_back(r.le(8));
-    }
-    if (r.off != len) fmt::bad("trailing bytes after the public inputs");
-    for (uint64_t v : m.hash) if (v >= gl::P) fmt::bad("non-canonical program hash element");
-    for (uint64_t v : m.stack_inputs) if (v >= gl::P) fmt::bad("non-canonical stack input");
-    return m;
-}
 std::string cairo_public_inputs(const uint8_t* b, size_t len) {
-    const MidenInputs m = parse_miden_inputs(b, len);
+    const fmt::MidenInputs m = fmt::parse_miden_inputs(b, len);
     CairoImage img;
     auto t = img.root();
     t.sized_felts(m.hash);
@@ -412,7 +397,7 @@ Bytes protobuf_proof(const Parsed& pr) {
 }
 // MidenPublicInputs { program_hash = 1, stack_inputs = 2, outputs = 3 { stack = 1, overflow_addrs = 2 } } (convert_proof.rs:257-280)
 Bytes protobuf_public_inputs(const uint8_t* b, size_t len) {
-    const MidenInputs m = parse_miden_inputs(b, len);
+    const fmt::MidenInputs m = fmt::parse_miden_inputs(b, len);
     Pb out, hash, outputs;
     hash.bytes(2, b, 32);
     out.msg(1, hash);
@@ -421,6 +406,15 @@ Bytes protobuf_public_inputs(const uint8_t* b, size_t len) {
     pb_felts(outputs, 2, m.overflow);
     out.msg(3, outputs);
     return out.b;
+}
+
+// MidenProgramOutputs { stack = 1, overflow_addrs = 2 } (miden_vm.proto:7-12): what the proving worker posts as `program_outputs`
+Bytes protobuf_program_outputs(const uint8_t* b, size_t len) {
+    const fmt::MidenInputs m = fmt::parse_miden_inputs(b, len);
+    Pb outputs;
+    pb_felts(outputs, 1, m.out_stack);
+    pb_felts(outputs, 2, m.overflow);
+    return outputs.b;
 }
 
 template <class Fn> int32_t guarded(char* err, size_t cap, Fn&& fn) {
@@ -499,6 +493,23 @@ int32_t aero_miden_public_inputs_to_protobuf(const uint8_t* input_bytes, size_t 
         if (!buf) throw std::bad_alloc();
         memcpy(buf, b.data(), b.size());
         *out = buf; *out_len = b.size();
+    });
+}
+
+// The message the reference's proving worker hands back to the SDK (proving_worker.rs:205-222, utils.rs:424-430): bincode
+// ProverOutput { proof, program_outputs, public_inputs }, each the protobuf encoding of the SDK type.
+int32_t aero_prover_output(const uint8_t* proof, size_t proof_len, const uint8_t* input_bytes, size_t input_len, uint8_t** out, size_t* out_len,
+                           char* err, size_t err_cap) {
+    using namespace aero;
+    return guarded(err, err_cap, [&] {
+        if (!proof || !input_bytes || !out || !out_len) fail("prover_output: null argument");
+        *out = nullptr; *out_len = 0;
+        const Bytes msg = wm::emit_prover_output(protobuf_proof(fmt::parse(proof, proof_len)), protobuf_program_outputs(input_bytes, input_len),
+                                                 protobuf_public_inputs(input_bytes, input_len));
+        uint8_t* buf = (uint8_t*)malloc(msg.size() ? msg.size() : 1);
+        if (!buf) throw std::bad_alloc();
+        memcpy(buf, msg.data(), msg.size());
+        *out = buf; *out_len = msg.size();
     });
 }
 

@@ -176,5 +176,24 @@ inline std::vector<std::vector<Digest>> batch_into_paths(size_t n_leaves, const 
     return out;
 }
 
+// Miden's `PublicInputs` as the bincode container and the worker messages carry them: program hash (4 elements),
+// then three u64-counted lists: stack inputs, outputs.stack, overflow addresses.
+struct MidenInputs { std::vector<uint64_t> hash, stack_inputs, out_stack, overflow; };
+inline MidenInputs parse_miden_inputs(const uint8_t* b, size_t len) {
+    Reader r{b, len};
+    MidenInputs m;
+    for (int i = 0; i < 4; i++) m.hash.push_back(r.le(8));
+    std::vector<uint64_t>* parts[3] = {&m.stack_inputs, &m.out_stack, &m.overflow};
+    for (auto* v : parts) {
+        const uint64_t cnt = r.le(8);
+        if (cnt > (len - r.off) / 8) bad("public inputs are truncated");
+        for (uint64_t i = 0; i < cnt; i++) v->push_back(r.le(8));
+    }
+    if (r.off != len) bad("trailing bytes after the public inputs");
+    for (uint64_t v : m.hash) if (v >= gl::P) bad("non-canonical program hash element");
+    for (uint64_t v : m.stack_inputs) if (v >= gl::P) bad("non-canonical stack input");
+    return m;
+}
+
 }  // namespace fmt
 }  // namespace aero

@@ -399,6 +399,33 @@ int32_t aero_proof_to_protobuf(const uint8_t* proof, size_t proof_len, uint8_t**
 int32_t aero_miden_public_inputs_to_protobuf(const uint8_t* input_bytes, size_t input_len, uint8_t** out, size_t* out_len, char* err,
                                              size_t err_cap);
 
+/* ---- the reference's worker seam at the message level --------------------------------------------------------------------------- */
+/* The browser SDK's proving worker off-loads row hashing and constraint evaluation to web workers with bincode 1.3 messages
+ * (aero-sdk/miden-wasm/src/utils.rs:442-450 `to_uint8array` / `from_uint8array`; pool.rs:84-125 posts them,
+ * proving_worker.rs:154-159,428-437 merges the answers). These entry points take the very bytes the pool posts and return the bytes
+ * the proving worker expects back (layouts restated in aero_amd/csrc/worker_messages.hpp); *result is malloc'd (aero_free).
+ *
+ * aero_worker_hash_rows: HashingWorkItem { data: Vec<Vec<Felt>>, batch_idx } (utils.rs:358-362) -> HashingResult { batch_idx,
+ *   hashes: Vec<[u8; 32]> } (utils.rs:411-415) = `blake2_hash_elements` (hashing_worker.rs:12-26): Blake2s_256::hash_elements of
+ *   every row, in row order. Rows may differ in length (one launch per distinct length); a value >= p is reduced like Felt::new
+ *   does; a row without elements is AERO_E_BAD_ARG.
+ * aero_worker_eval_constraints: ConstraintComputeWorkItem { trace_info, public_inputs, proof_options, aux_rand_elements,
+ *   constraint_coeffs, trace_lde_wrapper, computation_fragment } (utils.rs:302-347) -> ConstraintComputeResult { frag_index,
+ *   frag_num, constraint_evaluations } (utils.rs:417-422) = `constraint_compute` (constraints_worker.rs:14-79) for the built-in
+ *   FibAir: columns [transition, boundary(step 0), boundary(step n-1)] of the fragment, numerators only. The message has no AIR
+ *   identity (the reference's worker hard-wires Miden's ProcessorAir, which is absent here): `air` names the auxiliary segment's
+ *   constraint degree and must agree with the TraceLayout in the message (NULL without auxiliary columns); the width/2 asserted
+ *   results are read from `outputs.stack` of the Miden PublicInputs the message carries. Base field only (the message's
+ *   coefficients are base-field elements).
+ * aero_prover_output: what the proving worker hands back to the SDK (proving_worker.rs:205-222, utils.rs:424-430): bincode
+ *   ProverOutput { proof, program_outputs, public_inputs } - the protobuf encodings of sdk.StarkProof, sdk.MidenProgramOutputs
+ *   and sdk.MidenPublicInputs - from proof bytes and the container's input bytes. */
+int32_t aero_worker_hash_rows(aero_ctx* ctx, const uint8_t* work_item, size_t work_item_len, uint8_t** result, size_t* result_len);
+int32_t aero_worker_eval_constraints(aero_ctx* ctx, const uint8_t* work_item, size_t work_item_len, const aero_fib_air* air,
+                                     uint8_t** result, size_t* result_len);
+int32_t aero_prover_output(const uint8_t* proof, size_t proof_len, const uint8_t* input_bytes, size_t input_len, uint8_t** out,
+                           size_t* out_len, char* err, size_t err_cap);
+
 /* ---- instrumentation --------------------------------------------------------------------------------------------------------- */
 /* Per-stage wall-clock of the last aero_prove_* (ms; adds one stream sync per stage when enabled). Order:
  * interpolate, lde, trace_commit, constraints, composition, comp_commit, ood, deep, fri, grind, queries, total

@@ -333,7 +333,7 @@ def sdk_messages():
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
     get = message_factory.GetMessageClass
-    return {n: get(pool.FindMessageTypeByName("sdk." + n)) for n in ("StarkProof", "MidenPublicInputs")}
+    return {n: get(pool.FindMessageTypeByName("sdk." + n)) for n in ("StarkProof", "MidenPublicInputs", "MidenProgramOutputs")}
 
 
 def fe(vals):
@@ -439,3 +439,50 @@ def test_protobuf_refuses_what_the_schema_cannot_say(oracle):
     assert e.value.code == -5                      # FieldExtension::Quadratic => todo!() in convert_proof.rs:140-147
     with pytest.raises(aero_amd.AeroError):
         aero_amd.proof_to_protobuf(b"\x01\x02\x03")
+
+
+def test_prover_output_message_of_the_golden_proof(golden_dir):
+    """What the reference's proving worker posts back to the SDK (proving_worker.rs:205-222): bincode ProverOutput of the three
+    protobuf payloads (utils.rs:424-430: three Vec<u8> = u64 length + bytes each)."""
+    from aero_amd import messages
+    msgs = sdk_messages()
+    inputs, proof = golden(golden_dir)
+    blob = aero_amd.prover_output(proof, inputs)
+    pb_proof, pb_outputs, pb_inputs = messages.decode_prover_output(blob)
+    assert blob == b"".join(struct.pack("<Q", len(x)) + x for x in (pb_proof, pb_outputs, pb_inputs))
+    assert pb_proof == aero_amd.proof_to_protobuf(proof) and pb_inputs == aero_amd.miden_public_inputs_to_protobuf(inputs)
+    po = msgs["MidenProgramOutputs"]()
+    po.ParseFromString(pb_outputs)
+    assert po.SerializeToString(deterministic=True) == pb_outputs
+    pi = msgs["MidenPublicInputs"]()
+    pi.ParseFromString(pb_inputs)
+    assert fe(po.stack) == fe(pi.outputs.stack) and fe(po.stack)[:2] == [55, 34] and len(po.overflow_addrs) == 0
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.prover_output(proof[:-1], inputs)
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.prover_output(proof, inputs[:-3])
+
+
+def test_worker_message_layouts():
+    """The bincode layouts aero_amd.messages writes, byte by byte, on the data of the reference's own unit test
+    (utils.rs:460-478 `test_work_item_serialization`: rows [[1, 2], [3, 4]], batch 0)."""
+    from aero_amd import messages
+    item = messages.encode_hashing_work_item([[1, 2], [3, 4]], 0)
+    q = lambda *v: b"".join(struct.pack("<Q", x) for x in v)
+    assert item == q(2, 2, 1, 2, 2, 3, 4, 0)
+    digests = [hash_elements([1, 2]), hash_elements([3, 4])]
+    assert digests[0].hex() == "1466784a2149964c3bb5af60fb274365a73ced9e96459ea486fe330a3afa4177"       # SURVEY a5 known answer
+    assert messages.decode_hashing_result(q(7, 2) + digests[0] + digests[1]) == (7, digests)
+    # ConstraintComputeWorkItem of utils.rs:481-545 (layout (2, [1], [1]), 8 rows, coefficient pairs as in the test; a 2 x 16 LDE here)
+    pub = messages.miden_public_inputs([9, 8, 7, 6], [0, 1], [2, 3])
+    assert pub == q(9, 8, 7, 6, 2, 0, 1, 2, 2, 3, 0)
+    main = [list(range(16)), list(range(100, 116))]
+    aux = [[list(range(200, 216))]]
+    w = messages.encode_constraint_work_item((2, 1, 1), 8, pub, [27, 8, 17, 4, 1, 16, 7], [[5]], [(1, 2), (3, 4)], [(5, 6), (7, 8), (7, 8)],
+                                             main, aux, 2, 0, 8)
+    lde = q(3, 2, 16, *main[0], 16, *main[1], 1, 1, 16, *aux[0][0], 2)
+    want = (q(3, 3) + bytes([2, 1, 1]) + q(8, 0) + q(1, len(pub)) + pub + q(1, 7) + bytes([27, 8, 17, 4, 1, 16, 7]) + q(1, 1, 5) +
+            q(2, 2, 1, 2, 3, 4, 3, 5, 6, 7, 8, 7, 8) + q(len(lde)) + lde + q(0, 8))
+    assert w == want
+    fi, fn, cols = messages.decode_constraint_result(q(4, 8, 3, 2, 10, 11, 2, 20, 21, 2, 30, 31))
+    assert (fi, fn) == (4, 8) and cols.tolist() == [[10, 11], [20, 21], [30, 31]]
