@@ -714,17 +714,26 @@ def miden_public_inputs_to_protobuf(input_bytes: bytes) -> bytes:
     return _pb_call(lib().aero_miden_public_inputs_to_protobuf, input_bytes)
 
 
-def prover_output(proof: bytes, input_bytes: bytes) -> bytes:
-    """bincode ProverOutput { proof, program_outputs, public_inputs } with the three protobuf payloads (aero_prover_output)."""
+def _pb_call2(fn, proof: bytes, input_bytes: bytes) -> bytes:
     pb, ib = np.frombuffer(proof, np.uint8), np.frombuffer(input_bytes, np.uint8)
     out, n = u8p(), C.c_size_t(0)
     err = C.create_string_buffer(512)
-    rc = lib().aero_prover_output(_p8(pb), C.c_size_t(len(proof)), _p8(ib), C.c_size_t(len(input_bytes)), C.byref(out), C.byref(n), err, C.c_size_t(512))
+    rc = fn(_p8(pb), C.c_size_t(len(proof)), _p8(ib), C.c_size_t(len(input_bytes)), C.byref(out), C.byref(n), err, C.c_size_t(512))
     if rc != 0:
         raise AeroError(rc, err.value.decode(errors="replace"))
     res = C.string_at(out, n.value)
     lib().aero_free(out)
     return res
+
+
+def prover_output(proof: bytes, input_bytes: bytes) -> bytes:
+    """bincode ProverOutput { proof, program_outputs, public_inputs } with the three protobuf payloads (aero_prover_output)."""
+    return _pb_call2(lib().aero_prover_output, proof, input_bytes)
+
+
+def proof_submission_request(proof: bytes, input_bytes: bytes) -> bytes:
+    """sdk.ProofSubmissionRequest bytes (aero_proof_submission_request)."""
+    return _pb_call2(lib().aero_proof_submission_request, proof, input_bytes)
 
 
 def device_count():

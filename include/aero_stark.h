@@ -425,6 +425,10 @@ int32_t aero_worker_eval_constraints(aero_ctx* ctx, const uint8_t* work_item, si
                                      uint8_t** result, size_t* result_len);
 int32_t aero_prover_output(const uint8_t* proof, size_t proof_len, const uint8_t* input_bytes, size_t input_len, uint8_t** out,
                            size_t* out_len, char* err, size_t err_cap);
+/* protobuf sdk.ProofSubmissionRequest { proof, public_inputs, source_proof_system = MIDEN, target_chain = STARKNET }
+ * (aero-sdk/proto/service.proto:16-21): the request of the SDK's `ProofSubmissionService.SubmitProof`. */
+int32_t aero_proof_submission_request(const uint8_t* proof, size_t proof_len, const uint8_t* input_bytes, size_t input_len, uint8_t** out,
+                                      size_t* out_len, char* err, size_t err_cap);
 
 /* ---- instrumentation --------------------------------------------------------------------------------------------------------- */
 /* Per-stage wall-clock of the last aero_prove_* (ms; adds one stream sync per stage when enabled). Order:

@@ -330,10 +330,12 @@ def sdk_messages():
                        ("pow_nonce", 7, U64, 0, None)])
     msg("MidenProgramOutputs", [("stack", 1, MSG, 1, "FieldElement"), ("overflow_addrs", 2, MSG, 1, "FieldElement")])
     msg("MidenPublicInputs", [("program_hash", 1, MSG, 0, "Digest"), ("stack_inputs", 2, MSG, 1, "FieldElement"), ("outputs", 3, MSG, 0, "MidenProgramOutputs")])
+    msg("ProofSubmissionRequest", [("proof", 1, MSG, 0, "StarkProof"), ("public_inputs", 2, MSG, 0, "MidenPublicInputs"),
+                                   ("source_proof_system", 3, U32, 0, None), ("target_chain", 4, U32, 0, None)])   # enums: varints
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
     get = message_factory.GetMessageClass
-    return {n: get(pool.FindMessageTypeByName("sdk." + n)) for n in ("StarkProof", "MidenPublicInputs", "MidenProgramOutputs")}
+    return {n: get(pool.FindMessageTypeByName("sdk." + n)) for n in ("StarkProof", "MidenPublicInputs", "MidenProgramOutputs", "ProofSubmissionRequest")}
 
 
 def fe(vals):
@@ -486,3 +488,16 @@ def test_worker_message_layouts():
     assert w == want
     fi, fn, cols = messages.decode_constraint_result(q(4, 8, 3, 2, 10, 11, 2, 20, 21, 2, 30, 31))
     assert (fi, fn) == (4, 8) and cols.tolist() == [[10, 11], [20, 21], [30, 31]]
+
+
+def test_proof_submission_request_of_the_golden_proof(golden_dir):
+    """service.proto:16-21: the request of ProofSubmissionService.SubmitProof; MIDEN / STARKNET are the zero values (not written)."""
+    msgs = sdk_messages()
+    inputs, proof = golden(golden_dir)
+    data = aero_amd.proof_submission_request(proof, inputs)
+    req = msgs["ProofSubmissionRequest"]()
+    req.ParseFromString(data)
+    assert req.SerializeToString(deterministic=True) == data
+    assert req.proof.SerializeToString(deterministic=True) == aero_amd.proof_to_protobuf(proof)
+    assert req.public_inputs.SerializeToString(deterministic=True) == aero_amd.miden_public_inputs_to_protobuf(inputs)
+    assert req.source_proof_system == 0 and req.target_chain == 0
