@@ -71,6 +71,10 @@ struct RowSrc {   // rows of a column-major matrix
     size_t stride;   // column stride in elements
     int ncols;
 };
+struct MsgSrc {   // rows of a bincode HashingWorkItem as they lie in the message: words[offs[i]] = length of row i, the elements follow
+    const uint64_t* words;
+    const uint64_t* offs;
+};
 struct FriSrc {   // FRI layer rows: row i = (v[i + j*rows])_{j < fold}, each value = deg base components (c0, c1)
     const uint64_t* c0;
     const uint64_t* c1;
@@ -168,6 +172,7 @@ public:
     // FRI layer rows: row i = (v[i + j*rows] for j < fold), each value having `deg` base components stored as
     // component columns comp[k] (k < deg): leaf i = hash_elements(flattened row)
     void hash_fri_rows(const FriSrc& src, Digest* leaves);
+    void hash_message_rows(const MsgSrc& src, size_t rows, Digest* leaves);   // rows of any length, values >= p reduced
     // nodes[n + i] already hold the leaves; fills nodes[1 .. n-1]
     void merkle_build(Digest* nodes, size_t n, const CoinStep* coin = nullptr);
     // same when the leaf level holds 2^log_parts pieces in arrival order (leaf u in slot n + (u mod parts)*(n/parts) + u/parts)

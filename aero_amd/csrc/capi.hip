@@ -957,35 +957,24 @@ int32_t aero_worker_hash_rows(aero_ctx* ctx, const uint8_t* work_item, size_t wo
     return guard(ctx, [&] {
         REQUIRE(work_item && result && result_len, "worker_hash_rows: null argument");
         *result = nullptr; *result_len = 0;
-        const wm::HashingWorkItem w = wm::parse_hashing_work_item(work_item, work_item_len);
-        const size_t k = w.rows.size();
-        // rows of one width form one column-major matrix: one upload and one launch per distinct width (the reference's pool
-        // always posts rows of one width, pool.rs:84-99; a ragged item is still answered row by row like the worker would)
-        std::map<size_t, std::vector<size_t>> by_width;
-        for (size_t i = 0; i < k; i++) {
-            REQUIRE(!w.rows[i].empty(), "worker_hash_rows: a row without elements");
-            REQUIRE(w.rows[i].size() <= 4096, "worker_hash_rows: a row of more than 4096 elements");
-            by_width[w.rows[i].size()].push_back(i);
-        }
+        // the rows are hashed where they lie in the message: one scan of the row headers on the host, the bytes go to the device
+        // as they are (every field of this message is a u64), one lane per row
+        std::vector<uint64_t> offs;
+        const uint64_t batch_idx = wm::scan_hashing_work_item(work_item, work_item_len, offs);
+        const size_t k = offs.size();
         std::vector<uint8_t> digests(32 * k);
-        Context* c = ctx->c;
-        for (const auto& g : by_width) {
-            const size_t wd = g.first, m = g.second.size();
-            std::vector<uint64_t> cols(wd * m);
-            for (size_t r = 0; r < m; r++) {
-                const std::vector<uint64_t>& row = w.rows[g.second[r]];
-                for (size_t col = 0; col < wd; col++) cols[col * m + r] = row[col];
-            }
-            DevBuf<uint64_t> d(c, wd * m);
-            DevBuf<Digest> out(c, m);
-            AERO_HIP(hipMemcpyAsync(d.get(), cols.data(), cols.size() * 8, hipMemcpyHostToDevice, c->stream));
-            c->hash_rows(d.get(), m, (int)wd, m, out.get());
-            std::vector<Digest> hd(m);
-            AERO_HIP(hipMemcpyAsync(hd.data(), out.get(), m * sizeof(Digest), hipMemcpyDeviceToHost, c->stream));
+        if (k) {
+            Context* c = ctx->c;
+            const size_t words = work_item_len / 8;
+            DevBuf<uint64_t> d_msg(c, words), d_offs(c, k);
+            DevBuf<Digest> out(c, k);
+            AERO_HIP(hipMemcpyAsync(d_msg.get(), work_item, work_item_len, hipMemcpyHostToDevice, c->stream));
+            AERO_HIP(hipMemcpyAsync(d_offs.get(), offs.data(), k * 8, hipMemcpyHostToDevice, c->stream));
+            c->hash_message_rows(MsgSrc{d_msg.get(), d_offs.get()}, k, out.get());
+            AERO_HIP(hipMemcpyAsync(digests.data(), out.get(), k * sizeof(Digest), hipMemcpyDeviceToHost, c->stream));
             c->sync();
-            for (size_t r = 0; r < m; r++) memcpy(digests.data() + 32 * g.second[r], &hd[r], 32);
         }
-        const std::vector<uint8_t> msg = wm::emit_hashing_result(w.batch_idx, digests.data(), k);
+        const std::vector<uint8_t> msg = wm::emit_hashing_result(batch_idx, digests.data(), k);
         uint8_t* buf = (uint8_t*)malloc(msg.size() ? msg.size() : 1);
         if (!buf) throw std::bad_alloc();
         memcpy(buf, msg.data(), msg.size());

@@ -62,6 +62,25 @@ __device__ __forceinline__ Digest leaf_digest(const RowSrc& s, size_t j) {
     }
     return state_digest(st);
 }
+// rows of a worker message (row-major, each with its own length; an element >= p stands for its residue like Felt::new reads it;
+// a row without elements is BLAKE2s of the empty string, as hash_elements(&[]) is)
+__device__ __forceinline__ Digest leaf_digest(const MsgSrc& s, size_t i) {
+    b2s::State st;
+    b2s::init(st);
+    const uint64_t* row = s.words + s.offs[i];
+    const uint32_t n = (uint32_t)row[0];
+    const uint32_t total = n * 32;
+    if (n == 0) b2s::compress_elems(st, 0, 0, false, 0, true);
+    for (uint32_t c = 0; c < n; c += 2) {
+        const bool two = c + 1 < n;
+        uint64_t e0 = row[1 + c], e1 = two ? row[2 + c] : 0;
+        e0 = e0 >= gl::P ? e0 - gl::P : e0;
+        e1 = e1 >= gl::P ? e1 - gl::P : e1;
+        const uint32_t t = (two ? c + 2 : c + 1) * 32;
+        b2s::compress_elems(st, e0, e1, two, t, t == total);
+    }
+    return state_digest(st);
+}
 // FRI rows: element q of row i (q < fold*deg) = comp[q % deg][i + (q / deg) * rows]
 __device__ __forceinline__ Digest leaf_digest(const FriSrc& s, size_t i) {
     b2s::State st;
@@ -521,6 +540,11 @@ void Context::hash_rows(const uint64_t* cols, size_t col_stride, int ncols, size
     check_launch("hash_rows");
 }
 
+void Context::hash_message_rows(const MsgSrc& src, size_t rows, Digest* leaves) {
+    if (!rows) return;
+    AERO_LAUNCH(this, "hash_message_rows_kernel", 0, (hash_rows_kernel<MsgSrc>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, src, rows, leaves);
+    check_launch("hash_message_rows");
+}
 void Context::hash_fri_rows(const FriSrc& src, Digest* leaves) {
     if ((src.fold * src.deg) & 1) fail("hash_fri_rows: odd element count");
     AERO_LAUNCH(this, "hash_fri_rows_kernel", src.rows * ((size_t)src.fold * src.deg * 8 + 32), (hash_rows_kernel<FriSrc>),

@@ -73,19 +73,22 @@ struct Wr {
     void byte_vec(const void* q, size_t n) { u64(n); raw(q, n); }
 };
 
-struct HashingWorkItem {
-    std::vector<std::vector<uint64_t>> rows;
-    uint64_t batch_idx = 0;
-};
-inline HashingWorkItem parse_hashing_work_item(const uint8_t* p, size_t len) {
+// A HashingWorkItem without copying its rows: offsets[i] = position (in 8-byte words from the start of the message) of row i's
+// length field; every field of this message is a u64, so the rows can be hashed where they lie once the bytes are on the device.
+inline uint64_t scan_hashing_work_item(const uint8_t* p, size_t len, std::vector<uint64_t>& offsets) {
+    if (len % 8) bad("a HashingWorkItem is a sequence of 8-byte fields");
     Rd r{p, len};
-    HashingWorkItem w;
     const size_t n = r.count(8);
-    w.rows.reserve(n);
-    for (size_t i = 0; i < n; i++) w.rows.push_back(r.felts());
-    w.batch_idx = r.u64();
+    offsets.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        offsets[i] = r.off / 8;
+        const size_t k = r.count(8);
+        if (k > 0xFFFFFFu) bad("a row of more than 2^24 elements");
+        r.bytes(8 * k);
+    }
+    const uint64_t batch_idx = r.u64();
     r.end();
-    return w;
+    return batch_idx;
 }
 inline std::vector<uint8_t> emit_hashing_result(uint64_t batch_idx, const uint8_t* digests, size_t count) {
     Wr w;

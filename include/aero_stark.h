@@ -407,8 +407,9 @@ int32_t aero_miden_public_inputs_to_protobuf(const uint8_t* input_bytes, size_t 
  *
  * aero_worker_hash_rows: HashingWorkItem { data: Vec<Vec<Felt>>, batch_idx } (utils.rs:358-362) -> HashingResult { batch_idx,
  *   hashes: Vec<[u8; 32]> } (utils.rs:411-415) = `blake2_hash_elements` (hashing_worker.rs:12-26): Blake2s_256::hash_elements of
- *   every row, in row order. Rows may differ in length (one launch per distinct length); a value >= p is reduced like Felt::new
- *   does; a row without elements is AERO_E_BAD_ARG.
+ *   every row, in row order. The rows are hashed where they lie in the message (one copy of the bytes to the device, one lane
+ *   per row); they may differ in length, a row without elements hashes to BLAKE2s of the empty string like hash_elements(&[]),
+ *   a value >= p is reduced like Felt::new does.
  * aero_worker_eval_constraints: ConstraintComputeWorkItem { trace_info, public_inputs, proof_options, aux_rand_elements,
  *   constraint_coeffs, trace_lde_wrapper, computation_fragment } (utils.rs:302-347) -> ConstraintComputeResult { frag_index,
  *   frag_num, constraint_evaluations } (utils.rs:417-422) = `constraint_compute` (constraints_worker.rs:14-79) for the built-in

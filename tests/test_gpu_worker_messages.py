@@ -52,6 +52,9 @@ def test_hashing_worker_uniform_and_ragged_batches(ctx, oracle):
     assert batch == 2 ** 40 + 3 and digests == [hash_elements(r) for r in ragged]
     # an empty work item is a valid message
     assert messages.decode_hashing_result(ctx.worker_hash_rows(messages.encode_hashing_work_item([], 9))) == (9, [])
+    # a row without elements: hash_elements(&[]) = BLAKE2s of the empty string
+    _, d = messages.decode_hashing_result(ctx.worker_hash_rows(messages.encode_hashing_work_item([[7], [], [1, 2, 3]], 0)))
+    assert d == [hash_elements([7]), hashlib.blake2s(b"").digest(), hash_elements([1, 2, 3])]
     # Felt::new reduces: p + 5 is the element 5
     _, d = messages.decode_hashing_result(ctx.worker_hash_rows(messages.encode_hashing_work_item([[P + 5, 1]], 0)))
     assert d == [hash_elements([5, 1])]
@@ -59,7 +62,7 @@ def test_hashing_worker_uniform_and_ragged_batches(ctx, oracle):
 
 def test_hashing_worker_rejects_malformed_items(ctx):
     good = messages.encode_hashing_work_item([[1, 2], [3, 4]], 0)
-    for bad in (good[:-1], good + b"\0", good[:20], struct.pack("<Q", 2 ** 60) + good[8:], messages.encode_hashing_work_item([[1], []], 0)):
+    for bad in (good[:-1], good + b"\0", good[:20], struct.pack("<Q", 2 ** 60) + good[8:], good[:8] + struct.pack("<Q", 2 ** 40) + good[16:], good[:-3]):
         with pytest.raises(aero_amd.AeroError):
             ctx.worker_hash_rows(bad)
     assert messages.decode_hashing_result(ctx.worker_hash_rows(good))[0] == 0          # the context is still usable
