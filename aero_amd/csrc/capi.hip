@@ -998,13 +998,13 @@ int32_t aero_worker_eval_constraints(aero_ctx* ctx, const uint8_t* work_item, si
         REQUIRE(w.blowup >= 2 && w.blowup <= 128 && (w.blowup & (w.blowup - 1)) == 0 && w.blowup == w.options[1], "worker_eval_constraints: blowup of the LDE and of the proof options disagree");
         if (w.options[4] != EXT_NONE) fail("worker_eval_constraints: the message carries base-field coefficients (field extension must be None)", ST_UNSUPPORTED);
         const size_t N = (size_t)w.trace_len * w.blowup;
-        for (const auto& col : w.main_cols) REQUIRE(col.size() == N, "worker_eval_constraints: an LDE column is not trace_length * blowup long");
+        for (const auto& col : w.main_cols) REQUIRE(col.n == N, "worker_eval_constraints: an LDE column is not trace_length * blowup long");
         aero_fib_air shape{};
         if (A) {
             REQUIRE(air && air->aux_width == A && air->aux_rands == w.aux_rands, "worker_eval_constraints: the air descriptor does not match the auxiliary layout of the message");
             REQUIRE(w.aux_segments.size() == 1 && w.aux_segments[0].size() == A, "worker_eval_constraints: expected one auxiliary segment of the layout's width");
             REQUIRE(w.aux_rand_elements.size() == 1 && w.aux_rand_elements[0].size() == w.aux_rands, "worker_eval_constraints: auxiliary random elements do not match the layout");
-            for (const auto& col : w.aux_segments[0]) REQUIRE(col.size() == N, "worker_eval_constraints: an auxiliary LDE column is not trace_length * blowup long");
+            for (const auto& col : w.aux_segments[0]) REQUIRE(col.n == N, "worker_eval_constraints: an auxiliary LDE column is not trace_length * blowup long");
             shape = *air;
         } else {
             for (const auto& seg : w.aux_segments) REQUIRE(seg.empty(), "worker_eval_constraints: auxiliary columns without an auxiliary layout");
@@ -1016,12 +1016,15 @@ int32_t aero_worker_eval_constraints(aero_ctx* ctx, const uint8_t* work_item, si
         REQUIRE(w.num_fragments >= 1 && w.num_fragments <= ((uint64_t)1 << 30) && w.fragment_offset < w.num_fragments, "worker_eval_constraints: bad fragment");
         Context* c = ctx->c;
         Matrix lde(c, (int)W, N), aux;
+        // the columns go to the device straight from the message; Felt::new's reduction of raw values happens there
         for (uint32_t col = 0; col < W; col++)
-            AERO_HIP(hipMemcpyAsync(lde.data.get() + (size_t)col * N, w.main_cols[col].data(), N * 8, hipMemcpyHostToDevice, c->stream));
+            AERO_HIP(hipMemcpyAsync(lde.data.get() + (size_t)col * N, w.main_cols[col].data, N * 8, hipMemcpyHostToDevice, c->stream));
+        reduce_canonical(c, lde.data.get(), (size_t)W * N);
         if (A) {
             aux = Matrix(c, (int)A, N);
             for (uint32_t col = 0; col < A; col++)
-                AERO_HIP(hipMemcpyAsync(aux.data.get() + (size_t)col * N, w.aux_segments[0][col].data(), N * 8, hipMemcpyHostToDevice, c->stream));
+                AERO_HIP(hipMemcpyAsync(aux.data.get() + (size_t)col * N, w.aux_segments[0][col].data, N * 8, hipMemcpyHostToDevice, c->stream));
+            reduce_canonical(c, aux.data.get(), (size_t)A * N);
         }
         FibAir fa;
         fa.width = W; fa.aux_width = A; fa.aux_rands = A ? shape.aux_rands : 0; fa.aux_degree = A ? shape.aux_degree : 2;

@@ -547,6 +547,19 @@ bool all_canonical(Context* ctx, const uint64_t* vals, size_t count) {
     return bad == 0;
 }
 
+// v <- v mod p in place (what Felt::new does to a raw u64): for data that arrives in the reference's message formats
+__global__ __launch_bounds__(256) void reduce_canonical_kernel(uint64_t* __restrict__ v, size_t count) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < count; i += stride) { const uint64_t x = v[i]; if (x >= gl::P) v[i] = x - gl::P; }
+}
+void reduce_canonical(Context* ctx, uint64_t* vals, size_t count) {
+    if (!count) return;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    AERO_LAUNCH(ctx, "reduce_canonical_kernel", count * 8, reduce_canonical_kernel, dim3((unsigned)blocks), dim3(256), 0, vals, count);
+    ctx->check_launch("reduce_canonical");
+}
 // kernel only: ORs a 1 into *d_bad (device) when a value is not canonical
 void canonical_check_accumulate(Context* ctx, const uint64_t* vals, size_t count, unsigned int* d_bad) {
     if (!count) return;

@@ -105,6 +105,7 @@ template <class F> void launch_aux_columns(Context* ctx, const uint64_t* trace, 
 
 // true iff every one of the `count` device values is a canonical field element (< p); synchronises the stream
 bool all_canonical(Context* ctx, const uint64_t* vals, size_t count);
+void reduce_canonical(Context* ctx, uint64_t* vals, size_t count);   // v <- v mod p in place (Felt::new)
 void canonical_check_accumulate(Context* ctx, const uint64_t* vals, size_t count, unsigned int* d_bad);
 void canonical_check_enqueue(Context* ctx, const uint64_t* vals, size_t count, unsigned int* h_bad_pinned);
 

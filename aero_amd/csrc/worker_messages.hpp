@@ -106,20 +106,22 @@ struct ConstraintWorkItem {
     std::vector<std::vector<uint64_t>> aux_rand_elements;      // per auxiliary segment
     std::vector<uint64_t> coeffs;                              // (alpha, beta) per transition constraint, then per assertion
     size_t n_transition = 0, n_boundary = 0;
-    std::vector<std::vector<uint64_t>> main_cols;              // the trace LDE, column-major
-    std::vector<std::vector<std::vector<uint64_t>>> aux_segments;
+    struct Col { const uint8_t* data; size_t n; };            // a column where it lies in the message (n u64, possibly >= p)
+    std::vector<Col> main_cols;                                // the trace LDE, column-major
+    std::vector<std::vector<Col>> aux_segments;
     uint64_t blowup = 0, fragment_offset = 0, num_fragments = 0;
 };
 inline void parse_trace_lde(const uint8_t* p, size_t len, ConstraintWorkItem& w) {
     Rd r{p, len};
     r.expect_seq(3, "trace_lde");
+    auto col = [&]() { const size_t n = r.count(8); return ConstraintWorkItem::Col{r.bytes(8 * n), n}; };
     const size_t nc = r.count(8);
-    for (size_t c = 0; c < nc; c++) w.main_cols.push_back(r.felts());
+    for (size_t c = 0; c < nc; c++) w.main_cols.push_back(col());
     const size_t ns = r.count(8);
     for (size_t s = 0; s < ns; s++) {
         const size_t na = r.count(8);
-        std::vector<std::vector<uint64_t>> seg;
-        for (size_t c = 0; c < na; c++) seg.push_back(r.felts());
+        std::vector<ConstraintWorkItem::Col> seg;
+        for (size_t c = 0; c < na; c++) seg.push_back(col());
         w.aux_segments.push_back(std::move(seg));
     }
     w.blowup = r.u64();
