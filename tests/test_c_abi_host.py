@@ -43,3 +43,42 @@ def test_c_host_proves_verifies_and_writes_the_container(tmp_path, oracle):
     # the same container through the Python command line
     r = subprocess.run([sys.executable, "-m", "aero_amd", "verify", str(out), "--log-n", "12"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0 and "accepted" in r.stdout, r.stderr
+
+
+# ---- the C++ host surface (include/aero_prover.hpp: Winterfell's Prover / ProofOptions / TraceTable / StarkProof / verify names) ----
+CPP_SRC = os.path.join(ROOT, "tests", "c_abi", "fib_prover.cpp")
+
+
+def build_cpp(tmp_path):
+    exe = str(tmp_path / "fib_prover")
+    lib_dir = os.path.join(ROOT, "aero_amd")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), CPP_SRC, "-L", lib_dir, "-laero_stark",
+           f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_cpp_host_surface_compiles_and_refuses_without_a_gpu(tmp_path):
+    exe = build_cpp(tmp_path)
+    r = subprocess.run([exe, "2", "8", str(tmp_path / "p.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 3), (r.returncode, r.stdout, r.stderr)
+    if r.returncode == 3:                       # Context::Context threw ProverError: no device, no CPU fallback
+        assert "ProverError(-3)" in r.stderr and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width,log_n", [(2, 10), (8, 12)])
+def test_cpp_prover_trait_flow_matches_the_oracle(tmp_path, oracle, width, log_n):
+    """main.rs:20-51 in C++: build_trace -> Prover::prove -> verify -> ProofData on disk; bytes identical to the oracle's proof."""
+    import json
+    exe = build_cpp(tmp_path)
+    out = tmp_path / "p.bin"
+    r = subprocess.run([exe, str(width), str(log_n), str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["rejected"] == 3 and res["prover_errors"] == 2 and res["security_level"] == min(97, 64 - (log_n + 3)) and res["results"] == width // 2
+    inputs, proof = oracle.container_split(out.read_bytes())
+    want, want_pub, _ = oracle.prove_fib(width, log_n, [27, 8, 16, 4, 1, 8, 8])
+    assert proof == want and len(proof) == res["proof_bytes"]
+    assert inputs == b"".join(int(v).to_bytes(8, "little") for v in want_pub)
