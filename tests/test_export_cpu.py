@@ -501,3 +501,36 @@ def test_proof_submission_request_of_the_golden_proof(golden_dir):
     assert req.proof.SerializeToString(deterministic=True) == aero_amd.proof_to_protobuf(proof)
     assert req.public_inputs.SerializeToString(deterministic=True) == aero_amd.miden_public_inputs_to_protobuf(inputs)
     assert req.source_proof_system == 0 and req.target_chain == 0
+
+
+def test_stark_parser_command_line_is_the_reference_cli(golden_dir):
+    """bin/stark_parser (aero_amd/csrc/stark_parser.cpp): the command line the Cairo side's hints call (src/stark_verifier/utils.py:33-41,
+    tests/integration/utils.py:5-24: [parser, path, command, indexes]) - same sub-commands, the JSON array + the newline println! adds."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    aero_amd.lib()                                   # builds the library and the parser when they are missing
+    exe = os.path.join(root, "bin", "stark_parser")
+    assert os.path.exists(exe)
+    path = os.path.join(golden_dir, "fib.bin")
+    inputs, proof = golden(golden_dir)
+    pos = json.load(open(os.path.join(golden_dir, "fib_kat.json")))["G1"]["positions"]
+
+    def run(*args):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=120)
+        return r.returncode, r.stdout, r.stderr
+
+    assert run(path, "proof") == (0, aero_amd.cairo_memory("proof", proof, inputs) + "\n", "")
+    assert run(path, "public-inputs") == (0, aero_amd.cairo_memory("public-inputs", b"", inputs) + "\n", "")
+    for cmd in ("trace-queries", "constraint-queries", "fri-queries"):
+        rc, out, err = run(path, cmd, json.dumps(pos))
+        assert (rc, err) == (0, "") and out == aero_amd.cairo_memory(cmd, proof, inputs, pos) + "\n"
+        json.loads(out)
+    assert run(path, "trace-queries", json.dumps([p + 1 for p in pos]))[0] == 1          # paths that do not reach the commitment
+    assert run(path, "nonsense")[0] == 1 and run(os.path.join(golden_dir, "missing.bin"), "proof")[0] == 1
+    # interpolate-poly (main.rs:103-109): values as 8-byte little-endian hex, coefficients low to high, folded with ", "
+    hx = lambda vals: json.dumps([int(v).to_bytes(8, "little").hex() for v in vals])
+    xs = [3, 5, 7, 11, P - 2]
+    coeffs = [9, 0, P - 1, 12345678901234567, 4]
+    ys = [sum(c * pow(x, i, P) for i, c in enumerate(coeffs)) % P for x in xs]
+    rc, out, _ = run(path, "interpolate-poly", hx(xs), hx(ys))
+    assert rc == 0 and out == "".join(f", {c}" for c in coeffs) + "\n"
