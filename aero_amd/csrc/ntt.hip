@@ -102,6 +102,13 @@ __device__ __forceinline__ void ntt_round(uint64_t* lds, int log_e, int log_tl, 
     __syncthreads();
 }
 
+// exchange between the two halves of a wavefront (V_PERMLANE32_SWAP): x of lanes 32..63 <-> y of lanes 0..31
+__device__ __forceinline__ void swap_halves(uint64_t& x, uint64_t& y) {       // x of lanes 32..63 <-> y of lanes 0..31
+    const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)y, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(x >> 32), (uint32_t)(y >> 32), false, false);
+    x = gl::mk64(lo[0], hi[0]); y = gl::mk64(lo[1], hi[1]);
+}
+
 // Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2 and TLBs). Handing XCD x the x-th contiguous
 // eighth of the tiles keeps the tiles that are in flight on one XCD next to each other in memory: a strided pass touches
 // R rows per tile, and neighbouring tiles share those rows' pages and DRAM rows.
@@ -381,6 +388,98 @@ __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Contiguous LAST pass of the inverse transform (log_r = 11, 2048-point tiles) as the mirror of ntt_fwd_first_pass_8: two register
+// transforms around one exchange, one wavefront per tile, 32 values per lane, decimation in frequency with the inverse roots:
+//   B' lane k holds positions k + 64 i: pass-boundary twiddle w^-(rev(tile) p) as a geometric progression in i (its start carries
+//      the tile's share of the output scaling, which is uniform over the tile and therefore commutes with the transform), the
+//      32-point inverse transform (shift twiddles), one table multiplication per element (w_2048^-(k rev(i)));
+//   -- 32 x 64 transpose through XOR-swizzled LDS in two rounds of 16 rows (8 KiB per wave) --
+//   A' lane (h, half) holds columns [32 half, 32 half + 32) of row h: the 64-point inverse transform shared by two lanes - the first
+//      stage pairs column c with c + 32 across the halves (one V_PERMLANE32_SWAP round to form the pairs, the factor
+//      w_64^-16 = -2^48 of the upper half's twiddles as a select, a second round to hand each lane a complete 32-block), then the
+//      32-point inverse transform of each half; outputs (bit-reversed order, as everywhere) times the per-position scale table.
+// Against the LDS rounds of ntt_inv_pass (12 bits): 4 full multiplications per element instead of 6.6, no workgroup barrier.
+template <int I> __device__ __forceinline__ void first_stage_pairs_inv(uint64_t (&y)[32]) {
+    bfly_w64_inv<I>(y[I], y[16 + I]);
+    if constexpr (I + 1 < 16) first_stage_pairs_inv<I + 1>(y);
+}
+__global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_inv_last_pass_11(PassArgs a, const uint64_t* __restrict__ bftab) {
+    __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS / 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t* lds = f8_lds + wave * (F8_TILE_LDS / 2);
+    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * F8_WAVES + wave;
+    uint64_t* data = a.out + (size_t)blockIdx.y * a.out_col_stride + ((size_t)b << 11);       // in place
+    const int h = lane & 31;
+    const uint32_t half = (uint32_t)lane >> 5;
+    const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
+    const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
+    uint64_t y[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) y[i] = data[lane + 64 * i];
+    {
+        // input side: w^-(rbk p), p = lane + 64 i, times the tile's output factor
+        uint64_t cur = bftab[b];
+        if (!a.first && rbk) {
+            cur = mul(cur, tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)lane) & nmask), a.tw_h));
+            const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
+#pragma unroll
+            for (int i = 0; i < 32; i++) { y[i] = mul(y[i], cur); cur = mul(cur, step); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; i++) y[i] = mul(y[i], cur);
+        }
+    }
+    dft_dif_inv_reg<5>(y);                                   // natural i -> bit-reversed i'
+#pragma unroll
+    for (int i = 1; i < 32; i++) y[i] = mul(y[i], a.tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane]);
+    // exchange: register i' of lane k -> (row i', column k); lane (h, half) then reads columns [32 half, 32 half + 32) of row h
+    uint64_t v[32];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) lds[i * 64 + (lane ^ ((2 * (16 * r + i)) & 63))] = y[16 * r + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if ((h >> 4) == r) {
+            const uint64_t* row = lds + (h & 15) * 64;
+            const int sw = (2 * h) & 63;
+#pragma unroll
+            for (int j = 0; j < 32; j++) v[j] = row[(32 * (int)half + j) ^ sw];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // 64-point inverse transform of row h over the two halves: v = columns 32 half + j
+#pragma unroll
+    for (int i = 0; i < 16; i++) swap_halves(v[i], v[16 + i]);           // lower half: (u, v) of columns i, upper: of columns 16 + i
+    first_stage_pairs_inv<0>(v);                                         // (u + v, (u - v) w_64^-i)
+#pragma unroll
+    for (int i = 0; i < 16; i++) { const uint64_t t = gl::neg(mul_w4(v[16 + i])); v[16 + i] = half ? t : v[16 + i]; }    // upper: * w_64^-16 = -2^48
+#pragma unroll
+    for (int i = 0; i < 16; i++) swap_halves(v[i], v[16 + i]);           // lower half: the 32 sums, upper: the 32 twiddled differences
+    dft_dif_inv_reg<5>(v);
+    // position 64 h + 32 half + m of the tile (bit-reversed coefficient order), scaled per position
+    const size_t q0 = (size_t)64 * h + 32 * half;
+    const ulonglong2* kt = reinterpret_cast<const ulonglong2*>(a.ktab + q0);
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(data + q0);
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const ulonglong2 k2 = kt[m];
+        ulonglong2 o;
+        o.x = mul(v[2 * m], k2.x); o.y = mul(v[2 * m + 1], k2.y);
+        dst[m] = o;
+    }
+}
+// tab[b] = a^rev(b) * b2^(rev(b) >> shift), rev over `bits` bits: the tile factors of the inverse transform's output scaling
+__global__ void fill_block_factors(uint64_t* tab, int bits, uint64_t abase, uint64_t bbase, int shift) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (1u << bits)) return;
+    const uint32_t rb = gl::bitrev(b, bits);
+    tab[b] = mul(gl::pow(abase, rb), gl::pow(bbase, rb >> shift));
+}
+
+// ------------------------------------------------------------------------------------------------
 // Strided passes of radix <= 64 entirely in registers: a thread owns one column position `lo` of a block and the R = 2^LOGR
 // values at stride S; the R-point transform needs no LDS because every twiddle of a transform of up to 64 points is a power of
 // two in this field (dft_small.hpp). Consecutive threads own consecutive addresses, so each of the R loads / stores of a
@@ -425,11 +524,6 @@ template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void nt
 // each half (same shift twiddles in both), the last stage pairs row j with row j + 32 across the halves: one V_PERMLANE32_SWAP per
 // register pair hands each lane 16 complete (u, v) pairs - rows (i, i + 32) in the lower half, (16 + i, 48 + i) in the upper -
 // and the factor w_64^16 = 2^48 that separates the two sets of twiddles is applied to v in the upper half with a select.
-__device__ __forceinline__ void swap_halves(uint64_t& x, uint64_t& y) {       // x of lanes 32..63 <-> y of lanes 0..31
-    const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)y, false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(x >> 32), (uint32_t)(y >> 32), false, false);
-    x = gl::mk64(lo[0], hi[0]); y = gl::mk64(lo[1], hi[1]);
-}
 template <int I> __device__ __forceinline__ void last_stage_pairs(uint64_t (&y)[32]) {
     bfly_w64<I>(y[I], y[16 + I]);
     if constexpr (I + 1 < 16) last_stage_pairs<I + 1>(y);
@@ -663,7 +757,12 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
 void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift) {
     ensure_small_twiddles();
     NttTables* t = ntt_tables(log_n);
-    std::vector<NttPass> plan = plan_passes(log_n, reg_passes, 12);
+    // two-phase contiguous pass (11 bits) where the transform is large enough to keep its strided passes' count
+    static const bool inv2p_env = !(getenv("AERO_INV_2PHASE") && getenv("AERO_INV_2PHASE")[0] == '0');
+    // (measured: -20 % on 72 columns x 2^20 and on 2 x 2^24, -7 % on 2 x 2^21; on 2 x 2^20 - one wave per SIMD, pure latency - it
+    // equals the LDS rounds, which keep the smaller launches)
+    const bool inv2p = inv2p_env && reg_passes && log_n >= 13 && ((size_t)ncols << log_n) >= ((size_t)1 << 22);
+    std::vector<NttPass> plan = plan_passes(log_n, reg_passes, inv2p ? 11 : 12);
     const int r1 = plan[0].log_r;
     // per-k table for the final (contiguous) pass
     uint64_t ninv = gl::inv((uint64_t)1 << log_n);
@@ -711,6 +810,25 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
                 case 2: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<2>, rgrid, dim3(256), 0, a); break;
                 default: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<1>, rgrid, dim3(256), 0, a); break;
             }
+            continue;
+        }
+        if (inv2p && qi == 0 && a.log_r == 11) {
+            // per-tile factors a^rev(b) * b^(rev(b) >> shift): built once per (size, scale parameters) and kept
+            const int bbits = log_n - 11;
+            const std::vector<uint64_t> key{(uint64_t)(0x100 + bbits), sa, sb, (uint64_t)shift, 0};
+            uint64_t* bftab = nullptr;
+            auto it = ktab_cache.find(key);
+            if (it != ktab_cache.end()) bftab = it->second;
+            else {
+                const bool keep = ktab_cache.size() < 64;
+                bftab = keep ? (uint64_t*)dev_alloc(((size_t)1 << bbits) * 8) : (uint64_t*)scratch_alloc(((size_t)1 << bbits) * 8);
+                AERO_LAUNCH(this, "fill_block_factors", 0, fill_block_factors, dim3(((1u << bbits) + 255) / 256), dim3(256), 0, bftab, bbits, sa, sb, shift);
+                if (keep) ktab_cache[key] = bftab;
+            }
+            a.tw_mt = twmt_inv;
+            const size_t tiles = ((size_t)1 << log_n) >> 11;
+            AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_last_pass_11, dim3((unsigned)(tiles / F8_WAVES), ncols),
+                        dim3(64 * F8_WAVES), 0, a, (const uint64_t*)bftab);
             continue;
         }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
