@@ -71,3 +71,19 @@ def test_plain_invocation_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["h2d_included"] is True
     assert "sharded_proof" not in out
+
+
+def test_native_rccl_communicator_inside_a_torch_process():
+    """The sharded side measurement of `bench.py --gpus N` creates the library's RCCL communicator in a process that has torch (and
+    with it a second HIP runtime and a second librccl) loaded: the communicator must come up there too (world 1 on the test box:
+    ncclCommInitRank on the RCCL that belongs to the HIP runtime the library runs on) and the proof must flow through it."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--shard-worker", "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--sharded-workloads", SMALL, "--shard-comm", "rccl"]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=600, env=env)
+    text = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, text[-3000:]
+    line = [l for l in text.splitlines() if l.startswith("SHARDED_RESULT ")][-1]
+    res = json.loads(line[len("SHARDED_RESULT "):])[0]
+    assert "error" not in res, res
+    assert res["exchange"].startswith("native RCCL") and res["world"] == 1 and res["proof_identical_to_single_gpu_on_every_rank"] is True
