@@ -726,6 +726,20 @@ def _pb_call2(fn, proof: bytes, input_bytes: bytes) -> bytes:
     return res
 
 
+def worker_message_info(kind: str, msg: bytes):
+    """Shape of a worker message, validated on the host (aero_worker_message_info): kind = "hashing" | "constraints"."""
+    buf = np.frombuffer(msg, np.uint8)
+    out = (C.c_uint64 * 8)()
+    err = C.create_string_buffer(512)
+    rc = lib().aero_worker_message_info(C.c_uint32({"hashing": 0, "constraints": 1}[kind]), _p8(buf), C.c_size_t(len(msg)), out, err, C.c_size_t(512))
+    if rc != 0:
+        raise AeroError(rc, err.value.decode(errors="replace"))
+    v = list(out)
+    if kind == "hashing":
+        return dict(rows=v[0], batch_idx=v[1], min_width=v[2], max_width=v[3], elements=v[4])
+    return dict(main_width=v[0], aux_width=v[1], aux_rands=v[2], trace_len=v[3], blowup=v[4], fragment_offset=v[5], num_fragments=v[6], coefficient_pairs=v[7])
+
+
 def prover_output(proof: bytes, input_bytes: bytes) -> bytes:
     """bincode ProverOutput { proof, program_outputs, public_inputs } with the three protobuf payloads (aero_prover_output)."""
     return _pb_call2(lib().aero_prover_output, proof, input_bytes)

@@ -515,6 +515,25 @@ int32_t aero_proof_submission_request(const uint8_t* proof, size_t proof_len, co
         *out = buf; *out_len = req.b.size();
     });
 }
+// Host-side look at a worker message without touching a GPU: validates the layout and reports its shape.
+int32_t aero_worker_message_info(uint32_t kind, const uint8_t* msg, size_t len, uint64_t out[8], char* err, size_t err_cap) {
+    using namespace aero;
+    return guarded(err, err_cap, [&] {
+        if (!msg || !out) fail("worker_message_info: null argument");
+        for (int i = 0; i < 8; i++) out[i] = 0;
+        if (kind == AERO_MSG_HASHING_WORK_ITEM) {
+            std::vector<uint64_t> offs;
+            const uint64_t batch = wm::scan_hashing_work_item(msg, len, offs);
+            uint64_t lo = ~0ull, hi = 0, total = 0;
+            for (uint64_t o : offs) { uint64_t k; memcpy(&k, msg + 8 * o, 8); lo = k < lo ? k : lo; hi = k > hi ? k : hi; total += k; }
+            out[0] = offs.size(); out[1] = batch; out[2] = offs.empty() ? 0 : lo; out[3] = hi; out[4] = total;
+        } else if (kind == AERO_MSG_CONSTRAINT_WORK_ITEM) {
+            const wm::ConstraintWorkItem w = wm::parse_constraint_work_item(msg, len);
+            out[0] = w.main_width; out[1] = w.aux_width; out[2] = w.aux_rands; out[3] = w.trace_len; out[4] = w.blowup;
+            out[5] = w.fragment_offset; out[6] = w.num_fragments; out[7] = w.n_transition + w.n_boundary;
+        } else fail("worker_message_info: unknown message kind");
+    });
+}
 // The message the reference's proving worker hands back to the SDK (proving_worker.rs:205-222, utils.rs:424-430): bincode
 // ProverOutput { proof, program_outputs, public_inputs }, each the protobuf encoding of the SDK type.
 int32_t aero_prover_output(const uint8_t* proof, size_t proof_len, const uint8_t* input_bytes, size_t input_len, uint8_t** out, size_t* out_len,

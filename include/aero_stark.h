@@ -421,6 +421,13 @@ int32_t aero_miden_public_inputs_to_protobuf(const uint8_t* input_bytes, size_t 
  * aero_prover_output: what the proving worker hands back to the SDK (proving_worker.rs:205-222, utils.rs:424-430): bincode
  *   ProverOutput { proof, program_outputs, public_inputs } - the protobuf encodings of sdk.StarkProof, sdk.MidenProgramOutputs
  *   and sdk.MidenPublicInputs - from proof bytes and the container's input bytes. */
+/* Host-only look at a message (no GPU): validates the layout (AERO_E_BAD_ARG with the reason in err otherwise) and reports
+ *   AERO_MSG_HASHING_WORK_ITEM:    out = {rows, batch_idx, shortest row, longest row, total elements}
+ *   AERO_MSG_CONSTRAINT_WORK_ITEM: out = {main width, aux width, aux rands, trace length, blowup, fragment_offset, num_fragments,
+ *                                         number of (alpha, beta) pairs} */
+#define AERO_MSG_HASHING_WORK_ITEM 0u
+#define AERO_MSG_CONSTRAINT_WORK_ITEM 1u
+int32_t aero_worker_message_info(uint32_t kind, const uint8_t* msg, size_t len, uint64_t out[8], char* err, size_t err_cap);
 int32_t aero_worker_hash_rows(aero_ctx* ctx, const uint8_t* work_item, size_t work_item_len, uint8_t** result, size_t* result_len);
 int32_t aero_worker_eval_constraints(aero_ctx* ctx, const uint8_t* work_item, size_t work_item_len, const aero_fib_air* air,
                                      uint8_t** result, size_t* result_len);

@@ -534,3 +534,22 @@ def test_stark_parser_command_line_is_the_reference_cli(golden_dir):
     ys = [sum(c * pow(x, i, P) for i, c in enumerate(coeffs)) % P for x in xs]
     rc, out, _ = run(path, "interpolate-poly", hx(xs), hx(ys))
     assert rc == 0 and out == "".join(f", {c}" for c in coeffs) + "\n"
+
+
+def test_worker_messages_are_validated_on_the_host():
+    """aero_worker_message_info: the layouts of the SDK's worker messages checked without a GPU (what aero_worker_* will accept)."""
+    from aero_amd import messages
+    item = messages.encode_hashing_work_item([[1, 2], [3, 4, 5], []], 7)
+    assert aero_amd.worker_message_info("hashing", item) == dict(rows=3, batch_idx=7, min_width=0, max_width=3, elements=5)
+    for bad in (item[:-1], item + b"\0" * 8, struct.pack("<Q", 2 ** 61) + item[8:], item[:8] + struct.pack("<Q", 2 ** 30) + item[16:]):
+        with pytest.raises(aero_amd.AeroError):
+            aero_amd.worker_message_info("hashing", bad)
+    pub = messages.miden_public_inputs([9, 8, 7, 6], [0, 1], [2, 3])
+    main = [list(range(16)), list(range(100, 116))]
+    w = messages.encode_constraint_work_item((2, 1, 1), 8, pub, [27, 2, 17, 4, 1, 16, 7], [[5]], [(1, 2), (3, 4), (5, 6)], [(5, 6), (7, 8), (7, 8), (1, 1)],
+                                             main, [[list(range(200, 216))]], 2, 3, 8)
+    assert aero_amd.worker_message_info("constraints", w) == dict(main_width=2, aux_width=1, aux_rands=1, trace_len=8, blowup=2, fragment_offset=3,
+                                                                   num_fragments=8, coefficient_pairs=7)
+    for bad in (w[:-1], w + b"\1", w[:8] + struct.pack("<Q", 4) + w[16:], w.replace(bytes([27, 2, 17, 4, 1, 16, 7]), bytes([27, 2, 17, 4, 1, 16]), 1)):
+        with pytest.raises(aero_amd.AeroError):
+            aero_amd.worker_message_info("constraints", bad)
