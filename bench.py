@@ -605,7 +605,7 @@ def main():
             # mix, not of the kernel - the kernel alone is reported under "one_proof_in_flight")
             "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "limiter": ("valu: BLAKE2s is 32-bit integer issue-bound (about 1190 VALU ops per 64-byte block, 16 of which bytes come from HBM); "
+            "limiter": ("valu: BLAKE2s is 32-bit integer issue-bound (957 VALU instructions = about 1208 full-rate issue slots per 64-byte block, 16 of which bytes come from HBM; profiles/r2_isa_merkle_leaf8_rows2.json); "
                         "the HBM fraction is priced as the contract asks but is not what limits this kernel - see valu_view") if is_hash
                        else "valu (64-bit modular arithmetic on the 32-bit VALU) unless the achieved fraction says otherwise",
             "avg_launch_us": 1e3 * ms / max(calls, 1), "launches_timed": calls, "proofs_in_flight": S,
