@@ -1,5 +1,5 @@
 # Entry points under the names the reference repository uses for them (its Makefile: stark_parser, generate_proof, unit_test,
-# integration_test), mapped onto this backend. Everything else lives in aero_amd/csrc/Makefile, oracle/Makefile, bindings/node.
+# integration_test), mapped onto this backend. Everything else lives in aero_amd/csrc/Makefile, oracle/Makefile.
 PYTHON ?= python3
 PROOF ?= proofs/fibair_2p10.bin
 
@@ -7,7 +7,7 @@ PROOF ?= proofs/fibair_2p10.bin
 
 all: build
 
-# libaero_stark.so for gfx950 (hipcc cross-compiles without a GPU), bin/stark_parser, the test oracle, the Node addon
+# libaero_stark.so for gfx950 (hipcc cross-compiles without a GPU), bin/stark_parser, the test oracle
 build:
 	$(PYTHON) -c "import __graft_entry__ as g; g.build()"
 
@@ -38,5 +38,4 @@ bench:
 clean:
 	$(MAKE) -C aero_amd/csrc clean
 	$(MAKE) -C oracle clean
-	$(MAKE) -C bindings/node clean
 	rm -rf bin

@@ -375,11 +375,66 @@ class Context:
         """bincode HashingWorkItem -> bincode HashingResult (aero_worker_hash_rows; messages: aero_amd.messages)."""
         return self._msg_call(lib().aero_worker_hash_rows, work_item)
 
-    def worker_eval_constraints(self, work_item: bytes, air=None) -> bytes:
-        """bincode ConstraintComputeWorkItem -> bincode ConstraintComputeResult for the built-in FibAir (aero_worker_eval_constraints);
-        air = (aux_width, aux_rands, aux_degree) when the message's layout has auxiliary columns."""
-        desc = FibAirDesc(*air) if air and air[0] else None
-        return self._msg_call(lib().aero_worker_eval_constraints, work_item, C.byref(desc) if desc is not None else None)
+    def worker_eval_constraints(self, work_item: bytes, air: "Air", pub=None) -> bytes:
+        """bincode ConstraintComputeWorkItem -> bincode ConstraintComputeResult (aero_worker_eval_constraints); `air` = the program
+        (the message carries no AIR identity), `pub` = its public inputs (None: the elements of the message's Miden PublicInputs)."""
+        if pub is None:
+            return self._msg_call(lib().aero_worker_eval_constraints, work_item, air.h, None, C.c_uint32(0))
+        pb = np.array(pub, dtype=np.uint64, ndmin=1)
+        return self._msg_call(lib().aero_worker_eval_constraints, work_item, air.h, _p64(pb), C.c_uint32(pb.size))
+
+    # ---- program AIRs (include/aero_air.h)
+    def prove_air(self, air: "Air", trace, pub, options: ProofOptions, comm=None) -> bytes:
+        """Prover::prove for a program AIR: `trace` = device Matrix (resident) or host ndarray / PinnedTrace; `pub` = the program's
+        public inputs. Returns the proof bytes."""
+        pb = np.array(pub, dtype=np.uint64, ndmin=1) if len(pub) else np.zeros(1, np.uint64)
+        proof, plen = u8p(), C.c_size_t(0)
+        if isinstance(trace, Matrix):
+            rc = lib().aero_prove_air(self.h, C.byref(comm.struct) if comm is not None else None, air.h, trace.h, _p64(pb), C.c_uint32(len(pub)),
+                                      C.byref(options), C.byref(proof), C.byref(plen))
+        else:
+            assert comm is None, "sharded proofs take a device-resident trace"
+            t = trace.array if isinstance(trace, PinnedTrace) else np.ascontiguousarray(trace, np.uint64)
+            rc = lib().aero_prove_air_host(self.h, air.h, _p64(t), C.c_uint32(int(t.shape[1]).bit_length() - 1), _p64(pb), C.c_uint32(len(pub)),
+                                           C.byref(options), C.byref(proof), C.byref(plen))
+        if rc != 0 and getattr(comm, "last_error", None) is not None:
+            raise AeroError(rc, f"{lib().aero_last_error(self.h).decode()} ({comm.last_error!r})")
+        self._ck(rc)
+        data = C.string_at(proof, plen.value)
+        lib().aero_free(proof)
+        return data
+
+    def eval_constraints_program(self, air: "Air", lde: Matrix, aux_lde, log_blowup, pub, rands, coeffs, field_extension=1, fragment_offset=0,
+                                 num_fragments=1):
+        """ConstraintComputeWorkItem -> ConstraintComputeResult for a program AIR. Returns (frag_index, cols (divisors*deg, rows))."""
+        _, N = lde.shape
+        deg = 2 if field_extension == 2 else 1
+        n = N >> log_blowup
+        ncols = air.num_divisors(int(n).bit_length() - 1)
+        rows = air.info()["ce_blowup"] * n // num_fragments
+        pb = np.array(pub, dtype=np.uint64, ndmin=1) if len(pub) else np.zeros(1, np.uint64)
+        co = np.array(coeffs, dtype=np.uint64, ndmin=1)
+        rd = np.array(rands, dtype=np.uint64, ndmin=1) if aux_lde is not None else None
+        out = np.zeros((ncols * deg, rows), np.uint64)
+        fi = C.c_uint64(0)
+        self._ck(lib().aero_eval_constraints_program(self.h, air.h, lde.h, aux_lde.h if aux_lde is not None else None, C.c_uint32(log_blowup), _p64(pb),
+                                                     C.c_uint32(len(pub)), _p64(rd) if rd is not None else None, _p64(co), C.c_uint8(field_extension),
+                                                     C.c_uint32(fragment_offset), C.c_uint32(num_fragments), _p64(out), C.byref(fi)))
+        return fi.value, out
+
+    def aux_columns_program(self, air: "Air", trace: Matrix, pub, rands, field_extension=1) -> Matrix:
+        """`build_aux_segment` from the program's builders (aero_aux_columns_program)."""
+        pb = np.array(pub, dtype=np.uint64, ndmin=1) if len(pub) else np.zeros(1, np.uint64)
+        r = np.array(rands, dtype=np.uint64, ndmin=1)
+        h = C.c_void_p()
+        self._ck(lib().aero_aux_columns_program(self.h, air.h, trace.h, _p64(pb), C.c_uint32(len(pub)), _p64(r), C.c_uint8(field_extension), C.byref(h)))
+        return Matrix(self, h)
+
+    def composition_poly_program(self, air: "Air", numer_cols: np.ndarray, log_n: int, field_extension=1) -> Matrix:
+        a = np.ascontiguousarray(numer_cols, np.uint64)
+        h = C.c_void_p()
+        self._ck(lib().aero_composition_poly_program(self.h, air.h, _p64(a), C.c_uint32(log_n), C.c_uint8(field_extension), C.byref(h)))
+        return Matrix(self, h)
 
     def composition_poly_air(self, numer_cols: np.ndarray, log_n: int, num_columns: int, field_extension=1) -> Matrix:
         a = np.ascontiguousarray(numer_cols, np.uint64)
@@ -614,14 +669,71 @@ class Pool:
             pass
 
 
+class Air:
+    """A parsed, validated and compiled AEROAIR program (aero_air_load; format: include/aero_air.h; builder: aero_amd.air)."""
+    INFO = ["main_width", "aux_width", "aux_rands", "num_pub", "num_exemptions", "main_transition", "aux_transition", "main_assertions",
+            "aux_assertions", "ce_blowup", "num_periodic", "num_nodes", "instructions", "registers_base", "registers_ext", "has_aux_builders"]
+
+    def __init__(self, program: bytes):
+        self.program = bytes(program)
+        buf = np.frombuffer(self.program, np.uint8)
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib().aero_air_load(_p8(buf), C.c_size_t(len(self.program)), C.byref(self.h), err, C.c_size_t(512))
+        if rc != 0:
+            raise AeroError(rc, err.value.decode(errors="replace"))
+
+    def info(self):
+        out = (C.c_uint32 * 16)()
+        lib().aero_air_info(self.h, out)
+        return dict(zip(self.INFO, list(out)))
+
+    def num_divisors(self, log_n):
+        v = C.c_uint32(0)
+        rc = lib().aero_air_num_divisors(self.h, C.c_uint32(log_n), C.byref(v))
+        if rc != 0:
+            raise AeroError(rc, lib().aero_last_error(None).decode())
+        return v.value
+
+    def free(self):
+        if getattr(self, "h", None):
+            lib().aero_air_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def fib_program(width, aux=(0, 0, 2)) -> bytes:
+    """The built-in FibAir(width) [+ auxiliary segment (aux_width, aux_rands, aux_degree)] as an AEROAIR program (aero_air_fib_program)."""
+    out, n = u8p(), C.c_size_t(0)
+    desc = FibAirDesc(*aux) if aux and aux[0] else None
+    rc = lib().aero_air_fib_program(C.c_uint32(width), C.byref(desc) if desc is not None else None, C.byref(out), C.byref(n))
+    if rc != 0:
+        raise AeroError(rc, lib().aero_last_error(None).decode())
+    data = C.string_at(out, n.value)
+    lib().aero_free(out)
+    return data
+
+
 class VerifyPolicy(C.Structure):
     """aero_verify_policy (include/aero_stark.h)."""
     _fields_ = [("min_query_security_bits", C.c_uint32), ("expected_log_n", C.c_uint32), ("allow_unknown_air", C.c_uint32),
-                ("cairo_compat", C.c_uint32), ("require_options", C.c_uint32), ("options", ProofOptions)]
+                ("cairo_compat", C.c_uint32), ("require_options", C.c_uint32), ("options", ProofOptions),
+                ("min_conjectured_security_bits", C.c_uint32)]
+
+
+def _policy(min_query_security_bits, expected_log_n, allow_unknown_air, cairo_compat, require_options, min_conjectured_security_bits):
+    return VerifyPolicy(96 if min_query_security_bits is None else min_query_security_bits, expected_log_n, 1 if allow_unknown_air else 0,
+                        1 if cairo_compat else 0, 1 if require_options is not None else 0,
+                        require_options if require_options is not None else ProofOptions(), min_conjectured_security_bits)
 
 
 def verify_fib(proof: bytes, pub_elements, air, min_query_security_bits=None, expected_log_n=0, allow_unknown_air=False, cairo_compat=False,
-               require_options=None):
+               require_options=None, min_conjectured_security_bits=0):
     """aero_verify_fib (host only, no GPU): raises AeroError(-7, reason) when the proof is rejected.
     air = (aux_width, aux_rands, aux_degree) of the built-in FibAir - mandatory; None is accepted only together with
     allow_unknown_air=True (everything except the OOD constraint check, what the reference's Cairo verifier does).
@@ -630,11 +742,20 @@ def verify_fib(proof: bytes, pub_elements, air, min_query_security_bits=None, ex
     pub = np.array(pub_elements, dtype=np.uint64, ndmin=1)
     err = C.create_string_buffer(512)
     desc = FibAirDesc(*air) if air is not None else None
-    pol = VerifyPolicy(96 if min_query_security_bits is None else min_query_security_bits, expected_log_n, 1 if allow_unknown_air else 0,
-                       1 if cairo_compat else 0, 1 if require_options is not None else 0,
-                       require_options if require_options is not None else ProofOptions())
+    pol = _policy(min_query_security_bits, expected_log_n, allow_unknown_air, cairo_compat, require_options, min_conjectured_security_bits)
     rc = lib().aero_verify_fib(_p8(buf), C.c_size_t(len(proof)), _p64(pub) if pub.size else None, C.c_uint32(pub.size),
                                C.byref(desc) if desc is not None else None, C.byref(pol), err, C.c_size_t(512))
+    if rc != 0:
+        raise AeroError(rc, err.value.decode(errors="replace"))
+
+
+def verify_air(proof: bytes, pub, air: Air, min_query_security_bits=None, expected_log_n=0, require_options=None, min_conjectured_security_bits=0):
+    """aero_verify_air (host only): aero_verify_fib with the out-of-domain constraint check evaluated from the program."""
+    buf = np.frombuffer(proof, np.uint8)
+    pb = np.array(pub, dtype=np.uint64, ndmin=1) if len(pub) else np.zeros(1, np.uint64)
+    err = C.create_string_buffer(512)
+    pol = _policy(min_query_security_bits, expected_log_n, False, False, require_options, min_conjectured_security_bits)
+    rc = lib().aero_verify_air(_p8(buf), C.c_size_t(len(proof)), _p64(pb), C.c_uint32(len(pub)), air.h, C.byref(pol), err, C.c_size_t(512))
     if rc != 0:
         raise AeroError(rc, err.value.decode(errors="replace"))
 
@@ -743,11 +864,6 @@ def worker_message_info(kind: str, msg: bytes):
 def prover_output(proof: bytes, input_bytes: bytes) -> bytes:
     """bincode ProverOutput { proof, program_outputs, public_inputs } with the three protobuf payloads (aero_prover_output)."""
     return _pb_call2(lib().aero_prover_output, proof, input_bytes)
-
-
-def proof_submission_request(proof: bytes, input_bytes: bytes) -> bytes:
-    """sdk.ProofSubmissionRequest bytes (aero_proof_submission_request)."""
-    return _pb_call2(lib().aero_proof_submission_request, proof, input_bytes)
 
 
 def device_count():

@@ -1,0 +1,93 @@
+// Argument blocks and launchers of the AIR-program kernels (air_kernels.hip): the device interpreter of a compiled AEROAIR
+// program (air_program.hpp) over the constraint-evaluation domain, the auxiliary-segment builder and the generic division by the
+// constraint divisors.
+#pragma once
+#include "aero_internal.hpp"
+#include "air_program.hpp"
+
+namespace aero {
+
+// boundary divisor group as the kernels see it: divisor x^a - b; numerator multiplied by (alpha + beta x^adj)
+struct AirBGroupDev {
+    uint64_t a_exp;      // a mod rows: x^a = ha * w_rows^(s * a_exp mod rows)
+    uint64_t ha;         // offset^a
+    uint64_t b;
+    uint64_t adj_exp;    // adj mod rows (offset^adj is folded into the beta coefficients)
+    uint32_t m0, count;  // members [m0, m0 + count)
+};
+
+template <class F> struct AirConsArgs {
+    typedef typename F::T T;
+    // frame source: trace LDE (W columns) and auxiliary LDE (A * DEG component columns) with `N` rows each; evaluation row s sits at
+    // matrix row s * ce_step, its successor `blowup` rows further (mod N); split_log as in FibConsArgs (de-interleaved compact copy)
+    const uint64_t* lde;
+    const uint64_t* aux;
+    size_t N;
+    uint32_t W, A, blowup, ce_step, split_log;
+    size_t rows;                 // size of the evaluation domain (the points offset * w_rows^s)
+    size_t first, count;         // rows [first, first + count) are evaluated by this launch
+    // program
+    const air::Insn* code;
+    uint32_t slotsB, slotsE;
+    const uint64_t* scalB;
+    const T* scalE;
+    const uint64_t* ptab;        // periodic tables, concatenated; column k: ptab[p_off[k] + (s & p_mask[k])]
+    const uint32_t *p_off, *p_mask;
+    const T *ta, *tb;            // per transition constraint; tb pre-multiplied by offset^adj of its degree group
+    const uint64_t* dg_exp;      // per degree group: adj mod rows
+    const AirBGroupDev* bgroups;
+    uint32_t n_bgroups;
+    const air::BoundaryMember* members;
+    const T *ba, *bb;            // per assertion (sorted order); bb pre-multiplied by offset^adj of its group
+    // domain
+    const uint64_t *tw_lo, *tw_hi;   // two-level table of w_rows
+    int tw_h;
+    uint64_t offset;
+    // fused division (MODE 1)
+    const uint64_t* zn_inv;      // (xmask + 1) entries: (x^n - 1)^-1 for the distinct values of x^n, indexed by s & xmask
+    uint32_t xmask;
+    const uint64_t* exempt;      // n_exempt points w_n^(n-i): the transition divisor is (x^n - 1) / prod (x - exempt[i])
+    uint32_t n_exempt;
+    uint64_t* out_cols;          // MODE 0: ((1 + n_bgroups) * DEG) x count, column-major
+    uint64_t* out_h[2];          // MODE 1: DEG component arrays indexed by s
+};
+// mode 0: numerator columns; mode 1: divided and summed (H). Returns false when mode 1 cannot run fused (too many boundary
+// divisors): the caller then evaluates mode 0 and divides with launch_air_divide.
+template <class F> bool launch_air_constraints(Context* ctx, const AirConsArgs<F>& a, int mode);
+
+// H = sum_j column_j / divisor_j over the evaluation domain (the unfused `ConstraintEvaluationTable::into_poly` division)
+template <class F> struct AirDivideArgs {
+    const uint64_t* cols;        // ((1 + n_bgroups) * DEG) x rows numerators, column-major
+    size_t rows;
+    const AirBGroupDev* bgroups;
+    uint32_t n_bgroups;
+    const uint64_t *tw_lo, *tw_hi;
+    int tw_h;
+    uint64_t offset;
+    const uint64_t* zn_inv;
+    uint32_t xmask;
+    const uint64_t* exempt;
+    uint32_t n_exempt;
+    uint64_t* out_h[2];
+};
+template <class F> void launch_air_divide(Context* ctx, const AirDivideArgs<F>& a);
+
+// Auxiliary segment from the program's builders: column c(0) = init_c, c(i+1) = c(i) * num_c(i) / den_c(i).
+template <class F> struct AirAuxArgs {
+    typedef typename F::T T;
+    const uint64_t* trace;       // W x n main segment
+    size_t n;
+    uint32_t W, A;
+    const air::Insn* code;
+    uint32_t slotsB, slotsE;
+    const uint64_t* scalB;
+    const T* scalE;
+    const uint64_t* ptab;
+    const uint32_t *p_off, *p_mask;
+    const uint8_t* has_den;      // per aux column (device)
+    const T* init;               // per aux column (device)
+    uint64_t* out;               // (A * DEG) x n component columns
+};
+template <class F> void launch_air_aux(Context* ctx, const AirAuxArgs<F>& a, const std::vector<uint8_t>& has_den_host);
+
+}  // namespace aero

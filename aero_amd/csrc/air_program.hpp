@@ -1,0 +1,615 @@
+// AIR-as-data, host side: parse + validate an AEROAIR program (include/aero_air.h), compile it for the device interpreter
+// (air_kernels.hip), derive everything Winterfell's `Air` / `ConstraintEvaluator` derive from a trace length, and run the compiled
+// program on the host over E for the verifier's out-of-domain check.
+//
+// Reference seam: the `Air` object behind `ProcessorAir::new(trace_info, public_inputs, proof_options)` ->
+// `ConstraintEvaluator::new(&air, aux_rand_elements, &constraint_coeffs)` -> `evaluate_fragment`
+// (/root/reference/aero-sdk/miden-wasm/src/constraints_worker.rs:32-59, proving_worker.rs:255-259,374-395); the grouping /
+// degree-adjustment rules of winter-air 0.4 are restated from their verifier-side mirror in
+// src/stark_verifier/air/transitions/evaluator.cairo:79-86,131-150,216-218.
+//
+// Compilation (at load time, independent of the trace length):
+//   1. type inference: a node is E-valued iff it depends on the auxiliary frame or a random element; everything else stays in the
+//      base field (with the quadratic extension that is a third of the multiplications);
+//   2. constant folding: nodes that depend on no frame value and no periodic column (constants, public inputs, random elements)
+//      are evaluated once per proof on the host and become scalar operands;
+//   3. transition constraints are grouped by their declared degree (the key of Winterfell's degree groups); code is emitted group
+//      by group, each constraint's expression tree in post-order with common sub-expressions computed once, followed by an EMIT
+//      that folds the value into the group's two accumulators (sum alpha_k t_k and sum beta_k t_k); GROUP_END multiplies the
+//      second by x^adj - ONE power per group and row, obtained as a twiddle-table lookup, not an exponentiation;
+//   4. register allocation: a linear scan over the emitted stream assigns every live node a slot of the per-lane register file
+//      (LDS on the device), reusing slots after the last use.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "aero_internal.hpp"
+
+namespace aero {
+namespace air {
+
+enum Kind : uint32_t { K_NODE = 0, K_MAIN_CUR, K_MAIN_NXT, K_AUX_CUR, K_AUX_NXT, K_PERIODIC, K_CONST, K_PUB, K_RAND, K_COUNT };
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
+inline uint32_t ref_kind(uint32_t r) { return r >> 24; }
+inline uint32_t ref_index(uint32_t r) { return r & 0xFFFFFFu; }
+inline uint32_t mk_ref(uint32_t k, uint32_t i) { return (k << 24) | i; }
+
+// ---- the device program ------------------------------------------------------------------------------------------------------
+enum DKind : uint32_t { D_SLOT_B = 0, D_SLOT_E, D_MAIN_CUR, D_MAIN_NXT, D_AUX_CUR, D_AUX_NXT, D_PERIODIC, D_SCAL_B, D_SCAL_E };
+enum DOp : uint32_t {
+    OP_END = 0,
+    OP_ADD_B, OP_SUB_B, OP_MUL_B,            // base x base -> base slot
+    OP_ADD_E, OP_SUB_E, OP_MUL_E,            // operands of either type (base values are lifted) -> E slot
+    OP_MULB_E,                               // a in E, b in the base field -> E slot
+    OP_EMIT_B, OP_EMIT_E,                    // transition constraint `dst`: value a (base / E) into the group accumulators
+    OP_GROUP_END,                            // degree group `dst` complete: total += acc_beta * x^adj(dst)
+    OP_OUT_B, OP_OUT_E,                      // aux builder: value a -> output column dst
+};
+struct Insn { uint32_t op, dst, a, b; };     // op = DOp | kind(a) << 8 | kind(b) << 12
+inline bool dkind_is_ext(uint32_t k) { return k == D_SLOT_E || k == D_AUX_CUR || k == D_AUX_NXT || k == D_SCAL_E; }
+
+struct Node { uint32_t op, a, b; };
+struct Transition { uint32_t root, base; std::vector<uint32_t> cycles; uint32_t group; };
+struct Assertion { uint32_t col; int64_t first; uint32_t stride, value; };
+struct Builder { uint32_t init, num, den; };
+
+struct Program {
+    // ---- as written
+    uint32_t W = 0, A = 0, R = 0, num_pub = 0, exemptions = 1;
+    std::vector<uint64_t> consts;
+    std::vector<std::vector<uint64_t>> periodic;
+    std::vector<Node> nodes;
+    std::vector<Transition> trans;            // main first
+    uint32_t n_main_trans = 0;
+    std::vector<Assertion> masserts, aasserts;
+    std::vector<Builder> builders;
+    // ---- analysis
+    std::vector<uint8_t> is_ext, row_dep, uses_aux;
+    std::vector<int32_t> scalar_of;           // node -> index into scalB / scalE when folded, else -1
+    std::vector<uint32_t> fold_order;         // folded nodes in evaluation order
+    uint32_t n_scalB = 0, n_scalE = 0;        // scalB = consts | pubs | folded base nodes; scalE = rands | folded E nodes
+    struct DegGroup { uint32_t base; std::vector<uint32_t> cycles; };
+    std::vector<DegGroup> dgroups;
+    uint32_t ce_blowup = 2;
+    // ---- code
+    std::vector<Insn> cons_code, aux_code;
+    uint32_t cons_slotsB = 0, cons_slotsE = 0, aux_slotsB = 0, aux_slotsE = 0;
+    std::vector<uint8_t> has_den;             // per aux column
+
+    size_t num_transition() const { return trans.size(); }
+    size_t num_assertions() const { return masserts.size() + aasserts.size(); }
+    bool has_builders() const { return A > 0 && builders.size() == A; }
+};
+
+// operand reference -> device operand (kind, index); nodes that live in registers keep their node id as a virtual slot
+struct DOperand { uint32_t kind, idx; bool virt; };
+
+namespace detail {
+struct Reader {
+    const uint8_t* p; size_t len, off = 0;
+    void need(size_t k) const { if (off + k > len) fail("air program: truncated"); }
+    uint32_t u32() { need(4); uint32_t v; memcpy(&v, p + off, 4); off += 4; return v; }
+    uint64_t felt() { need(8); uint64_t v; memcpy(&v, p + off, 8); off += 8; if (v >= gl::P) fail("air program: non-canonical field element"); return v; }
+};
+}  // namespace detail
+
+inline DOperand device_operand(const Program& p, uint32_t ref) {
+    const uint32_t k = ref_kind(ref), i = ref_index(ref);
+    switch (k) {
+        case K_NODE:
+            if (p.scalar_of[i] >= 0) return DOperand{p.is_ext[i] ? D_SCAL_E : D_SCAL_B, (uint32_t)p.scalar_of[i], false};
+            return DOperand{p.is_ext[i] ? D_SLOT_E : D_SLOT_B, i, true};
+        case K_MAIN_CUR: return DOperand{D_MAIN_CUR, i, false};
+        case K_MAIN_NXT: return DOperand{D_MAIN_NXT, i, false};
+        case K_AUX_CUR: return DOperand{D_AUX_CUR, i, false};
+        case K_AUX_NXT: return DOperand{D_AUX_NXT, i, false};
+        case K_PERIODIC: return DOperand{D_PERIODIC, i, false};
+        case K_CONST: return DOperand{D_SCAL_B, i, false};
+        case K_PUB: return DOperand{D_SCAL_B, (uint32_t)p.consts.size() + i, false};
+        default: return DOperand{D_SCAL_E, i, false};
+    }
+}
+inline bool ref_is_ext(const Program& p, uint32_t ref) {
+    const uint32_t k = ref_kind(ref);
+    return k == K_AUX_CUR || k == K_AUX_NXT || k == K_RAND || (k == K_NODE && p.is_ext[ref_index(ref)]);
+}
+inline bool ref_row_dep(const Program& p, uint32_t ref) {
+    const uint32_t k = ref_kind(ref);
+    return (k >= K_MAIN_CUR && k <= K_PERIODIC) || (k == K_NODE && p.row_dep[ref_index(ref)]);
+}
+inline bool ref_uses_aux(const Program& p, uint32_t ref) {
+    const uint32_t k = ref_kind(ref);
+    return k == K_AUX_CUR || k == K_AUX_NXT || (k == K_NODE && p.uses_aux[ref_index(ref)]);
+}
+
+// Emit the code that makes `roots` available, then call `sink(i)` after root i; linear-scan register allocation over the result.
+struct CodeGen {
+    const Program& p;
+    std::vector<Insn> code;
+    std::vector<uint8_t> done;
+    explicit CodeGen(const Program& prog) : p(prog), done(prog.nodes.size(), 0) {}
+    void gen(uint32_t ref) {
+        if (ref_kind(ref) != K_NODE) return;
+        std::vector<std::pair<uint32_t, int>> st;     // (node, stage)
+        st.push_back({ref_index(ref), 0});
+        while (!st.empty()) {
+            auto [i, stage] = st.back();
+            st.pop_back();
+            if (done[i] || p.scalar_of[i] >= 0) continue;
+            const Node& nd = p.nodes[i];
+            if (stage == 0) {
+                st.push_back({i, 1});
+                for (uint32_t r : {nd.b, nd.a})
+                    if (ref_kind(r) == K_NODE && !done[ref_index(r)] && p.scalar_of[ref_index(r)] < 0) st.push_back({ref_index(r), 0});
+                continue;
+            }
+            DOperand a = device_operand(p, nd.a), b = device_operand(p, nd.b);
+            uint32_t op;
+            if (!p.is_ext[i]) op = nd.op == 1 ? OP_ADD_B : nd.op == 2 ? OP_SUB_B : OP_MUL_B;
+            else if (nd.op != 3) op = nd.op == 1 ? OP_ADD_E : OP_SUB_E;
+            else {
+                const bool ea = dkind_is_ext(a.kind), eb = dkind_is_ext(b.kind);
+                if (ea && eb) op = OP_MUL_E;
+                else { op = OP_MULB_E; if (!ea) std::swap(a, b); }
+            }
+            code.push_back(Insn{op | (a.kind << 8) | (b.kind << 12), i, a.idx, b.idx});
+            done[i] = 1;
+        }
+    }
+    void emit(uint32_t op, uint32_t dst, uint32_t ref) {
+        const DOperand a = device_operand(p, ref);
+        code.push_back(Insn{op | (a.kind << 8), dst, a.idx, 0});
+    }
+    static bool writes_slot(uint32_t op) { return op >= OP_ADD_B && op <= OP_MULB_E; }
+    // virtual registers (node ids) -> slots; returns the slot counts
+    void allocate(uint32_t* slotsB, uint32_t* slotsE) {
+        std::map<uint32_t, size_t> last;     // node -> index of its last reading instruction
+        auto reads = [&](const Insn& in, std::function<void(uint32_t)> f) {
+            const uint32_t op = in.op & 0xff, ka = (in.op >> 8) & 0xf, kb = (in.op >> 12) & 0xf;
+            if (op == OP_END || op == OP_GROUP_END) return;
+            if (ka == D_SLOT_B || ka == D_SLOT_E) f(in.a);
+            if (writes_slot(op) && (kb == D_SLOT_B || kb == D_SLOT_E)) f(in.b);
+        };
+        for (size_t i = 0; i < code.size(); i++) reads(code[i], [&](uint32_t n) { last[n] = i; });
+        std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> freeB, freeE;
+        uint32_t nB = 0, nE = 0;
+        std::map<uint32_t, uint32_t> slot;
+        for (size_t i = 0; i < code.size(); i++) {
+            Insn& in = code[i];
+            const uint32_t op = in.op & 0xff, ka = (in.op >> 8) & 0xf, kb = (in.op >> 12) & 0xf;
+            std::vector<uint32_t> dying;
+            const bool ra = op != OP_END && op != OP_GROUP_END && (ka == D_SLOT_B || ka == D_SLOT_E);
+            const bool rb = writes_slot(op) && (kb == D_SLOT_B || kb == D_SLOT_E);
+            const uint32_t na = in.a, nb = in.b;
+            if (ra) { in.a = slot.at(na); if (last[na] == i) dying.push_back(na); }
+            if (rb) { in.b = slot.at(nb); if (last[nb] == i && (!ra || nb != na)) dying.push_back(nb); }
+            for (uint32_t n : dying) { (p.is_ext[n] ? freeE : freeB).push(slot[n]); }
+            if (writes_slot(op)) {
+                const uint32_t n = in.dst;
+                auto& fl = p.is_ext[n] ? freeE : freeB;
+                uint32_t s;
+                if (!fl.empty()) { s = fl.top(); fl.pop(); } else s = p.is_ext[n] ? nE++ : nB++;
+                slot[n] = s;
+                in.dst = s;
+                if (!last.count(n)) (p.is_ext[n] ? freeE : freeB).push(s);   // never read (cannot happen for generated code)
+            }
+        }
+        *slotsB = nB; *slotsE = nE;
+    }
+};
+
+inline Program load(const uint8_t* bytes, size_t len) {
+    if (!bytes || len < 8 + 64) fail("air program: too short");
+    if (memcmp(bytes, "AEROAIR\x01", 8) != 0) fail("air program: not an AEROAIR version-1 program");
+    detail::Reader rd{bytes, len, 8};
+    uint32_t h[16];
+    for (auto& v : h) v = rd.u32();
+    Program p;
+    p.W = h[0]; p.A = h[1]; p.R = h[2]; p.num_pub = h[3]; p.exemptions = h[4];
+    const uint32_t nc = h[5], np = h[6], nn = h[7], nmt = h[8], nat = h[9], nma = h[10], naa = h[11], nb = h[12];
+    if (p.W < 1 || p.W > 255) fail("air program: main width must be in [1, 255]");
+    if (p.A > 255 - p.W) fail("air program: main + aux width must not exceed 255");
+    if ((p.A == 0) != (p.R == 0) || p.R > 255) fail("air program: an auxiliary segment needs 1..255 random elements (and none without one)");
+    if (p.num_pub > 4096) fail("air program: at most 4096 public inputs");
+    if (p.exemptions < 1 || p.exemptions > 64) fail("air program: 1..64 transition exemptions");
+    if (h[13] || h[14] || h[15]) fail("air program: reserved header words must be zero");
+    if (nb != 0 && nb != p.A) fail("air program: one aux builder per auxiliary column, or none");
+    if (nn > (1u << 22) || nc > (1u << 22) || np > 4096 || (uint64_t)nmt + nat > (1u << 20) || (uint64_t)nma + naa > (1u << 20)) fail("air program: section too large", ST_UNSUPPORTED);
+    if (nmt + nat == 0) fail("air program: no transition constraints");
+    if (nat && !p.A) fail("air program: auxiliary constraints without an auxiliary segment");
+    if (naa && !p.A) fail("air program: auxiliary assertions without an auxiliary segment");
+    p.consts.resize(nc);
+    for (auto& v : p.consts) v = rd.felt();
+    for (uint32_t i = 0; i < np; i++) {
+        const uint32_t cl = rd.u32();
+        if (cl < 2 || (cl & (cl - 1)) || cl > (1u << 24)) fail("air program: a periodic column's cycle length must be a power of two >= 2");
+        std::vector<uint64_t> v(cl);
+        for (auto& x : v) x = rd.felt();
+        p.periodic.push_back(std::move(v));
+    }
+    auto check_ref = [&](uint32_t ref, uint32_t node_limit, const char* what) {
+        const uint32_t k = ref_kind(ref), i = ref_index(ref);
+        const uint32_t lim[K_COUNT] = {node_limit, p.W, p.W, p.A, p.A, np, nc, p.num_pub, p.R};
+        if (k >= K_COUNT || i >= lim[k]) fail(std::string("air program: operand out of range in ") + what);
+    };
+    p.nodes.resize(nn);
+    p.is_ext.assign(nn, 0); p.row_dep.assign(nn, 0); p.uses_aux.assign(nn, 0); p.scalar_of.assign(nn, -1);
+    p.n_scalB = nc + p.num_pub; p.n_scalE = p.R;
+    for (uint32_t i = 0; i < nn; i++) {
+        Node nd{rd.u32(), rd.u32(), rd.u32()};
+        if (nd.op < 1 || nd.op > 3) fail("air program: unknown node opcode");
+        check_ref(nd.a, i, "a node"); check_ref(nd.b, i, "a node");
+        p.nodes[i] = nd;
+        p.is_ext[i] = ref_is_ext(p, nd.a) || ref_is_ext(p, nd.b);
+        p.row_dep[i] = ref_row_dep(p, nd.a) || ref_row_dep(p, nd.b);
+        p.uses_aux[i] = ref_uses_aux(p, nd.a) || ref_uses_aux(p, nd.b);
+        if (!p.row_dep[i]) { p.scalar_of[i] = (int32_t)(p.is_ext[i] ? p.n_scalE++ : p.n_scalB++); p.fold_order.push_back(i); }
+    }
+    p.n_main_trans = nmt;
+    std::map<std::pair<uint32_t, std::vector<uint32_t>>, uint32_t> gkey;
+    for (uint32_t i = 0; i < nmt + nat; i++) {
+        Transition t;
+        t.root = rd.u32(); t.base = rd.u32();
+        const uint32_t ncy = rd.u32();
+        if (t.base < 1 || t.base > 255) fail("air program: a constraint's degree must be in [1, 255]");
+        if (ncy > 32) fail("air program: more than 32 cycles in a constraint degree");
+        for (uint32_t j = 0; j < ncy; j++) {
+            const uint32_t c = rd.u32();
+            if (c < 2 || (c & (c - 1))) fail("air program: cycle lengths must be powers of two >= 2");
+            t.cycles.push_back(c);
+        }
+        check_ref(t.root, nn, "a transition constraint");
+        if (i < nmt && ref_is_ext(p, t.root)) fail("air program: a main transition constraint may not depend on the auxiliary segment or the random elements");
+        std::vector<uint32_t> sc = t.cycles;
+        std::sort(sc.begin(), sc.end());
+        auto key = std::make_pair(t.base, sc);
+        auto it = gkey.find(key);
+        if (it == gkey.end()) { it = gkey.insert({key, (uint32_t)p.dgroups.size()}).first; p.dgroups.push_back(Program::DegGroup{t.base, sc}); }
+        t.group = it->second;
+        size_t d = t.base + ncy, e = 2;
+        while (e < d) e <<= 1;
+        if (e > p.ce_blowup) p.ce_blowup = (uint32_t)e;
+        p.trans.push_back(std::move(t));
+    }
+    if (p.ce_blowup > 128) fail("air program: constraint-evaluation blowup above 128", ST_UNSUPPORTED);
+    for (uint32_t i = 0; i < nma + naa; i++) {
+        Assertion s;
+        s.col = rd.u32(); s.first = (int32_t)rd.u32(); s.stride = rd.u32(); s.value = rd.u32();
+        const bool aux = i >= nma;
+        check_ref(s.value, nn, "an assertion");
+        if (s.col >= (aux ? p.A : p.W)) fail("air program: assertion column out of range");
+        if (ref_row_dep(p, s.value)) fail("air program: an assertion's value must not depend on the trace or a periodic column");
+        if (!aux && ref_is_ext(p, s.value)) fail("air program: a main assertion's value must be a base-field quantity (constant or public input)");
+        if (s.stride && (s.stride < 2 || (s.stride & (s.stride - 1)))) fail("air program: an assertion's stride must be 0 or a power of two >= 2");
+        (aux ? p.aasserts : p.masserts).push_back(s);
+    }
+    for (uint32_t i = 0; i < nb; i++) {
+        Builder b{rd.u32(), rd.u32(), rd.u32()};
+        check_ref(b.init, nn, "an aux builder"); check_ref(b.num, nn, "an aux builder");
+        if (b.den != REF_NONE) check_ref(b.den, nn, "an aux builder");
+        if (ref_row_dep(p, b.init)) fail("air program: an aux builder's initial value must not depend on the trace");
+        if (ref_uses_aux(p, b.num) || (b.den != REF_NONE && ref_uses_aux(p, b.den))) fail("air program: an aux builder's factors may only read the main segment");
+        p.builders.push_back(b);
+    }
+    if (rd.off != len) fail("air program: trailing bytes");
+
+    // ---- constraint code: degree group by degree group
+    {
+        CodeGen cg(p);
+        for (uint32_t g = 0; g < p.dgroups.size(); g++) {
+            for (uint32_t k = 0; k < p.trans.size(); k++) {
+                if (p.trans[k].group != g) continue;
+                cg.gen(p.trans[k].root);
+                cg.emit(ref_is_ext(p, p.trans[k].root) ? OP_EMIT_E : OP_EMIT_B, k, p.trans[k].root);
+            }
+            cg.code.push_back(Insn{OP_GROUP_END, g, 0, 0});
+        }
+        cg.code.push_back(Insn{OP_END, 0, 0, 0});
+        cg.allocate(&p.cons_slotsB, &p.cons_slotsE);
+        p.cons_code = std::move(cg.code);
+    }
+    // ---- aux builder code: output column 2c = numerator factor, 2c + 1 = denominator factor of aux column c
+    if (p.has_builders()) {
+        CodeGen cg(p);
+        p.has_den.assign(p.A, 0);
+        for (uint32_t c = 0; c < p.A; c++) {
+            cg.gen(p.builders[c].num);
+            cg.emit(ref_is_ext(p, p.builders[c].num) ? OP_OUT_E : OP_OUT_B, 2 * c, p.builders[c].num);
+            if (p.builders[c].den != REF_NONE) {
+                p.has_den[c] = 1;
+                cg.gen(p.builders[c].den);
+                cg.emit(ref_is_ext(p, p.builders[c].den) ? OP_OUT_E : OP_OUT_B, 2 * c + 1, p.builders[c].den);
+            }
+        }
+        cg.code.push_back(Insn{OP_END, 0, 0, 0});
+        cg.allocate(&p.aux_slotsB, &p.aux_slotsE);
+        p.aux_code = std::move(cg.code);
+    }
+    if (p.cons_slotsB + 2 * p.cons_slotsE > 1024 || p.aux_slotsB + 2 * p.aux_slotsE > 1024)
+        fail("air program: more than 1024 live values at one point (the per-lane register file of the interpreter)", ST_UNSUPPORTED);
+    return p;
+}
+
+// ---- instance: what depends on the trace length -------------------------------------------------------------------------------
+struct BoundaryMember { uint32_t col, aux, coef, val_ext, val_idx; };   // value = scalB[val_idx] or scalE[val_idx]
+struct BoundaryGroup { uint32_t stride; uint64_t first, a, b, adj; uint32_t m0, count; };
+struct Instance {
+    int log_n = 0;
+    uint64_t n = 0, ce_n = 0;
+    std::vector<uint64_t> dgroup_adj;          // per degree group
+    std::vector<BoundaryGroup> bgroups;        // numerator column 1 + j
+    std::vector<BoundaryMember> members;       // group j = members[m0 .. m0 + count)
+    size_t num_columns() const { return 1 + bgroups.size(); }
+};
+inline Instance instantiate(const Program& p, int log_n) {
+    Instance in;
+    if (log_n < 3 || log_n > 29) fail("air program: trace length must be between 2^3 and 2^29");
+    in.log_n = log_n; in.n = 1ull << log_n; in.ce_n = in.n * p.ce_blowup;
+    const uint64_t n = in.n;
+    if (p.exemptions >= n) fail("air program: more transition exemptions than trace steps");
+    for (auto& v : p.periodic) if (v.size() > n) fail("air program: a periodic column's cycle is longer than the trace");
+    const uint64_t target = in.ce_n - 1 + (n - p.exemptions);
+    for (auto& g : p.dgroups) {
+        uint64_t ed = (uint64_t)g.base * (n - 1);
+        for (uint32_t c : g.cycles) { if (c > n) fail("air program: a degree cycle is longer than the trace"); ed += (n / c) * (c - 1); }
+        if (ed > target) fail("air program: a constraint's evaluation degree exceeds the composition degree");
+        in.dgroup_adj.push_back(target - ed);
+    }
+    const uint64_t g = gl::root_of_unity(log_n);
+    uint32_t coef = 0;
+    std::vector<std::vector<BoundaryMember>> gm;
+    for (int seg = 0; seg < 2; seg++) {
+        std::vector<Assertion> v = seg == 0 ? p.masserts : p.aasserts;
+        for (auto& s : v) {
+            if (s.first < 0) s.first += (int64_t)n;
+            if (s.first < 0 || (uint64_t)s.first >= n) fail("air program: assertion step outside the trace");
+            if (s.stride && (s.stride >= n || (uint64_t)s.first >= s.stride)) fail("air program: a periodic assertion needs first_step < stride < trace length");
+        }
+        std::stable_sort(v.begin(), v.end(), [](const Assertion& x, const Assertion& y) {
+            return std::make_tuple(x.stride, x.first, x.col) < std::make_tuple(y.stride, y.first, y.col);
+        });
+        for (size_t i = 1; i < v.size(); i++)
+            if (v[i].col == v[i - 1].col && v[i].stride == v[i - 1].stride && v[i].first == v[i - 1].first) fail("air program: two assertions on the same column and step");
+        for (auto& s : v) {
+            size_t j = 0;
+            for (; j < in.bgroups.size(); j++) if (in.bgroups[j].stride == s.stride && in.bgroups[j].first == (uint64_t)s.first) break;
+            if (j == in.bgroups.size()) {
+                BoundaryGroup bg{};
+                bg.stride = s.stride; bg.first = (uint64_t)s.first;
+                bg.a = s.stride ? n / s.stride : 1;
+                bg.b = gl::pow(g, bg.first * bg.a);
+                bg.adj = (in.ce_n - 1 + bg.a) - (n - 1);
+                in.bgroups.push_back(bg);
+                gm.emplace_back();
+            }
+            const DOperand val = device_operand(p, s.value);     // row-independent: a scalar
+            gm[j].push_back(BoundaryMember{s.col, (uint32_t)seg, coef++, val.kind == D_SCAL_E ? 1u : 0u, val.idx});
+        }
+    }
+    for (size_t j = 0; j < gm.size(); j++) {
+        in.bgroups[j].m0 = (uint32_t)in.members.size();
+        in.bgroups[j].count = (uint32_t)gm[j].size();
+        in.members.insert(in.members.end(), gm[j].begin(), gm[j].end());
+    }
+    return in;
+}
+
+// ---- per proof: the scalar operands (constants, public inputs, random elements, folded nodes) --------------------------------
+template <class F> struct Scalars {
+    std::vector<uint64_t> b;
+    std::vector<typename F::T> e;
+};
+template <class F> Scalars<F> fold_scalars(const Program& p, const uint64_t* pub, const typename F::T* rands) {
+    typedef typename F::T T;
+    Scalars<F> s;
+    s.b.assign(p.n_scalB, 0); s.e.assign(p.n_scalE, F::zero());
+    for (size_t i = 0; i < p.consts.size(); i++) s.b[i] = p.consts[i];
+    for (uint32_t i = 0; i < p.num_pub; i++) s.b[p.consts.size() + i] = pub[i];
+    for (uint32_t i = 0; i < p.R; i++) s.e[i] = rands ? rands[i] : F::zero();
+    auto val_b = [&](uint32_t ref) { return s.b[device_operand(p, ref).idx]; };
+    auto val_e = [&](uint32_t ref) { const DOperand o = device_operand(p, ref); return o.kind == D_SCAL_E ? s.e[o.idx] : F::from(s.b[o.idx]); };
+    for (uint32_t i : p.fold_order) {
+        const Node& nd = p.nodes[i];
+        if (!p.is_ext[i]) {
+            const uint64_t a = val_b(nd.a), b = val_b(nd.b);
+            s.b[p.scalar_of[i]] = nd.op == 1 ? gl::add(a, b) : nd.op == 2 ? gl::sub(a, b) : gl::mul(a, b);
+        } else {
+            const T a = val_e(nd.a), b = val_e(nd.b);
+            s.e[p.scalar_of[i]] = nd.op == 1 ? F::add(a, b) : nd.op == 2 ? F::sub(a, b) : F::mul(a, b);
+        }
+    }
+    return s;
+}
+
+// ---- host transforms for the periodic columns -----------------------------------------------------------------------------------
+inline void host_ntt(std::vector<uint64_t>& a, bool inverse) {     // natural order in and out, size a power of two
+    const size_t n = a.size();
+    int lg = 0;
+    while (((size_t)1 << lg) < n) lg++;
+    for (size_t i = 0; i < n; i++) { const size_t j = gl::bitrev((uint32_t)i, lg); if (i < j) std::swap(a[i], a[j]); }
+    for (int s = 1; s <= lg; s++) {
+        const size_t m = (size_t)1 << s;
+        uint64_t wm = gl::root_of_unity(s);
+        if (inverse) wm = gl::inv(wm);
+        for (size_t k = 0; k < n; k += m) {
+            uint64_t w = 1;
+            for (size_t j = 0; j < m / 2; j++) {
+                const uint64_t t = gl::mul(w, a[k + j + m / 2]), u = a[k + j];
+                a[k + j] = gl::add(u, t); a[k + j + m / 2] = gl::sub(u, t);
+                w = gl::mul(w, wm);
+            }
+        }
+    }
+    if (inverse) { const uint64_t ni = gl::inv(n); for (auto& v : a) v = gl::mul(v, ni); }
+}
+// Values of periodic column k on a domain of `rows` points x_s = h w_rows^s (rows a multiple of n): the column's value at x is
+// P_k(x^(n/c)), P_k = interpolant of one cycle; x_s^(n/c) = h^(n/c) * (root of order rows c / n)^s, so the table has
+// rows * c / n entries and is indexed by s mod that. (rows = n, h = 1: the cycle itself.)
+inline std::vector<uint64_t> periodic_table(const std::vector<uint64_t>& cycle, uint64_t n, uint64_t rows, uint64_t h) {
+    const uint64_t c = cycle.size(), period = rows / n * c;
+    std::vector<uint64_t> co = cycle;
+    host_ntt(co, true);
+    const uint64_t hs = gl::pow(h, n / c);
+    std::vector<uint64_t> t(period, 0);
+    uint64_t sc = 1;
+    for (uint64_t i = 0; i < c; i++) { t[i] = gl::mul(co[i], sc); sc = gl::mul(sc, hs); }
+    host_ntt(t, false);
+    return t;
+}
+
+// ---- host execution of the compiled constraint program over E (the verifier's out-of-domain check) ------------------------------
+// Frame, periodic values and x are E-valued; `xpow(e)` returns x^e. Returns the numerator of every column.
+template <class F>
+std::vector<typename F::T> host_evaluate(const Program& p, const Instance& in, const Scalars<F>& sc, const typename F::T* cur, const typename F::T* nxt,
+                                         const std::vector<typename F::T>& per, const std::vector<typename F::T>& ta, const std::vector<typename F::T>& tb,
+                                         const std::vector<typename F::T>& ba, const std::vector<typename F::T>& bb,
+                                         const std::function<typename F::T(uint64_t)>& xpow) {
+    typedef typename F::T T;
+    std::vector<T> slotB(p.cons_slotsB, F::zero()), slotE(p.cons_slotsE, F::zero());
+    auto fetch = [&](uint32_t kind, uint32_t idx) -> T {
+        switch (kind) {
+            case D_SLOT_B: return slotB[idx];
+            case D_SLOT_E: return slotE[idx];
+            case D_MAIN_CUR: return cur[idx];
+            case D_MAIN_NXT: return nxt[idx];
+            case D_AUX_CUR: return cur[p.W + idx];
+            case D_AUX_NXT: return nxt[p.W + idx];
+            case D_PERIODIC: return per[idx];
+            case D_SCAL_B: return F::from(sc.b[idx]);
+            default: return sc.e[idx];
+        }
+    };
+    std::vector<T> out(in.num_columns(), F::zero());
+    T acc_a = F::zero(), acc_b = F::zero(), total = F::zero();
+    for (const Insn& I : p.cons_code) {
+        const uint32_t op = I.op & 0xff, ka = (I.op >> 8) & 0xf, kb = (I.op >> 12) & 0xf;
+        if (op == OP_END) break;
+        switch (op) {
+            case OP_ADD_B: slotB[I.dst] = F::add(fetch(ka, I.a), fetch(kb, I.b)); break;
+            case OP_SUB_B: slotB[I.dst] = F::sub(fetch(ka, I.a), fetch(kb, I.b)); break;
+            case OP_MUL_B: slotB[I.dst] = F::mul(fetch(ka, I.a), fetch(kb, I.b)); break;
+            case OP_ADD_E: slotE[I.dst] = F::add(fetch(ka, I.a), fetch(kb, I.b)); break;
+            case OP_SUB_E: slotE[I.dst] = F::sub(fetch(ka, I.a), fetch(kb, I.b)); break;
+            case OP_MUL_E: case OP_MULB_E: slotE[I.dst] = F::mul(fetch(ka, I.a), fetch(kb, I.b)); break;
+            case OP_EMIT_B: case OP_EMIT_E: {
+                const T v = fetch(ka, I.a);
+                acc_a = F::add(acc_a, F::mul(ta[I.dst], v));
+                acc_b = F::add(acc_b, F::mul(tb[I.dst], v));
+                break;
+            }
+            case OP_GROUP_END: total = F::add(total, F::mul(acc_b, xpow(in.dgroup_adj[I.dst]))); acc_b = F::zero(); break;
+            default: fail("air program: corrupt constraint code", ST_INTERNAL);
+        }
+    }
+    out[0] = F::add(total, acc_a);
+    for (size_t j = 0; j < in.bgroups.size(); j++) {
+        const BoundaryGroup& g = in.bgroups[j];
+        T sa = F::zero(), sb = F::zero();
+        for (uint32_t m = g.m0; m < g.m0 + g.count; m++) {
+            const BoundaryMember& bm = in.members[m];
+            const T val = bm.val_ext ? sc.e[bm.val_idx] : F::from(sc.b[bm.val_idx]);
+            const T d = F::sub(cur[bm.aux ? p.W + bm.col : bm.col], val);
+            sa = F::add(sa, F::mul(ba[bm.coef], d));
+            sb = F::add(sb, F::mul(bb[bm.coef], d));
+        }
+        out[1 + j] = F::add(sa, F::mul(sb, xpow(g.adj)));
+    }
+    return out;
+}
+
+// ---- built-in AIRs as programs ------------------------------------------------------------------------------------------------
+struct Writer {
+    std::vector<uint8_t> out;
+    void u32(uint32_t v) { for (int i = 0; i < 4; i++) out.push_back((uint8_t)(v >> (8 * i))); }
+    void u64(uint64_t v) { for (int i = 0; i < 8; i++) out.push_back((uint8_t)(v >> (8 * i))); }
+};
+// Minimal expression builder used by the emitters below (hash-consing of nodes and constants)
+struct Emitter {
+    uint32_t W, A, R, num_pub, exemptions;
+    std::vector<uint64_t> consts;
+    std::map<uint64_t, uint32_t> const_idx;
+    std::vector<std::vector<uint64_t>> periodic;
+    std::vector<Node> nodes;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> node_idx;
+    struct T { uint32_t root, base; std::vector<uint32_t> cycles; };
+    std::vector<T> mtrans, atrans;
+    std::vector<Assertion> masserts, aasserts;
+    std::vector<Builder> builders;
+    uint32_t cst(uint64_t v) {
+        v %= gl::P;
+        auto it = const_idx.find(v);
+        if (it == const_idx.end()) { it = const_idx.insert({v, (uint32_t)consts.size()}).first; consts.push_back(v); }
+        return mk_ref(K_CONST, it->second);
+    }
+    uint32_t node(uint32_t op, uint32_t a, uint32_t b) {
+        if (op != 2 && b < a) std::swap(a, b);
+        auto key = std::make_tuple(op, a, b);
+        auto it = node_idx.find(key);
+        if (it == node_idx.end()) { it = node_idx.insert({key, (uint32_t)nodes.size()}).first; nodes.push_back(Node{op, a, b}); }
+        return mk_ref(K_NODE, it->second);
+    }
+    uint32_t add(uint32_t a, uint32_t b) { return node(1, a, b); }
+    uint32_t sub(uint32_t a, uint32_t b) { return node(2, a, b); }
+    uint32_t mul(uint32_t a, uint32_t b) { return node(3, a, b); }
+    uint32_t pow(uint32_t a, uint32_t e) {
+        uint32_t r = REF_NONE, base = a;
+        while (e) {
+            if (e & 1) r = r == REF_NONE ? base : mul(r, base);
+            e >>= 1;
+            if (e) base = mul(base, base);
+        }
+        return r;
+    }
+    uint32_t per(const std::vector<uint64_t>& cycle) { periodic.push_back(cycle); return mk_ref(K_PERIODIC, (uint32_t)periodic.size() - 1); }
+    std::vector<uint8_t> bytes() const {
+        Writer w;
+        for (char ch : std::string("AEROAIR")) w.out.push_back((uint8_t)ch);
+        w.out.push_back(1);
+        const uint32_t h[16] = {W, A, R, num_pub, exemptions, (uint32_t)consts.size(), (uint32_t)periodic.size(), (uint32_t)nodes.size(),
+                                (uint32_t)mtrans.size(), (uint32_t)atrans.size(), (uint32_t)masserts.size(), (uint32_t)aasserts.size(),
+                                (uint32_t)builders.size(), 0, 0, 0};
+        for (uint32_t v : h) w.u32(v);
+        for (uint64_t v : consts) w.u64(v);
+        for (auto& c : periodic) { w.u32((uint32_t)c.size()); for (uint64_t v : c) w.u64(v); }
+        for (auto& n : nodes) { w.u32(n.op); w.u32(n.a); w.u32(n.b); }
+        for (auto* v : {&mtrans, &atrans}) for (auto& t : *v) { w.u32(t.root); w.u32(t.base); w.u32((uint32_t)t.cycles.size()); for (uint32_t c : t.cycles) w.u32(c); }
+        for (auto* v : {&masserts, &aasserts}) for (auto& s : *v) { w.u32(s.col); w.u32((uint32_t)(int32_t)s.first); w.u32(s.stride); w.u32(s.value); }
+        for (auto& b : builders) { w.u32(b.init); w.u32(b.num); w.u32(b.den); }
+        return w.out;
+    }
+};
+// FibAir(width) [+ auxiliary segment]: the constraint set prover.hpp's FibAir hard-wires
+inline std::vector<uint8_t> fib_program(uint32_t width, uint32_t aux_width, uint32_t aux_rands, uint32_t aux_degree) {
+    if (width < 2 || (width & 1) || width > 254) fail("fib_program: even width in [2, 254]");
+    if (aux_width && (aux_degree < 2 || aux_degree > 8 || aux_rands < 1 || aux_rands > 255 || aux_width > 255 - width)) fail("fib_program: bad auxiliary segment");
+    Emitter e{};
+    e.W = width; e.A = aux_width; e.R = aux_width ? aux_rands : 0; e.num_pub = width / 2; e.exemptions = 1;
+    for (uint32_t k = 0; k < width / 2; k++) {
+        const uint32_t a = mk_ref(K_MAIN_CUR, 2 * k), b = mk_ref(K_MAIN_CUR, 2 * k + 1), na = mk_ref(K_MAIN_NXT, 2 * k), nb = mk_ref(K_MAIN_NXT, 2 * k + 1);
+        e.mtrans.push_back({e.sub(na, e.add(a, b)), 1, {}});
+        e.mtrans.push_back({e.sub(nb, e.add(b, na)), 1, {}});
+    }
+    for (uint32_t c = 0; c < width; c++) e.masserts.push_back(Assertion{c, 0, 0, e.cst(1 + c)});
+    for (uint32_t k = 0; k < width / 2; k++) e.masserts.push_back(Assertion{2 * k + 1, -1, 0, mk_ref(K_PUB, k)});
+    for (uint32_t c = 0; c < aux_width; c++) {
+        const uint32_t f = e.pow(e.add(mk_ref(K_RAND, c % aux_rands), mk_ref(K_MAIN_CUR, c % width)), aux_degree - 1);
+        e.atrans.push_back({e.sub(mk_ref(K_AUX_NXT, c), e.mul(mk_ref(K_AUX_CUR, c), f)), aux_degree, {}});
+        e.aasserts.push_back(Assertion{c, 0, 0, e.cst(1)});
+        e.builders.push_back(Builder{e.cst(1), f, REF_NONE});
+    }
+    return e.bytes();
+}
+
+}  // namespace air
+}  // namespace aero
+
+// the opaque handle of include/aero_air.h
+struct aero_air {
+    aero::air::Program prog;
+    std::vector<uint8_t> bytes;
+};

@@ -7,64 +7,14 @@
 #include <mutex>
 #include <thread>
 
-#include "../../include/aero_stark.h"
-#include "prover.hpp"
+#include "capi_internal.hpp"
 #include "proof_format.hpp"
 #include "stark_kernels.hpp"
 #include "worker_messages.hpp"
 
-using namespace aero;
-
-struct aero_ctx {
-    std::shared_ptr<Context> keep;   // device objects created from this context share ownership, so destroying the
-    Context* c = nullptr;            // context handle before its matrices / trees is safe
-    std::string err;
-    StageMs last_ms;
-    bool stage_timing = false;
-};
-struct aero_matrix {
-    std::shared_ptr<Context> keep;   // declared first: destroyed after `m`, whose buffers return to the context pool
-    Matrix m;
-    explicit aero_matrix(aero_ctx* ctx) : keep(ctx->keep) {}
-};
-struct aero_tree {
-    std::shared_ptr<Context> keep;
-    MerkleTree t;
-    explicit aero_tree(aero_ctx* ctx) : keep(ctx->keep) {}
-};
-
-struct aero_fri {
-    std::shared_ptr<Context> keep;
-    FriLayers fl;
-    ProofOptions opt{};
-    explicit aero_fri(aero_ctx* ctx) : keep(ctx->keep) {}
-};
-
-static thread_local std::string g_create_err;
+thread_local std::string g_create_err;
 
 namespace aero { Context* ctx_of(aero_ctx* c) { return c ? c->c : nullptr; } }   // for comm_rccl.hip
-
-template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
-    try {
-        if (!ctx || !ctx->c) { g_create_err = "null context"; return AERO_E_BAD_ARG; }
-        AERO_HIP(hipSetDevice(ctx->c->device));
-        fn();
-        return AERO_OK;
-    } catch (const Error& e) {
-        (void)hipGetLastError();   // leave no stale HIP error behind for the next call's launch checks
-        if (ctx) { ctx->err = e.what(); if (ctx->c) ctx->c->scratch_reset(); }
-        return e.code;
-    } catch (const std::bad_alloc&) {
-        if (ctx) ctx->err = "host allocation failed";
-        return AERO_E_OOM;
-    } catch (const std::exception& e) {
-        if (ctx) ctx->err = e.what();
-        return AERO_E_INTERNAL;
-    }
-}
-#define REQUIRE(cond, msg) do { if (!(cond)) fail(msg); } while (0)
-
-static int ilog2u(uint64_t x) { int r = 0; while ((1ull << r) < x) r++; return r; }
 
 extern "C" {
 
@@ -975,68 +925,6 @@ int32_t aero_worker_hash_rows(aero_ctx* ctx, const uint8_t* work_item, size_t wo
             c->sync();
         }
         const std::vector<uint8_t> msg = wm::emit_hashing_result(batch_idx, digests.data(), k);
-        uint8_t* buf = (uint8_t*)malloc(msg.size() ? msg.size() : 1);
-        if (!buf) throw std::bad_alloc();
-        memcpy(buf, msg.data(), msg.size());
-        *result = buf; *result_len = msg.size();
-    });
-}
-// constraints_worker.rs:14-79 for the built-in FibAir: the work item's trace LDE (main columns + one auxiliary segment), composition
-// coefficients, auxiliary random elements and fragment -> the fragment's merged numerator columns. The message carries Miden's
-// PublicInputs; the built-in AIR takes its width/2 asserted results from `outputs.stack`. `air` names the auxiliary segment's
-// constraint degree (the message has no AIR identity: the reference's worker hard-wires ProcessorAir) and must agree with the
-// layout in the message; NULL when the layout has no auxiliary columns.
-int32_t aero_worker_eval_constraints(aero_ctx* ctx, const uint8_t* work_item, size_t work_item_len, const aero_fib_air* air, uint8_t** result,
-                                     size_t* result_len) {
-    return guard(ctx, [&] {
-        REQUIRE(work_item && result && result_len, "worker_eval_constraints: null argument");
-        *result = nullptr; *result_len = 0;
-        const wm::ConstraintWorkItem w = wm::parse_constraint_work_item(work_item, work_item_len);
-        const uint32_t W = w.main_width, A = w.aux_width;
-        REQUIRE(W >= 2 && !(W & 1) && w.main_cols.size() == W, "worker_eval_constraints: the main segment does not have the width the layout names (even, >= 2)");
-        REQUIRE(w.trace_len >= 8 && (w.trace_len & (w.trace_len - 1)) == 0 && w.trace_len <= ((uint64_t)1 << 29), "worker_eval_constraints: trace length must be a power of two in [8, 2^29]");
-        REQUIRE(w.blowup >= 2 && w.blowup <= 128 && (w.blowup & (w.blowup - 1)) == 0 && w.blowup == w.options[1], "worker_eval_constraints: blowup of the LDE and of the proof options disagree");
-        if (w.options[4] != EXT_NONE) fail("worker_eval_constraints: the message carries base-field coefficients (field extension must be None)", ST_UNSUPPORTED);
-        const size_t N = (size_t)w.trace_len * w.blowup;
-        for (const auto& col : w.main_cols) REQUIRE(col.n == N, "worker_eval_constraints: an LDE column is not trace_length * blowup long");
-        aero_fib_air shape{};
-        if (A) {
-            REQUIRE(air && air->aux_width == A && air->aux_rands == w.aux_rands, "worker_eval_constraints: the air descriptor does not match the auxiliary layout of the message");
-            REQUIRE(w.aux_segments.size() == 1 && w.aux_segments[0].size() == A, "worker_eval_constraints: expected one auxiliary segment of the layout's width");
-            REQUIRE(w.aux_rand_elements.size() == 1 && w.aux_rand_elements[0].size() == w.aux_rands, "worker_eval_constraints: auxiliary random elements do not match the layout");
-            for (const auto& col : w.aux_segments[0]) REQUIRE(col.n == N, "worker_eval_constraints: an auxiliary LDE column is not trace_length * blowup long");
-            shape = *air;
-        } else {
-            for (const auto& seg : w.aux_segments) REQUIRE(seg.empty(), "worker_eval_constraints: auxiliary columns without an auxiliary layout");
-        }
-        REQUIRE(w.n_transition == (size_t)W + A && w.n_boundary == (size_t)W + W / 2 + A, "worker_eval_constraints: coefficient counts do not match the AIR (width transition constraints, width + width/2 assertions, one of each per auxiliary column)");
-        const fmt::MidenInputs pub = fmt::parse_miden_inputs(w.public_inputs.data(), w.public_inputs.size());
-        REQUIRE(pub.out_stack.size() == W / 2, "worker_eval_constraints: outputs.stack must hold the width/2 asserted results");
-        for (uint64_t v : pub.out_stack) REQUIRE(v < gl::P, "worker_eval_constraints: non-canonical asserted result");
-        REQUIRE(w.num_fragments >= 1 && w.num_fragments <= ((uint64_t)1 << 30) && w.fragment_offset < w.num_fragments, "worker_eval_constraints: bad fragment");
-        Context* c = ctx->c;
-        Matrix lde(c, (int)W, N), aux;
-        // the columns go to the device straight from the message; Felt::new's reduction of raw values happens there
-        for (uint32_t col = 0; col < W; col++)
-            AERO_HIP(hipMemcpyAsync(lde.data.get() + (size_t)col * N, w.main_cols[col].data, N * 8, hipMemcpyHostToDevice, c->stream));
-        reduce_canonical(c, lde.data.get(), (size_t)W * N);
-        if (A) {
-            aux = Matrix(c, (int)A, N);
-            for (uint32_t col = 0; col < A; col++)
-                AERO_HIP(hipMemcpyAsync(aux.data.get() + (size_t)col * N, w.aux_segments[0][col].data, N * 8, hipMemcpyHostToDevice, c->stream));
-            reduce_canonical(c, aux.data.get(), (size_t)A * N);
-        }
-        FibAir fa;
-        fa.width = W; fa.aux_width = A; fa.aux_rands = A ? shape.aux_rands : 0; fa.aux_degree = A ? shape.aux_degree : 2;
-        const size_t ceN = fa.ce_blowup_factor() * (size_t)w.trace_len;
-        REQUIRE(ceN % w.num_fragments == 0, "worker_eval_constraints: the fragments do not divide the constraint domain");
-        const size_t rows = ceN / (size_t)w.num_fragments;
-        std::vector<uint64_t> cols(3 * rows);
-        uint64_t first = 0;
-        eval_constraints_air<gl::FB>(c, lde, A ? &aux : nullptr, A ? &shape : nullptr, (uint32_t)ilog2u(w.blowup), pub.out_stack.data(),
-                                     A ? w.aux_rand_elements[0].data() : nullptr, w.coeffs.data(), (uint32_t)w.fragment_offset, (uint32_t)w.num_fragments,
-                                     cols.data(), &first);
-        const std::vector<uint8_t> msg = wm::emit_constraint_result(first, w.num_fragments, cols.data(), 3, rows);
         uint8_t* buf = (uint8_t*)malloc(msg.size() ? msg.size() : 1);
         if (!buf) throw std::bad_alloc();
         memcpy(buf, msg.data(), msg.size());

@@ -1,0 +1,64 @@
+// Handle types and the exception guard shared by the C-ABI translation units (capi.hip, capi_air.hip).
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "../../include/aero_stark.h"
+#include "prover.hpp"
+
+using namespace aero;
+
+struct aero_ctx {
+    std::shared_ptr<Context> keep;   // device objects created from this context share ownership, so destroying the
+    Context* c = nullptr;            // context handle before its matrices / trees is safe
+    std::string err;
+    StageMs last_ms;
+    bool stage_timing = false;
+};
+struct aero_matrix {
+    std::shared_ptr<Context> keep;   // declared first: destroyed after `m`, whose buffers return to the context pool
+    Matrix m;
+    explicit aero_matrix(aero_ctx* ctx) : keep(ctx->keep) {}
+};
+struct aero_tree {
+    std::shared_ptr<Context> keep;
+    MerkleTree t;
+    explicit aero_tree(aero_ctx* ctx) : keep(ctx->keep) {}
+};
+
+struct aero_fri {
+    std::shared_ptr<Context> keep;
+    FriLayers fl;
+    ProofOptions opt{};
+    explicit aero_fri(aero_ctx* ctx) : keep(ctx->keep) {}
+};
+
+extern thread_local std::string g_create_err;
+
+
+template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
+    try {
+        if (!ctx || !ctx->c) { g_create_err = "null context"; return AERO_E_BAD_ARG; }
+        AERO_HIP(hipSetDevice(ctx->c->device));
+        fn();
+        return AERO_OK;
+    } catch (const Error& e) {
+        (void)hipGetLastError();   // leave no stale HIP error behind for the next call's launch checks
+        // work enqueued before the failure may still read the caller's (pinned) buffers and the scratch blocks: let the stream drain
+        // before the scratch blocks return to the pool and the caller gets its memory back
+        if (ctx) { ctx->err = e.what(); if (ctx->c) { (void)hipStreamSynchronize(ctx->c->stream); (void)hipGetLastError(); ctx->c->scratch_reset(); } }
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        if (ctx) ctx->err = "host allocation failed";
+        return AERO_E_OOM;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->err = e.what();
+        return AERO_E_INTERNAL;
+    }
+}
+#define REQUIRE(cond, msg) do { if (!(cond)) fail(msg); } while (0)
+
+static inline int ilog2u(uint64_t x) { int r = 0; while ((1ull << r) < x) r++; return r; }
+

@@ -496,25 +496,6 @@ int32_t aero_miden_public_inputs_to_protobuf(const uint8_t* input_bytes, size_t 
     });
 }
 
-// sdk.ProofSubmissionRequest { proof = 1, public_inputs = 2, source_proof_system = 3 (MIDEN = 0), target_chain = 4 (STARKNET = 0) }
-// (aero-sdk/proto/service.proto:16-21): what the SDK submits with `SubmitProof`; the two enums are the zero value, which proto3 omits.
-int32_t aero_proof_submission_request(const uint8_t* proof, size_t proof_len, const uint8_t* input_bytes, size_t input_len, uint8_t** out,
-                                      size_t* out_len, char* err, size_t err_cap) {
-    using namespace aero;
-    return guarded(err, err_cap, [&] {
-        if (!proof || !input_bytes || !out || !out_len) fail("proof_submission_request: null argument");
-        *out = nullptr; *out_len = 0;
-        Pb req, p, pi;
-        p.b = protobuf_proof(fmt::parse(proof, proof_len));
-        pi.b = protobuf_public_inputs(input_bytes, input_len);
-        req.msg(1, p);
-        req.msg(2, pi);
-        uint8_t* buf = (uint8_t*)malloc(req.b.size() ? req.b.size() : 1);
-        if (!buf) throw std::bad_alloc();
-        memcpy(buf, req.b.data(), req.b.size());
-        *out = buf; *out_len = req.b.size();
-    });
-}
 // Host-side look at a worker message without touching a GPU: validates the layout and reports its shape.
 int32_t aero_worker_message_info(uint32_t kind, const uint8_t* msg, size_t len, uint64_t out[8], char* err, size_t err_cap) {
     using namespace aero;

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <set>
 
+#include "air_host.hpp"
 #include "stark_kernels.hpp"
 
 namespace aero {
@@ -475,29 +476,6 @@ template <class F> static Digest hash_e(const typename F::T* v, size_t n) {
     flatten<F>(v, n, f);
     return b2s::hash_elements(f.data(), (uint32_t)f.size());
 }
-// Several small host arrays -> ONE pinned staging block -> ONE async H2D copy; pointers are handed out afterwards.
-struct ParamPack {
-    Context* ctx;
-    struct Item { const void* src; size_t bytes, off; };
-    std::vector<Item> items;
-    size_t total = 0;
-    uint8_t* dev = nullptr;
-    explicit ParamPack(Context* c) : ctx(c) {}
-    template <class T> size_t add(const std::vector<T>& v) {
-        Item it{v.data(), v.size() * sizeof(T), total};
-        items.push_back(it);
-        total += (it.bytes + 15) & ~(size_t)15;
-        return items.size() - 1;
-    }
-    void commit() {
-        uint8_t* host = (uint8_t*)ctx->stage_alloc(total + 16);
-        for (auto& it : items) if (it.bytes) memcpy(host + it.off, it.src, it.bytes);
-        dev = (uint8_t*)ctx->scratch_alloc(total + 16);
-        AERO_HIP(hipMemcpyAsync(dev, host, total + 16, hipMemcpyHostToDevice, ctx->stream));
-    }
-    template <class T> const T* ptr(size_t id) const { return reinterpret_cast<const T*>(dev + items[id].off); }
-};
-
 struct StageClock {
     Context* ctx; bool on; std::chrono::steady_clock::time_point t0;
     StageClock(Context* c, bool enable) : ctx(c), on(enable) { if (on) { ctx->sync(); } t0 = std::chrono::steady_clock::now(); }
@@ -749,13 +727,24 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     AERO_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << log_n, B = opt_.blowup_factor, Fd = opt_.fri_folding_factor;
     const int log_B = ilog2(B);
-    const uint32_t A = aux_width_, R = aux_rands_, D = aux_degree_;
-    if (A && (D < 2 || D > 8)) fail("prove: auxiliary constraint degree must be in [2, 8]");
+    // the AIR: a program (air_program.hpp) or the built-in FibAir with its optional auxiliary segment
+    const air::Program* const prog = program_;
+    air::Instance pinst;
+    if (prog) {
+        if (W != prog->W) fail("prove: the trace does not have the program's main width");
+        if (program_pub_.size() != prog->num_pub) fail("prove: wrong number of public inputs for this program");
+        for (uint64_t v : program_pub_) if (v >= gl::P) fail("prove: non-canonical public input");
+        pinst = air::instantiate(*prog, log_n);
+    }
+    const uint32_t A = prog ? prog->A : aux_width_, R = prog ? prog->R : aux_rands_, D = prog ? 2 : aux_degree_;
+    if (!prog && A && (D < 2 || D > 8)) fail("prove: auxiliary constraint degree must be in [2, 8]");
     FibAir air;
     air.width = W; air.log_n = log_n; air.aux_width = A; air.aux_rands = R; air.aux_degree = D;
-    const size_t N = n * B, C = air.ce_blowup_factor(), ceN = C * n;
+    const size_t N = n * B, C = prog ? prog->ce_blowup : air.ce_blowup_factor(), ceN = C * n;
     const int log_N = log_n + log_B, log_ce = ilog2(ceN);
-    if (W < 2 || (W & 1) || W > 254) fail("prove: FibAir needs an even column count in [2, 254]");
+    const size_t n_trans = prog ? prog->num_transition() : air.num_transition_constraints();
+    const size_t n_assert = prog ? prog->num_assertions() : air.num_assertions();
+    if (!prog && (W < 2 || (W & 1) || W > 254)) fail("prove: FibAir needs an even column count in [2, 254]");
     if (A > 255 - W || (A && (R == 0 || R > 255))) fail("prove: auxiliary segment needs 1..255 random elements and main + aux width <= 255");
     const uint32_t TW = W + A;
     if (B < C) fail("prove: blowup factor smaller than the constraint evaluation blowup");
@@ -862,7 +851,8 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     ms.lde = clk.lap();
     // 3. row hashes, Merkle tree, commit [a5, a6, a8]
     Commitment tcom = commit_matrix(tlde);          // synchronises the stream: the last trace row has arrived as well
-    for (uint32_t k = 0; k < W / 2; k++) air.results[k] = h_last_row[2 * k + 1];
+    if (prog) air.results = program_pub_;      // a program's public inputs are the caller's (FibAir reads its own off the trace)
+    else for (uint32_t k = 0; k < W / 2; k++) air.results[k] = h_last_row[2 * k + 1];
     if (pub_out) *pub_out = air.results;
     HostCoin coin = HostCoin::from_elements(air.results.data(), (uint32_t)air.results.size());
     wdigest(proof.commitments, tcom.root);
@@ -880,7 +870,8 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         pp.commit();
         d_rands = pp.ptr<T>(ir);
         apolys = Matrix(ctx, (int)(A * F::DEG), n);
-        launch_aux_columns<F>(ctx, trace_dev, n, W, A, R, D, d_rands, apolys.data.get());
+        if (prog) air_build_aux<F>(ctx, *prog, trace_dev, log_n, air.results.data(), rands.data(), apolys.data.get());
+        else launch_aux_columns<F>(ctx, trace_dev, n, W, A, R, D, d_rands, apolys.data.get());
         ctx->ntt_inverse(apolys.data.get(), n, (int)(A * F::DEG), log_n, 1, h, 1, 0);
         alde = Matrix(ctx, (int)(A * F::DEG), M);
         {
@@ -896,8 +887,8 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
 
     // 4. constraint composition coefficients + evaluation + division (fused) [a9, a10, a11]
     std::vector<T> ta, tb, ba, bb;
-    for (size_t i = 0; i < air.num_transition_constraints(); i++) { ta.push_back(coin.draw<F>()); tb.push_back(coin.draw<F>()); }
-    for (size_t i = 0; i < air.num_assertions(); i++) { ba.push_back(coin.draw<F>()); bb.push_back(coin.draw<F>()); }
+    for (size_t i = 0; i < n_trans; i++) { ta.push_back(coin.draw<F>()); tb.push_back(coin.draw<F>()); }
+    for (size_t i = 0; i < n_assert; i++) { ba.push_back(coin.draw<F>()); bb.push_back(coin.draw<F>()); }
     DevBuf<uint64_t> hbuf(ctx, (size_t)F::DEG * ceN);   // H evaluations over h<w_ce>, then coefficients: [DEG][ceN]
     {
         // H (degree < C*n) is interpolated from its values on the coset h<w_ce> of the constraint domain:
@@ -923,42 +914,62 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             frame_rows = M >> tc_log;
             cons_split = tc_split;
         }
-        FibConsArgs<F> a{};
-        a.split_log = (uint32_t)cons_split;
-        a.lde = frame_src; a.N = frame_rows; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)(frame_rows / n); a.ce_step = (uint32_t)(frame_rows / rows_eval);
-        a.xmask = (uint32_t)xcount - 1;
-        a.first = 0; a.count = rows_eval;
-        ParamPack pp(ctx);
-        const size_t i_ta = pp.add(ta), i_tb = pp.add(tb), i_ba = pp.add(ba), i_bb = pp.add(bb), i_res = pp.add(air.results);
-        a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.twi_lo = tce->lo_inv; a.twi_hi = tce->hi_inv; a.tw_h = tce->h;
-        a.offset = h; a.gen_inv = h_inv; a.k7 = gl::pow(h, ceN);       // x^ce_n is constant on every coset of <w_ce>
-        std::vector<uint64_t> xn(xcount), zn(xcount), xnp(xcount);
-        uint64_t hn = gl::pow(h, n), wX = gl::root_of_unity(ilog2(xcount));
-        for (size_t k = 0; k < xcount; k++) {
-            uint64_t xnk = gl::mul(hn, gl::pow(wX, k));
-            // aux degree adjustment x^((E + 1 - D) n + (D - 2)): the x^n part is constant on each coset of <w_n>
-            xnp[k] = gl::pow(xnk, C + 1 - D);
-            xn[k] = gl::inv(xnk);
-            zn[k] = gl::inv(gl::sub(xnk, 1));
-        }
-        const size_t i_xn = pp.add(xn), i_zn = pp.add(zn), i_xnp = pp.add(xnp);
-        pp.commit();
-        a.aux = aux_src; a.A = A; a.R = R; a.D = D; a.rands = d_rands; a.xn = pp.ptr<uint64_t>(i_xnp);
-        a.ta = pp.ptr<T>(i_ta); a.tb = pp.ptr<T>(i_tb); a.ba = pp.ptr<T>(i_ba); a.bb = pp.ptr<T>(i_bb);
-        a.results = pp.ptr<uint64_t>(i_res); a.xn_inv = pp.ptr<uint64_t>(i_xn); a.zn_inv = pp.ptr<uint64_t>(i_zn);
-        a.w_last = gl::pow(g, n - 1);
-        a.out_cols = nullptr;
-        if (!gather_h) {
-            for (int d = 0; d < F::DEG; d++) a.out_h[d] = hbuf.get() + (size_t)d * ceN;
-            launch_fib_constraints<F>(ctx, a, 1);
+        if (prog) {
+            // program AIR: the device interpreter over the same rows (air_kernels.hip)
+            AirGeometry ge;
+            ge.lde = frame_src; ge.aux = aux_src; ge.frame_rows = frame_rows; ge.split_log = (uint32_t)cons_split;
+            ge.rows = rows_eval; ge.first = 0; ge.count = rows_eval; ge.offset = h;
+            AirCoeffs<F> cc{ta, tb, ba, bb};
+            if (!gather_h) {
+                uint64_t* oh[2] = {hbuf.get(), hbuf.get() + (F::DEG > 1 ? ceN : 0)};
+                air_eval_constraints<F>(ctx, *prog, pinst, ge, cc, air.results.data(), rands.data(), 1, nullptr, oh);
+            } else {
+                DevBuf<uint64_t> hloc(ctx, (size_t)F::DEG * M), hall(ctx, (size_t)F::DEG * N);
+                uint64_t* oh[2] = {hloc.get(), hloc.get() + (F::DEG > 1 ? M : 0)};
+                air_eval_constraints<F>(ctx, *prog, pinst, ge, cc, air.results.data(), rands.data(), 1, nullptr, oh);
+                comm_all_gather(hloc.get(), hall.get(), (size_t)F::DEG * M * 8);          // [rank][component][t]
+                for (int d = 0; d < F::DEG; d++)
+                    launch_select_coset_u64(ctx, hall.get() + (size_t)d * M, (size_t)F::DEG * M, hbuf.get() + (size_t)d * ceN, ceN, (uint32_t)rank,
+                                            N / ceN, N, (uint32_t)G);
+            }
         } else {
-            DevBuf<uint64_t> hloc(ctx, (size_t)F::DEG * M), hall(ctx, (size_t)F::DEG * N);
-            for (int d = 0; d < F::DEG; d++) a.out_h[d] = hloc.get() + (size_t)d * M;
-            launch_fib_constraints<F>(ctx, a, 1);
-            comm_all_gather(hloc.get(), hall.get(), (size_t)F::DEG * M * 8);          // [rank][component][t]
-            for (int d = 0; d < F::DEG; d++)
-                launch_select_coset_u64(ctx, hall.get() + (size_t)d * M, (size_t)F::DEG * M, hbuf.get() + (size_t)d * ceN, ceN, (uint32_t)rank,
-                                        N / ceN, N, (uint32_t)G);
+            FibConsArgs<F> a{};
+            a.split_log = (uint32_t)cons_split;
+            a.lde = frame_src; a.N = frame_rows; a.W = W; a.C = (uint32_t)C; a.blowup = (uint32_t)(frame_rows / n); a.ce_step = (uint32_t)(frame_rows / rows_eval);
+            a.xmask = (uint32_t)xcount - 1;
+            a.first = 0; a.count = rows_eval;
+            ParamPack pp(ctx);
+            const size_t i_ta = pp.add(ta), i_tb = pp.add(tb), i_ba = pp.add(ba), i_bb = pp.add(bb), i_res = pp.add(air.results);
+            a.tw_lo = tce->lo_fwd; a.tw_hi = tce->hi_fwd; a.twi_lo = tce->lo_inv; a.twi_hi = tce->hi_inv; a.tw_h = tce->h;
+            a.offset = h; a.gen_inv = h_inv; a.k7 = gl::pow(h, ceN);       // x^ce_n is constant on every coset of <w_ce>
+            std::vector<uint64_t> xn(xcount), zn(xcount), xnp(xcount);
+            uint64_t hn = gl::pow(h, n), wX = gl::root_of_unity(ilog2(xcount));
+            for (size_t k = 0; k < xcount; k++) {
+                uint64_t xnk = gl::mul(hn, gl::pow(wX, k));
+                // aux degree adjustment x^((E + 1 - D) n + (D - 2)): the x^n part is constant on each coset of <w_n>
+                xnp[k] = gl::pow(xnk, C + 1 - D);
+                xn[k] = gl::inv(xnk);
+                zn[k] = gl::inv(gl::sub(xnk, 1));
+            }
+            const size_t i_xn = pp.add(xn), i_zn = pp.add(zn), i_xnp = pp.add(xnp);
+            pp.commit();
+            a.aux = aux_src; a.A = A; a.R = R; a.D = D; a.rands = d_rands; a.xn = pp.ptr<uint64_t>(i_xnp);
+            a.ta = pp.ptr<T>(i_ta); a.tb = pp.ptr<T>(i_tb); a.ba = pp.ptr<T>(i_ba); a.bb = pp.ptr<T>(i_bb);
+            a.results = pp.ptr<uint64_t>(i_res); a.xn_inv = pp.ptr<uint64_t>(i_xn); a.zn_inv = pp.ptr<uint64_t>(i_zn);
+            a.w_last = gl::pow(g, n - 1);
+            a.out_cols = nullptr;
+            if (!gather_h) {
+                for (int d = 0; d < F::DEG; d++) a.out_h[d] = hbuf.get() + (size_t)d * ceN;
+                launch_fib_constraints<F>(ctx, a, 1);
+            } else {
+                DevBuf<uint64_t> hloc(ctx, (size_t)F::DEG * M), hall(ctx, (size_t)F::DEG * N);
+                for (int d = 0; d < F::DEG; d++) a.out_h[d] = hloc.get() + (size_t)d * M;
+                launch_fib_constraints<F>(ctx, a, 1);
+                comm_all_gather(hloc.get(), hall.get(), (size_t)F::DEG * M * 8);          // [rank][component][t]
+                for (int d = 0; d < F::DEG; d++)
+                    launch_select_coset_u64(ctx, hall.get() + (size_t)d * M, (size_t)F::DEG * M, hbuf.get() + (size_t)d * ceN, ceN, (uint32_t)rank,
+                                            N / ceN, N, (uint32_t)G);
+            }
         }
     }
     ms.constraints = clk.lap();
@@ -1310,6 +1321,8 @@ Bytes Prover::prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::v
         if (opt_.field_extension == EXT_NONE) return prove_impl<FB>(trace_dev, width, log_n, pub_out);
         return prove_impl<FQ>(trace_dev, width, log_n, pub_out);
     } catch (...) {
+        (void)hipStreamSynchronize(ctx_->stream);     // nothing enqueued by the failed proof may outlive its scratch blocks
+        (void)hipGetLastError();
         ctx_->scratch_reset();
         throw;
     }

@@ -21,6 +21,8 @@
 
 namespace aero {
 
+namespace air { struct Program; }
+
 typedef std::vector<uint8_t> Bytes;
 
 enum HashFn : uint8_t { HASH_BLAKE2S_256 = 4 };
@@ -171,6 +173,10 @@ public:
     // The next prove() takes its trace from HOST memory (column-major width x 2^log_n; `trace_dev` is then ignored): it is copied
     // straight into the interpolation buffer. *verdict (pinned) receives 0 when every element was canonical. FibAir without aux segment.
     void set_host_trace(const uint64_t* trace_host, unsigned int* verdict) { host_trace_ = trace_host; host_verdict_ = verdict; }
+    // Prove against a program AIR (air_program.hpp; include/aero_air.h) instead of the built-in FibAir: the constraint set, the
+    // assertions, the auxiliary segment's shape and construction all come from the program; `pub` = its public inputs (they seed
+    // the coin). The program must outlive the proof.
+    void set_program(const air::Program* prog, const std::vector<uint64_t>& pub) { program_ = prog; program_pub_ = pub; }
     const ProofOptions& options() const { return opt_; }
     // trace: device, column-major W x 2^log_n (not modified). Returns StarkProof::to_bytes().
     Bytes prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_inputs_out);
@@ -223,6 +229,8 @@ private:
     uint32_t aux_width_ = 0, aux_rands_ = 0, aux_degree_ = 2;
     const uint64_t* host_trace_ = nullptr;
     unsigned int* host_verdict_ = nullptr;
+    const air::Program* program_ = nullptr;
+    std::vector<uint64_t> program_pub_;
 };
 
 // BatchMerkleProof node selection (winter-crypto 0.4 MerkleTree::prove_batch restated):

@@ -11,7 +11,8 @@
 #include <cstring>
 #include <map>
 
-#include "../../include/aero_stark.h"
+#include "../../include/aero_air.h"
+#include "air_program.hpp"
 #include "prover.hpp"
 #include "proof_format.hpp"
 
@@ -74,7 +75,8 @@ void intt_host(std::vector<uint64_t>& a) {
     for (auto& v : a) v = gl::mul(v, ninv);
 }
 
-template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t>& pub, const aero_fib_air* air_desc, const aero_verify_policy& policy) {
+template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t>& pub, const aero_fib_air* air_desc, const aero_verify_policy& policy,
+                                    const air::Program* prog = nullptr) {
     typedef typename F::T T;
     const size_t n = (size_t)1 << pr.log_n, B = pr.opt.blowup_factor, N = n * B, Fd = pr.opt.fri_folding_factor;
     const uint32_t W = pr.W, A = pr.A, TW = W + A;
@@ -90,6 +92,11 @@ template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t
         if (query_bits < policy.min_query_security_bits)
             reject("proof options give " + std::to_string(query_bits) + " query-security bits (num_queries * log2(blowup) + grinding), the policy requires " +
                    std::to_string(policy.min_query_security_bits));
+        // Winterfell's conjectured security is min(query term, field term): 64 * extension degree - log2(LDE domain) caps it
+        const uint32_t field_bits = 64u * (uint32_t)F::DEG - (uint32_t)(pr.log_n + log_b);
+        if (policy.min_conjectured_security_bits && std::min(query_bits, field_bits) < policy.min_conjectured_security_bits)
+            reject("conjectured security is min(" + std::to_string(query_bits) + " query bits, " + std::to_string(field_bits) + " field bits), the policy requires " +
+                   std::to_string(policy.min_conjectured_security_bits) + (field_bits < policy.min_conjectured_security_bits ? " (an extension field is needed)" : ""));
         if (policy.expected_log_n && (int)policy.expected_log_n != pr.log_n)
             reject("trace length 2^" + std::to_string(pr.log_n) + " is not the expected 2^" + std::to_string(policy.expected_log_n));
         if (policy.require_options) {
@@ -122,9 +129,16 @@ template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t
     while (((size_t)1 << log_N) < N) log_N++;
     const uint64_t gN = gl::root_of_unity(log_N);
 
-    // the AIR, when known
+    // the AIR, when known: a program, or the built-in FibAir
     FibAir air;
-    const bool have_air = air_desc != nullptr;
+    air::Instance pinst;
+    if (prog) {
+        if (W != prog->W || A != prog->A || pr.R != prog->R) reject("proof shape does not match the program's trace layout");
+        if (pub.size() != prog->num_pub) reject("wrong number of public inputs for this program");
+        if (C != prog->ce_blowup) reject("wrong number of composition columns for this program");
+        try { pinst = air::instantiate(*prog, pr.log_n); } catch (const Error& e) { reject(e.what()); }
+    }
+    const bool have_air = air_desc != nullptr && !prog;
     if (have_air) {
         air.width = W; air.log_n = pr.log_n; air.results = pub;
         air.aux_width = air_desc->aux_width; air.aux_rands = air_desc->aux_width ? air_desc->aux_rands : 0;
@@ -142,9 +156,10 @@ template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t
     std::vector<T> rands;
     if (A) { for (uint32_t i = 0; i < pr.R; i++) rands.push_back(coin.draw<F>()); coin.reseed(roots[ri++]); }
     std::vector<T> ta, tb, ba, bb;
-    if (have_air) {
-        for (size_t i = 0; i < air.num_transition_constraints(); i++) { ta.push_back(coin.draw<F>()); tb.push_back(coin.draw<F>()); }
-        for (size_t i = 0; i < air.num_assertions(); i++) { ba.push_back(coin.draw<F>()); bb.push_back(coin.draw<F>()); }
+    if (have_air || prog) {
+        const size_t nt = prog ? prog->num_transition() : air.num_transition_constraints(), na = prog ? prog->num_assertions() : air.num_assertions();
+        for (size_t i = 0; i < nt; i++) { ta.push_back(coin.draw<F>()); tb.push_back(coin.draw<F>()); }
+        for (size_t i = 0; i < na; i++) { ba.push_back(coin.draw<F>()); bb.push_back(coin.draw<F>()); }
     }
     const Digest croot = roots[ri++];
     coin.reseed(croot);
@@ -157,6 +172,30 @@ template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t
     coin.reseed(hash_elems<F>(ood_cur));
     coin.reseed(hash_elems<F>(ood_next));
     coin.reseed(hash_elems<F>(ood_h));
+    if (prog) {
+        // out-of-domain consistency for a program AIR: the compiled constraint program runs on the host over E, periodic columns
+        // through their interpolants at z^(n / cycle), degree adjustments as plain powers of z
+        std::vector<T> per;
+        for (auto& cyc : prog->periodic) {
+            std::vector<uint64_t> co = cyc;
+            air::host_ntt(co, true);
+            const T y = gl::fpow<F>(z, n / cyc.size());
+            T acc = F::zero();
+            for (size_t i = co.size(); i-- > 0;) acc = F::add(F::mul(acc, y), F::from(co[i]));
+            per.push_back(acc);
+        }
+        const air::Scalars<F> sc = air::fold_scalars<F>(*prog, pub.data(), rands.data());
+        const std::vector<T> num = air::host_evaluate<F>(*prog, pinst, sc, ood_cur.data(), ood_next.data(), per, ta, tb, ba, bb,
+                                                         [&](uint64_t e) { return gl::fpow<F>(z, e); });
+        T tdiv = F::inv(F::sub(gl::fpow<F>(z, n), F::one()));
+        for (uint32_t i = 1; i <= prog->exemptions; i++) tdiv = F::mul(tdiv, F::sub(z, F::from(gl::pow(g, n - i))));
+        T lhs = F::mul(num[0], tdiv);
+        for (size_t j = 0; j < pinst.bgroups.size(); j++)
+            lhs = F::add(lhs, F::mul(num[1 + j], F::inv(F::sub(gl::fpow<F>(z, pinst.bgroups[j].a), F::from(pinst.bgroups[j].b)))));
+        T rhs = F::zero(), zp = F::one();
+        for (size_t c = 0; c < C; c++) { rhs = F::add(rhs, F::mul(zp, ood_h[c])); zp = F::mul(zp, z); }
+        if (!feq<F>(lhs, rhs)) reject("out-of-domain constraint evaluations are inconsistent");
+    }
     if (have_air) {
         // sum over divisor groups of numerator(z) / divisor(z)  ==  sum_c z^c H_c(z^C)
         const uint64_t ce_n = (uint64_t)C * n;
@@ -331,15 +370,15 @@ template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t
 }  // namespace
 }  // namespace aero
 
-extern "C" int32_t aero_verify_fib(const uint8_t* proof, size_t proof_len, const uint64_t* pub_elements, uint32_t n_pub, const aero_fib_air* air,
-                                   const aero_verify_policy* policy, char* err, size_t err_cap) {
+static int32_t verify_entry(const uint8_t* proof, size_t proof_len, const uint64_t* pub_elements, uint32_t n_pub, const aero_fib_air* air,
+                            const aero::air::Program* prog, const aero_verify_policy* policy, char* err, size_t err_cap) {
     using namespace aero;
     auto put = [&](const std::string& s) { if (err && err_cap) { size_t k = std::min(err_cap - 1, s.size()); memcpy(err, s.data(), k); err[k] = 0; } };
     try {
         if (!proof || (!pub_elements && n_pub)) { put("verify: null argument"); return AERO_E_BAD_ARG; }
         aero_verify_policy pol{};
         if (policy) pol = *policy; else pol.min_query_security_bits = 96;
-        if (!air && !pol.allow_unknown_air) {
+        if (!air && !prog && !pol.allow_unknown_air) {
             put("verify: the AIR descriptor is mandatory (without it the out-of-domain constraint check cannot run and any low-degree "
                 "commitment would be accepted); set policy.allow_unknown_air to verify everything but that check");
             return AERO_E_BAD_ARG;
@@ -349,8 +388,8 @@ extern "C" int32_t aero_verify_fib(const uint8_t* proof, size_t proof_len, const
         try { pr.opt.validate(); } catch (const Error& e) { reject(e.what()); }
         std::vector<uint64_t> pub(pub_elements, pub_elements + n_pub);
         for (uint64_t v : pub) if (v >= gl::P) reject("non-canonical public input");
-        if (pr.opt.field_extension == EXT_NONE) verify_impl<gl::FB>(pr, pub, air, pol);
-        else verify_impl<gl::FQ>(pr, pub, air, pol);
+        if (pr.opt.field_extension == EXT_NONE) verify_impl<gl::FB>(pr, pub, air, pol, prog);
+        else verify_impl<gl::FQ>(pr, pub, air, pol, prog);
         return AERO_OK;
     } catch (const Error& e) {
         put(e.what());
@@ -359,6 +398,16 @@ extern "C" int32_t aero_verify_fib(const uint8_t* proof, size_t proof_len, const
         put(std::string("verify: ") + e.what());
         return AERO_E_INTERNAL;
     }
+}
+
+extern "C" int32_t aero_verify_fib(const uint8_t* proof, size_t proof_len, const uint64_t* pub_elements, uint32_t n_pub, const aero_fib_air* air,
+                                   const aero_verify_policy* policy, char* err, size_t err_cap) {
+    return verify_entry(proof, proof_len, pub_elements, n_pub, air, nullptr, policy, err, err_cap);
+}
+extern "C" int32_t aero_verify_air(const uint8_t* proof, size_t proof_len, const uint64_t* pub, uint32_t n_pub, const aero_air* air,
+                                   const aero_verify_policy* policy, char* err, size_t err_cap) {
+    if (!air) { if (err && err_cap) snprintf(err, err_cap, "verify: null program"); return AERO_E_BAD_ARG; }
+    return verify_entry(proof, proof_len, pub, n_pub, nullptr, &air->prog, policy, err, err_cap);
 }
 
 // num_queries * log2(blowup) + grinding, and the field-size term 64 * extension degree - log2(LDE domain) that caps any

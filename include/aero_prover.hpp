@@ -200,15 +200,21 @@ private:
     aero_fib_air air_;
 };
 
-// winter_verifier::AcceptableOptions::MinConjecturedSecurity: what the verifier demands of a proof's self-declared parameters
+// What the verifier demands of a proof's self-declared parameters (upstream later added winter_verifier::AcceptableOptions):
+//   min_query_security ......... floor on num_queries * log2(blowup) + grinding (the soundness of the query phase)
+//   min_conjectured_security ... floor on min(query term, 64 * extension degree - log2(LDE domain)) - the quantity
+//                                StarkProof::security_level() reports and AcceptableOptions::MinConjecturedSecurity means;
+//                                0 = not required. A base-field proof of a 2^20-row trace has 41 bits of it.
 struct AcceptableOptions {
-    uint32_t min_conjectured_security = 96;
+    uint32_t min_query_security = 96;
+    uint32_t min_conjectured_security = 0;
     uint32_t expected_log_trace_length = 0;      // 0 = any
 };
 // winter_verifier::verify::<FibAir>(proof, pub_inputs, &acceptable_options): host code, throws VerifierError when rejected
 inline void verify(const StarkProof& proof, const FibPublicInputs& pub_inputs, const aero_fib_air& air, const AcceptableOptions& acceptable = AcceptableOptions()) {
     aero_verify_policy policy{};
-    policy.min_query_security_bits = acceptable.min_conjectured_security;
+    policy.min_query_security_bits = acceptable.min_query_security;
+    policy.min_conjectured_security_bits = acceptable.min_conjectured_security;
     policy.expected_log_n = acceptable.expected_log_trace_length;
     char err[512] = {0};
     const std::vector<uint8_t>& b = proof.to_bytes();

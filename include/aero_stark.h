@@ -350,6 +350,9 @@ int32_t aero_pool_prove_fib_host(aero_pool* pool, const uint64_t* const* host_tr
  *   cairo_compat             non-zero: additionally require the shape src/stark_verifier hard-codes (72 + 9 columns, 8
  *                            composition columns, 27 queries, blowup 8, FRI folding factor 8, no extension field)
  *   require_options/options  non-zero: the proof's 7 option bytes must equal `options`
+ *   min_conjectured_security_bits  non-zero: reject when min(query bits, 64 * extension degree - log2(LDE domain size)) is below
+ *                            this - Winterfell's conjectured-security estimate (what aero_proof_security_bits reports); a base-field
+ *                            proof of a 2^20-row trace has 41 field bits however many queries it carries
  * air: the built-in FibAir descriptor (aux fields must match the proof); pub_elements = the width/2 results.
  * Returns AERO_OK, AERO_E_VERIFY (rejected; reason in err) or AERO_E_BAD_ARG (incl. air == NULL without allow_unknown_air). */
 typedef struct aero_verify_policy {
@@ -359,6 +362,7 @@ typedef struct aero_verify_policy {
     uint32_t cairo_compat;
     uint32_t require_options;
     aero_proof_options options;
+    uint32_t min_conjectured_security_bits;
 } aero_verify_policy;
 int32_t aero_verify_fib(const uint8_t* proof, size_t proof_len, const uint64_t* pub_elements, uint32_t n_pub, const aero_fib_air* air,
                         const aero_verify_policy* policy, char* err, size_t err_cap);
@@ -410,14 +414,10 @@ int32_t aero_miden_public_inputs_to_protobuf(const uint8_t* input_bytes, size_t 
  *   every row, in row order. The rows are hashed where they lie in the message (one copy of the bytes to the device, one lane
  *   per row); they may differ in length, a row without elements hashes to BLAKE2s of the empty string like hash_elements(&[]),
  *   a value >= p is reduced like Felt::new does.
- * aero_worker_eval_constraints: ConstraintComputeWorkItem { trace_info, public_inputs, proof_options, aux_rand_elements,
- *   constraint_coeffs, trace_lde_wrapper, computation_fragment } (utils.rs:302-347) -> ConstraintComputeResult { frag_index,
- *   frag_num, constraint_evaluations } (utils.rs:417-422) = `constraint_compute` (constraints_worker.rs:14-79) for the built-in
- *   FibAir: columns [transition, boundary(step 0), boundary(step n-1)] of the fragment, numerators only. The message has no AIR
- *   identity (the reference's worker hard-wires Miden's ProcessorAir, which is absent here): `air` names the auxiliary segment's
- *   constraint degree and must agree with the TraceLayout in the message (NULL without auxiliary columns); the width/2 asserted
- *   results are read from `outputs.stack` of the Miden PublicInputs the message carries. Base field only (the message's
- *   coefficients are base-field elements).
+ * aero_worker_eval_constraints (declared in aero_air.h: it takes the AIR as a program): ConstraintComputeWorkItem { trace_info,
+ *   public_inputs, proof_options, aux_rand_elements, constraint_coeffs, trace_lde_wrapper, computation_fragment } (utils.rs:302-347)
+ *   -> ConstraintComputeResult { frag_index, frag_num, constraint_evaluations } (utils.rs:417-422) = `constraint_compute`
+ *   (constraints_worker.rs:14-79): one numerator column per divisor, for the fragment.
  * aero_prover_output: what the proving worker hands back to the SDK (proving_worker.rs:205-222, utils.rs:424-430): bincode
  *   ProverOutput { proof, program_outputs, public_inputs } - the protobuf encodings of sdk.StarkProof, sdk.MidenProgramOutputs
  *   and sdk.MidenPublicInputs - from proof bytes and the container's input bytes. */
@@ -429,15 +429,8 @@ int32_t aero_miden_public_inputs_to_protobuf(const uint8_t* input_bytes, size_t 
 #define AERO_MSG_CONSTRAINT_WORK_ITEM 1u
 int32_t aero_worker_message_info(uint32_t kind, const uint8_t* msg, size_t len, uint64_t out[8], char* err, size_t err_cap);
 int32_t aero_worker_hash_rows(aero_ctx* ctx, const uint8_t* work_item, size_t work_item_len, uint8_t** result, size_t* result_len);
-int32_t aero_worker_eval_constraints(aero_ctx* ctx, const uint8_t* work_item, size_t work_item_len, const aero_fib_air* air,
-                                     uint8_t** result, size_t* result_len);
 int32_t aero_prover_output(const uint8_t* proof, size_t proof_len, const uint8_t* input_bytes, size_t input_len, uint8_t** out,
                            size_t* out_len, char* err, size_t err_cap);
-/* protobuf sdk.ProofSubmissionRequest { proof, public_inputs, source_proof_system = MIDEN, target_chain = STARKNET }
- * (aero-sdk/proto/service.proto:16-21): the request of the SDK's `ProofSubmissionService.SubmitProof`. */
-int32_t aero_proof_submission_request(const uint8_t* proof, size_t proof_len, const uint8_t* input_bytes, size_t input_len, uint8_t** out,
-                                      size_t* out_len, char* err, size_t err_cap);
-
 /* ---- instrumentation --------------------------------------------------------------------------------------------------------- */
 /* Per-stage wall-clock of the last aero_prove_* (ms; adds one stream sync per stage when enabled). Order:
  * interpolate, lde, trace_commit, constraints, composition, comp_commit, ood, deep, fri, grind, queries, total

@@ -197,6 +197,66 @@ int orc_verify_fib_aux(const uint8_t* proof, size_t len, const uint64_t* pub, si
         return 0;
     } catch (std::exception& e) { return fail(e); }
 }
+// ---- AIR-as-data (oracle/air.hpp): prove / verify against an AEROAIR program ------------------------------------------------
+static ProgramAir load_air(const uint8_t* program, size_t plen, int log_n, const uint64_t* pub, size_t npub) {
+    ProgramAir air = ProgramAir::parse(program, plen);
+    air.bind(log_n, Col(pub, pub + npub));
+    return air;
+}
+// trace: column-major W x 2^log_n; pub: the program's public inputs (they seed the coin)
+int orc_prove_air(const uint8_t* program, size_t plen, const uint64_t* trace, uint32_t W, int log_n, const uint64_t* pub, size_t npub,
+                  const uint8_t opt7[7], uint8_t** proof, size_t* proof_len, double* times, int keep_artifacts) {
+    try {
+        const size_t n = (size_t)1 << log_n;
+        ProgramAir air = load_air(program, plen, log_n, pub, npub);
+        if (W != air.W) throw Err("prove_air: trace width does not match the program");
+        std::vector<Col> tr(W);
+        for (uint32_t c = 0; c < W; c++) tr[c].assign(trace + (size_t)c * n, trace + (size_t)(c + 1) * n);
+        Options o{opt7[0], opt7[1], opt7[2], opt7[3], opt7[4], opt7[5], opt7[6]};
+        StageTimes tm; Bytes pf;
+        if (o.field_ext == EXT_NONE) {
+            if (keep_artifacts) { g_art = ProverArtifacts<FB>(); g_art_is_q = false; }
+            pf = prove_model<FB, ProgramAir>(air, tr, log_n, o, &tm, keep_artifacts ? &g_art : nullptr);
+        } else if (o.field_ext == EXT_QUADRATIC) {
+            if (keep_artifacts) { g_art_q = ProverArtifacts<FQ>(); g_art_is_q = true; }
+            pf = prove_model<FQ, ProgramAir>(air, tr, log_n, o, &tm, keep_artifacts ? &g_art_q : nullptr);
+        } else throw Err("prove_air: unsupported field extension");
+        *proof = (uint8_t*)malloc(pf.size()); memcpy(*proof, pf.data(), pf.size()); *proof_len = pf.size();
+        if (times) { double t[12] = {tm.interpolate, tm.lde, tm.trace_commit, tm.constraints, tm.composition, tm.comp_commit, tm.ood, tm.deep, tm.fri, tm.grind, tm.queries, tm.total}; memcpy(times, t, sizeof t); }
+        return 0;
+    } catch (std::exception& e) { return fail(e); }
+}
+// full verification incl. the OOD constraint check evaluated from the program
+int orc_verify_air(const uint8_t* proof, size_t len, const uint8_t* program, size_t plen, const uint64_t* pub, size_t npub, int log_n) {
+    try {
+        ProgramAir air = load_air(program, plen, log_n, pub, npub);
+        verify_with<ProgramAir>(Bytes(proof, proof + len), air.pub, &air, nullptr);
+        return 0;
+    } catch (std::exception& e) { return fail(e); }
+}
+// out = { ce_blowup, numerator columns, transition constraints, assertions, main width, aux width, aux rands, nodes }
+int orc_air_info(const uint8_t* program, size_t plen, int log_n, uint64_t out[8]) {
+    try {
+        ProgramAir air = ProgramAir::parse(program, plen);
+        air.bind(log_n, Col(air.num_pub, 0));
+        const uint64_t v[8] = {air.ce_blowup(), air.num_columns(), air.num_transition(), air.num_assertions(), air.W, air.A, air.R, air.nodes.size()};
+        memcpy(out, v, sizeof v);
+        return 0;
+    } catch (std::exception& e) { return fail(e); }
+}
+// 0 when the main trace satisfies the program's main transition constraints (test helper for hand-made traces)
+int orc_air_check_trace(const uint8_t* program, size_t plen, const uint64_t* trace, uint32_t W, int log_n, const uint64_t* pub, size_t npub) {
+    try {
+        const size_t n = (size_t)1 << log_n;
+        ProgramAir air = load_air(program, plen, log_n, pub, npub);
+        if (W != air.W) throw Err("check_trace: width mismatch");
+        std::vector<Col> tr(W);
+        for (uint32_t c = 0; c < W; c++) tr[c].assign(trace + (size_t)c * n, trace + (size_t)(c + 1) * n);
+        const std::string why = air.check_main_trace(tr);
+        if (!why.empty()) throw Err(why);
+        return 0;
+    } catch (std::exception& e) { return fail(e); }
+}
 // Fetch an intermediate of the last keep_artifacts prove. Column-major for matrices. Returns element count
 // (u64 units; digests count 4 per digest) or -1.
 long orc_artifact(const char* name, uint64_t* out, size_t cap) {

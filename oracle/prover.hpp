@@ -17,6 +17,7 @@
 #pragma once
 #include <chrono>
 #include "stark.hpp"
+#include "air.hpp"
 
 namespace orc {
 
@@ -56,17 +57,17 @@ static std::vector<Digest> hash_rows(const std::vector<Col>& cols, size_t rows) 
     return out;
 }
 
-template <class F>
-static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& opt, Col* pub_out,
-                       StageTimes* times = nullptr, ProverArtifacts<F>* art = nullptr, uint32_t A = 0, uint32_t R = 0, uint32_t D = 2) {
+// The prover, generic over the AIR model M (FibAir in oracle/stark.hpp, ProgramAir in oracle/air.hpp). `air` arrives complete:
+// shape, trace length and the public inputs that seed the coin.
+template <class F, class M>
+static Bytes prove_model(const M& air, const std::vector<Col>& trace, int log_n, const Options& opt,
+                         StageTimes* times = nullptr, ProverArtifacts<F>* art = nullptr) {
     typedef typename F::T T;
-    const uint32_t W = (uint32_t)trace.size();
+    const uint32_t W = (uint32_t)trace.size(), A = air.A, R = air.R;
     const size_t n = (size_t)1 << log_n, B = opt.blowup, N = n * B, Fd = opt.fri_fold;
-    if (D < 2 || D > 8) throw Err("prove: aux constraint degree must be in [2, 8]");
-    FibAir shape; shape.W = W; shape.log_n = log_n; shape.A = A; shape.R = A ? R : 0; shape.D = D;
-    const size_t C = shape.ce_blowup(), ceN = C * n, ce_step = B / C;
-    if (W < 2 || (W & 1) || W > 254) throw Err("prove: FibAir needs an even column count in [2, 254]");
-    if (B < C || (B & (B - 1))) throw Err("prove: blowup must be a power of two >= 2");
+    const size_t C = air.ce_blowup(), ceN = C * n, ce_step = B / C, NC = air.num_columns();
+    if (W != air.W || log_n != air.log_n) throw Err("prove: trace shape does not match the AIR");
+    if (B < C || (B & (B - 1))) throw Err("prove: blowup must be a power of two >= the constraint-evaluation blowup");
     if (Fd != 2 && Fd != 4 && Fd != 8 && Fd != 16) throw Err("prove: unsupported FRI folding factor");
     if (opt.hash_fn != HASH_BLAKE2S_256) throw Err("prove: only Blake2s_256 is supported");
     if (ilog2(N) > TWO_ADICITY) throw Err("prove: LDE domain exceeds field two-adicity");
@@ -75,10 +76,7 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
     StageTimes tm; double t0 = now_s(), t1;
 
     // 0. AIR + channel [proving_worker.rs:248-268]
-    FibAir air = shape;
-    for (uint32_t k = 0; k < W / 2; k++) air.results.push_back(trace[2 * k + 1][n - 1]);
-    if (pub_out) *pub_out = air.results;
-    Coin coin = Coin::from_pub_elements(air.results.data(), air.results.size());
+    Coin coin = Coin::from_pub_elements(air.pub_elements().data(), air.pub_elements().size());
     const uint64_t g = gl_root_of_unity(log_n), gN = gl_root_of_unity(ilog2(N));
     Proof pr;
     pr.main_width = (uint8_t)W; pr.aux_width = (uint8_t)A; pr.aux_rands = (uint8_t)(A ? R : 0); pr.log_n = (uint8_t)log_n;
@@ -106,14 +104,7 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
     if (A) {
         for (uint32_t i = 0; i < R; i++) rands.push_back(coin.draw<F>());
         for (auto& c : apolys) c.resize(n);
-#pragma omp parallel for schedule(dynamic, 1)
-        for (uint32_t c = 0; c < A; c++) {
-            T p = F::one();
-            for (size_t i = 0; i < n; i++) {
-                for (int k = 0; k < F::DEG; k++) apolys[c * F::DEG + k][i] = F::comp(p, k);
-                p = F::mul(p, f_pow<F>(F::add(rands[c % R], F::from(trace[c % W][i])), D - 1));
-            }
-        }
+        air.template build_aux<F>(trace, rands, apolys);
         if (art) { art->aux_cols = apolys; f_flatten<F>(rands.data(), rands.size(), art->aux_rands); }
         for (size_t c = 0; c < A * F::DEG; c++) { intt(apolys[c].data(), n, true); alde[c] = lde(apolys[c].data(), n, B, GEN); }
         if (art) art->aux_lde = alde;
@@ -126,13 +117,12 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
 
     // 4. constraint evaluation over the ce domain [a9, a10]
     auto cc = draw_constraint_coeffs<F>(coin, air.num_transition(), air.num_assertions());
-    FibCombine cb(air);
-    std::vector<std::vector<T>> ce(3, std::vector<T>(ceN));
+    std::vector<std::vector<T>> ce(NC, std::vector<T>(ceN));
     const uint64_t gce = gl_root_of_unity(ilog2(ceN));
 #pragma omp parallel
     {
         std::vector<uint64_t> cur(W), nxt(W);
-        std::vector<T> acur(A), anxt(A);
+        std::vector<T> acur(A), anxt(A), o(NC);
 #pragma omp for schedule(static)
         for (size_t s = 0; s < ceN; s++) {
             size_t r = s * ce_step, rn = (r + B) % N;     // frame = (row j, row j + blowup mod N)
@@ -143,43 +133,15 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
                 acur[c] = F::make(a0); anxt[c] = F::make(a1);
             }
             uint64_t x = gl_mul(GEN, gl_pow(gce, s));
-            T o[3];
-            fib_eval_point<F, FB>(air, cb, cc, cur.data(), nxt.data(), x, o, acur.data(), anxt.data(), rands.data());
-            ce[0][s] = o[0]; ce[1][s] = o[1]; ce[2][s] = o[2];
+            air.template eval_row<F>(cc, cur.data(), nxt.data(), acur.data(), anxt.data(), rands.data(), x, o.data());
+            for (size_t k = 0; k < NC; k++) ce[k][s] = o[k];
         }
     }
     t1 = now_s(); tm.constraints = t1 - t0; t0 = t1;
 
     // 5. composition polynomial [a11]: divide by divisors, sum, interpolate over the coset, split into C columns
     std::vector<Col> hcomp(F::DEG, Col(ceN));
-    {
-        const uint64_t wl = gl_pow(g, n - 1);
-        // x^n takes only C distinct values on the ce domain: (7 w_ce^s)^n = 7^n * w_C^(s mod C)
-        Col zinv(C);
-        for (size_t k = 0; k < C; k++) zinv[k] = gl_inv(gl_sub(gl_mul(gl_pow(GEN, n), gl_pow(gl_root_of_unity(ilog2(C)), k)), 1));
-        const size_t CH = 1024;
-#pragma omp parallel for schedule(static)
-        for (size_t c0 = 0; c0 < ceN; c0 += CH) {
-            size_t m = std::min(CH, ceN - c0);
-            // batch-invert (x - 1) and (x - w^(n-1)) for the chunk
-            Col d(2 * m), pre(2 * m);
-            uint64_t x = gl_mul(GEN, gl_pow(gce, c0));
-            Col xs(m);
-            for (size_t i = 0; i < m; i++) { xs[i] = x; d[2 * i] = gl_sub(x, 1); d[2 * i + 1] = gl_sub(x, wl); x = gl_mul(x, gce); }
-            uint64_t acc = 1;
-            for (size_t i = 0; i < 2 * m; i++) { pre[i] = acc; acc = gl_mul(acc, d[i]); }
-            uint64_t ia = gl_inv(acc);
-            for (size_t i = 2 * m; i-- > 0;) { uint64_t inv = gl_mul(ia, pre[i]); ia = gl_mul(ia, d[i]); d[i] = inv; }
-            for (size_t i = 0; i < m; i++) {
-                size_t s = c0 + i;
-                uint64_t tdiv = gl_mul(gl_sub(xs[i], wl), zinv[s % C]);    // 1 / ((x^n - 1)/(x - w^(n-1)))
-                T h = F::mulb(ce[0][s], tdiv);
-                h = F::add(h, F::mulb(ce[1][s], d[2 * i]));
-                h = F::add(h, F::mulb(ce[2][s], d[2 * i + 1]));
-                for (int k = 0; k < F::DEG; k++) hcomp[k][s] = F::comp(h, k);
-            }
-        }
-    }
+    air.template divide<F>(ce, hcomp);
     for (int k = 0; k < F::DEG; k++) intt_coset(hcomp[k].data(), ceN, GEN, true);
     // split: coefficient i -> column i mod C (H(x) = sum_c x^c H_c(x^C); stark_verifier.cairo:166-176)
     std::vector<Col> cpolys(C * F::DEG, Col(n));   // index c*DEG + k
@@ -409,6 +371,21 @@ static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& 
         for (size_t i = 0; i < cc.ba.size(); i++) { f_flatten<F>(&cc.ba[i], 1, art->cons_coeffs); f_flatten<F>(&cc.bb[i], 1, art->cons_coeffs); }
     }
     return pr.to_bytes();
+}
+
+// FibAir(W) [+ auxiliary segment (A, R, D)] on a given trace: the public inputs are read off the trace's last row.
+template <class F>
+static Bytes prove_fib(const std::vector<Col>& trace, int log_n, const Options& opt, Col* pub_out,
+                       StageTimes* times = nullptr, ProverArtifacts<F>* art = nullptr, uint32_t A = 0, uint32_t R = 0, uint32_t D = 2) {
+    const uint32_t W = (uint32_t)trace.size();
+    const size_t n = (size_t)1 << log_n;
+    if (D < 2 || D > 8) throw Err("prove: aux constraint degree must be in [2, 8]");
+    if (W < 2 || (W & 1) || W > 254) throw Err("prove: FibAir needs an even column count in [2, 254]");
+    for (auto& c : trace) if (c.size() != n) throw Err("prove: ragged trace");
+    FibAir air; air.W = W; air.log_n = log_n; air.A = A; air.R = A ? R : 0; air.D = D;
+    for (uint32_t k = 0; k < W / 2; k++) air.results.push_back(trace[2 * k + 1][n - 1]);
+    if (pub_out) *pub_out = air.results;
+    return prove_model<F, FibAir>(air, trace, log_n, opt, times, art);
 }
 
 static Bytes prove_fib_any(const std::vector<Col>& trace, int log_n, const Options& opt, Col* pub_out, StageTimes* times = nullptr,

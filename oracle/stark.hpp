@@ -511,6 +511,7 @@ enum AirKind { AIR_OPAQUE = 0, AIR_FIB = 1 };
 // follow stark_verifier.cairo:117-130,266-294 (pinned by fib.bin, which has one aux segment); the constraint set itself
 // is restatement-defined.
 struct FibAir {
+    enum { KNOWN = 1 };                   // the verifier can run the OOD constraint check against this AIR
     uint32_t W; int log_n; Col results;   // results[k] = b_k(n-1)
     uint32_t A = 0, R = 0;                // aux columns / aux random elements (A > 0 requires R > 0)
     uint32_t D = 2;                       // degree of the aux transition constraint: p' = p * (r + main)^(D-1), D in [2, 8]
@@ -519,7 +520,25 @@ struct FibAir {
     size_t num_assertions() const { return W + W / 2 + A; }
     // constraint-evaluation blowup = number of composition columns = max(next_pow2(max constraint degree), 2)
     size_t ce_blowup() const { size_t d = A ? D : 1, e = 2; while (e < d) e <<= 1; return e; }
+    size_t num_columns() const { return 3; }   // numerator columns = distinct divisors: transition, step 0, step n-1
+    const Col& pub_elements() const { return results; }
     static Col seed(uint32_t k) { return Col{1 + 2 * (uint64_t)k, 2 + 2 * (uint64_t)k}; }
+    // the model interface shared with ProgramAir (oracle/air.hpp); bodies below fib_eval_point
+    template <class F> void build_aux(const std::vector<Col>& trace, const std::vector<typename F::T>& rands, std::vector<Col>& acols) const;
+    template <class F, class CC> void eval_row(const CC& cc, const uint64_t* cur, const uint64_t* nxt, const typename F::T* acur,
+                                               const typename F::T* anxt, const typename F::T* rands, uint64_t x, typename F::T* out) const;
+    template <class F> void divide(const std::vector<std::vector<typename F::T>>& ce, std::vector<Col>& hcomp) const;
+    template <class F, class CC> typename F::T ood_lhs(const CC& cc, const typename F::T* ood_cur, const typename F::T* ood_next,
+                                                       const typename F::T* rands, typename F::T z) const;
+};
+// An AIR whose constraint system is not available (the golden Miden proof): no coefficient draws, no OOD check.
+struct OpaqueAir {
+    enum { KNOWN = 0 };
+    uint32_t W = 0, A = 0, R = 0; int log_n = 0;
+    size_t num_transition() const { return 0; }
+    size_t num_assertions() const { return 0; }
+    size_t ce_blowup() const { return 0; }
+    template <class F, class CC> typename F::T ood_lhs(const CC&, const typename F::T*, const typename F::T*, const typename F::T*, typename F::T) const { return F::zero(); }
 };
 // Synthetic trace generator (column-major W x n). Pure function of (W, log_n).
 static std::vector<Col> fib_trace(uint32_t W, int log_n) {
@@ -604,6 +623,71 @@ static void fib_eval_point(const FibAir& air, const FibCombine& cb, const typena
     out[1] = g0; out[2] = g1;
 }
 
+// ---- FibAir as a model (the AIR-specific steps of the prover and the verifier's OOD check) ----------------------------------
+template <class F> void FibAir::build_aux(const std::vector<Col>& trace, const std::vector<typename F::T>& rands, std::vector<Col>& acols) const {
+    typedef typename F::T T;
+    const size_t n_ = n();
+#pragma omp parallel for schedule(dynamic, 1)
+    for (uint32_t c = 0; c < A; c++) {
+        T p = F::one();
+        for (size_t i = 0; i < n_; i++) {
+            for (int k = 0; k < F::DEG; k++) acols[c * F::DEG + k][i] = F::comp(p, k);
+            p = F::mul(p, f_pow<F>(F::add(rands[c % R], F::from(trace[c % W][i])), D - 1));
+        }
+    }
+}
+template <class F, class CC> void FibAir::eval_row(const CC& cc, const uint64_t* cur, const uint64_t* nxt, const typename F::T* acur,
+                                                    const typename F::T* anxt, const typename F::T* rands, uint64_t x, typename F::T* out) const {
+    FibCombine cb(*this);
+    fib_eval_point<F, FB>(*this, cb, cc, cur, nxt, x, out, acur, anxt, rands);
+}
+// `ConstraintEvaluationTable::into_poly`: divide each numerator column by its divisor on the constraint domain, sum -> H
+template <class F> void FibAir::divide(const std::vector<std::vector<typename F::T>>& ce, std::vector<Col>& hcomp) const {
+    typedef typename F::T T;
+    const size_t n_ = n(), C = ce_blowup(), ceN = C * n_;
+    const uint64_t g = gl_root_of_unity(log_n), gce = gl_root_of_unity(ilog2(ceN));
+    const uint64_t wl = gl_pow(g, n_ - 1);
+    // x^n takes only C distinct values on the ce domain: (7 w_ce^s)^n = 7^n * w_C^(s mod C)
+    Col zinv(C);
+    for (size_t k = 0; k < C; k++) zinv[k] = gl_inv(gl_sub(gl_mul(gl_pow(GEN, n_), gl_pow(gl_root_of_unity(ilog2(C)), k)), 1));
+    const size_t CH = 1024;
+#pragma omp parallel for schedule(static)
+    for (size_t c0 = 0; c0 < ceN; c0 += CH) {
+        size_t m = std::min(CH, ceN - c0);
+        // batch-invert (x - 1) and (x - w^(n-1)) for the chunk
+        Col d(2 * m), pre(2 * m);
+        uint64_t x = gl_mul(GEN, gl_pow(gce, c0));
+        Col xs(m);
+        for (size_t i = 0; i < m; i++) { xs[i] = x; d[2 * i] = gl_sub(x, 1); d[2 * i + 1] = gl_sub(x, wl); x = gl_mul(x, gce); }
+        uint64_t acc = 1;
+        for (size_t i = 0; i < 2 * m; i++) { pre[i] = acc; acc = gl_mul(acc, d[i]); }
+        uint64_t ia = gl_inv(acc);
+        for (size_t i = 2 * m; i-- > 0;) { uint64_t inv = gl_mul(ia, pre[i]); ia = gl_mul(ia, d[i]); d[i] = inv; }
+        for (size_t i = 0; i < m; i++) {
+            size_t s = c0 + i;
+            uint64_t tdiv = gl_mul(gl_sub(xs[i], wl), zinv[s % C]);    // 1 / ((x^n - 1)/(x - w^(n-1)))
+            T h = F::mulb(ce[0][s], tdiv);
+            h = F::add(h, F::mulb(ce[1][s], d[2 * i]));
+            h = F::add(h, F::mulb(ce[2][s], d[2 * i + 1]));
+            for (int k = 0; k < F::DEG; k++) hcomp[k][s] = F::comp(h, k);
+        }
+    }
+}
+// sum over the divisor groups of numerator(z) / divisor(z) at the out-of-domain point
+template <class F, class CC> typename F::T FibAir::ood_lhs(const CC& cc, const typename F::T* ood_cur, const typename F::T* ood_next,
+                                                            const typename F::T* rands, typename F::T z) const {
+    typedef typename F::T T;
+    FibCombine cb(*this);
+    T num[3];
+    fib_eval_point<F, F>(*this, cb, cc, ood_cur, ood_next, z, num, ood_cur + W, ood_next + W, rands);
+    const uint64_t g = gl_root_of_unity(log_n);
+    T zn = f_pow<F>(z, n()), wl = F::from(gl_pow(g, n() - 1));
+    T lhs = F::mul(num[0], F::mul(F::sub(z, wl), F::inv(F::sub(zn, F::one()))));
+    lhs = F::add(lhs, F::mul(num[1], F::inv(F::sub(z, F::one()))));
+    lhs = F::add(lhs, F::mul(num[2], F::inv(F::sub(z, wl))));
+    return lhs;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Verifier — stark_verifier.cairo:105-264 restated for any (W, aux, C, queries, fold, blowup) shape.
 struct VerifyInfo {   // transcript values exposed for the golden-vector tests
@@ -615,8 +699,8 @@ struct VerifyInfo {   // transcript values exposed for the golden-vector tests (
     std::vector<std::pair<int, int>> batch_shapes;   // (vectors, total digests) per batch proof
 };
 
-template <class F>
-static void verify_impl(const Proof& pr, const Col& pub_elements, AirKind kind, const FibAir* fib, VerifyInfo* info) {
+template <class F, class M>
+static void verify_impl(const Proof& pr, const Col& pub_elements, const M* air, VerifyInfo* info) {
     typedef typename F::T T;
     const size_t n = (size_t)1 << pr.log_n, B = pr.opt.blowup, N = n * B, Fd = pr.opt.fri_fold;
     const size_t W = pr.main_width, A = pr.aux_width, TW = W + A;
@@ -643,7 +727,7 @@ static void verify_impl(const Proof& pr, const Col& pub_elements, AirKind kind, 
     // constraint composition coefficients (air_instance.cairo:115-142). Draws never change the seed
     // (reseed resets the counter), so an opaque AIR may skip them.
     typename FibCombine::Coeffs<F> cc;
-    if (kind == AIR_FIB) cc = draw_constraint_coeffs<F>(coin, fib->num_transition(), fib->num_assertions());
+    if (M::KNOWN) cc = draw_constraint_coeffs<F>(coin, air->num_transition(), air->num_assertions());
     // 2. constraint commitment, z (stark_verifier.cairo:139-144)
     const Digest& croot = roots[ri++];
     coin.reseed(croot);
@@ -665,18 +749,12 @@ static void verify_impl(const Proof& pr, const Col& pub_elements, AirKind kind, 
     coin.reseed(f_hash<F>(ood_cur.data(), TW));
     coin.reseed(f_hash<F>(ood_next.data(), TW));
     coin.reseed(f_hash<F>(ood_h.data(), C));
-    if (kind == AIR_FIB) {
+    if (M::KNOWN) {
         // OOD consistency check (commented out in stark_verifier.cairo:151-159,183-187; winter-verifier does it):
         // sum_groups numerator(z)/divisor(z)  ==  sum_c z^c * H_c(z^C)     (reduce_evaluations, :296-304)
-        if (W != fib->W || A != fib->A || (A && (size_t)pr.aux_rands != fib->R) || C != fib->ce_blowup() || pr.log_n != fib->log_n)
-            throw Err("verify: proof shape does not match FibAir");
-        FibCombine cb(*fib);
-        T num[3];
-        fib_eval_point<F, F>(*fib, cb, cc, ood_cur.data(), ood_next.data(), z, num, ood_cur.data() + W, ood_next.data() + W, aux_rands.data());
-        T zn = f_pow<F>(z, n), wl = F::from(gl_pow(g, n - 1));
-        T lhs = F::mul(num[0], F::mul(F::sub(z, wl), F::inv(F::sub(zn, F::one()))));
-        lhs = F::add(lhs, F::mul(num[1], F::inv(F::sub(z, F::one()))));
-        lhs = F::add(lhs, F::mul(num[2], F::inv(F::sub(z, wl))));
+        if (W != air->W || A != air->A || (A && (size_t)pr.aux_rands != air->R) || C != air->ce_blowup() || pr.log_n != air->log_n)
+            throw Err("verify: proof shape does not match the AIR");
+        T lhs = air->template ood_lhs<F>(cc, ood_cur.data(), ood_next.data(), aux_rands.data(), z);
         T rhs = F::zero(), zp = F::one();
         for (size_t c = 0; c < C; c++) { rhs = F::add(rhs, F::mul(zp, ood_h[c])); zp = F::mul(zp, z); }
         if (!F::eq(lhs, rhs)) throw Err("verify: OOD constraint evaluations differ");
@@ -835,11 +913,16 @@ static void verify_impl(const Proof& pr, const Col& pub_elements, AirKind kind, 
     }
 }
 
-static void verify(const Bytes& proof_bytes, const Col& pub_elements, AirKind kind, const FibAir* fib, VerifyInfo* info = nullptr) {
+template <class M> static void verify_with(const Bytes& proof_bytes, const Col& pub_elements, const M* air, VerifyInfo* info = nullptr) {
     Proof pr = Proof::parse(proof_bytes.data(), proof_bytes.size());
-    if (pr.opt.field_ext == EXT_NONE) verify_impl<FB>(pr, pub_elements, kind, fib, info);
-    else if (pr.opt.field_ext == EXT_QUADRATIC) verify_impl<FQ>(pr, pub_elements, kind, fib, info);
+    if (pr.opt.field_ext == EXT_NONE) verify_impl<FB, M>(pr, pub_elements, air, info);
+    else if (pr.opt.field_ext == EXT_QUADRATIC) verify_impl<FQ, M>(pr, pub_elements, air, info);
     else throw Err("verify: unsupported field extension");
+}
+static void verify(const Bytes& proof_bytes, const Col& pub_elements, AirKind kind, const FibAir* fib, VerifyInfo* info = nullptr) {
+    OpaqueAir opaque;
+    if (kind == AIR_FIB) verify_with<FibAir>(proof_bytes, pub_elements, fib, info);
+    else verify_with<OpaqueAir>(proof_bytes, pub_elements, &opaque, info);
 }
 
 }  // namespace orc

@@ -18,7 +18,7 @@ u64p = C.POINTER(C.c_uint64)
 
 
 def build(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("capi.cpp", "stark.hpp", "prover.hpp", "gl.hpp", "blake2s.hpp")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("capi.cpp", "stark.hpp", "prover.hpp", "air.hpp", "gl.hpp", "blake2s.hpp")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return LIB_PATH
@@ -250,6 +250,48 @@ class Oracle:
         p = np.ascontiguousarray(pub, np.uint64)
         self._ck(self.lib.orc_verify_fib_aux(_p8(buf), C.c_size_t(len(proof)), _p64(p), C.c_size_t(p.size), C.c_uint32(W),
                                              C.c_int(log_n), C.c_uint32(A), C.c_uint32(R), C.c_uint32(D)))
+
+    # ---- AIR-as-data (oracle/air.hpp)
+    def prove_air(self, program: bytes, trace, pub, opt7, keep_artifacts=False):
+        """Prove `trace` (W, n) against an AEROAIR program with public inputs `pub`. Returns (proof_bytes, times)."""
+        tr = np.ascontiguousarray(trace, np.uint64)
+        W, n = tr.shape
+        pg = np.frombuffer(program, np.uint8)
+        pb = np.array(pub, dtype=np.uint64, ndmin=1) if len(pub) else np.zeros(1, np.uint64)
+        o = (C.c_uint8 * 7)(*opt7)
+        proof = u8p(); plen = C.c_size_t(0)
+        times = np.zeros(12, np.float64)
+        self._ck(self.lib.orc_prove_air(_p8(pg), C.c_size_t(len(program)), _p64(tr), C.c_uint32(W), C.c_int(int(n).bit_length() - 1), _p64(pb),
+                                        C.c_size_t(len(pub)), o, C.byref(proof), C.byref(plen), times.ctypes.data_as(C.POINTER(C.c_double)),
+                                        C.c_int(1 if keep_artifacts else 0)))
+        data = C.string_at(proof, plen.value)
+        self.lib.orc_free(proof)
+        names = ["interpolate", "lde", "trace_commit", "constraints", "composition", "comp_commit", "ood", "deep", "fri",
+                 "grind", "queries", "total"]
+        return data, dict(zip(names, times.tolist()))
+
+    def verify_air(self, proof: bytes, program: bytes, pub, log_n):
+        """Full verification incl. the OOD constraint check evaluated from the program; raises when rejected."""
+        buf = np.frombuffer(proof, np.uint8)
+        pg = np.frombuffer(program, np.uint8)
+        pb = np.array(pub, dtype=np.uint64, ndmin=1) if len(pub) else np.zeros(1, np.uint64)
+        self._ck(self.lib.orc_verify_air(_p8(buf), C.c_size_t(len(proof)), _p8(pg), C.c_size_t(len(program)), _p64(pb), C.c_size_t(len(pub)),
+                                         C.c_int(log_n)))
+
+    def air_info(self, program: bytes, log_n):
+        pg = np.frombuffer(program, np.uint8)
+        out = (C.c_uint64 * 8)()
+        self._ck(self.lib.orc_air_info(_p8(pg), C.c_size_t(len(program)), C.c_int(log_n), out))
+        keys = ["ce_blowup", "columns", "transition", "assertions", "main_width", "aux_width", "aux_rands", "nodes"]
+        return dict(zip(keys, list(out)))
+
+    def air_check_trace(self, program: bytes, trace, pub):
+        tr = np.ascontiguousarray(trace, np.uint64)
+        W, n = tr.shape
+        pg = np.frombuffer(program, np.uint8)
+        pb = np.array(pub, dtype=np.uint64, ndmin=1) if len(pub) else np.zeros(1, np.uint64)
+        self._ck(self.lib.orc_air_check_trace(_p8(pg), C.c_size_t(len(program)), _p64(tr), C.c_uint32(W), C.c_int(int(n).bit_length() - 1),
+                                              _p64(pb), C.c_size_t(len(pub))))
 
     def artifact(self, name: str, count: int) -> np.ndarray:
         out = np.zeros(count, np.uint64)

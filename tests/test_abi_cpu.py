@@ -20,7 +20,9 @@ def lib():
 
 
 def declared_symbols():
-    text = open(aero_amd.HEADER).read()
+    import os
+    inc = os.path.dirname(aero_amd.HEADER)
+    text = open(aero_amd.HEADER).read() + open(os.path.join(inc, "aero_air.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(aero_[a-z0-9_]+)\s*\(", text)))
 

@@ -1,0 +1,106 @@
+"""AIR-as-data without a GPU: the oracle's program evaluator against the oracle's hard-wired FibAir (byte-identical proofs), the
+library's host side (parser / validator / compiler, and the verifier that runs the COMPILED program over E for the
+out-of-domain check) against proofs the oracle produced. Format: include/aero_air.h; reference seam:
+aero-sdk/miden-wasm/src/constraints_worker.rs:32-59."""
+import numpy as np
+import pytest
+
+import aero_amd
+from aero_amd import air as A
+from tests import air_examples as ex
+
+
+@pytest.mark.parametrize("width,log_n,aux,opt", [
+    (2, 6, (0, 0, 2), [8, 8, 4, 4, 1, 8, 5]),
+    (4, 7, (3, 2, 2), [8, 8, 4, 4, 1, 4, 5]),
+    (2, 6, (2, 3, 5), [8, 8, 4, 4, 2, 8, 5]),
+    (6, 8, (9, 16, 8), [10, 8, 8, 4, 1, 4, 6]),
+    (2, 5, (1, 1, 3), [6, 4, 0, 4, 2, 2, 4]),
+])
+def test_oracle_program_evaluator_reproduces_the_hard_wired_fibair(oracle, width, log_n, aux, opt):
+    trace = oracle.fib_trace(width, log_n)
+    want, pub, _ = oracle.prove_fib_aux(width, log_n, aux[0], aux[1], opt, D=aux[2]) if aux[0] else oracle.prove_fib(width, log_n, opt)
+    for program in (A.fib_air(width, aux).to_bytes(), aero_amd.fib_program(width, aux)):
+        got, _ = oracle.prove_air(program, trace, pub, opt)
+        assert got == want
+        oracle.verify_air(got, program, pub, log_n)
+        air = aero_amd.Air(program)
+        aero_amd.verify_air(got, pub, air, min_query_security_bits=0)       # the library's verifier: compiled program on the host
+        aero_amd.verify_fib(got, pub, aux, min_query_security_bits=0)       # and its hard-wired FibAir check
+
+
+@pytest.mark.parametrize("log_n,pairs,aux,opt", [
+    (5, 1, 0, [6, 8, 0, 4, 1, 2, 4]),
+    (6, 2, 3, [8, 8, 4, 4, 1, 4, 5]),
+    (7, 2, 4, [8, 8, 4, 4, 2, 8, 5]),
+    (8, 13, 9, [10, 16, 4, 4, 1, 4, 6]),
+])
+def test_vm_shaped_program_oracle_and_library_verifier(oracle, log_n, pairs, aux, opt):
+    b, trace, pub = ex.synth_vm(log_n, pairs, aux)
+    program = b.to_bytes()
+    oracle.air_check_trace(program, trace, pub)
+    proof, _ = oracle.prove_air(program, trace, pub, opt)
+    oracle.verify_air(proof, program, pub, log_n)
+    air = aero_amd.Air(program)
+    info = air.info()
+    assert info["ce_blowup"] == 8 and info["main_transition"] == 24 + 2 * pairs and info["aux_transition"] == aux
+    assert air.num_divisors(log_n) == oracle.air_info(program, log_n)["columns"] == 8
+    assert info["registers_base"] + info["registers_ext"] <= 8            # register allocation, not one slot per node
+    aero_amd.verify_air(proof, pub, air, min_query_security_bits=0, expected_log_n=log_n)
+    # a trace that breaks one constraint: both verifiers refuse the proof the (non-validating) prover makes of it
+    bad = trace.copy()
+    bad[7][3] ^= 1
+    with pytest.raises(RuntimeError):
+        oracle.air_check_trace(program, bad, pub)
+    forged, _ = oracle.prove_air(program, bad, pub, opt)
+    with pytest.raises(RuntimeError):
+        oracle.verify_air(forged, program, pub, log_n)
+    with pytest.raises(aero_amd.AeroError) as e:
+        aero_amd.verify_air(forged, pub, air, min_query_security_bits=0)
+    assert e.value.code == -7
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.verify_air(proof, pub, air, min_query_security_bits=0, expected_log_n=log_n + 1)
+
+
+def test_conjectured_security_policy(oracle):
+    # 41 field bits over the base field at 2^20 x 8 ... here 2^6 x 8: 64 - 9 = 55 field bits; the quadratic extension has 119
+    for ext, ok in ((1, False), (2, True)):
+        opt = [27, 8, 16, 4, ext, 8, 5]
+        proof, pub, _ = oracle.prove_fib(2, 6, opt)
+        q, f = aero_amd.proof_security_bits(proof)
+        assert q == 97 and f == 64 * ext - 9
+        aero_amd.verify_fib(proof, pub, (0, 0, 2))                                              # query term alone: 97 >= 96
+        if ok:
+            aero_amd.verify_fib(proof, pub, (0, 0, 2), min_conjectured_security_bits=96)
+        else:
+            with pytest.raises(aero_amd.AeroError) as e:
+                aero_amd.verify_fib(proof, pub, (0, 0, 2), min_conjectured_security_bits=96)
+            assert e.value.code == -7 and "field bits" in str(e.value)
+
+
+def test_malformed_programs_are_refused_on_the_host():
+    good = A.fib_air(2).to_bytes()
+    aero_amd.Air(good)
+    cases = {
+        "magic": b"AEROAIX\x01" + good[8:],
+        "truncated": good[:-3],
+        "trailing": good + b"\0",
+        "opcode": None,
+    }
+    b = A.AirBuilder(2)
+    b.transition(b.main_next(0) - b.main(1), 1)
+    raw = bytearray(b.to_bytes())
+    raw[8 + 64] = 9                       # first node's opcode (no constants, no periodic columns in front of it)
+    cases["opcode"] = bytes(raw)
+    bb = A.AirBuilder(2, 1, 1)
+    bb.transition(bb.main_next(0) - bb.rand(0), 1)        # a main constraint reading a random element
+    bb.aux_transition(bb.aux_next(0) - bb.aux(0), 1)
+    cases["main constraint over E"] = bb.to_bytes()
+    b3 = A.AirBuilder(1)
+    b3.transition(b3.main_next(0) - b3.main(0), 1)
+    b3.main_asserts.append((0, 0, 0, b3.main(0).ref))     # an assertion whose value depends on the trace
+    cases["row-dependent assertion"] = b3.to_bytes()
+    for name, data in cases.items():
+        with pytest.raises(aero_amd.AeroError) as e:
+            aero_amd.Air(data)
+        assert e.value.code == -1, name

@@ -490,19 +490,6 @@ def test_worker_message_layouts():
     assert (fi, fn) == (4, 8) and cols.tolist() == [[10, 11], [20, 21], [30, 31]]
 
 
-def test_proof_submission_request_of_the_golden_proof(golden_dir):
-    """service.proto:16-21: the request of ProofSubmissionService.SubmitProof; MIDEN / STARKNET are the zero values (not written)."""
-    msgs = sdk_messages()
-    inputs, proof = golden(golden_dir)
-    data = aero_amd.proof_submission_request(proof, inputs)
-    req = msgs["ProofSubmissionRequest"]()
-    req.ParseFromString(data)
-    assert req.SerializeToString(deterministic=True) == data
-    assert req.proof.SerializeToString(deterministic=True) == aero_amd.proof_to_protobuf(proof)
-    assert req.public_inputs.SerializeToString(deterministic=True) == aero_amd.miden_public_inputs_to_protobuf(inputs)
-    assert req.source_proof_system == 0 and req.target_chain == 0
-
-
 def test_stark_parser_command_line_is_the_reference_cli(golden_dir):
     """bin/stark_parser (aero_amd/csrc/stark_parser.cpp): the command line the Cairo side's hints call (src/stark_verifier/utils.py:33-41,
     tests/integration/utils.py:5-24: [parser, path, command, indexes]) - same sub-commands, the JSON array + the newline println! adds."""

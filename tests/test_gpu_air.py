@@ -1,0 +1,202 @@
+"""AIR-as-data on the GPU (include/aero_air.h): a constraint program interpreted per row by the device replaces the hard-wired
+FibAir kernel. Reference seam: `ProcessorAir::new` -> `ConstraintEvaluator::new` -> `evaluate_fragment`
+(aero-sdk/miden-wasm/src/constraints_worker.rs:32-59, proving_worker.rs:374-437).
+
+Parity (bit-exact, through the C ABI):
+  (a) FibAir and the stand-in AIR re-expressed as programs give the SAME proof bytes as the hard-wired kernels and as the oracle,
+      both fields, 2^5 ... 2^20 rows;
+  (b) a VM-shaped synthetic AIR (periodic columns, >= 8 degree groups up to degree 8, interior and periodic assertions, two
+      exemptions, auxiliary running products with denominators; > 49 transition constraints) is GPU == oracle bytes and accepted
+      by both verifiers with the out-of-domain constraint check;
+  (c) the stage entry points (numerator fragments, auxiliary columns, composition polynomial) against the oracle's intermediates."""
+import numpy as np
+import pytest
+
+import aero_amd
+from aero_amd import air as A
+from tests import air_examples as ex
+
+pytestmark = pytest.mark.gpu
+
+OPT = [27, 8, 16, 4, 1, 8, 8]
+
+
+def options(o):
+    return aero_amd.ProofOptions(*o)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = aero_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("width,log_n,aux,opt", [
+    (2, 5, (0, 0, 2), [6, 4, 0, 4, 1, 2, 3]),
+    (2, 10, (0, 0, 2), OPT),
+    (2, 10, (0, 0, 2), [27, 8, 16, 4, 2, 8, 8]),
+    (8, 12, (3, 4, 2), [27, 8, 8, 4, 1, 4, 7]),
+    (4, 11, (2, 3, 3), [20, 8, 8, 4, 2, 8, 6]),
+    (6, 10, (9, 16, 8), [27, 8, 8, 4, 1, 4, 7]),
+    (72, 10, (9, 16, 8), [27, 8, 16, 4, 1, 4, 8]),
+    (4, 13, (2, 2, 5), [27, 16, 8, 4, 2, 2, 6]),
+    (2, 16, (0, 0, 2), OPT),
+    (2, 15, (1, 1, 2), [27, 8, 16, 4, 2, 8, 8]),
+])
+def test_fibair_as_program_gives_the_hard_wired_bytes(ctx, oracle, width, log_n, aux, opt):
+    trace = aero_amd.fib_trace(width, log_n)
+    dev = ctx.trace_upload(trace)
+    want, pub = ctx.prove_fib_aux(dev, aux[0], aux[1], options(opt), aux_degree=aux[2])
+    ref, ref_pub, _ = oracle.prove_fib_aux(width, log_n, aux[0], aux[1], opt, D=aux[2]) if aux[0] else oracle.prove_fib(width, log_n, opt)
+    assert pub == ref_pub and want == ref
+    for program in (aero_amd.fib_program(width, aux), A.fib_air(width, aux).to_bytes()):      # the library's emitter and the Python builder
+        air = aero_amd.Air(program)
+        got = ctx.prove_air(air, dev, pub, options(opt))
+        assert got == want
+        assert ctx.prove_air(air, trace, pub, options(opt)) == want                           # trace handed over in host memory
+        aero_amd.verify_air(got, pub, air, min_query_security_bits=0)
+
+
+@pytest.mark.parametrize("ext", [1, 2])
+def test_fibair_program_at_full_size(ctx, ext):
+    # BASELINE config 2 / 3 shape: 2^20 x 2; the program path against the hard-wired kernels (which are pinned to the oracle
+    # at this size in test_gpu_parity.py / test_gpu_full_configs.py)
+    opt = [27, 8, 16, 4, ext, 8, 8]
+    dev = ctx.trace_upload(aero_amd.fib_trace(2, 20))
+    want, pub = ctx.prove_fib(dev, options(opt))
+    assert ctx.prove_air(aero_amd.Air(aero_amd.fib_program(2)), dev, pub, options(opt)) == want
+
+
+@pytest.mark.parametrize("log_n,pairs,aux,opt", [
+    (5, 1, 0, [6, 8, 0, 4, 1, 2, 4]),
+    (8, 2, 3, [27, 8, 8, 4, 1, 8, 6]),
+    (10, 13, 9, [27, 8, 8, 4, 1, 4, 7]),          # 50 main + 9 aux transition constraints
+    (9, 4, 4, [20, 8, 8, 4, 2, 8, 6]),            # quadratic extension
+    (11, 26, 9, [27, 8, 16, 4, 1, 4, 8]),         # 72 + 9 columns: Miden's shape, fold 4
+    (12, 2, 2, [27, 16, 8, 4, 2, 4, 6]),          # blowup 16 > constraint blowup 8
+    (14, 3, 5, [27, 8, 16, 4, 1, 8, 8]),
+])
+def test_vm_shaped_program_matches_the_oracle(ctx, oracle, log_n, pairs, aux, opt):
+    b, trace, pub = ex.synth_vm(log_n, pairs, aux)
+    program = b.to_bytes()
+    oracle.air_check_trace(program, trace, pub)
+    air = aero_amd.Air(program)
+    info = air.info()
+    assert info["ce_blowup"] == 8 and info["main_transition"] == 24 + 2 * pairs and info["aux_transition"] == aux
+    want, _ = oracle.prove_air(program, trace, pub, opt)
+    got = ctx.prove_air(air, ctx.trace_upload(trace), pub, options(opt))
+    assert got == want
+    assert ctx.prove_air(air, trace, pub, options(opt)) == want
+    oracle.verify_air(got, program, pub, log_n)
+    aero_amd.verify_air(got, pub, air, min_query_security_bits=0, expected_log_n=log_n)
+    with pytest.raises(aero_amd.AeroError):                       # another statement
+        aero_amd.verify_air(got, [pub[0] ^ 1] + pub[1:], air, min_query_security_bits=0)
+
+
+def test_a_trace_that_violates_the_program_does_not_verify(ctx, oracle):
+    b, trace, pub = ex.synth_vm(8, 2, 3)
+    air = aero_amd.Air(b.to_bytes())
+    bad = trace.copy()
+    bad[7][100] ^= 1
+    proof = ctx.prove_air(air, bad, pub, options([27, 8, 8, 4, 1, 8, 6]))       # the prover does not validate the trace (release-mode winterfell neither)
+    with pytest.raises(aero_amd.AeroError) as e:
+        aero_amd.verify_air(proof, pub, air, min_query_security_bits=0)
+    assert e.value.code == -7
+    with pytest.raises(RuntimeError):
+        oracle.verify_air(proof, b.to_bytes(), pub, 8)
+
+
+def test_smallest_program_and_a_degree_nine_constraint(ctx, oracle):
+    b, trace, pub = ex.tiny_no_assertion_groups(6)
+    opt = [8, 4, 0, 4, 1, 2, 3]
+    want, _ = oracle.prove_air(b.to_bytes(), trace, pub, opt)
+    assert ctx.prove_air(aero_amd.Air(b.to_bytes()), trace, pub, options(opt)) == want
+    # degree 8 gated by a periodic selector: base 8 + 1 cycle = 9 -> constraint-evaluation blowup 16 (needs blowup >= 16)
+    n = 1 << 7
+    bb = A.AirBuilder(2, num_pub=1)
+    sel = bb.periodic([1, 0, 1, 1])
+    bb.transition(bb.main_next(0) - (sel * bb.main(0) ** 8 + (1 - sel) * (bb.main(0) + bb.main(1))), 8, cycles=[4])
+    bb.transition(bb.main_next(1) - bb.main(1) - 3, 1)
+    bb.assert_single(0, 0, 7)
+    bb.assert_single(1, 0, 1)
+    bb.assert_single(0, -1, bb.pub(0))
+    c0, c1 = [7], [1]
+    for i in range(n - 1):
+        c0.append(pow(c0[i], 8, A.P) if [1, 0, 1, 1][i % 4] else (c0[i] + c1[i]) % A.P)
+        c1.append((c1[i] + 3) % A.P)
+    tr = np.array([c0, c1], dtype=np.uint64)
+    air = aero_amd.Air(bb.to_bytes())
+    assert air.info()["ce_blowup"] == 16
+    opt = [27, 16, 8, 4, 1, 4, 6]
+    want, _ = oracle.prove_air(bb.to_bytes(), tr, [c0[-1]], opt)
+    got = ctx.prove_air(air, tr, [c0[-1]], options(opt))
+    assert got == want
+    aero_amd.verify_air(got, [c0[-1]], air, min_query_security_bits=0)
+    with pytest.raises(aero_amd.AeroError):      # blowup 8 < constraint blowup 16
+        ctx.prove_air(air, tr, [c0[-1]], options([27, 8, 8, 4, 1, 4, 6]))
+
+
+@pytest.mark.parametrize("ext,nfrag", [(1, 1), (1, 8), (2, 4)])
+def test_stage_entry_points_against_the_oracle_intermediates(ctx, oracle, ext, nfrag):
+    log_n, pairs, aux = 9, 3, 4
+    deg = 2 if ext == 2 else 1
+    opt = [27, 8, 8, 4, ext, 8, 6]
+    b, trace, pub = ex.synth_vm(log_n, pairs, aux)
+    program = b.to_bytes()
+    air = aero_amd.Air(program)
+    n, W = 1 << log_n, trace.shape[0]
+    ncols, C = air.num_divisors(log_n), air.info()["ce_blowup"]
+    oracle.prove_air(program, trace, pub, opt, keep_artifacts=True)
+    nt, na = air.info()["main_transition"] + air.info()["aux_transition"], air.info()["main_assertions"] + air.info()["aux_assertions"]
+    coeffs = oracle.artifact("cons_coeffs", 2 * deg * (nt + na))
+    rands = oracle.artifact("aux_rands", deg * 4)
+    dev = ctx.trace_upload(trace)
+    # build_aux_segment
+    auxm = ctx.aux_columns_program(air, dev, pub, rands, ext)
+    assert (auxm.download() == oracle.artifact("aux_cols", aux * deg * n).reshape(aux * deg, n)).all()
+    lde = ctx.evaluate_columns_over(ctx.interpolate_columns(dev), 3)
+    alde = ctx.evaluate_columns_over(ctx.interpolate_columns(auxm), 3)
+    # evaluate_fragment: numerator columns, stitched from `nfrag` fragments
+    want = oracle.artifact("ce_cols", ncols * deg * C * n).reshape(ncols * deg, C * n)
+    got = np.zeros_like(want)
+    for k in range(nfrag):
+        fi, cols = ctx.eval_constraints_program(air, lde, alde, 3, pub, rands, coeffs, ext, k, nfrag)
+        assert fi == k * (C * n // nfrag)
+        got[:, fi:fi + cols.shape[1]] = cols
+    assert (got == want).all()
+    # ConstraintEvaluationTable::into_poly -> composition columns, then their LDE
+    polys = ctx.composition_poly_program(air, want, log_n, ext)
+    clde = ctx.evaluate_columns_over(polys, 3).download()
+    ref = oracle.artifact("comp_lde", C * deg * 8 * n).reshape(C * deg, 8 * n)            # column c * deg + d
+    for d in range(deg):
+        for q in range(C):
+            c = int(format(q, "03b")[::-1], 2)                                         # chunk q = composition column bitrev(q)
+            assert (clde[d * C + q] == ref[c * deg + d]).all()
+
+
+def test_constraint_worker_message_with_a_program(ctx, oracle):
+    from aero_amd import messages
+    log_n, pairs, aux = 8, 2, 3
+    opt = [27, 8, 8, 4, 1, 8, 6]
+    b, trace, pub = ex.synth_vm(log_n, pairs, aux)
+    air = aero_amd.Air(b.to_bytes())
+    n = 1 << log_n
+    ncols, C = air.num_divisors(log_n), 8
+    oracle.prove_air(b.to_bytes(), trace, pub, opt, keep_artifacts=True)
+    info = air.info()
+    nt, na = info["main_transition"] + info["aux_transition"], info["main_assertions"] + info["aux_assertions"]
+    coeffs = oracle.artifact("cons_coeffs", 2 * (nt + na)).reshape(-1, 2)
+    rands = oracle.artifact("aux_rands", 4)
+    want = oracle.artifact("ce_cols", ncols * C * n).reshape(ncols, C * n)
+    dev = ctx.trace_upload(trace)
+    lde = ctx.evaluate_columns_over(ctx.interpolate_columns(dev), 3).download()
+    alde = ctx.evaluate_columns_over(ctx.interpolate_columns(ctx.aux_columns_program(air, dev, pub, rands, 1)), 3).download()
+    pub_bytes = messages.miden_public_inputs([1, 2, 3, 4], [0, 1], [5])
+    got = np.zeros_like(want)
+    for k in range(4):
+        item = messages.encode_constraint_work_item((trace.shape[0], aux, 4), n, pub_bytes, opt, [rands], coeffs[:nt], coeffs[nt:], list(lde), [list(alde)], 8, k, 4)
+        fi, fn, cols = messages.decode_constraint_result(ctx.worker_eval_constraints(item, air, pub))
+        assert fn == 4 and cols.shape == (ncols, C * n // 4)
+        got[:, fi:fi + cols.shape[1]] = cols
+    assert (got == want).all()

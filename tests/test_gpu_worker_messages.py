@@ -88,11 +88,12 @@ def test_constraint_worker_matches_the_oracle_fragments(ctx, oracle, log_n, widt
         aux_segments = [list(ctx.evaluate_columns_over(ctx.interpolate_columns(aux), 3).download())]
     pub_bytes = messages.miden_public_inputs([1, 2, 3, 4], [0, 1], pub)
     nt = width + A
+    program = aero_amd.Air(aero_amd.fib_program(width, (A, R, D)))     # the AIR travels as a program: the message names none
     got = np.zeros_like(want)
     for k in range(nfrag):
         item = messages.encode_constraint_work_item((width, A, R), n, pub_bytes, opt, [rands] if A else [], coeffs[:nt], coeffs[nt:], list(lde),
                                                     aux_segments, 8, k, nfrag)
-        fi, fn, cols = messages.decode_constraint_result(ctx.worker_eval_constraints(item, (A, R, D) if A else None))
+        fi, fn, cols = messages.decode_constraint_result(ctx.worker_eval_constraints(item, program, pub))
         assert fn == nfrag and fi == k * (Cc * n // nfrag) and cols.shape == (3, Cc * n // nfrag)
         got[:, fi:fi + cols.shape[1]] = cols
     assert (got == want).all()
@@ -113,12 +114,20 @@ def test_constraint_worker_rejects_inconsistent_items(ctx, oracle):
         a.update(kw)
         return messages.encode_constraint_work_item(**a)
 
-    ok = ctx.worker_eval_constraints(item())
+    program = aero_amd.Air(aero_amd.fib_program(width))
+    ok = ctx.worker_eval_constraints(item(), program, pub)
     assert messages.decode_constraint_result(ok)[2].shape == (3, n)
     bads = [item(blowup=4), item(layout=(4, 0, 0)), item(trace_len=2 * n), item(transition=coeffs[:1]), item(fragment_offset=2),
-            item(num_fragments=3), item(public_inputs=messages.miden_public_inputs([1, 2, 3, 4], [0, 1], [])), item(main_cols=lde[:1]),
+            item(num_fragments=3), item(main_cols=lde[:1]),
             item(options=[27, 8, 16, 4, 2, 8, 5]), item(layout=(width, 1, 1)), item()[:-5], item() + b"\1"]
     for bad in bads:
         with pytest.raises(aero_amd.AeroError):
-            ctx.worker_eval_constraints(bad)
-    assert ctx.worker_eval_constraints(item()) == ok
+            ctx.worker_eval_constraints(bad, program, pub)
+    # public inputs taken from the message: the program reads 1 element, Miden's PublicInputs carry 4 + 2 + len(outputs) of them
+    with pytest.raises(aero_amd.AeroError) as e:
+        ctx.worker_eval_constraints(item(), program)
+    assert e.value.code == -1
+    with pytest.raises(aero_amd.AeroError) as e:       # malformed public inputs are a bad argument, not a verification failure
+        ctx.worker_eval_constraints(item(public_inputs=b"\1\2\3"), program)
+    assert e.value.code == -1
+    assert ctx.worker_eval_constraints(item(), program, pub) == ok
