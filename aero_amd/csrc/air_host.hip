@@ -26,11 +26,49 @@ PeriodicTables periodic_tables(const Program& p, uint64_t n, uint64_t rows, uint
     if (t.tab.empty()) { t.tab.push_back(0); t.off.push_back(0); t.mask.push_back(0); }
     return t;
 }
-std::vector<Insn> padded(const std::vector<Insn>& code) {
-    std::vector<Insn> c = code;
-    c.push_back(Insn{OP_END, 0, 0, 0});      // the interpreter reads one instruction ahead
-    c.push_back(Insn{OP_END, 0, 0, 0});
-    return c;
+// The per-proof pool (u64 words): scalar operands | (alpha, beta') per transition constraint | (alpha, beta') per assertion |
+// LOAD descriptors | one spare block; and the code with every instruction's position in it written into `poff`.
+template <class F> struct Pool {
+    std::vector<uint64_t> words;
+    std::vector<Insn> code;
+};
+template <class F>
+Pool<F> build_pool(const Program& p, const std::vector<Insn>& code, const std::vector<uint32_t>& desc, const Scalars<F>& sc, const PeriodicTables& pt,
+                   const std::vector<typename F::T>& ta, const std::vector<typename F::T>& tb, const std::vector<typename F::T>& ba,
+                   const std::vector<typename F::T>& bb, const std::vector<uint32_t>& mem_group) {
+    Pool<F> pool;
+    auto& w = pool.words;
+    auto put = [&](typename F::T v) { for (int d = 0; d < F::DEG; d++) w.push_back(F::comp(v, d)); };
+    const uint32_t oSB = 0;
+    w.insert(w.end(), sc.b.begin(), sc.b.end());
+    const uint32_t oSE = (uint32_t)w.size();
+    for (auto& v : sc.e) put(v);
+    const uint32_t oT = (uint32_t)w.size();
+    for (size_t k = 0; k < ta.size(); k++) { put(ta[k]); put(tb[k]); }
+    const uint32_t oB = (uint32_t)w.size();
+    for (size_t m = 0; m < ba.size(); m++) { put(ba[m]); put(bb[m]); }
+    const uint32_t oD = (uint32_t)w.size();
+    for (uint32_t d : desc) {
+        const bool next = d >> 31, periodic = (d >> 30) & 1;
+        const uint32_t slot = (d >> 16) & 0xfff, col = d & 0xffff;
+        if (periodic) { int lg = 0; while ((1u << lg) <= pt.mask[col]) lg++; w.push_back(air_dev_desc(false, true, slot, pt.off[col], (uint32_t)lg)); }
+        else w.push_back(air_dev_desc(next, false, slot, col, 0));
+    }
+    for (int i = 0; i < 8; i++) w.push_back(0);
+    if (w.size() >= (1ull << 31)) fail("air program: scalar pool too large", ST_UNSUPPORTED);
+    pool.code = code;
+    for (Insn& I : pool.code) {
+        switch (I.pk) {
+            case PK_SCAL_B: I.poff = oSB + I.pi; break;
+            case PK_SCAL_E: I.poff = oSE + I.pi * F::DEG; break;
+            case PK_TCOEF: I.poff = oT + I.pi * 2 * F::DEG; if ((I.op & 0xff) == OP_EMIT3_B) I.dst = I.pad; break;      // device: dst = third register
+            case PK_BCOEF: I.poff = oB + I.pi * 2 * F::DEG; I.dst = mem_group[I.pi]; break;
+            case PK_DESC: I.poff = oD + I.pi; break;
+            default: I.poff = 0;
+        }
+    }
+    for (int i = 0; i < 3; i++) pool.code.push_back(Insn{OP_END, 0, 0, 0, 0, PK_NONE, 0, 0});      // the interpreter fetches two instructions ahead
+    return pool;
 }
 struct DivisorTables {
     std::vector<AirBGroupDev> groups;
@@ -45,7 +83,7 @@ DivisorTables divisor_tables(const Program& p, const Instance& in, uint64_t rows
     const uint64_t g = gl::root_of_unity(in.log_n);
     for (uint32_t i = 1; i <= p.exemptions; i++) d.exempt.push_back(gl::pow(g, n - i));
     for (auto& bg : in.bgroups)
-        d.groups.push_back(AirBGroupDev{bg.a & (rows - 1), gl::pow(h, bg.a), bg.b, bg.adj & (rows - 1), bg.m0, bg.count});
+        d.groups.push_back(AirBGroupDev{bg.a & (rows - 1), gl::pow(h, bg.a), bg.b, bg.adj & (rows - 1)});
     if (d.groups.empty()) d.groups.push_back(AirBGroupDev{});
     return d;
 }
@@ -61,45 +99,46 @@ void air_eval_constraints(Context* ctx, const Program& p, const Instance& in, co
     const uint64_t rows = g.rows, h = g.offset;
     const Scalars<F> sc = fold_scalars<F>(p, pub, rands);
     // offset^adj goes into the beta coefficients; the device multiplies by w^(s adj) from the twiddle table
-    std::vector<T> tb(cc.tb), bb(cc.bb);
+    std::vector<T> tb(cc.tb);
     std::vector<uint64_t> dg_exp;
     {
         std::vector<uint64_t> hadj;
         for (uint64_t adj : in.dgroup_adj) { hadj.push_back(gl::pow(h, adj)); dg_exp.push_back(adj & (rows - 1)); }
         for (size_t k = 0; k < tb.size(); k++) tb[k] = F::mulb(tb[k], hadj[p.trans[k].group]);
-        for (auto& bg : in.bgroups) {
-            const uint64_t ha = gl::pow(h, bg.adj);
-            for (uint32_t m = bg.m0; m < bg.m0 + bg.count; m++) bb[in.members[m].coef] = F::mulb(bb[in.members[m].coef], ha);
+    }
+    // assertions by member id; their constant parts sum alpha value, sum beta' value per divisor group
+    const size_t nm = in.members.size(), ng = in.bgroups.size();
+    std::vector<T> ba(nm ? nm : 1, F::zero()), bb(nm ? nm : 1, F::zero()), gA(ng ? ng : 1, F::zero()), gB(ng ? ng : 1, F::zero());
+    std::vector<uint32_t> mem_group(nm ? nm : 1, 0);
+    {
+        std::vector<uint64_t> hadj;
+        for (auto& bg : in.bgroups) hadj.push_back(gl::pow(h, bg.adj));
+        for (size_t m = 0; m < nm; m++) {
+            const BoundaryMember& bm = in.members[m];
+            ba[m] = cc.ba[bm.coef];
+            bb[m] = F::mulb(cc.bb[bm.coef], hadj[bm.group]);
+            mem_group[m] = bm.group;
+            const T val = bm.val_ext ? sc.e[bm.val_idx] : F::from(sc.b[bm.val_idx]);
+            gA[bm.group] = F::add(gA[bm.group], F::mul(ba[m], val));
+            gB[bm.group] = F::add(gB[bm.group], F::mul(bb[m], val));
         }
     }
     const PeriodicTables pt = periodic_tables(p, in.n, rows, h);
     const DivisorTables dv = divisor_tables(p, in, rows, h);
-    const std::vector<Insn> code = padded(p.cons_code);
-    std::vector<BoundaryMember> members = in.members;
-    if (members.empty()) members.push_back(BoundaryMember{});
-    std::vector<uint64_t> scb = sc.b;
-    std::vector<T> sce = sc.e;
-    if (scb.empty()) scb.push_back(0);
-    if (sce.empty()) sce.push_back(F::zero());
-    if (bb.empty()) bb.push_back(F::zero());
-    std::vector<T> ba(cc.ba);
-    if (ba.empty()) ba.push_back(F::zero());
+    const Pool<F> pool = build_pool<F>(p, p.cons_code, p.cons_desc, sc, pt, cc.ta, tb, nm ? ba : std::vector<T>(), nm ? bb : std::vector<T>(), mem_group);
     ParamPack pp(ctx);
-    const size_t i_code = pp.add(code), i_scb = pp.add(scb), i_sce = pp.add(sce), i_pt = pp.add(pt.tab), i_po = pp.add(pt.off), i_pm = pp.add(pt.mask),
-                 i_ta = pp.add(cc.ta), i_tb = pp.add(tb), i_dg = pp.add(dg_exp), i_bg = pp.add(dv.groups), i_mem = pp.add(members), i_ba = pp.add(ba),
-                 i_bb = pp.add(bb), i_zn = pp.add(dv.zn_inv), i_ex = pp.add(dv.exempt);
+    const size_t i_code = pp.add(pool.code), i_pool = pp.add(pool.words), i_pt = pp.add(pt.tab), i_dg = pp.add(dg_exp), i_bg = pp.add(dv.groups),
+                 i_ga = pp.add(gA), i_gb = pp.add(gB), i_zn = pp.add(dv.zn_inv), i_ex = pp.add(dv.exempt);
     pp.commit();
     NttTables* tw = ctx->ntt_tables(ilog2z(rows));
     AirConsArgs<F> a{};
     a.lde = g.lde; a.aux = g.aux; a.N = g.frame_rows; a.W = p.W; a.A = p.A;
     a.blowup = (uint32_t)(g.frame_rows / in.n); a.ce_step = (uint32_t)(g.frame_rows / rows); a.split_log = g.split_log;
     a.rows = rows; a.first = g.first; a.count = g.count;
-    a.code = pp.ptr<Insn>(i_code); a.slotsB = p.cons_slotsB; a.slotsE = p.cons_slotsE;
-    a.scalB = pp.ptr<uint64_t>(i_scb); a.scalE = pp.ptr<T>(i_sce);
-    a.ptab = pp.ptr<uint64_t>(i_pt); a.p_off = pp.ptr<uint32_t>(i_po); a.p_mask = pp.ptr<uint32_t>(i_pm);
-    a.ta = pp.ptr<T>(i_ta); a.tb = pp.ptr<T>(i_tb); a.dg_exp = pp.ptr<uint64_t>(i_dg);
-    a.bgroups = pp.ptr<AirBGroupDev>(i_bg); a.n_bgroups = (uint32_t)in.bgroups.size(); a.members = pp.ptr<BoundaryMember>(i_mem);
-    a.ba = pp.ptr<T>(i_ba); a.bb = pp.ptr<T>(i_bb);
+    a.code = pp.ptr<Insn>(i_code); a.pool = pp.ptr<uint64_t>(i_pool); a.slotsB = p.cons_slotsB; a.slotsE = p.cons_slotsE;
+    a.ptab = pp.ptr<uint64_t>(i_pt); a.dg_exp = pp.ptr<uint64_t>(i_dg);
+    a.bgroups = pp.ptr<AirBGroupDev>(i_bg); a.n_bgroups = (uint32_t)in.bgroups.size();
+    a.gA = pp.ptr<T>(i_ga); a.gB = pp.ptr<T>(i_gb);
     a.tw_lo = tw->lo_fwd; a.tw_hi = tw->hi_fwd; a.tw_h = tw->h; a.offset = h;
     a.zn_inv = pp.ptr<uint64_t>(i_zn); a.xmask = (uint32_t)(rows / in.n) - 1;
     a.exempt = pp.ptr<uint64_t>(i_ex); a.n_exempt = p.exemptions;
@@ -147,25 +186,19 @@ void air_build_aux(Context* ctx, const Program& p, const uint64_t* trace_dev, in
     for (auto& v : p.periodic) if (v.size() > n) fail("air program: a periodic column's cycle is longer than the trace");
     const Scalars<F> sc = fold_scalars<F>(p, pub, rands);
     const PeriodicTables pt = periodic_tables(p, n, n, 1);      // on the trace domain the tables are the cycles themselves
-    const std::vector<Insn> code = padded(p.aux_code);
     std::vector<T> init(p.A);
     for (uint32_t c = 0; c < p.A; c++) {
         const DOperand o = device_operand(p, p.builders[c].init);
         init[c] = o.kind == D_SCAL_E ? sc.e[o.idx] : F::from(sc.b[o.idx]);
     }
-    std::vector<uint64_t> scb = sc.b;
-    std::vector<T> sce = sc.e;
-    if (scb.empty()) scb.push_back(0);
-    if (sce.empty()) sce.push_back(F::zero());
+    const Pool<F> pool = build_pool<F>(p, p.aux_code, p.aux_desc, sc, pt, {}, {}, {}, {}, {});
     ParamPack pp(ctx);
-    const size_t i_code = pp.add(code), i_scb = pp.add(scb), i_sce = pp.add(sce), i_pt = pp.add(pt.tab), i_po = pp.add(pt.off), i_pm = pp.add(pt.mask),
-                 i_hd = pp.add(p.has_den), i_in = pp.add(init);
+    const size_t i_code = pp.add(pool.code), i_pool = pp.add(pool.words), i_pt = pp.add(pt.tab), i_hd = pp.add(p.has_den), i_in = pp.add(init);
     pp.commit();
     AirAuxArgs<F> a{};
     a.trace = trace_dev; a.n = n; a.W = p.W; a.A = p.A;
-    a.code = pp.ptr<Insn>(i_code); a.slotsB = p.aux_slotsB; a.slotsE = p.aux_slotsE;
-    a.scalB = pp.ptr<uint64_t>(i_scb); a.scalE = pp.ptr<T>(i_sce);
-    a.ptab = pp.ptr<uint64_t>(i_pt); a.p_off = pp.ptr<uint32_t>(i_po); a.p_mask = pp.ptr<uint32_t>(i_pm);
+    a.code = pp.ptr<Insn>(i_code); a.pool = pp.ptr<uint64_t>(i_pool); a.slotsB = p.aux_slotsB; a.slotsE = p.aux_slotsE;
+    a.ptab = pp.ptr<uint64_t>(i_pt);
     a.has_den = pp.ptr<uint8_t>(i_hd); a.init = pp.ptr<T>(i_in); a.out = out;
     launch_air_aux<F>(ctx, a, p.has_den);
 }

@@ -4,17 +4,18 @@
 // (/root/reference/aero-sdk/miden-wasm/src/constraints_worker.rs:32-59; divisor list and fragment stitching
 // proving_worker.rs:374-437) and the `build_aux_segment` step of `commit_to_trace_and_validate` (proving_worker.rs:323-332).
 //
-// Execution model. One lane = one row of the constraint-evaluation domain; one wavefront = one workgroup, so control flow is
-// the PROGRAM's control flow and uniform by construction: instruction words, scalar operands (constants, public inputs, random
-// elements, folded nodes), composition coefficients and table offsets are the same address in every lane and are fetched with
-// scalar loads; the opcode dispatch is a scalar branch. Per-lane state: the row's frame (read straight from the column-major LDE,
-// lane <-> row, coalesced; the trace is never staged), and a register file in LDS - slot s of lane l at word s * 64 + l, one
-// 8-byte bank-conflict-free access per operand - sized by the host's register allocation, not by the program length. Transition
-// constraints accumulate into two registers per degree group (sum alpha_k t_k, sum beta_k t_k); the group's degree adjustment
-// x^adj is ONE lookup in the two-level table of the domain generator (x^adj = offset^adj * w^(s adj mod rows), offset^adj folded
-// into the beta coefficients on the host). Boundary divisors x^a - b are batch-inverted over the K rows a lane owns
-// (Montgomery's trick through LDS, any number of divisors) before the rows are interpreted, so the fused division costs one
-// field inversion per K rows.
+// Execution model. One lane = R rows of the constraint-evaluation domain, interpreted in lockstep; one wavefront = one
+// workgroup, so control flow is the PROGRAM's control flow and uniform by construction: the opcode dispatch is a scalar branch
+// and is paid once per R x 64 rows. Nothing an instruction needs is reached through a dependent scalar load: instructions are
+// 32-byte words fetched two ahead, and every scalar they can use (constants, public inputs, random elements, folded nodes, the
+// (alpha, beta') pair of the constraint or assertion they feed) lies in one per-proof pool whose block for instruction i + 1 is
+// requested while instruction i executes. Per-lane state: a register file in LDS - slot s of row q of lane l at word
+// (s R + q) 64 + l, bank-conflict-free 8-byte accesses - sized by the host's register allocation; LOAD instructions bring eight
+// frame values per row at a time from the column-major LDE (lane <-> row, coalesced, all loads of a batch in flight together);
+// the transition accumulators (sum alpha_k t_k, sum beta'_k t_k per degree group) and the boundary accumulators of up to four
+// divisor groups live in VGPRs. A degree adjustment x^adj is ONE lookup in the two-level table of the domain generator
+// (x^adj = offset^adj w^(s adj mod rows), offset^adj folded into beta' on the host). The boundary divisors x^a - b of a lane's R
+// rows are inverted with one field inversion (Montgomery's trick in registers), so the fused division costs 1/R inversion a row.
 #include "air_kernels.hpp"
 
 namespace aero {
@@ -29,97 +30,131 @@ __device__ __forceinline__ uint64_t air_tw(const uint64_t* __restrict__ lo, cons
     return gl::mul(lo[e & ((1ull << h) - 1)], hi[e >> h]);
 }
 
-template <class F> struct AirRow {
+// ---- the interpreter core: R rows per lane ------------------------------------------------------------------------------------
+template <class F, int R> struct AirLane {
     typedef typename F::T T;
     const uint64_t* main;
     const uint64_t* aux;
-    size_t stride, r, rn;
-    uint32_t s;                  // row index for the periodic tables
-    const uint64_t* scalB;
-    const T* scalE;
     const uint64_t* ptab;
-    const uint32_t *p_off, *p_mask;
-    uint64_t *ldsB, *ldsE;       // already offset by the lane
+    const uint64_t* pool;
+    size_t stride;
+    uint32_t r[R], rn[R], s[R];      // matrix row of the frame's current / next row, evaluation row (periodic index)
+    uint64_t *ldsB, *ldsE;           // register file, already offset by the lane
 };
-template <class F> __device__ __forceinline__ uint64_t air_fetch_b(const AirRow<F>& c, uint32_t kind, uint32_t idx) {
-    switch (kind) {
-        case D_SLOT_B: return c.ldsB[idx * AIR_WG];
-        case D_MAIN_CUR: return c.main[(size_t)idx * c.stride + c.r];
-        case D_MAIN_NXT: return c.main[(size_t)idx * c.stride + c.rn];
-        case D_PERIODIC: return c.ptab[c.p_off[idx] + (c.s & c.p_mask[idx])];
-        default: return c.scalB[idx];
-    }
+struct PoolBlock { uint64_t w[4]; };
+template <class F, int R> __device__ __forceinline__ uint64_t air_get_b(const AirLane<F, R>& c, const PoolBlock& P, uint32_t kind, uint32_t idx, int q) {
+    return kind == D_SLOT_B ? c.ldsB[(idx * R + q) * AIR_WG] : P.w[0];
 }
-template <class F> __device__ __forceinline__ typename F::T air_fetch_e(const AirRow<F>& c, uint32_t kind, uint32_t idx) {
-    switch (kind) {
-        case D_SLOT_E: return F::make(c.ldsE[(idx * F::DEG) * AIR_WG], F::DEG > 1 ? c.ldsE[(idx * F::DEG + 1) * AIR_WG] : 0);
-        case D_AUX_CUR: { const size_t o = (size_t)(idx * F::DEG) * c.stride + c.r; return F::make(c.aux[o], F::DEG > 1 ? c.aux[o + c.stride] : 0); }
-        case D_AUX_NXT: { const size_t o = (size_t)(idx * F::DEG) * c.stride + c.rn; return F::make(c.aux[o], F::DEG > 1 ? c.aux[o + c.stride] : 0); }
-        case D_SCAL_E: return c.scalE[idx];
-        default: return F::from(air_fetch_b<F>(c, kind, idx));
-    }
+template <class F, int R> __device__ __forceinline__ typename F::T air_get_e(const AirLane<F, R>& c, const PoolBlock& P, uint32_t kind, uint32_t idx, int q) {
+    if (kind == D_SLOT_E) return F::make(c.ldsE[((idx * F::DEG) * R + q) * AIR_WG], F::DEG > 1 ? c.ldsE[((idx * F::DEG + 1) * R + q) * AIR_WG] : 0);
+    if (kind == D_SCAL_E) return F::make(P.w[0], P.w[1]);
+    return F::from(air_get_b<F, R>(c, P, kind, idx, q));
 }
-template <class F> __device__ __forceinline__ void air_store_e(const AirRow<F>& c, uint32_t slot, typename F::T v) {
-    c.ldsE[(slot * F::DEG) * AIR_WG] = F::comp(v, 0);
-    if (F::DEG > 1) c.ldsE[(slot * F::DEG + 1) * AIR_WG] = F::comp(v, 1);
+template <class F, int R> __device__ __forceinline__ void air_put_e(const AirLane<F, R>& c, uint32_t slot, int q, typename F::T v) {
+    c.ldsE[((slot * F::DEG) * R + q) * AIR_WG] = F::comp(v, 0);
+    if (F::DEG > 1) c.ldsE[((slot * F::DEG + 1) * R + q) * AIR_WG] = F::comp(v, 1);
 }
-// the arithmetic opcodes (OP_ADD_B .. OP_MULB_E)
-template <class F> __device__ __forceinline__ void air_arith(const AirRow<F>& c, uint32_t op, uint32_t ka, uint32_t kb, uint32_t dst, uint32_t ia, uint32_t ib) {
+// OP_ADD_B .. OP_MULB_E on all R rows: operands first, then the arithmetic (R independent chains), then the stores
+template <class F, int R> __device__ __forceinline__ void air_arith(const AirLane<F, R>& c, const PoolBlock& P, uint32_t op, uint32_t ka, uint32_t kb, uint32_t dst, uint32_t ia, uint32_t ib) {
     typedef typename F::T T;
     if (op <= OP_MUL_B) {
-        const uint64_t a = air_fetch_b<F>(c, ka, ia), b = air_fetch_b<F>(c, kb, ib);
-        c.ldsB[dst * AIR_WG] = op == OP_ADD_B ? gl::add(a, b) : op == OP_SUB_B ? gl::sub(a, b) : gl::mul(a, b);
+        uint64_t x[R], y[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) { x[q] = air_get_b<F, R>(c, P, ka, ia, q); y[q] = air_get_b<F, R>(c, P, kb, ib, q); }
+#pragma unroll
+        for (int q = 0; q < R; q++) x[q] = op == OP_ADD_B ? gl::add(x[q], y[q]) : op == OP_SUB_B ? gl::sub(x[q], y[q]) : gl::mul(x[q], y[q]);
+#pragma unroll
+        for (int q = 0; q < R; q++) c.ldsB[(dst * R + q) * AIR_WG] = x[q];
     } else if (op == OP_MULB_E) {
-        const T a = air_fetch_e<F>(c, ka, ia);
-        air_store_e<F>(c, dst, F::mulb(a, air_fetch_b<F>(c, kb, ib)));
+        T x[R];
+        uint64_t y[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) { x[q] = air_get_e<F, R>(c, P, ka, ia, q); y[q] = air_get_b<F, R>(c, P, kb, ib, q); }
+#pragma unroll
+        for (int q = 0; q < R; q++) air_put_e<F, R>(c, dst, q, F::mulb(x[q], y[q]));
     } else {
-        const T a = air_fetch_e<F>(c, ka, ia), b = air_fetch_e<F>(c, kb, ib);
-        air_store_e<F>(c, dst, op == OP_ADD_E ? F::add(a, b) : op == OP_SUB_E ? F::sub(a, b) : F::mul(a, b));
+        T x[R], y[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) { x[q] = air_get_e<F, R>(c, P, ka, ia, q); y[q] = air_get_e<F, R>(c, P, kb, ib, q); }
+#pragma unroll
+        for (int q = 0; q < R; q++) air_put_e<F, R>(c, dst, q, op == OP_ADD_E ? F::add(x[q], y[q]) : op == OP_SUB_E ? F::sub(x[q], y[q]) : F::mul(x[q], y[q]));
     }
 }
-
-// MODE 0: numerator columns (the reference's ConstraintEvaluationTable seam); MODE 1: divided by the divisors and summed (H)
-template <class F, int MODE> __global__ __launch_bounds__(AIR_WG) void air_constraints_kernel(AirConsArgs<F> a, uint32_t K) {
-    typedef typename F::T T;
-    extern __shared__ uint64_t air_lds[];
-    const uint32_t lane = threadIdx.x;
-    const size_t nthreads = a.count / K;
-    size_t t = (size_t)blockIdx.x * AIR_WG + lane;
-    const bool active = t < nthreads;
-    if (!active) t = nthreads - 1;        // the wavefront stays convergent: idle lanes shadow the last row and store nothing
-    const uint64_t rmask = a.rows - 1;
-    const uint32_t nb = a.n_bgroups;
-    AirRow<F> c;
-    c.main = a.lde; c.aux = a.aux; c.stride = a.N; c.scalB = a.scalB; c.scalE = a.scalE; c.ptab = a.ptab; c.p_off = a.p_off; c.p_mask = a.p_mask;
-    c.ldsB = air_lds + lane;
-    c.ldsE = air_lds + (size_t)a.slotsB * AIR_WG + lane;
-    uint64_t* const ldsD = air_lds + ((size_t)a.slotsB + (size_t)a.slotsE * F::DEG) * AIR_WG + lane;   // K * nb inverse divisors
-    uint64_t* const ldsP = ldsD + (size_t)K * nb * AIR_WG;                                              // prefix products
-    if (MODE == 1 && nb) {
-        // boundary divisors x^a - b of the K rows, inverted with ONE field inversion
-        uint64_t run = 1;
-        for (uint32_t q = 0; q < K; q++) {
-            const uint64_t s = a.first + t + (uint64_t)q * nthreads;
-            for (uint32_t j = 0; j < nb; j++) {
-                const AirBGroupDev& g = a.bgroups[j];
-                const uint64_t d = gl::sub(gl::mul(g.ha, air_tw(a.tw_lo, a.tw_hi, (s * g.a_exp) & rmask, a.tw_h)), g.b);
-                const uint32_t i = q * nb + j;
-                ldsD[i * AIR_WG] = d;
-                ldsP[i * AIR_WG] = run;
-                run = gl::mul(run, d);
-            }
-        }
-        uint64_t ia = gl::inv(run);
-        for (uint32_t i = K * nb; i-- > 0;) {
-            const uint64_t d = ldsD[i * AIR_WG];
-            ldsD[i * AIR_WG] = gl::mul(ia, ldsP[i * AIR_WG]);
-            ia = gl::mul(ia, d);
+// LOAD: the descriptors are the one thing an instruction fetches itself; all R x 8 loads are issued before the first store
+template <class F, int R> __device__ __forceinline__ void air_load_main(const AirLane<F, R>& c, uint32_t poff) {
+    uint64_t v[LOAD_WIDTH][R];
+    uint64_t d[LOAD_WIDTH];
+#pragma unroll
+    for (uint32_t k = 0; k < LOAD_WIDTH; k++) {
+        d[k] = c.pool[poff + k];
+        const uint32_t lo = (uint32_t)d[k];
+        if (d[k] >> 62 & 1) {
+            const uint32_t mask = (1u << (uint32_t)((d[k] >> 44) & 63)) - 1;
+#pragma unroll
+            for (int q = 0; q < R; q++) v[k][q] = c.ptab[lo + (c.s[q] & mask)];
+        } else {
+            const uint64_t* col = c.main + (size_t)lo * c.stride;
+            const bool nx = d[k] >> 63;
+#pragma unroll
+            for (int q = 0; q < R; q++) v[k][q] = col[nx ? c.rn[q] : c.r[q]];
         }
     }
-    const uint4* const code = reinterpret_cast<const uint4*>(a.code);
-#pragma unroll 1
-    for (uint32_t q = 0; q < K; q++) {
+#pragma unroll
+    for (uint32_t k = 0; k < LOAD_WIDTH; k++) {
+        const uint32_t slot = (uint32_t)(d[k] >> 32) & 0xfff;
+#pragma unroll
+        for (int q = 0; q < R; q++) c.ldsB[(slot * R + q) * AIR_WG] = v[k][q];
+    }
+}
+template <class F, int R> __device__ __forceinline__ void air_load_aux(const AirLane<F, R>& c, uint32_t poff) {
+    uint64_t v[LOAD_WIDTH / 2][R][2];
+    uint64_t d[LOAD_WIDTH / 2];
+#pragma unroll
+    for (uint32_t k = 0; k < LOAD_WIDTH / 2; k++) {
+        d[k] = c.pool[poff + k];
+        const uint64_t* col = c.aux + (size_t)((uint32_t)d[k] * F::DEG) * c.stride;
+        const bool nx = d[k] >> 63;
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const uint32_t row = nx ? c.rn[q] : c.r[q];
+            v[k][q][0] = col[row];
+            v[k][q][1] = F::DEG > 1 ? col[c.stride + row] : 0;
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < LOAD_WIDTH / 2; k++) {
+        const uint32_t slot = (uint32_t)(d[k] >> 32) & 0xfff;
+#pragma unroll
+        for (int q = 0; q < R; q++) air_put_e<F, R>(c, slot, q, F::make(v[k][q][0], v[k][q][1]));
+    }
+}
+__device__ __forceinline__ uint4 air_word(const uint4* code, uint32_t pc, uint32_t half) { return code[2 * pc + half]; }
+
+// MODE 0: numerator columns (the reference's ConstraintEvaluationTable seam); MODE 1: divided by the divisors and summed (H).
+// NB = boundary divisor groups whose accumulators and inverse divisors are held in registers (n_bgroups <= NB); NB = 0: any number
+// of groups, accumulators in LDS behind the register file, one inversion per row (R = 1).
+template <class F, int MODE, int R, int NB> __global__ __launch_bounds__(AIR_WG) void air_constraints_kernel(AirConsArgs<F> a) {
+    typedef typename F::T T;
+    static_assert(NB > 0 || R == 1, "the LDS-accumulator form interprets one row per lane");
+    constexpr int NBR = NB > 0 ? NB : 1;
+    extern __shared__ uint64_t air_lds[];
+    const uint32_t lane = threadIdx.x;
+    const size_t nthreads = a.count / R;
+    size_t t = (size_t)blockIdx.x * AIR_WG + lane;
+    const bool active = t < nthreads;
+    if (!active) t = nthreads - 1;        // the wavefront stays convergent: idle lanes shadow the last rows and store nothing
+    const uint64_t rmask = a.rows - 1;
+    const uint32_t nb = a.n_bgroups;
+    AirLane<F, R> c;
+    c.main = a.lde; c.aux = a.aux; c.ptab = a.ptab; c.pool = a.pool; c.stride = a.N;
+    c.ldsB = air_lds + lane;
+    c.ldsE = air_lds + (size_t)a.slotsB * R * AIR_WG + lane;
+    uint64_t* const ldsG = air_lds + ((size_t)a.slotsB + (size_t)a.slotsE * F::DEG) * R * AIR_WG + lane;   // NB == 0: [group][sa, sb][component]
+    uint64_t srow[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
         const uint64_t s = a.first + t + (uint64_t)q * nthreads;
+        srow[q] = s;
         size_t r = (size_t)s * a.ce_step;
         size_t rn = (r + a.blowup) & (a.N - 1);
         if (a.split_log) {
@@ -127,65 +162,186 @@ template <class F, int MODE> __global__ __launch_bounds__(AIR_WG) void air_const
             r = (r & pm) * part_len + (r >> a.split_log);
             rn = (rn & pm) * part_len + (rn >> a.split_log);
         }
-        c.r = r; c.rn = rn; c.s = (uint32_t)s;
-        // ---- transition constraints: the program
-        T acc_a = F::zero(), acc_b = F::zero(), total = F::zero();
-        uint4 I = code[0];
-#pragma unroll 1
-        for (uint32_t pc = 1;; pc++) {
-            const uint4 In = code[pc];            // the stream ends with two END words: the look-ahead stays inside it
-            const uint32_t op = I.x & 0xff, ka = (I.x >> 8) & 0xf, kb = (I.x >> 12) & 0xf;
-            if (op == OP_END) break;
-            if (op <= OP_MULB_E) {
-                air_arith<F>(c, op, ka, kb, I.y, I.z, I.w);
-            } else if (op == OP_EMIT_B) {
-                const uint64_t v = air_fetch_b<F>(c, ka, I.z);
-                acc_a = F::add(acc_a, F::mulb(a.ta[I.y], v));
-                acc_b = F::add(acc_b, F::mulb(a.tb[I.y], v));
-            } else if (op == OP_EMIT_E) {
-                const T v = air_fetch_e<F>(c, ka, I.z);
-                acc_a = F::add(acc_a, F::mul(a.ta[I.y], v));
-                acc_b = F::add(acc_b, F::mul(a.tb[I.y], v));
-            } else {                              // OP_GROUP_END
-                total = F::add(total, F::mulb(acc_b, air_tw(a.tw_lo, a.tw_hi, (s * a.dg_exp[I.y]) & rmask, a.tw_h)));
-                acc_b = F::zero();
+        c.r[q] = (uint32_t)r; c.rn[q] = (uint32_t)rn; c.s[q] = (uint32_t)s;
+    }
+    // ---- boundary divisors x^a - b of the lane's rows, inverted with ONE field inversion
+    uint64_t dinv[R][NBR];
+    if (MODE == 1 && NB > 0) {
+        uint64_t pre[R][NBR];
+        uint64_t run = 1;
+#pragma unroll
+        for (int q = 0; q < R; q++)
+#pragma unroll
+            for (int j = 0; j < NBR; j++) {
+                dinv[q][j] = 1; pre[q][j] = run;
+                if ((uint32_t)j < nb) {
+                    const AirBGroupDev g = a.bgroups[j];
+                    dinv[q][j] = gl::sub(gl::mul(g.ha, air_tw(a.tw_lo, a.tw_hi, (srow[q] * g.a_exp) & rmask, a.tw_h)), g.b);
+                    run = gl::mul(run, dinv[q][j]);
+                }
             }
-            I = In;
+        uint64_t ia = gl::inv(run);
+#pragma unroll
+        for (int q = R - 1; q >= 0; q--)
+#pragma unroll
+            for (int j = NBR - 1; j >= 0; j--)
+                if ((uint32_t)j < nb) { const uint64_t d = dinv[q][j]; dinv[q][j] = gl::mul(ia, pre[q][j]); ia = gl::mul(ia, d); }
+    }
+    if (NB == 0) for (uint32_t i = 0; i < 2 * nb * F::DEG; i++) ldsG[i * AIR_WG] = 0;
+    // ---- the program
+    T acc_a[R], acc_b[R], total[R], gsa[R][NBR], gsb[R][NBR];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        acc_a[q] = acc_b[q] = total[q] = F::zero();
+#pragma unroll
+        for (int j = 0; j < NBR; j++) gsa[q][j] = gsb[q][j] = F::zero();
+    }
+    const uint4* const code = reinterpret_cast<const uint4*>(a.code);
+    uint4 I = air_word(code, 0, 0);
+    uint32_t Ipoff = air_word(code, 0, 1).x;
+    uint4 In = air_word(code, 1, 0);
+    uint32_t Inpoff = air_word(code, 1, 1).x;
+    PoolBlock P;
+#pragma unroll
+    for (int k = 0; k < 4; k++) P.w[k] = a.pool[Ipoff + k];
+#pragma unroll 1
+    for (uint32_t pc = 2;; pc++) {
+        // two instructions and one pool block ahead (the stream ends with spare END words, the pool with a spare block)
+        const uint4 Inn = air_word(code, pc, 0);
+        const uint32_t Innpoff = air_word(code, pc, 1).x;
+        PoolBlock Pn;
+#pragma unroll
+        for (int k = 0; k < 4; k++) Pn.w[k] = a.pool[Inpoff + k];
+        const uint32_t op = I.x & 0xff, ka = (I.x >> 8) & 0xf, kb = (I.x >> 12) & 0xf;
+        if (op == OP_END) break;
+        if (op <= OP_MULB_E) {
+            air_arith<F, R>(c, P, op, ka, kb, I.y, I.z, I.w);
+        } else if (op == OP_LOAD_MAIN) {
+            air_load_main<F, R>(c, Ipoff);
+        } else if (op == OP_EMIT_B) {
+            const T ca = F::make(P.w[0], P.w[1]), cb = F::DEG > 1 ? F::make(P.w[2], P.w[3]) : F::make(P.w[1], 0);
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const uint64_t v = c.ldsB[(I.z * R + q) * AIR_WG];
+                acc_a[q] = F::add(acc_a[q], F::mulb(ca, v));
+                acc_b[q] = F::add(acc_b[q], F::mulb(cb, v));
+            }
+        } else if (op == OP_EMIT3_B) {            // the last two nodes of the constraint folded into the EMIT: a o1 (b o2 c) / (b o2 c) o1 a
+            const T ca = F::make(P.w[0], P.w[1]), cb = F::DEG > 1 ? F::make(P.w[2], P.w[3]) : F::make(P.w[1], 0);
+            const uint32_t o1 = (I.x >> 16) & 3, o2 = (I.x >> 18) & 3, left = (I.x >> 20) & 1;
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const uint64_t x = c.ldsB[(I.z * R + q) * AIR_WG], y = c.ldsB[(I.w * R + q) * AIR_WG], z = c.ldsB[(I.y * R + q) * AIR_WG];
+                const uint64_t in = o2 == 1 ? gl::add(y, z) : o2 == 2 ? gl::sub(y, z) : gl::mul(y, z);
+                const uint64_t l = left ? in : x, r = left ? x : in;
+                const uint64_t v = o1 == 1 ? gl::add(l, r) : o1 == 2 ? gl::sub(l, r) : gl::mul(l, r);
+                acc_a[q] = F::add(acc_a[q], F::mulb(ca, v));
+                acc_b[q] = F::add(acc_b[q], F::mulb(cb, v));
+            }
+        } else if (op >= OP_EMIT_ADD_B) {         // OP_EMIT_ADD_B / SUB / MUL: the root operation folded into the EMIT
+            const T ca = F::make(P.w[0], P.w[1]), cb = F::DEG > 1 ? F::make(P.w[2], P.w[3]) : F::make(P.w[1], 0);
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const uint64_t x = c.ldsB[(I.z * R + q) * AIR_WG], y = c.ldsB[(I.w * R + q) * AIR_WG];
+                const uint64_t v = op == OP_EMIT_ADD_B ? gl::add(x, y) : op == OP_EMIT_SUB_B ? gl::sub(x, y) : gl::mul(x, y);
+                acc_a[q] = F::add(acc_a[q], F::mulb(ca, v));
+                acc_b[q] = F::add(acc_b[q], F::mulb(cb, v));
+            }
+        } else if (op == OP_BOUND_B || op == OP_BOUND_E) {
+            const T ca = F::make(P.w[0], P.w[1]), cb = F::DEG > 1 ? F::make(P.w[2], P.w[3]) : F::make(P.w[1], 0);
+            const uint32_t g = I.y;
+            T pa[R], pb[R];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                if (op == OP_BOUND_B) { const uint64_t v = c.ldsB[(I.z * R + q) * AIR_WG]; pa[q] = F::mulb(ca, v); pb[q] = F::mulb(cb, v); }
+                else { const T v = air_get_e<F, R>(c, P, D_SLOT_E, I.z, q); pa[q] = F::mul(ca, v); pb[q] = F::mul(cb, v); }
+            }
+            if (NB > 0) {
+                // the group is uniform: a scalar branch picks the accumulator registers (no per-lane selects)
+#pragma unroll
+                for (int j = 0; j < NBR; j++)
+                    if (__builtin_amdgcn_readfirstlane(g) == (uint32_t)j) {
+#pragma unroll
+                        for (int q = 0; q < R; q++) { gsa[q][j] = F::add(gsa[q][j], pa[q]); gsb[q][j] = F::add(gsb[q][j], pb[q]); }
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                if (NB > 0) {
+                } else {
+                    uint64_t* gp = ldsG + (size_t)g * 2 * F::DEG * AIR_WG;
+                    const T sa = F::add(F::make(gp[0], F::DEG > 1 ? gp[AIR_WG] : 0), pa[q]);
+                    const T sb = F::add(F::make(gp[F::DEG * AIR_WG], F::DEG > 1 ? gp[(F::DEG + 1) * AIR_WG] : 0), pb[q]);
+                    for (int d = 0; d < F::DEG; d++) { gp[d * AIR_WG] = F::comp(sa, d); gp[(F::DEG + d) * AIR_WG] = F::comp(sb, d); }
+                }
+            }
+        } else if (op == OP_EMIT_E) {
+            const T ca = F::make(P.w[0], P.w[1]), cb = F::DEG > 1 ? F::make(P.w[2], P.w[3]) : F::make(P.w[1], 0);
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const T v = air_get_e<F, R>(c, P, D_SLOT_E, I.z, q);
+                acc_a[q] = F::add(acc_a[q], F::mul(ca, v));
+                acc_b[q] = F::add(acc_b[q], F::mul(cb, v));
+            }
+        } else if (op == OP_LOAD_AUX) {
+            air_load_aux<F, R>(c, Ipoff);
+        } else {                                  // OP_GROUP_END
+            const uint64_t e = a.dg_exp[I.y];
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                total[q] = F::add(total[q], F::mulb(acc_b[q], air_tw(a.tw_lo, a.tw_hi, (srow[q] * e) & rmask, a.tw_h)));
+                acc_b[q] = F::zero();
+            }
         }
-        total = F::add(total, acc_a);
+        I = In; Ipoff = Inpoff; P = Pn; In = Inn; Inpoff = Innpoff;
+    }
+    // ---- per row: transition numerator (/ divisor), boundary groups (sa - A) + x^adj (sb - B) (/ divisor)
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        const uint64_t s = srow[q];
         const size_t o = (size_t)(s - a.first);
+        const T tot = F::add(total[q], acc_a[q]);
         T h = F::zero();
         if (MODE == 0) {
-            if (active) for (int d = 0; d < F::DEG; d++) a.out_cols[(size_t)d * a.count + o] = F::comp(total, d);
+            if (active) for (int d = 0; d < F::DEG; d++) a.out_cols[(size_t)d * a.count + o] = F::comp(tot, d);
         } else {
             // 1 / ((x^n - 1) / prod (x - w^(n-i))) = prod (x - w^(n-i)) * (x^n - 1)^-1
             const uint64_t x = gl::mul(a.offset, air_tw(a.tw_lo, a.tw_hi, s & rmask, a.tw_h));
             uint64_t tdiv = a.zn_inv[s & a.xmask];
             for (uint32_t i = 0; i < a.n_exempt; i++) tdiv = gl::mul(tdiv, gl::sub(x, a.exempt[i]));
-            h = F::mulb(total, tdiv);
+            h = F::mulb(tot, tdiv);
         }
-        // ---- boundary constraints, one group per divisor
-        for (uint32_t j = 0; j < nb; j++) {
-            const AirBGroupDev& g = a.bgroups[j];
-            T sa = F::zero(), sb = F::zero();
-            for (uint32_t m = g.m0; m < g.m0 + g.count; m++) {
-                const BoundaryMember bm = a.members[m];
-                if (!bm.aux && !bm.val_ext) {
-                    const uint64_t d = gl::sub(a.lde[(size_t)bm.col * a.N + r], a.scalB[bm.val_idx]);
-                    sa = F::add(sa, F::mulb(a.ba[bm.coef], d));
-                    sb = F::add(sb, F::mulb(a.bb[bm.coef], d));
-                } else {
-                    const T v = bm.aux ? air_fetch_e<F>(c, D_AUX_CUR, bm.col) : F::from(a.lde[(size_t)bm.col * a.N + r]);
-                    const T d = F::sub(v, bm.val_ext ? a.scalE[bm.val_idx] : F::from(a.scalB[bm.val_idx]));
-                    sa = F::add(sa, F::mul(a.ba[bm.coef], d));
-                    sb = F::add(sb, F::mul(a.bb[bm.coef], d));
-                }
+        if (NB > 0) {
+#pragma unroll
+            for (int j = 0; j < NBR; j++) {
+                if ((uint32_t)j >= nb) continue;
+                const T sa = F::sub(gsa[q][j], a.gA[j]), sb = F::sub(gsb[q][j], a.gB[j]);
+                const T gnum = F::add(sa, F::mulb(sb, air_tw(a.tw_lo, a.tw_hi, (s * a.bgroups[j].adj_exp) & rmask, a.tw_h)));
+                if (MODE == 0) { if (active) for (int d = 0; d < F::DEG; d++) a.out_cols[(size_t)((1 + j) * F::DEG + d) * a.count + o] = F::comp(gnum, d); }
+                else h = F::add(h, F::mulb(gnum, dinv[q][j]));
             }
-            const T gnum = F::add(sa, F::mulb(sb, air_tw(a.tw_lo, a.tw_hi, (s * g.adj_exp) & rmask, a.tw_h)));
-            if (MODE == 0) {
-                if (active) for (int d = 0; d < F::DEG; d++) a.out_cols[(size_t)((1 + j) * F::DEG + d) * a.count + o] = F::comp(gnum, d);
-            } else {
-                h = F::add(h, F::mulb(gnum, ldsD[(q * nb + j) * AIR_WG]));
+        } else {
+            // any number of groups: Montgomery over this row's divisors through LDS (prefix products behind the accumulators)
+            uint64_t* const ldsD = ldsG + (size_t)2 * nb * F::DEG * AIR_WG;
+            uint64_t* const ldsP = ldsD + (size_t)nb * AIR_WG;
+            uint64_t ia = 0;
+            if (MODE == 1) {
+                uint64_t run = 1;
+                for (uint32_t j = 0; j < nb; j++) {
+                    const AirBGroupDev g = a.bgroups[j];
+                    const uint64_t d = gl::sub(gl::mul(g.ha, air_tw(a.tw_lo, a.tw_hi, (s * g.a_exp) & rmask, a.tw_h)), g.b);
+                    ldsD[j * AIR_WG] = d; ldsP[j * AIR_WG] = run;
+                    run = gl::mul(run, d);
+                }
+                ia = gl::inv(run);
+            }
+            for (uint32_t j = nb; j-- > 0;) {
+                const uint64_t* gp = ldsG + (size_t)j * 2 * F::DEG * AIR_WG;
+                const T sa = F::sub(F::make(gp[0], F::DEG > 1 ? gp[AIR_WG] : 0), a.gA[j]);
+                const T sb = F::sub(F::make(gp[F::DEG * AIR_WG], F::DEG > 1 ? gp[(F::DEG + 1) * AIR_WG] : 0), a.gB[j]);
+                const T gnum = F::add(sa, F::mulb(sb, air_tw(a.tw_lo, a.tw_hi, (s * a.bgroups[j].adj_exp) & rmask, a.tw_h)));
+                if (MODE == 0) { if (active) for (int d = 0; d < F::DEG; d++) a.out_cols[(size_t)((1 + j) * F::DEG + d) * a.count + o] = F::comp(gnum, d); }
+                else { h = F::add(h, F::mulb(gnum, gl::mul(ia, ldsP[j * AIR_WG]))); ia = gl::mul(ia, ldsD[j * AIR_WG]); }
             }
         }
         if (MODE == 1 && active) for (int d = 0; d < F::DEG; d++) a.out_h[d][s] = F::comp(h, d);
@@ -196,28 +352,37 @@ static void air_set_lds(const void* kern, size_t bytes) {
     if (bytes > 160 * 1024) fail("air program: the interpreter's register file does not fit the 160 KiB of LDS", ST_UNSUPPORTED);
     if (bytes > 48 * 1024) AERO_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
-
-template <class F> bool launch_air_constraints(Context* ctx, const AirConsArgs<F>& a, int mode) {
-    const size_t cnt = a.count;
-    const size_t in_cols = (size_t)a.W + (size_t)a.A * F::DEG;
+template <class F, int MODE, int R, int NB> static bool air_launch_variant(Context* ctx, const AirConsArgs<F>& a, size_t abytes) {
     const size_t slots = (size_t)a.slotsB + (size_t)a.slotsE * F::DEG;
-    if (mode == 0) {
-        const size_t lds = (slots ? slots : 1) * AIR_WG * 8;
-        air_set_lds((const void*)air_constraints_kernel<F, 0>, lds);
-        AERO_LAUNCH(ctx, "air_constraints_kernel", cnt * 8 * (in_cols + (1 + a.n_bgroups) * F::DEG), (air_constraints_kernel<F, 0>),
-                    dim3((unsigned)((cnt + AIR_WG - 1) / AIR_WG)), dim3(AIR_WG), lds, a, 1u);
-    } else {
-        // rows per lane sharing one batched inversion: 4 while the inverse-divisor block stays small, 1 when the count does not divide
-        uint32_t K = cnt % 4 == 0 && cnt >= 4 * AIR_WG ? 4 : 1;
-        if (a.n_bgroups > 8) K = 1;
-        const size_t lds = (slots + 2 * (size_t)K * a.n_bgroups + 1) * AIR_WG * 8;
-        if (lds > 160 * 1024) return false;
-        air_set_lds((const void*)air_constraints_kernel<F, 1>, lds);
-        AERO_LAUNCH(ctx, "air_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (air_constraints_kernel<F, 1>),
-                    dim3((unsigned)((cnt / K + AIR_WG - 1) / AIR_WG)), dim3(AIR_WG), lds, a, K);
-    }
+    size_t words = slots * R;
+    if (NB == 0) words += (size_t)a.n_bgroups * (2 * F::DEG + 2);
+    const size_t lds = (words ? words : 1) * AIR_WG * 8;
+    if (lds > 160 * 1024) return false;
+    air_set_lds((const void*)air_constraints_kernel<F, MODE, R, NB>, lds);
+    const size_t nthreads = a.count / R;
+    AERO_LAUNCH(ctx, "air_constraints_kernel", abytes, (air_constraints_kernel<F, MODE, R, NB>), dim3((unsigned)((nthreads + AIR_WG - 1) / AIR_WG)), dim3(AIR_WG), lds, a);
     ctx->check_launch("air_constraints");
     return true;
+}
+template <class F, int MODE> static bool air_launch_mode(Context* ctx, const AirConsArgs<F>& a, size_t abytes) {
+    // Rows per lane. Measured on fib_2^20 x 72 (MI355X, tools/air_bench.py): 2 rows per lane 1.48 ms, 4 rows 1.71 ms (170 VGPRs and
+    // 16 KiB of LDS per wave leave 2.5 waves per SIMD), 1 row with LDS accumulators 1.94 ms.
+    constexpr int RW = 2;
+    static const int r_env = getenv("AERO_AIR_ROWS") ? atoi(getenv("AERO_AIR_ROWS")) : 0;      // experiments: 1 = one row per lane, 4 = four
+    const bool wide = a.count % 4 == 0 && a.count >= (size_t)4 * AIR_WG * 64;       // enough rows to fill the chip several at a time
+    if (wide && r_env == 4 && F::DEG == 1 && a.n_bgroups <= 2 && air_launch_variant<F, MODE, 4, 2>(ctx, a, abytes)) return true;
+    if (wide && r_env != 1 && a.n_bgroups <= 2 && air_launch_variant<F, MODE, RW, 2>(ctx, a, abytes)) return true;
+    if (wide && r_env != 1 && a.n_bgroups <= 4 && air_launch_variant<F, MODE, RW, 4>(ctx, a, abytes)) return true;
+    return air_launch_variant<F, MODE, 1, 0>(ctx, a, abytes);
+}
+template <class F> bool launch_air_constraints(Context* ctx, const AirConsArgs<F>& a, int mode) {
+    const size_t in_cols = (size_t)a.W + (size_t)a.A * F::DEG;
+    if (mode == 0) {
+        if (!air_launch_mode<F, 0>(ctx, a, a.count * 8 * (in_cols + (1 + a.n_bgroups) * F::DEG)))
+            fail("air program: the interpreter's register file does not fit the 160 KiB of LDS", ST_UNSUPPORTED);
+        return true;
+    }
+    return air_launch_mode<F, 1>(ctx, a, a.count * 8 * (in_cols + F::DEG));
 }
 template bool launch_air_constraints<FB>(Context*, const AirConsArgs<FB>&, int);
 template bool launch_air_constraints<FQ>(Context*, const AirConsArgs<FQ>&, int);
@@ -270,25 +435,28 @@ template <class F> __global__ __launch_bounds__(AIR_WG) void air_aux_factors_ker
     size_t i = (size_t)blockIdx.x * AIR_WG + lane;
     const bool active = i < a.n;
     if (!active) i = a.n - 1;
-    AirRow<F> c;
-    c.main = a.trace; c.aux = nullptr; c.stride = a.n; c.r = i; c.rn = (i + 1) & (a.n - 1); c.s = (uint32_t)i;
-    c.scalB = a.scalB; c.scalE = a.scalE; c.ptab = a.ptab; c.p_off = a.p_off; c.p_mask = a.p_mask;
+    AirLane<F, 1> c;
+    c.main = a.trace; c.aux = nullptr; c.ptab = a.ptab; c.pool = a.pool; c.stride = a.n;
+    c.r[0] = (uint32_t)i; c.rn[0] = (uint32_t)((i + 1) & (a.n - 1)); c.s[0] = (uint32_t)i;
     c.ldsB = air_lds + lane;
     c.ldsE = air_lds + (size_t)a.slotsB * AIR_WG + lane;
     const uint4* const code = reinterpret_cast<const uint4*>(a.code);
-    uint4 I = code[0];
 #pragma unroll 1
-    for (uint32_t pc = 1;; pc++) {
-        const uint4 In = code[pc];
+    for (uint32_t pc = 0;; pc++) {
+        const uint4 I = air_word(code, pc, 0);
+        const uint32_t poff = air_word(code, pc, 1).x;
         const uint32_t op = I.x & 0xff, ka = (I.x >> 8) & 0xf, kb = (I.x >> 12) & 0xf;
         if (op == OP_END) break;
+        PoolBlock P;
+        P.w[0] = a.pool[poff]; P.w[1] = a.pool[poff + 1]; P.w[2] = P.w[3] = 0;
         if (op <= OP_MULB_E) {
-            air_arith<F>(c, op, ka, kb, I.y, I.z, I.w);
+            air_arith<F, 1>(c, P, op, ka, kb, I.y, I.z, I.w);
+        } else if (op == OP_LOAD_MAIN) {
+            air_load_main<F, 1>(c, poff);
         } else {                                  // OP_OUT_B / OP_OUT_E
-            const T v = op == OP_OUT_B ? F::from(air_fetch_b<F>(c, ka, I.z)) : air_fetch_e<F>(c, ka, I.z);
+            const T v = op == OP_OUT_B ? F::from(air_get_b<F, 1>(c, P, ka, I.z, 0)) : air_get_e<F, 1>(c, P, ka, I.z, 0);
             if (active) for (int d = 0; d < F::DEG; d++) fac[((size_t)I.y * F::DEG + d) * a.n + i] = F::comp(v, d);
         }
-        I = In;
     }
 }
 constexpr int SCAN_K = 8;

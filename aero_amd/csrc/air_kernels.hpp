@@ -13,8 +13,13 @@ struct AirBGroupDev {
     uint64_t ha;         // offset^a
     uint64_t b;
     uint64_t adj_exp;    // adj mod rows (offset^adj is folded into the beta coefficients)
-    uint32_t m0, count;  // members [m0, m0 + count)
 };
+
+// LOAD descriptor on the device (one u64): bits 0-31 column index (main / aux) or offset into the periodic tables, bits 32-43
+// register slot, bits 44-49 log2 of the periodic table's length, bit 62 periodic, bit 63 next row.
+inline uint64_t air_dev_desc(bool next, bool periodic, uint32_t slot, uint32_t col_or_off, uint32_t log_period) {
+    return (uint64_t)col_or_off | ((uint64_t)slot << 32) | ((uint64_t)log_period << 44) | ((uint64_t)(periodic ? 1 : 0) << 62) | ((uint64_t)(next ? 1 : 0) << 63);
+}
 
 template <class F> struct AirConsArgs {
     typedef typename F::T T;
@@ -27,18 +32,14 @@ template <class F> struct AirConsArgs {
     size_t rows;                 // size of the evaluation domain (the points offset * w_rows^s)
     size_t first, count;         // rows [first, first + count) are evaluated by this launch
     // program
-    const air::Insn* code;
+    const air::Insn* code;       // patched for this proof: poff = position of the instruction's scalars in `pool`; BOUND: dst = group
+    const uint64_t* pool;        // scalar operands | coefficient pairs (alpha, beta') per constraint / assertion | LOAD descriptors
     uint32_t slotsB, slotsE;
-    const uint64_t* scalB;
-    const T* scalE;
-    const uint64_t* ptab;        // periodic tables, concatenated; column k: ptab[p_off[k] + (s & p_mask[k])]
-    const uint32_t *p_off, *p_mask;
-    const T *ta, *tb;            // per transition constraint; tb pre-multiplied by offset^adj of its degree group
-    const uint64_t* dg_exp;      // per degree group: adj mod rows
+    const uint64_t* ptab;        // periodic tables, concatenated
+    const uint64_t* dg_exp;      // per degree group: adj mod rows (offset^adj is folded into beta')
     const AirBGroupDev* bgroups;
     uint32_t n_bgroups;
-    const air::BoundaryMember* members;
-    const T *ba, *bb;            // per assertion (sorted order); bb pre-multiplied by offset^adj of its group
+    const T *gA, *gB;            // per group: sum alpha_m value_m, sum beta'_m value_m (the assertions' constant parts)
     // domain
     const uint64_t *tw_lo, *tw_hi;   // two-level table of w_rows
     int tw_h;
@@ -51,8 +52,8 @@ template <class F> struct AirConsArgs {
     uint64_t* out_cols;          // MODE 0: ((1 + n_bgroups) * DEG) x count, column-major
     uint64_t* out_h[2];          // MODE 1: DEG component arrays indexed by s
 };
-// mode 0: numerator columns; mode 1: divided and summed (H). Returns false when mode 1 cannot run fused (too many boundary
-// divisors): the caller then evaluates mode 0 and divides with launch_air_divide.
+// mode 0: numerator columns; mode 1: divided and summed (H). Returns false when mode 1 cannot run fused (register file too large
+// for the LDS): the caller then evaluates mode 0 and divides with launch_air_divide.
 template <class F> bool launch_air_constraints(Context* ctx, const AirConsArgs<F>& a, int mode);
 
 // H = sum_j column_j / divisor_j over the evaluation domain (the unfused `ConstraintEvaluationTable::into_poly` division)
@@ -78,12 +79,10 @@ template <class F> struct AirAuxArgs {
     const uint64_t* trace;       // W x n main segment
     size_t n;
     uint32_t W, A;
-    const air::Insn* code;
+    const air::Insn* code;       // patched: poff
+    const uint64_t* pool;
     uint32_t slotsB, slotsE;
-    const uint64_t* scalB;
-    const T* scalE;
     const uint64_t* ptab;
-    const uint32_t *p_off, *p_mask;
     const uint8_t* has_den;      // per aux column (device)
     const T* init;               // per aux column (device)
     uint64_t* out;               // (A * DEG) x n component columns

@@ -40,6 +40,8 @@ inline uint32_t ref_index(uint32_t r) { return r & 0xFFFFFFu; }
 inline uint32_t mk_ref(uint32_t k, uint32_t i) { return (k << 24) | i; }
 
 // ---- the device program ------------------------------------------------------------------------------------------------------
+// Operand kinds of the emitted code. Frame values (D_MAIN_* / D_AUX_*) appear only in the descriptors of the LOAD instructions:
+// arithmetic reads registers, scalars and periodic tables.
 enum DKind : uint32_t { D_SLOT_B = 0, D_SLOT_E, D_MAIN_CUR, D_MAIN_NXT, D_AUX_CUR, D_AUX_NXT, D_PERIODIC, D_SCAL_B, D_SCAL_E };
 enum DOp : uint32_t {
     OP_END = 0,
@@ -49,9 +51,27 @@ enum DOp : uint32_t {
     OP_EMIT_B, OP_EMIT_E,                    // transition constraint `dst`: value a (base / E) into the group accumulators
     OP_GROUP_END,                            // degree group `dst` complete: total += acc_beta * x^adj(dst)
     OP_OUT_B, OP_OUT_E,                      // aux builder: value a -> output column dst
+    OP_LOAD_MAIN,                            // LOAD_WIDTH frame values of the main segment -> base slots; dst = first descriptor
+    OP_LOAD_AUX,                             // LOAD_WIDTH / 2 frame values of the auxiliary segment -> E slots
+    OP_BOUND_B, OP_BOUND_E,                  // assertion `dst` on the (current-row) value a: into its divisor group's accumulators
+    OP_EMIT_ADD_B, OP_EMIT_SUB_B, OP_EMIT_MUL_B,   // transition constraint `dst` = a (+, -, *) b, both base registers: the root node never
+                                             // travels through the register file
+    OP_EMIT3_B,                              // transition constraint = a o1 (b o2 c) or (b o2 c) o1 a over three base registers: the last TWO
+                                             // nodes of the expression folded into the EMIT. op bits 16-17: o1, 18-19: o2 (1 +, 2 -, 3 *),
+                                             // bit 20: inner node on the left; on the device `dst` carries register c
 };
-struct Insn { uint32_t op, dst, a, b; };     // op = DOp | kind(a) << 8 | kind(b) << 12
+constexpr uint32_t LOAD_WIDTH = 8;           // loads issued back to back by one LOAD instruction (memory-level parallelism per lane)
+// One instruction = 32 bytes. op = DOp | kind(a) << 8 | kind(b) << 12; dst / a / b = register slots or table indices. The device
+// never follows an index into a table: per proof the host lays every scalar an instruction can need (scalar operands,
+// composition-coefficient pairs, LOAD descriptors) out in ONE pool and writes the instruction's position in it into `poff`
+// (`pk` says which table `pi` indexes); the interpreter prefetches pool[poff] one instruction ahead.
+enum PoolKind : uint32_t { PK_NONE = 0, PK_SCAL_B, PK_SCAL_E, PK_TCOEF, PK_BCOEF, PK_DESC };
+struct Insn { uint32_t op, dst, a, b, poff, pk, pi, pad; };
+// LOAD descriptor as compiled: next-row flag << 31 | periodic flag << 30 | slot << 16 | column (or periodic column id)
+inline uint32_t mk_desc(bool next, bool periodic, uint32_t slot, uint32_t col) { return (next ? 0x80000000u : 0u) | (periodic ? 0x40000000u : 0u) | (slot << 16) | col; }
 inline bool dkind_is_ext(uint32_t k) { return k == D_SLOT_E || k == D_AUX_CUR || k == D_AUX_NXT || k == D_SCAL_E; }
+inline bool dkind_is_frame(uint32_t k) { return k >= D_MAIN_CUR && k <= D_PERIODIC; }      // arrives through a LOAD (periodic values too)
+inline bool dkind_is_scalar(uint32_t k) { return k == D_SCAL_B || k == D_SCAL_E; }
 
 struct Node { uint32_t op, a, b; };
 struct Transition { uint32_t root, base; std::vector<uint32_t> cycles; uint32_t group; };
@@ -78,6 +98,7 @@ struct Program {
     uint32_t ce_blowup = 2;
     // ---- code
     std::vector<Insn> cons_code, aux_code;
+    std::vector<uint32_t> cons_desc, aux_desc;       // LOAD descriptors
     uint32_t cons_slotsB = 0, cons_slotsE = 0, aux_slotsB = 0, aux_slotsE = 0;
     std::vector<uint8_t> has_den;             // per aux column
 
@@ -127,12 +148,29 @@ inline bool ref_uses_aux(const Program& p, uint32_t ref) {
     return k == K_AUX_CUR || k == K_AUX_NXT || (k == K_NODE && p.uses_aux[ref_index(ref)]);
 }
 
-// Emit the code that makes `roots` available, then call `sink(i)` after root i; linear-scan register allocation over the result.
+// Code generation. gen(root) emits the not-yet-computed nodes of an expression in post-order (common sub-expressions once);
+// lower() then makes every frame access explicit: LOAD instructions fetch LOAD_WIDTH frame values at a time into registers (the
+// loads of one instruction are issued back to back - a lane waits once per batch, not once per operand), looking ahead in the
+// stream for the values the following instructions need; the assertions on a column are evaluated right behind the load that
+// brings its current-row value (no second read of the row); a value whose next use is far away is dropped and re-loaded.
+// allocate() is a linear scan over the result: every live value gets a slot of the per-lane register file, reused after its last use.
+struct VOperand { uint32_t kind, idx; bool virt; };            // virt: idx is a virtual register
+struct VInsn {
+    uint32_t op = OP_END, dst = 0;
+    VOperand a{D_SCAL_B, 0, false}, b{D_SCAL_B, 0, false}, c{D_SCAL_B, 0, false};   // c: third operand of OP_EMIT3_B
+    std::vector<std::pair<uint32_t, uint32_t>> loads;          // LOAD: (frame operand key, virtual register)
+};
 struct CodeGen {
     const Program& p;
-    std::vector<Insn> code;
+    std::vector<VInsn> code;
     std::vector<uint8_t> done;
-    explicit CodeGen(const Program& prog) : p(prog), done(prog.nodes.size(), 0) {}
+    std::vector<uint8_t> vreg_ext;                              // per virtual register: E-valued?
+    static constexpr uint32_t RELOAD_GAP = 96;                  // instructions a frame value may wait in a register for its next use
+    explicit CodeGen(const Program& prog) : p(prog), done(prog.nodes.size(), 0) {
+        vreg_ext.assign(prog.nodes.size(), 0);
+        for (size_t i = 0; i < prog.nodes.size(); i++) vreg_ext[i] = prog.is_ext[i];
+    }
+    static VOperand vop(const DOperand& o) { return VOperand{o.kind, o.idx, o.virt}; }
     void gen(uint32_t ref) {
         if (ref_kind(ref) != K_NODE) return;
         std::vector<std::pair<uint32_t, int>> st;     // (node, stage)
@@ -157,49 +195,204 @@ struct CodeGen {
                 if (ea && eb) op = OP_MUL_E;
                 else { op = OP_MULB_E; if (!ea) std::swap(a, b); }
             }
-            code.push_back(Insn{op | (a.kind << 8) | (b.kind << 12), i, a.idx, b.idx});
+            VInsn in;
+            in.op = op; in.dst = i; in.a = vop(a); in.b = vop(b);
+            code.push_back(in);
             done[i] = 1;
         }
     }
     void emit(uint32_t op, uint32_t dst, uint32_t ref) {
-        const DOperand a = device_operand(p, ref);
-        code.push_back(Insn{op | (a.kind << 8), dst, a.idx, 0});
+        VInsn in;
+        in.op = op; in.dst = dst; in.a = vop(device_operand(p, ref));
+        code.push_back(in);
     }
-    static bool writes_slot(uint32_t op) { return op >= OP_ADD_B && op <= OP_MULB_E; }
-    // virtual registers (node ids) -> slots; returns the slot counts
-    void allocate(uint32_t* slotsB, uint32_t* slotsE) {
-        std::map<uint32_t, size_t> last;     // node -> index of its last reading instruction
-        auto reads = [&](const Insn& in, std::function<void(uint32_t)> f) {
-            const uint32_t op = in.op & 0xff, ka = (in.op >> 8) & 0xf, kb = (in.op >> 12) & 0xf;
-            if (op == OP_END || op == OP_GROUP_END) return;
-            if (ka == D_SLOT_B || ka == D_SLOT_E) f(in.a);
-            if (writes_slot(op) && (kb == D_SLOT_B || kb == D_SLOT_E)) f(in.b);
+    // a transition constraint whose root is a base-field node nobody else reads: its operands are generated, the root operation
+    // itself is folded into the EMIT (one instruction and one register-file round trip less per constraint)
+    bool emit_fused(uint32_t k, uint32_t ref, const std::vector<uint32_t>& node_uses) {
+        if (ref_kind(ref) != K_NODE) return false;
+        const uint32_t i = ref_index(ref);
+        if (done[i] || p.scalar_of[i] >= 0 || p.is_ext[i] || node_uses[i] != 1) return false;
+        const Node& nd = p.nodes[i];
+        const DOperand a = device_operand(p, nd.a), b = device_operand(p, nd.b);
+        if (dkind_is_scalar(a.kind) || dkind_is_scalar(b.kind)) return false;          // the pool block is taken by the coefficients
+        // one level deeper: an operand that is itself a single-use base node over two registers
+        for (int side = 1; side >= 0; side--) {                                        // side 1: the inner node is operand a (left)
+            const uint32_t inner_ref = side ? nd.a : nd.b, other_ref = side ? nd.b : nd.a;
+            if (ref_kind(inner_ref) != K_NODE) continue;
+            const uint32_t j = ref_index(inner_ref);
+            if (done[j] || p.scalar_of[j] >= 0 || p.is_ext[j] || node_uses[j] != 1) continue;
+            const Node& in2 = p.nodes[j];
+            const DOperand x = device_operand(p, in2.a), y = device_operand(p, in2.b), o = device_operand(p, other_ref);
+            if (dkind_is_scalar(x.kind) || dkind_is_scalar(y.kind)) continue;
+            gen(other_ref); gen(in2.a); gen(in2.b);
+            VInsn in;
+            in.op = OP_EMIT3_B | (nd.op << 16) | (in2.op << 18) | ((uint32_t)side << 20);
+            in.dst = k; in.a = vop(o); in.b = vop(x); in.c = vop(y);
+            code.push_back(in);
+            done[i] = done[j] = 1;
+            return true;
+        }
+        gen(nd.a); gen(nd.b);
+        VInsn in;
+        in.op = nd.op == 1 ? OP_EMIT_ADD_B : nd.op == 2 ? OP_EMIT_SUB_B : OP_EMIT_MUL_B;
+        in.dst = k; in.a = vop(a); in.b = vop(b);
+        code.push_back(in);
+        done[i] = 1;
+        return true;
+    }
+    void marker(uint32_t op, uint32_t dst) { VInsn in; in.op = op; in.dst = dst; code.push_back(in); }
+    static bool writes_slot(uint32_t op) { op &= 0xff; return op >= OP_ADD_B && op <= OP_MULB_E; }
+    static bool is_emit2(uint32_t op) { op &= 0xff; return op >= OP_EMIT_ADD_B && op <= OP_EMIT_MUL_B; }
+    static bool is_emit3(uint32_t op) { return (op & 0xff) == OP_EMIT3_B; }
+    static bool reads_b(uint32_t op) { return writes_slot(op) || is_emit2(op) || is_emit3(op); }
+    static bool reads_c(uint32_t op) { return is_emit3(op); }
+    static bool reads_a(uint32_t op) { op &= 0xff; return op != OP_END && op != OP_GROUP_END && op != OP_LOAD_MAIN && op != OP_LOAD_AUX; }
+    static uint32_t frame_key(const VOperand& o) { return (o.kind << 16) | o.idx; }
+
+    // the operands an instruction reads
+    static std::vector<VOperand*> reads(VInsn& in) {
+        std::vector<VOperand*> r;
+        if (reads_a(in.op)) r.push_back(&in.a);
+        if (reads_b(in.op)) r.push_back(&in.b);
+        if (reads_c(in.op)) r.push_back(&in.c);
+        return r;
+    }
+    // `bound[k]` = assertions (member ids) on the current-row value with frame key k
+    void lower(const std::map<uint32_t, std::vector<uint32_t>>& bound) {
+        std::vector<VInsn> in;
+        in.swap(code);
+        // use positions of every frame operand
+        std::map<uint32_t, std::vector<size_t>> uses;
+        for (size_t i = 0; i < in.size(); i++)
+            for (VOperand* o : reads(in[i]))
+                if (dkind_is_frame(o->kind)) { auto& u = uses[frame_key(*o)]; if (u.empty() || u.back() != i) u.push_back(i); }
+        std::map<uint32_t, uint32_t> avail;          // frame key -> virtual register holding it
+        std::map<uint32_t, uint8_t> bound_done;
+        auto is_aux = [](uint32_t key) { const uint32_t k = key >> 16; return k == D_AUX_CUR || k == D_AUX_NXT; };     // periodic values travel with the main batches
+        auto emit_load = [&](const std::vector<uint32_t>& keys, bool aux) {
+            VInsn ld;
+            ld.op = aux ? OP_LOAD_AUX : OP_LOAD_MAIN;
+            for (uint32_t k : keys) {
+                const uint32_t v = (uint32_t)vreg_ext.size();
+                vreg_ext.push_back(aux ? 1 : 0);
+                ld.loads.push_back({k, v});
+                avail[k] = v;
+            }
+            code.push_back(ld);
+            for (auto& kv : ld.loads) {
+                auto it = bound.find(kv.first);
+                if (it == bound.end() || bound_done[kv.first]) continue;
+                bound_done[kv.first] = 1;
+                for (uint32_t m : it->second) {
+                    VInsn bi;
+                    bi.op = aux ? OP_BOUND_E : OP_BOUND_B; bi.dst = m; bi.a = VOperand{aux ? D_SLOT_E : D_SLOT_B, kv.second, true};
+                    code.push_back(bi);
+                }
+            }
         };
-        for (size_t i = 0; i < code.size(); i++) reads(code[i], [&](uint32_t n) { last[n] = i; });
+        // the frame value `key` is needed at position i: load it together with the next values the stream will ask for
+        auto demand = [&](uint32_t key, size_t i) {
+            const bool aux = is_aux(key);
+            const uint32_t width = aux ? LOAD_WIDTH / 2 : LOAD_WIDTH;
+            std::vector<uint32_t> keys{key};
+            for (size_t j = i; j < in.size() && keys.size() < width && j < i + 4 * RELOAD_GAP; j++)
+                for (VOperand* o : reads(in[j])) {
+                    if (!dkind_is_frame(o->kind)) continue;
+                    const uint32_t k = frame_key(*o);
+                    if (is_aux(k) != aux || avail.count(k) || std::find(keys.begin(), keys.end(), k) != keys.end()) continue;
+                    if (keys.size() < width) keys.push_back(k);
+                }
+            emit_load(keys, aux);
+        };
+        for (size_t i = 0; i < in.size(); i++) {
+            VInsn cur = in[i];
+            for (VOperand* o : reads(cur)) {
+                if (!dkind_is_frame(o->kind)) continue;
+                const uint32_t key = frame_key(*o);
+                if (!avail.count(key)) demand(key, i);
+                *o = VOperand{is_aux(key) ? D_SLOT_E : D_SLOT_B, avail[key], true};
+            }
+            code.push_back(cur);
+            // retire values whose next use is far away (or never)
+            for (VOperand* o : reads(in[i])) {
+                if (!dkind_is_frame(o->kind)) continue;
+                const uint32_t key = frame_key(*o);
+                const auto& u = uses[key];
+                auto nx = std::upper_bound(u.begin(), u.end(), i);
+                if (nx == u.end() || *nx - i > RELOAD_GAP) avail.erase(key);
+            }
+        }
+        // columns that are only asserted, never read by a constraint
+        std::vector<uint32_t> rest_main, rest_aux;
+        for (auto& kv : bound) if (!bound_done[kv.first]) (is_aux(kv.first) ? rest_aux : rest_main).push_back(kv.first);
+        for (size_t o = 0; o < rest_main.size(); o += LOAD_WIDTH)
+            emit_load(std::vector<uint32_t>(rest_main.begin() + o, rest_main.begin() + std::min(rest_main.size(), o + LOAD_WIDTH)), false);
+        for (size_t o = 0; o < rest_aux.size(); o += LOAD_WIDTH / 2)
+            emit_load(std::vector<uint32_t>(rest_aux.begin() + o, rest_aux.begin() + std::min(rest_aux.size(), o + LOAD_WIDTH / 2)), true);
+    }
+    // virtual registers -> slots; encodes the instructions and the LOAD descriptors
+    void allocate(std::vector<Insn>& out, std::vector<uint32_t>& desc, uint32_t* slotsB, uint32_t* slotsE) {
+        std::map<uint32_t, size_t> last;
+        for (size_t i = 0; i < code.size(); i++)
+            for (VOperand* o : reads(code[i])) if (o->virt) last[o->idx] = i;
         std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> freeB, freeE;
         uint32_t nB = 0, nE = 0;
         std::map<uint32_t, uint32_t> slot;
+        auto take = [&](uint32_t v) {
+            auto& fl = vreg_ext[v] ? freeE : freeB;
+            uint32_t s;
+            if (!fl.empty()) { s = fl.top(); fl.pop(); } else s = vreg_ext[v] ? nE++ : nB++;
+            slot[v] = s;
+            return s;
+        };
+        auto give = [&](uint32_t v) { (vreg_ext[v] ? freeE : freeB).push(slot.at(v)); };
         for (size_t i = 0; i < code.size(); i++) {
-            Insn& in = code[i];
-            const uint32_t op = in.op & 0xff, ka = (in.op >> 8) & 0xf, kb = (in.op >> 12) & 0xf;
-            std::vector<uint32_t> dying;
-            const bool ra = op != OP_END && op != OP_GROUP_END && (ka == D_SLOT_B || ka == D_SLOT_E);
-            const bool rb = writes_slot(op) && (kb == D_SLOT_B || kb == D_SLOT_E);
-            const uint32_t na = in.a, nb = in.b;
-            if (ra) { in.a = slot.at(na); if (last[na] == i) dying.push_back(na); }
-            if (rb) { in.b = slot.at(nb); if (last[nb] == i && (!ra || nb != na)) dying.push_back(nb); }
-            for (uint32_t n : dying) { (p.is_ext[n] ? freeE : freeB).push(slot[n]); }
-            if (writes_slot(op)) {
-                const uint32_t n = in.dst;
-                auto& fl = p.is_ext[n] ? freeE : freeB;
-                uint32_t s;
-                if (!fl.empty()) { s = fl.top(); fl.pop(); } else s = p.is_ext[n] ? nE++ : nB++;
-                slot[n] = s;
-                in.dst = s;
-                if (!last.count(n)) (p.is_ext[n] ? freeE : freeB).push(s);   // never read (cannot happen for generated code)
+            VInsn& in = code[i];
+            const uint32_t opc = in.op & 0xff;
+            if (opc == OP_LOAD_MAIN || opc == OP_LOAD_AUX) {
+                const uint32_t width = opc == OP_LOAD_AUX ? LOAD_WIDTH / 2 : LOAD_WIDTH;
+                const uint32_t first = (uint32_t)desc.size();
+                std::vector<uint32_t> dead;
+                for (auto& kv : in.loads) {
+                    const uint32_t k = kv.first >> 16, col = kv.first & 0xffff;
+                    desc.push_back(mk_desc(k == D_MAIN_NXT || k == D_AUX_NXT, k == D_PERIODIC, take(kv.second), col));
+                    if (!last.count(kv.second)) dead.push_back(kv.second);
+                }
+                while (desc.size() < first + width) desc.push_back(desc.back());     // padding: the last value once more
+                for (uint32_t v : dead) give(v);
+                out.push_back(Insn{in.op, first, (uint32_t)in.loads.size(), 0, 0, PK_DESC, first, 0});
+                continue;
             }
+            Insn e{in.op | (in.a.kind << 8) | (in.b.kind << 12), in.dst, in.a.idx, in.b.idx, 0, PK_NONE, 0, 0};
+            // what the instruction needs from the pool: its scalar operand (at most one: scalar-only nodes were folded), or the
+            // coefficient pair of the constraint / assertion it feeds
+            if (opc == OP_EMIT_B || opc == OP_EMIT_E || is_emit2(in.op) || is_emit3(in.op)) { e.pk = PK_TCOEF; e.pi = in.dst; }
+            else if (opc == OP_BOUND_B || opc == OP_BOUND_E) { e.pk = PK_BCOEF; e.pi = in.dst; }
+            else if (reads_a(in.op) && dkind_is_scalar(in.a.kind)) { e.pk = in.a.kind == D_SCAL_E ? PK_SCAL_E : PK_SCAL_B; e.pi = in.a.idx; }
+            else if (reads_b(in.op) && dkind_is_scalar(in.b.kind)) { e.pk = in.b.kind == D_SCAL_E ? PK_SCAL_E : PK_SCAL_B; e.pi = in.b.idx; }
+            if ((opc == OP_EMIT_B || opc == OP_EMIT_E) && dkind_is_scalar(in.a.kind))
+                fail("air program: a transition constraint that does not depend on the trace");
+            if (writes_slot(in.op) && dkind_is_scalar(in.a.kind) && dkind_is_scalar(in.b.kind)) fail("air program: unfolded constant node", ST_INTERNAL);
+            std::vector<uint32_t> dying;
+            uint32_t* fields[3] = {&e.a, &e.b, &e.pad};       // the third operand of EMIT3 travels in `pad` (host) and in `dst` on the device
+            int fi = 0;
+            for (VOperand* o : {&in.a, &in.b, &in.c}) {
+                const int f = fi++;
+                if (f == 0 ? !reads_a(in.op) : f == 1 ? !reads_b(in.op) : !reads_c(in.op)) continue;
+                if (f == 2) *fields[2] = o->idx;
+                if (!o->virt) continue;
+                *fields[f] = slot.at(o->idx);
+                if (last[o->idx] == i && std::find(dying.begin(), dying.end(), o->idx) == dying.end()) dying.push_back(o->idx);
+            }
+            for (uint32_t v : dying) give(v);
+            if (writes_slot(in.op)) {
+                e.dst = take(in.dst);
+                if (!last.count(in.dst)) give(in.dst);
+            }
+            out.push_back(e);
         }
         *slotsB = nB; *slotsE = nE;
+        if (nB >= 4096 || nE >= 4096) fail("air program: register file too large", ST_UNSUPPORTED);
     }
 };
 
@@ -298,20 +491,30 @@ inline Program load(const uint8_t* bytes, size_t len) {
     }
     if (rd.off != len) fail("air program: trailing bytes");
 
-    // ---- constraint code: degree group by degree group
+    // ---- constraint code: degree group by degree group, then the assertions woven in behind the loads of their columns
     {
         CodeGen cg(p);
+        std::vector<uint32_t> node_uses(p.nodes.size(), 0);        // readers of every node: other nodes, constraint roots, builders
+        auto count_use = [&](uint32_t ref) { if (ref != REF_NONE && ref_kind(ref) == K_NODE) node_uses[ref_index(ref)]++; };
+        for (auto& nd : p.nodes) { count_use(nd.a); count_use(nd.b); }
+        for (auto& t : p.trans) count_use(t.root);
+        for (auto& b : p.builders) { count_use(b.init); count_use(b.num); count_use(b.den); }
+        for (auto* v : {&p.masserts, &p.aasserts}) for (auto& as : *v) count_use(as.value);
         for (uint32_t g = 0; g < p.dgroups.size(); g++) {
             for (uint32_t k = 0; k < p.trans.size(); k++) {
                 if (p.trans[k].group != g) continue;
+                if (cg.emit_fused(k, p.trans[k].root, node_uses)) continue;
                 cg.gen(p.trans[k].root);
                 cg.emit(ref_is_ext(p, p.trans[k].root) ? OP_EMIT_E : OP_EMIT_B, k, p.trans[k].root);
             }
-            cg.code.push_back(Insn{OP_GROUP_END, g, 0, 0});
+            cg.marker(OP_GROUP_END, g);
         }
-        cg.code.push_back(Insn{OP_END, 0, 0, 0});
-        cg.allocate(&p.cons_slotsB, &p.cons_slotsE);
-        p.cons_code = std::move(cg.code);
+        std::map<uint32_t, std::vector<uint32_t>> bound;       // frame key of the asserted column -> member ids (main, then aux)
+        for (uint32_t m = 0; m < p.masserts.size(); m++) bound[(D_MAIN_CUR << 16) | p.masserts[m].col].push_back(m);
+        for (uint32_t m = 0; m < p.aasserts.size(); m++) bound[(D_AUX_CUR << 16) | p.aasserts[m].col].push_back((uint32_t)p.masserts.size() + m);
+        cg.lower(bound);
+        cg.marker(OP_END, 0);
+        cg.allocate(p.cons_code, p.cons_desc, &p.cons_slotsB, &p.cons_slotsE);
     }
     // ---- aux builder code: output column 2c = numerator factor, 2c + 1 = denominator factor of aux column c
     if (p.has_builders()) {
@@ -326,9 +529,9 @@ inline Program load(const uint8_t* bytes, size_t len) {
                 cg.emit(ref_is_ext(p, p.builders[c].den) ? OP_OUT_E : OP_OUT_B, 2 * c + 1, p.builders[c].den);
             }
         }
-        cg.code.push_back(Insn{OP_END, 0, 0, 0});
-        cg.allocate(&p.aux_slotsB, &p.aux_slotsE);
-        p.aux_code = std::move(cg.code);
+        cg.lower({});
+        cg.marker(OP_END, 0);
+        cg.allocate(p.aux_code, p.aux_desc, &p.aux_slotsB, &p.aux_slotsE);
     }
     if (p.cons_slotsB + 2 * p.cons_slotsE > 1024 || p.aux_slotsB + 2 * p.aux_slotsE > 1024)
         fail("air program: more than 1024 live values at one point (the per-lane register file of the interpreter)", ST_UNSUPPORTED);
@@ -336,14 +539,16 @@ inline Program load(const uint8_t* bytes, size_t len) {
 }
 
 // ---- instance: what depends on the trace length -------------------------------------------------------------------------------
-struct BoundaryMember { uint32_t col, aux, coef, val_ext, val_idx; };   // value = scalB[val_idx] or scalE[val_idx]
-struct BoundaryGroup { uint32_t stride; uint64_t first, a, b, adj; uint32_t m0, count; };
+// An assertion as the instance sees it: member id = position in the program (main assertions, then aux); `coef` = its place in
+// the sorted order that hands out the composition coefficients; `group` = its divisor group (numerator column 1 + group).
+struct BoundaryMember { uint32_t col, aux, coef, group, val_ext, val_idx; };   // value = scalB[val_idx] or scalE[val_idx]
+struct BoundaryGroup { uint32_t stride; uint64_t first, a, b, adj; };
 struct Instance {
     int log_n = 0;
     uint64_t n = 0, ce_n = 0;
     std::vector<uint64_t> dgroup_adj;          // per degree group
     std::vector<BoundaryGroup> bgroups;        // numerator column 1 + j
-    std::vector<BoundaryMember> members;       // group j = members[m0 .. m0 + count)
+    std::vector<BoundaryMember> members;       // by member id
     size_t num_columns() const { return 1 + bgroups.size(); }
 };
 inline Instance instantiate(const Program& p, int log_n) {
@@ -362,20 +567,25 @@ inline Instance instantiate(const Program& p, int log_n) {
     }
     const uint64_t g = gl::root_of_unity(log_n);
     uint32_t coef = 0;
-    std::vector<std::vector<BoundaryMember>> gm;
+    in.members.resize(p.masserts.size() + p.aasserts.size());
     for (int seg = 0; seg < 2; seg++) {
-        std::vector<Assertion> v = seg == 0 ? p.masserts : p.aasserts;
-        for (auto& s : v) {
+        struct Item { Assertion s; uint32_t id; };
+        std::vector<Item> v;
+        const auto& src = seg == 0 ? p.masserts : p.aasserts;
+        for (uint32_t i = 0; i < src.size(); i++) v.push_back(Item{src[i], (uint32_t)(seg == 0 ? i : p.masserts.size() + i)});
+        for (auto& it : v) {
+            Assertion& s = it.s;
             if (s.first < 0) s.first += (int64_t)n;
             if (s.first < 0 || (uint64_t)s.first >= n) fail("air program: assertion step outside the trace");
             if (s.stride && (s.stride >= n || (uint64_t)s.first >= s.stride)) fail("air program: a periodic assertion needs first_step < stride < trace length");
         }
-        std::stable_sort(v.begin(), v.end(), [](const Assertion& x, const Assertion& y) {
-            return std::make_tuple(x.stride, x.first, x.col) < std::make_tuple(y.stride, y.first, y.col);
+        std::stable_sort(v.begin(), v.end(), [](const Item& x, const Item& y) {
+            return std::make_tuple(x.s.stride, x.s.first, x.s.col) < std::make_tuple(y.s.stride, y.s.first, y.s.col);
         });
         for (size_t i = 1; i < v.size(); i++)
-            if (v[i].col == v[i - 1].col && v[i].stride == v[i - 1].stride && v[i].first == v[i - 1].first) fail("air program: two assertions on the same column and step");
-        for (auto& s : v) {
+            if (v[i].s.col == v[i - 1].s.col && v[i].s.stride == v[i - 1].s.stride && v[i].s.first == v[i - 1].s.first) fail("air program: two assertions on the same column and step");
+        for (auto& it : v) {
+            const Assertion& s = it.s;
             size_t j = 0;
             for (; j < in.bgroups.size(); j++) if (in.bgroups[j].stride == s.stride && in.bgroups[j].first == (uint64_t)s.first) break;
             if (j == in.bgroups.size()) {
@@ -385,17 +595,12 @@ inline Instance instantiate(const Program& p, int log_n) {
                 bg.b = gl::pow(g, bg.first * bg.a);
                 bg.adj = (in.ce_n - 1 + bg.a) - (n - 1);
                 in.bgroups.push_back(bg);
-                gm.emplace_back();
             }
             const DOperand val = device_operand(p, s.value);     // row-independent: a scalar
-            gm[j].push_back(BoundaryMember{s.col, (uint32_t)seg, coef++, val.kind == D_SCAL_E ? 1u : 0u, val.idx});
+            in.members[it.id] = BoundaryMember{s.col, (uint32_t)seg, coef++, (uint32_t)j, val.kind == D_SCAL_E ? 1u : 0u, val.idx};
         }
     }
-    for (size_t j = 0; j < gm.size(); j++) {
-        in.bgroups[j].m0 = (uint32_t)in.members.size();
-        in.bgroups[j].count = (uint32_t)gm[j].size();
-        in.members.insert(in.members.end(), gm[j].begin(), gm[j].end());
-    }
+    if (in.bgroups.size() > 64) fail("air program: more than 64 boundary divisors", ST_UNSUPPORTED);
     return in;
 }
 
@@ -485,6 +690,7 @@ std::vector<typename F::T> host_evaluate(const Program& p, const Instance& in, c
         }
     };
     std::vector<T> out(in.num_columns(), F::zero());
+    std::vector<T> gsa(in.bgroups.size(), F::zero()), gsb(in.bgroups.size(), F::zero());
     T acc_a = F::zero(), acc_b = F::zero(), total = F::zero();
     for (const Insn& I : p.cons_code) {
         const uint32_t op = I.op & 0xff, ka = (I.op >> 8) & 0xf, kb = (I.op >> 12) & 0xf;
@@ -502,23 +708,49 @@ std::vector<typename F::T> host_evaluate(const Program& p, const Instance& in, c
                 acc_b = F::add(acc_b, F::mul(tb[I.dst], v));
                 break;
             }
+            case OP_EMIT_ADD_B: case OP_EMIT_SUB_B: case OP_EMIT_MUL_B: {
+                const T x = fetch(ka, I.a), y = fetch(kb, I.b);
+                const T v = op == OP_EMIT_ADD_B ? F::add(x, y) : op == OP_EMIT_SUB_B ? F::sub(x, y) : F::mul(x, y);
+                acc_a = F::add(acc_a, F::mul(ta[I.dst], v));
+                acc_b = F::add(acc_b, F::mul(tb[I.dst], v));
+                break;
+            }
+            case OP_EMIT3_B: {
+                const uint32_t o1 = (I.op >> 16) & 3, o2 = (I.op >> 18) & 3, left = (I.op >> 20) & 1;
+                auto ap = [&](uint32_t o, T x, T y) { return o == 1 ? F::add(x, y) : o == 2 ? F::sub(x, y) : F::mul(x, y); };
+                const T inner = ap(o2, slotB[I.b], slotB[I.pad]), other = slotB[I.a];
+                const T v = left ? ap(o1, inner, other) : ap(o1, other, inner);
+                acc_a = F::add(acc_a, F::mul(ta[I.dst], v));
+                acc_b = F::add(acc_b, F::mul(tb[I.dst], v));
+                break;
+            }
             case OP_GROUP_END: total = F::add(total, F::mul(acc_b, xpow(in.dgroup_adj[I.dst]))); acc_b = F::zero(); break;
+            case OP_LOAD_MAIN: case OP_LOAD_AUX:
+                for (uint32_t k = 0; k < I.a; k++) {
+                    const uint32_t d = p.cons_desc[I.dst + k], col = d & 0xffff, slot = (d >> 16) & 0xfff;
+                    const T* row = (d >> 31) ? nxt : cur;
+                    if (op == OP_LOAD_AUX) slotE[slot] = row[p.W + col];
+                    else slotB[slot] = (d & 0x40000000u) ? per[col] : row[col];
+                }
+                break;
+            case OP_BOUND_B: case OP_BOUND_E: {
+                const BoundaryMember& bm = in.members[I.dst];
+                const T v = fetch(ka, I.a);
+                gsa[bm.group] = F::add(gsa[bm.group], F::mul(ba[bm.coef], v));
+                gsb[bm.group] = F::add(gsb[bm.group], F::mul(bb[bm.coef], v));
+                break;
+            }
             default: fail("air program: corrupt constraint code", ST_INTERNAL);
         }
     }
     out[0] = F::add(total, acc_a);
-    for (size_t j = 0; j < in.bgroups.size(); j++) {
-        const BoundaryGroup& g = in.bgroups[j];
-        T sa = F::zero(), sb = F::zero();
-        for (uint32_t m = g.m0; m < g.m0 + g.count; m++) {
-            const BoundaryMember& bm = in.members[m];
-            const T val = bm.val_ext ? sc.e[bm.val_idx] : F::from(sc.b[bm.val_idx]);
-            const T d = F::sub(cur[bm.aux ? p.W + bm.col : bm.col], val);
-            sa = F::add(sa, F::mul(ba[bm.coef], d));
-            sb = F::add(sb, F::mul(bb[bm.coef], d));
-        }
-        out[1 + j] = F::add(sa, F::mul(sb, xpow(g.adj)));
+    // the assertions' values: sum (alpha + beta x^adj)(v - value) = [sa - sum alpha value] + x^adj [sb - sum beta value]
+    for (const BoundaryMember& bm : in.members) {
+        const T val = bm.val_ext ? sc.e[bm.val_idx] : F::from(sc.b[bm.val_idx]);
+        gsa[bm.group] = F::sub(gsa[bm.group], F::mul(ba[bm.coef], val));
+        gsb[bm.group] = F::sub(gsb[bm.group], F::mul(bb[bm.coef], val));
     }
+    for (size_t j = 0; j < in.bgroups.size(); j++) out[1 + j] = F::add(gsa[j], F::mul(gsb[j], xpow(in.bgroups[j].adj)));
     return out;
 }
 

@@ -45,7 +45,7 @@ def test_vm_shaped_program_oracle_and_library_verifier(oracle, log_n, pairs, aux
     info = air.info()
     assert info["ce_blowup"] == 8 and info["main_transition"] == 24 + 2 * pairs and info["aux_transition"] == aux
     assert air.num_divisors(log_n) == oracle.air_info(program, log_n)["columns"] == 8
-    assert info["registers_base"] + info["registers_ext"] <= 8            # register allocation, not one slot per node
+    assert info["registers_base"] + info["registers_ext"] <= 40           # register allocation (frame values included), not one slot per node
     aero_amd.verify_air(proof, pub, air, min_query_security_bits=0, expected_log_n=log_n)
     # a trace that breaks one constraint: both verifiers refuse the proof the (non-validating) prover makes of it
     bad = trace.copy()
