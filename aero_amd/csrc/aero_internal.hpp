@@ -120,6 +120,10 @@ public:
 
     explicit Context(int dev);
     ~Context();
+    // second stream + events for the host-to-device copy of a wide trace: column group g + 1 travels while group g is transformed
+    hipStream_t copy_stream = nullptr;
+    hipStream_t get_copy_stream();
+    hipEvent_t sync_event(size_t i);
 
     // ---- memory: size-keyed free lists so steady-state proving performs no hipMalloc/hipFree ----
     void* pool_alloc(size_t bytes);
@@ -164,7 +168,8 @@ public:
     // contiguous pass alone do not produce it and the caller falls back to strided reads of the full matrix)
     bool ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad,
                      const CompactOut* compact = nullptr);
-    void ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift);
+    // bad (optional, device): 1 is ORed in when an input element is >= p (checked by the pass that reads the input)
+    void ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift, unsigned int* bad = nullptr);
 
     // ---- hashing (hash.hip) ----
     // leaf j = hash_elements(row j) of a column-major matrix (ncols columns, `rows` rows, column stride in elements)
@@ -202,6 +207,7 @@ private:
     std::multimap<size_t, void*> free_blocks;
     std::map<void*, size_t> live_blocks;
     std::vector<void*> persistent, scratch;
+    std::vector<hipEvent_t> sync_events;
     uint8_t* stage_base = nullptr;
     unsigned int* pinned_flag = nullptr;
     size_t stage_cap = 0, stage_off = 0;

@@ -536,6 +536,7 @@ static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, i
         p.set_comm(sc);
     }
     p.collect_stage_times = ctx->stage_timing;
+    if (ctx->concurrent_peers) p.h2d_pipeline = false;
     std::vector<uint64_t> pub;
     Bytes b = p.prove(trace_dev, width, log_n, &pub);
     ctx->last_ms = p.last_stage_ms;
@@ -593,16 +594,11 @@ static void prove_from_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint
     const size_t n = (size_t)1 << log_n;
     unsigned int* verdict = c->pinned_word();
     *verdict = 0;
+    // no device copy of the trace outlives the proof: the columns go straight into the interpolation buffer (Prover::set_host_trace;
+    // with an auxiliary segment a copy is kept until its columns are built)
     const uint32_t A = air ? air->aux_width : 0;
-    if (A == 0) {
-        // no device copy of the trace at all: the columns go straight into the interpolation buffer (Prover::set_host_trace)
-        do_prove(ctx, nullptr, width, (int)log_n, options, proof, proof_len, pub_out, nullptr, 0, 0, 2, trace_col_major, verdict);
-    } else {
-        DevBuf<uint64_t> d(c, (size_t)width * n);
-        AERO_HIP(hipMemcpyAsync(d.get(), trace_col_major, (size_t)width * n * 8, hipMemcpyHostToDevice, c->stream));
-        canonical_check_enqueue(c, d.get(), (size_t)width * n, verdict);
-        do_prove(ctx, d.get(), width, (int)log_n, options, proof, proof_len, pub_out, nullptr, A, air->aux_rands, air->aux_degree);
-    }
+    (void)n; (void)c;
+    do_prove(ctx, nullptr, width, (int)log_n, options, proof, proof_len, pub_out, nullptr, A, A ? air->aux_rands : 0, A ? air->aux_degree : 2, trace_col_major, verdict);
     if (*verdict != 0) {   // the proof's own synchronisations have long passed the check
         free(*proof);
         *proof = nullptr; *proof_len = 0;
@@ -864,6 +860,7 @@ static int32_t pool_run(aero_pool* pool, const aero_matrix* const* traces, const
         for (uint32_t i = 0; i < count; i++) {
             pool->slots[i]->trace = traces ? traces[i] : nullptr;
             pool->slots[i]->host_trace = host_traces ? host_traces[i] : nullptr;
+            pool->slots[i]->ctx->concurrent_peers = count > 1;
             pool->slots[i]->has_job = true;
         }
         pool->pending = (int)count;

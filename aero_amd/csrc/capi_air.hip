@@ -105,6 +105,7 @@ static void prove_program(aero_ctx* ctx, const aero_comm* comm, const aero_air* 
         pr.set_comm(sc);
     }
     pr.collect_stage_times = ctx->stage_timing;
+    if (ctx->concurrent_peers) pr.h2d_pipeline = false;
     const Bytes b = pr.prove(trace_dev, width, log_n, nullptr);
     ctx->last_ms = pr.last_stage_ms;
     *proof = to_malloc(b, proof_len);
@@ -130,16 +131,10 @@ int32_t aero_prove_air_host(aero_ctx* ctx, const aero_air* air, const uint64_t* 
         const size_t n = (size_t)1 << log_n;
         unsigned int* verdict = c->pinned_word();
         *verdict = 0;
-        if (air->prog.A == 0) {
-            // the columns go straight into the interpolation buffer (Prover::set_host_trace): no device copy of the trace is kept
-            prove_program(ctx, nullptr, air, nullptr, trace_col_major, verdict, W, (int)log_n, pub, n_pub, options, proof, proof_len);
-        } else {
-            // the auxiliary builders read the main segment after the first commitment: keep it on the device
-            DevBuf<uint64_t> d(c, (size_t)W * n);
-            AERO_HIP(hipMemcpyAsync(d.get(), trace_col_major, (size_t)W * n * 8, hipMemcpyHostToDevice, c->stream));
-            canonical_check_enqueue(c, d.get(), (size_t)W * n, verdict);
-            prove_program(ctx, nullptr, air, d.get(), nullptr, nullptr, W, (int)log_n, pub, n_pub, options, proof, proof_len);
-        }
+        // the columns go straight into the interpolation buffer (Prover::set_host_trace); with auxiliary builders a device copy of the
+        // main segment is kept until the auxiliary columns are built
+        (void)n; (void)c;
+        prove_program(ctx, nullptr, air, nullptr, trace_col_major, verdict, W, (int)log_n, pub, n_pub, options, proof, proof_len);
         if (*verdict != 0) {
             free(*proof);
             *proof = nullptr; *proof_len = 0;

@@ -61,6 +61,9 @@ struct PassArgs {
     const uint64_t* ktab;     // R entries: c0 * (a^(2^(L-r)) * b^(2^(L-r-shift)))^rev_r(k)
     uint64_t sc_a, sc_b;      // per-block factor = a^rev(block) * b^(rev(block) >> shift)
     int sc_shift;
+    // inverse, first executed pass only (optional): OR 1 into *bad when an input element is not canonical (>= p) - the validation
+    // of a trace handed over by the host rides on the pass that reads it anyway
+    unsigned int* bad;
 };
 
 // LDS index skew: one extra slot per 32 elements breaks the power-of-two strides of the radix-8 gathers
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
     for (int e = threadIdx.x; e < E; e += 256) {
         int tl = e & (TL - 1), k = e >> a.log_tl;
         uint64_t v = in[base + tl + ((size_t)k << a.log_s)];
+        if (a.bad && v >= gl::P) atomicOr(a.bad, 1u);
         if (!a.first && rb && k) {
             uint32_t ex = (uint32_t)((((uint64_t)rb * (uint32_t)k) << a.log_s) & ((1ull << a.log_n) - 1));
             v = mul(v, tw_lookup(a.tw_lo, a.tw_hi, ex, a.tw_h));
@@ -416,6 +420,12 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_inv_last_pass_11(PassArg
     uint64_t y[32];
 #pragma unroll
     for (int i = 0; i < 32; i++) y[i] = data[lane + 64 * i];
+    if (a.bad) {
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 32; i++) any |= y[i] >= gl::P;
+        if (any) atomicOr(a.bad, 1u);
+    }
     {
         // input side: w^-(rbk p), p = lane + 64 i, times the tile's output factor
         uint64_t cur = bftab[b];
@@ -580,6 +590,12 @@ template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void nt
 #pragma unroll
     for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
     if (LOGR == 6) __builtin_amdgcn_sched_barrier(0);
+    if (a.bad) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < R; k++) any |= y[k] >= gl::P;
+        if (any) atomicOr(a.bad, 1u);
+    }
     if (!a.first && b) {
         const uint64_t* tw = a.tw_pass + ((size_t)b << LOGR);
 #pragma unroll
@@ -754,7 +770,7 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
 
 // evaluations in natural order over <w_n> (n = 2^log_n) -> coefficients in bit-reversed order, where coefficient
 // with natural index I is multiplied by c0 * sa^I * sb^(I >> shift). In place.
-void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift) {
+void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift, unsigned int* bad) {
     ensure_small_twiddles();
     NttTables* t = ntt_tables(log_n);
     // two-phase contiguous pass (11 bits) where the transform is large enough to keep its strided passes' count
@@ -796,6 +812,7 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
         a.in = data; a.out = data; a.in_col_stride = stride; a.out_col_stride = stride;
         a.log_n = log_n; a.log_s = plan[qi].log_s; a.log_r = plan[qi].log_r; a.log_tl = plan[qi].log_tl;
         a.first = (qi + 1 == plan.size());
+        a.bad = a.first ? bad : nullptr;      // the pass that reads the caller's values
         a.tw_r = tw4096_inv; a.tw_lo = t->lo_inv; a.tw_hi = t->hi_inv; a.tw_h = t->h;
         if (qi == 0) { a.ktab = ktab; a.sc_a = sa; a.sc_b = sb; a.sc_shift = shift; }
         if (qi > 0 && reg_passes) {

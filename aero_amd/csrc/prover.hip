@@ -39,7 +39,21 @@ Context::~Context() {
     if (pinned_flag) (void)hipHostFree(pinned_flag);
     for (auto& r : kt_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (hipEvent_t e : kt_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : sync_events) (void)hipEventDestroy(e);
+    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (stream) (void)hipStreamDestroy(stream);
+}
+hipStream_t Context::get_copy_stream() {
+    if (!copy_stream) AERO_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    return copy_stream;
+}
+hipEvent_t Context::sync_event(size_t i) {
+    while (sync_events.size() <= i) {
+        hipEvent_t e;
+        AERO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sync_events.push_back(e);
+    }
+    return sync_events[i];
 }
 void* Context::pool_alloc(size_t bytes) {
     if (bytes == 0) bytes = 256;
@@ -813,25 +827,6 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     };
 
     // 1. interpolate_columns [a3]: coefficient i scaled by h^i, so the coset LDE below needs no shift pass
-    Matrix polys(ctx, (int)W, n);
-    if (host_trace) {
-        // Direct hand-over: the columns are copied straight into the buffer the interpolation works in (no device-side copy of
-        // the trace is kept, no device-to-device pass), canonical-form check and inverse transform follow on the same stream.
-        // (Measured and dropped: copying column groups on a SECOND stream so that group g + 1 travels while group g is being
-        // transformed. One proof gained 40 us of 2.93 ms; with 8 proofs in flight the 16 streams and their cross-stream waits
-        // cost 9 % of the throughput. Other proofs' kernels are what a transfer should overlap with, and they already do.)
-        if (A) fail("prove: the direct host hand-over does not cover the auxiliary segment", ST_INTERNAL);
-        unsigned int* d_bad = (unsigned int*)ctx->scratch_alloc(4);
-        AERO_HIP(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-        AERO_HIP(hipMemcpyAsync(polys.data.get(), host_trace, (size_t)W * n * 8, hipMemcpyHostToDevice, ctx->stream));
-        canonical_check_accumulate(ctx, polys.data.get(), (size_t)W * n, d_bad);
-        ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0);
-        AERO_HIP(hipMemcpyAsync(host_verdict_, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        AERO_HIP(hipMemcpyAsync(polys.data.get(), trace_dev, (size_t)W * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0);
-    }
-    ms.interpolate = clk.lap();
     // 2. evaluate_columns_over [a4] (this rank's coset: M rows)
     // Compact copies for the per-row kernels that walk an LDE with a stride (one GPU only): the trace / aux LDE's last pass also
     // writes every ce_step-th row densely (what constraint evaluation reads; DEEP reads every (B / ce_step)-th row of that), or
@@ -841,12 +836,71 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     // every (B / ce_step)-th compact row is a DEEP row: de-interleave so that DEEP reads part 0 contiguously
     const int tc_split = log_ce_step > 0 ? log_B - log_ce_step : 0;
     const int cc_log = (G == 1 && compact_rows) ? log_B : 0;
+    Matrix polys(ctx, (int)W, n);
     Matrix tlde(ctx, (int)W, M), tlde_c, alde_c, clde_c;
     bool have_tc = false, have_ac = false, have_cc = false;
-    {
-        CompactOut co;
-        if (tc_log > 0 && log_M >= 14) { tlde_c = Matrix(ctx, (int)W, M >> tc_log); co.ptr = tlde_c.data.get(); co.col_stride = M >> tc_log; co.log_step = tc_log; co.log_split = tc_split; }
-        have_tc = ctx->ntt_forward(polys.data.get(), n, tlde.data.get(), M, (int)W, log_M, log_Bl, &co);
+    CompactOut tco;
+    if (tc_log > 0 && log_M >= 14) { tlde_c = Matrix(ctx, (int)W, M >> tc_log); tco.ptr = tlde_c.data.get(); tco.col_stride = M >> tc_log; tco.log_step = tc_log; tco.log_split = tc_split; }
+    // columns [c0, c0 + nc): coefficients -> this rank's coset of the LDE (+ the compact copy)
+    auto extend_columns = [&](uint32_t c0, uint32_t nc) {
+        CompactOut co = tco;
+        if (co.ptr) co.ptr += (size_t)c0 * co.col_stride;
+        return ctx->ntt_forward(polys.data.get() + (size_t)c0 * n, n, tlde.data.get() + (size_t)c0 * M, M, (int)nc, log_M, log_Bl, &co);
+    };
+    DevBuf<uint64_t> trace_keep;              // device copy of a HOST trace, kept when the AIR reads the main segment again (aux builders)
+    const uint64_t* trace_src = trace_dev;
+    if (host_trace) {
+        // Direct hand-over: the columns are copied straight into the buffer the interpolation works in; the canonical-form check
+        // rides on the first inverse pass (the pass that reads the values anyway: no separate read of the trace).
+        // Wide traces travel in column groups on a second stream: while group g + 1 is on the PCIe link, group g is interpolated
+        // AND extended on the proving stream, so the copy hides behind the two transforms (2^20 x 72: 604 MB, 11 ms of link time
+        // against 8 ms of transforms). For narrow traces the groups are not worth their events: with 8 proofs of 2^20 x 2 in
+        // flight a second stream per proof cost 9 % of the throughput (round 2), and other proofs' kernels already overlap the copy.
+        unsigned int* d_bad = (unsigned int*)ctx->scratch_alloc(4);
+        AERO_HIP(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+        if (A) trace_keep = DevBuf<uint64_t>(ctx, (size_t)W * n);
+        uint64_t* const land = A ? trace_keep.get() : polys.data.get();
+        const size_t col_bytes = n * 8;
+        uint32_t gw = W;
+        if (h2d_pipeline && W >= 16) {
+            gw = (W + 15) / 16;                                                   // at most 16 groups ...
+            const uint32_t min_cols = (uint32_t)(((size_t)32 << 20) / col_bytes);   // ... of at least 32 MiB
+            if (gw < min_cols) gw = min_cols;
+            if (gw > W) gw = W;
+        }
+        if (gw == W) {
+            AERO_HIP(hipMemcpyAsync(land, host_trace, (size_t)W * col_bytes, hipMemcpyHostToDevice, ctx->stream));
+            if (A) AERO_HIP(hipMemcpyAsync(polys.data.get(), land, (size_t)W * col_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0, d_bad);
+            ms.interpolate = clk.lap();
+            have_tc = extend_columns(0, W);
+        } else {
+            hipStream_t cs = ctx->get_copy_stream();
+            const uint32_t groups = (W + gw - 1) / gw;
+            AERO_HIP(hipEventRecord(ctx->sync_event(0), ctx->stream));           // the buffers are free once the proving stream gets here
+            AERO_HIP(hipStreamWaitEvent(cs, ctx->sync_event(0), 0));
+            for (uint32_t g = 0; g < groups; g++) {
+                const uint32_t c0 = g * gw, nc = std::min(gw, W - c0);
+                AERO_HIP(hipMemcpyAsync(land + (size_t)c0 * n, host_trace + (size_t)c0 * n, (size_t)nc * col_bytes, hipMemcpyHostToDevice, cs));
+                AERO_HIP(hipEventRecord(ctx->sync_event(1 + g), cs));
+            }
+            have_tc = true;
+            for (uint32_t g = 0; g < groups; g++) {
+                const uint32_t c0 = g * gw, nc = std::min(gw, W - c0);
+                AERO_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_event(1 + g), 0));
+                if (A) AERO_HIP(hipMemcpyAsync(polys.data.get() + (size_t)c0 * n, land + (size_t)c0 * n, (size_t)nc * col_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                ctx->ntt_inverse(polys.data.get() + (size_t)c0 * n, n, (int)nc, log_n, 1, h, 1, 0, d_bad);
+                if (!extend_columns(c0, nc)) have_tc = false;
+            }
+            ms.interpolate = 0;
+        }
+        AERO_HIP(hipMemcpyAsync(host_verdict_, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        trace_src = A ? trace_keep.get() : nullptr;
+    } else {
+        AERO_HIP(hipMemcpyAsync(polys.data.get(), trace_dev, (size_t)W * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0);
+        ms.interpolate = clk.lap();
+        have_tc = extend_columns(0, W);
     }
     ms.lde = clk.lap();
     // 3. row hashes, Merkle tree, commit [a5, a6, a8]
@@ -870,8 +924,9 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         pp.commit();
         d_rands = pp.ptr<T>(ir);
         apolys = Matrix(ctx, (int)(A * F::DEG), n);
-        if (prog) air_build_aux<F>(ctx, *prog, trace_dev, log_n, air.results.data(), rands.data(), apolys.data.get());
-        else launch_aux_columns<F>(ctx, trace_dev, n, W, A, R, D, d_rands, apolys.data.get());
+        if (prog) air_build_aux<F>(ctx, *prog, trace_src, log_n, air.results.data(), rands.data(), apolys.data.get());
+        else launch_aux_columns<F>(ctx, trace_src, n, W, A, R, D, d_rands, apolys.data.get());
+        trace_keep.release();
         ctx->ntt_inverse(apolys.data.get(), n, (int)(A * F::DEG), log_n, 1, h, 1, 0);
         alde = Matrix(ctx, (int)(A * F::DEG), M);
         {
@@ -1321,6 +1376,7 @@ Bytes Prover::prove(const uint64_t* trace_dev, uint32_t width, int log_n, std::v
         if (opt_.field_extension == EXT_NONE) return prove_impl<FB>(trace_dev, width, log_n, pub_out);
         return prove_impl<FQ>(trace_dev, width, log_n, pub_out);
     } catch (...) {
+        if (ctx_->copy_stream) (void)hipStreamSynchronize(ctx_->copy_stream);     // a column-group copy may still read the caller's buffer
         (void)hipStreamSynchronize(ctx_->stream);     // nothing enqueued by the failed proof may outlive its scratch blocks
         (void)hipGetLastError();
         ctx_->scratch_reset();

@@ -171,7 +171,8 @@ public:
         aux_width_ = aux_width; aux_rands_ = aux_width ? aux_rands : 0; aux_degree_ = aux_degree;
     }
     // The next prove() takes its trace from HOST memory (column-major width x 2^log_n; `trace_dev` is then ignored): it is copied
-    // straight into the interpolation buffer. *verdict (pinned) receives 0 when every element was canonical. FibAir without aux segment.
+    // straight into the interpolation buffer (a device copy is kept only while an auxiliary segment still has to be built from it).
+    // *verdict (pinned) receives 0 when every element was canonical.
     void set_host_trace(const uint64_t* trace_host, unsigned int* verdict) { host_trace_ = trace_host; host_verdict_ = verdict; }
     // Prove against a program AIR (air_program.hpp; include/aero_air.h) instead of the built-in FibAir: the constraint set, the
     // assertions, the auxiliary segment's shape and construction all come from the program; `pub` = its public inputs (they seed
@@ -185,6 +186,7 @@ public:
     bool fri_tail = getenv("AERO_FRI_TAIL") ? getenv("AERO_FRI_TAIL")[0] != '0' : true;   // small FRI layers in one launch (Context::fri_tail)
     bool compact_rows = getenv("AERO_COMPACT_ROWS") ? getenv("AERO_COMPACT_ROWS")[0] != '0' : true;   // compact every-k-th-row LDE copies for constraints / DEEP
     bool low_level_skip = true;         // large trees: the 3 lowest Merkle levels are not stored but recomputed by the openings
+    bool h2d_pipeline = getenv("AERO_H2D_PIPELINE") ? getenv("AERO_H2D_PIPELINE")[0] != '0' : true;   // wide host traces travel in column groups behind the transforms
 
     // ---- stage-level entry points (the reference's split API; also what the C ABI exposes) ----
     // interpolate_columns: evaluations on <w_n> -> polys (bit-reversed coefficients pre-scaled by 7^i)
