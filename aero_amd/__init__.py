@@ -516,6 +516,23 @@ class Context:
         lib().aero_free(proof)
         return data, pub.tolist()
 
+    def prove_fib_sharded_host(self, comm, trace, options: ProofOptions, aux=(0, 0, 2)):
+        """ONE proof over comm.world GPUs with the trace in HOST memory (aero_prove_fib_sharded_host): this rank copies only its
+        share of the columns. Returns (proof_bytes, public_inputs)."""
+        t = trace.array if isinstance(trace, PinnedTrace) else np.ascontiguousarray(trace, np.uint64)
+        w, n = t.shape
+        pub = np.zeros(w // 2, np.uint64)
+        proof, plen = u8p(), C.c_size_t(0)
+        air = FibAirDesc(*aux)
+        rc = lib().aero_prove_fib_sharded_host(self.h, C.byref(comm.struct) if comm is not None else None, _p64(t), C.c_uint32(w),
+                                               C.c_uint32(int(n).bit_length() - 1), C.byref(air), C.byref(options), C.byref(proof), C.byref(plen), _p64(pub))
+        if rc != 0 and getattr(comm, "last_error", None) is not None:
+            raise AeroError(rc, f"{lib().aero_last_error(self.h).decode()} ({comm.last_error!r})")
+        self._ck(rc)
+        data = C.string_at(proof, plen.value)
+        lib().aero_free(proof)
+        return data, pub.tolist()
+
     def prove_fib_aux(self, trace: "Matrix", aux_width, aux_rands, options: ProofOptions, comm=None, aux_degree=2):
         """FibAir plus one auxiliary segment of `aux_width` columns built from `aux_rands` coin elements, aux transition
         constraint of degree `aux_degree` (aero_prove_fib_air); comm = None or a shard communicator.
@@ -717,6 +734,29 @@ def fib_program(width, aux=(0, 0, 2)) -> bytes:
     data = C.string_at(out, n.value)
     lib().aero_free(out)
     return data
+
+
+def prove_fib_sharded_local(trace, options: ProofOptions, world, aux=(0, 0, 2), devices=None, min_peer_digests=0):
+    """aero_prove_fib_sharded_local: ONE proof by `world` ranks of this process (a context and a thread per rank inside the library,
+    exchanges through the in-process communicator), trace in host memory. Returns (proofs [bytes per rank], public_inputs, rank_ms,
+    bytes_sent per rank)."""
+    t = trace.array if isinstance(trace, PinnedTrace) else np.ascontiguousarray(trace, np.uint64)
+    w, n = t.shape
+    dev = (C.c_int32 * world)(*(devices or [0] * world))
+    proofs, lens = (u8p * world)(), (C.c_size_t * world)()
+    pub = np.zeros(w // 2 + 1, np.uint64)
+    ms, sent = (C.c_double * world)(), (C.c_uint64 * world)()
+    err = C.create_string_buffer(512)
+    air = FibAirDesc(*aux)
+    rc = lib().aero_prove_fib_sharded_local(dev, C.c_uint32(world), _p64(t), C.c_uint32(w), C.c_uint32(int(n).bit_length() - 1), C.byref(air),
+                                            C.byref(options), C.c_uint32(min_peer_digests), proofs, lens, _p64(pub), ms, sent, err, C.c_size_t(512))
+    if rc != 0:
+        raise AeroError(rc, err.value.decode(errors="replace"))
+    out = []
+    for r in range(world):
+        out.append(C.string_at(proofs[r], lens[r]))
+        lib().aero_free(proofs[r])
+    return out, pub[:w // 2].tolist(), list(ms), list(sent)
 
 
 class VerifyPolicy(C.Structure):

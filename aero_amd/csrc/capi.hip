@@ -587,7 +587,7 @@ int32_t aero_prove_fib_air(aero_ctx* ctx, const aero_comm* comm, const aero_matr
 // behind it WITHOUT a stream synchronisation of its own (its verdict is read after the proof, which is discarded when the
 // trace held an element >= p), then the proof. Pinned host memory (aero_host_register) makes the copy a true async DMA.
 static void prove_from_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n, const aero_fib_air* air,
-                            const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out) {
+                            const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out, const aero_comm* comm = nullptr) {
     REQUIRE(trace_col_major, "prove_fib_host: null trace");
     REQUIRE(width >= 2 && width <= 254 && log_n >= 3 && log_n <= 29, "prove_fib_host: bad shape");
     Context* c = ctx->c;
@@ -598,7 +598,7 @@ static void prove_from_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint
     // with an auxiliary segment a copy is kept until its columns are built)
     const uint32_t A = air ? air->aux_width : 0;
     (void)n; (void)c;
-    do_prove(ctx, nullptr, width, (int)log_n, options, proof, proof_len, pub_out, nullptr, A, A ? air->aux_rands : 0, A ? air->aux_degree : 2, trace_col_major, verdict);
+    do_prove(ctx, nullptr, width, (int)log_n, options, proof, proof_len, pub_out, comm, A, A ? air->aux_rands : 0, A ? air->aux_degree : 2, trace_col_major, verdict);
     if (*verdict != 0) {   // the proof's own synchronisations have long passed the check
         free(*proof);
         *proof = nullptr; *proof_len = 0;
@@ -613,6 +613,10 @@ int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint
 int32_t aero_prove_fib_air_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n, const aero_fib_air* air,
                                 const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out) {
     return guard(ctx, [&] { prove_from_host(ctx, trace_col_major, width, log_n, air, options, proof, proof_len, pub_out); });
+}
+int32_t aero_prove_fib_sharded_host(aero_ctx* ctx, const aero_comm* comm, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n,
+                                    const aero_fib_air* air, const aero_proof_options* options, uint8_t** proof, size_t* proof_len, uint64_t* pub_out) {
+    return guard(ctx, [&] { prove_from_host(ctx, trace_col_major, width, log_n, air, options, proof, proof_len, pub_out, comm); });
 }
 int32_t aero_host_register(void* p, size_t bytes) {
     if (!p || !bytes) return AERO_E_BAD_ARG;

@@ -541,6 +541,36 @@ Commitment Prover::commit_exchange(DevBuf<Digest>& local, size_t L) {
             AERO_HIP(hipMemcpyAsync(c.tree.nodes.get() + 1, recv.get(), sizeof(Digest), hipMemcpyDeviceToDevice, ctx->stream));
         }
     }
+    finish_exchange(c);
+    return c;
+}
+// The same commitment when a row is SHORTER than its digest (8 * columns < 32 bytes: the 2-column trace and composition matrices
+// of the Fibonacci workloads): the ranks exchange the rows and each hashes the leaves of its own contiguous range - half the bytes
+// on the links, the same number of compressions per rank.
+Commitment Prover::commit_exchange_rows(const Matrix& lde) {
+    Context* ctx = ctx_;
+    const int G = comm_.world;
+    const size_t L = lde.rows, per = L / G, W = (size_t)lde.cols;
+    Commitment c;
+    c.sharded = true;
+    c.n_global = L * G;
+    c.tree = MerkleTree(ctx, L);
+    DevBuf<uint64_t> send(ctx, W * L), recv(ctx, W * L);
+    // chunk p = my rows [p * per, (p + 1) * per) of every column, column-major inside the chunk
+    for (int p = 0; p < G; p++)
+        AERO_HIP(hipMemcpy2DAsync(send.get() + (size_t)p * W * per, per * 8, lde.data.get() + (size_t)p * per, L * 8, per * 8, W, hipMemcpyDeviceToDevice, ctx->stream));
+    comm_all_to_all(send.get(), recv.get(), W * per * 8);
+    // chunk q holds rows of rank q's coset: global leaf u G + q of my range -> leaf slot q per + u (arrival order, as for digests)
+    for (int q = 0; q < G; q++) ctx->hash_rows(recv.get() + (size_t)q * W * per, per, (int)W, per, c.tree.leaves() + (size_t)q * per);
+    c.leaf_parts_log = ilog2(G);
+    ctx->merkle_build_parts(c.tree.nodes.get(), L, c.leaf_parts_log);
+    finish_exchange(c);
+    return c;
+}
+// all-gather of the G subtree roots (the only collective on the transcript's critical path); the top log2 G levels on the host
+void Prover::finish_exchange(Commitment& c) {
+    Context* ctx = ctx_;
+    const int G = comm_.world;
     DevBuf<Digest> roots(ctx, G);
     comm_all_gather(c.tree.nodes.get() + 1, roots.get(), sizeof(Digest));
     c.top.assign(2 * (size_t)G, Digest{});
@@ -549,7 +579,6 @@ Commitment Prover::commit_exchange(DevBuf<Digest>& local, size_t L) {
     for (int i = G - 1; i >= 1; i--) c.top[i] = b2s::merge(c.top[2 * i], c.top[2 * i + 1]);
     c.root = c.top[1];
     c.tree.root_host = c.top[G + comm_.rank];
-    return c;
 }
 
 // ---- stage functions shared by prove_impl and the C ABI ---------------------------------------------------
@@ -821,6 +850,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             c.root = c.tree.root();
             return c;
         }
+        if (exchange_rows && (size_t)lde.cols * 8 < sizeof(Digest) && lde.rows >= 8 * (size_t)G && lde.rows % G == 0) return commit_exchange_rows(lde);
         DevBuf<Digest> local(ctx, lde.rows);
         ctx->hash_rows(lde.data.get(), lde.rows, lde.cols, lde.rows, local.get());
         return commit_exchange(local, lde.rows);
@@ -856,19 +886,48 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         // AND extended on the proving stream, so the copy hides behind the two transforms (2^20 x 72: 604 MB, 11 ms of link time
         // against 8 ms of transforms). For narrow traces the groups are not worth their events: with 8 proofs of 2^20 x 2 in
         // flight a second stream per proof cost 9 % of the throughput (round 2), and other proofs' kernels already overlap the copy.
-        unsigned int* d_bad = (unsigned int*)ctx->scratch_alloc(4);
-        AERO_HIP(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+        unsigned int* d_bad = (unsigned int*)ctx->scratch_alloc(8);
+        AERO_HIP(hipMemsetAsync(d_bad, 0, 8, ctx->stream));
         if (A) trace_keep = DevBuf<uint64_t>(ctx, (size_t)W * n);
         uint64_t* const land = A ? trace_keep.get() : polys.data.get();
         const size_t col_bytes = n * 8;
         uint32_t gw = W;
-        if (h2d_pipeline && W >= 16) {
+        if (h2d_pipeline && W >= 16 && G == 1) {
             gw = (W + 15) / 16;                                                   // at most 16 groups ...
             const uint32_t min_cols = (uint32_t)(((size_t)32 << 20) / col_bytes);   // ... of at least 32 MiB
             if (gw < min_cols) gw = min_cols;
             if (gw > W) gw = W;
         }
-        if (gw == W) {
+        if (G > 1 && W >= (uint32_t)G && W % (uint32_t)G == 0) {
+            // One proof over G GPUs, trace in host memory: this rank copies and interpolates only ITS W / G columns (1 / G of the
+            // PCIe traffic and of the interpolation), the coefficients are all-gathered (in place) and every rank applies the
+            // pre-scaling h^i of its own coset afterwards. An AIR with an auxiliary segment reads main columns again when it builds
+            // it: the evaluations are all-gathered as well (over the GPU links instead of G whole-trace copies over PCIe).
+            const uint32_t cpr = W / (uint32_t)G, c0 = (uint32_t)rank * cpr;
+            uint64_t* const mine = polys.data.get() + (size_t)c0 * n;
+            AERO_HIP(hipMemcpyAsync(A ? land + (size_t)c0 * n : mine, host_trace + (size_t)c0 * n, (size_t)cpr * col_bytes, hipMemcpyHostToDevice, ctx->stream));
+            if (A) {
+                AERO_HIP(hipMemcpyAsync(mine, land + (size_t)c0 * n, (size_t)cpr * col_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                comm_all_gather(land + (size_t)c0 * n, land, (size_t)cpr * col_bytes);
+            }
+            ctx->ntt_inverse(mine, n, (int)cpr, log_n, 1, 1, 1, 0, d_bad);          // plain coefficients: no coset yet
+            comm_all_gather(mine, polys.data.get(), (size_t)cpr * col_bytes);
+            {
+                const int lo_bits = (log_n + 1) / 2;
+                std::vector<uint64_t> lo((size_t)1 << lo_bits), hi((size_t)1 << (log_n - lo_bits));
+                uint64_t v = 1;
+                for (auto& x : lo) { x = v; v = gl::mul(v, h); }
+                const uint64_t step = v;                                              // h^(2^lo_bits)
+                v = 1;
+                for (auto& x : hi) { x = v; v = gl::mul(v, step); }
+                ParamPack pp(ctx);
+                const size_t i_lo = pp.add(lo), i_hi = pp.add(hi);
+                pp.commit();
+                launch_scale_pow_bitrev(ctx, polys.data.get(), n, (int)W, log_n, pp.ptr<uint64_t>(i_lo), pp.ptr<uint64_t>(i_hi), lo_bits);
+            }
+            ms.interpolate = clk.lap();
+            have_tc = extend_columns(0, W);
+        } else if (gw == W) {
             AERO_HIP(hipMemcpyAsync(land, host_trace, (size_t)W * col_bytes, hipMemcpyHostToDevice, ctx->stream));
             if (A) AERO_HIP(hipMemcpyAsync(polys.data.get(), land, (size_t)W * col_bytes, hipMemcpyDeviceToDevice, ctx->stream));
             ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0, d_bad);
@@ -894,6 +953,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             }
             ms.interpolate = 0;
         }
+        if (G > 1) comm_all_reduce(reinterpret_cast<uint64_t*>(d_bad), 1);       // every rank checked its own columns: one verdict for all
         AERO_HIP(hipMemcpyAsync(host_verdict_, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
         trace_src = A ? trace_keep.get() : nullptr;
     } else {

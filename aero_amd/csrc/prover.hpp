@@ -186,6 +186,7 @@ public:
     bool fri_tail = getenv("AERO_FRI_TAIL") ? getenv("AERO_FRI_TAIL")[0] != '0' : true;   // small FRI layers in one launch (Context::fri_tail)
     bool compact_rows = getenv("AERO_COMPACT_ROWS") ? getenv("AERO_COMPACT_ROWS")[0] != '0' : true;   // compact every-k-th-row LDE copies for constraints / DEEP
     bool low_level_skip = true;         // large trees: the 3 lowest Merkle levels are not stored but recomputed by the openings
+    bool exchange_rows = getenv("AERO_EXCHANGE_ROWS") ? getenv("AERO_EXCHANGE_ROWS")[0] != '0' : true;   // sharded: rows instead of digests when shorter
     bool h2d_pipeline = getenv("AERO_H2D_PIPELINE") ? getenv("AERO_H2D_PIPELINE")[0] != '0' : true;   // wide host traces travel in column groups behind the transforms
 
     // ---- stage-level entry points (the reference's split API; also what the C ABI exposes) ----
@@ -222,6 +223,8 @@ private:
     template <class F> Bytes prove_impl(const uint64_t* trace_dev, uint32_t width, int log_n, std::vector<uint64_t>* pub_out);
     // sharded commitment: `local` = this rank's coset leaves (count L); returns the subtree over global leaves [rank*L, (rank+1)*L)
     Commitment commit_exchange(DevBuf<Digest>& local, size_t L);
+    Commitment commit_exchange_rows(const Matrix& lde);    // rows shorter than a digest: exchange the rows, hash on arrival
+    void finish_exchange(Commitment& c);
     void comm_all_to_all(const void* send, void* recv, size_t bytes);
     void comm_all_gather(const void* send, void* recv, size_t bytes);
     void comm_all_reduce(uint64_t* buf, size_t count);

@@ -752,6 +752,21 @@ void launch_select_coset_u64(Context* ctx, const uint64_t* in, size_t src_stride
                 first, step, rows_total, parts);
     ctx->check_launch("select_coset");
 }
+// data[c][p] *= h^rev(p) for every column c: coefficients in bit-reversed order take the coset pre-scaling h^i after the fact
+// (the sharded host hand-over all-gathers PLAIN coefficients; every rank then applies its own coset offset). h^i from a two-level
+// table of powers of h; one thread walks all columns of its position, so the factor is formed once per position.
+__global__ __launch_bounds__(256) void scale_pow_bitrev_kernel(uint64_t* __restrict__ data, size_t n, int ncols, int log_n, const uint64_t* __restrict__ lo,
+                                                             const uint64_t* __restrict__ hi, int lo_bits) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t i = gl::bitrev((uint32_t)p, log_n);
+    const uint64_t f = gl::mul(lo[i & ((1u << lo_bits) - 1)], hi[i >> lo_bits]);
+    for (int c = 0; c < ncols; c++) data[(size_t)c * n + p] = gl::mul(data[(size_t)c * n + p], f);
+}
+void launch_scale_pow_bitrev(Context* ctx, uint64_t* data, size_t n, int ncols, int log_n, const uint64_t* lo, const uint64_t* hi, int lo_bits) {
+    AERO_LAUNCH(ctx, "scale_pow_bitrev_kernel", (size_t)ncols * n * 16, scale_pow_bitrev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, data, n, ncols, log_n, lo, hi, lo_bits);
+    ctx->check_launch("scale_pow_bitrev");
+}
 void launch_interleave_u64(Context* ctx, const uint64_t* in, size_t src_stride, uint64_t* out, int parts, size_t len) {
     AERO_LAUNCH(ctx, "interleave_kernel", 2 * len * parts * 8, (interleave_kernel<uint64_t>), dim3((unsigned)((len + 255) / 256)), dim3(256), 0, in, src_stride, out, parts, len);
     ctx->check_launch("interleave_u64");

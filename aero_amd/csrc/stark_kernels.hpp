@@ -127,6 +127,8 @@ void launch_gather_addr(Context* ctx, const uint64_t* addr, uint32_t n_u64, uint
 // out[u * parts + k] = in[k * src_stride + u], u < len: merges `parts` equally long pieces into their interleaved order
 void launch_interleave_digests(Context* ctx, const Digest* in, size_t src_stride, Digest* out, int parts, size_t len);
 void launch_interleave_u64(Context* ctx, const uint64_t* in, size_t src_stride, uint64_t* out, int parts, size_t len);
+// data[c][p] *= h^rev_(log_n)(p), h^i = lo[i & (2^lo_bits - 1)] * hi[i >> lo_bits]
+void launch_scale_pow_bitrev(Context* ctx, uint64_t* data, size_t n, int ncols, int log_n, const uint64_t* lo, const uint64_t* hi, int lo_bits);
 void launch_select_coset_u64(Context* ctx, const uint64_t* in, size_t src_stride, uint64_t* out, size_t count, uint32_t first, size_t step,
                              size_t rows_total, uint32_t parts);
 

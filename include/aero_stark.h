@@ -285,6 +285,38 @@ void aero_rccl_destroy(aero_rccl* r);
 int32_t aero_prove_fib_sharded(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_proof_options* options,
                                uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
 
+/* The same with the trace in HOST memory - the hand-over the metric is defined on (`Prover::prove(trace)` receives a host
+ * ExecutionTrace, proving_worker.rs:465-467): every rank is given the same column-major host buffer (one process per GPU on one
+ * node: e.g. a shared mapping) and copies only ITS width / world columns to its GPU (1 / world of the PCIe traffic per rank),
+ * interpolates them, and the coefficients are all-gathered over the GPU links; with width < world every rank copies the whole
+ * trace. air may be NULL (plain FibAir); with an auxiliary segment the evaluations are all-gathered as well (its builders read the
+ * main segment). comm == NULL or world == 1 is aero_prove_fib_air_host. Same bytes on every rank as the single-GPU proof. */
+int32_t aero_prove_fib_sharded_host(aero_ctx* ctx, const aero_comm* comm, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n,
+                                    const aero_fib_air* air, const aero_proof_options* options, uint8_t** proof, size_t* proof_len,
+                                    uint64_t* pub_out);
+
+/* In-process communicator: `world` ranks = `world` contexts of THIS process (one host thread each), on one GPU or on several
+ * (peer access) - no RCCL, no second process. Exchanges are device-to-device copies enqueued on the ranks' own streams and ordered
+ * by events (AERO_COMM_STREAM_ORDERED); the host threads only rendezvous. For hosts that drive several GPUs from one process, and
+ * for exercising the sharded prover's stream-ordered contract on a one-GPU box.
+ *   aero_local_group_create ... world = power of two
+ *   aero_local_group_comm ..... binds rank `rank` to its context and fills the aero_comm to pass to the sharded entry points
+ *   aero_local_group_abort .... releases ranks waiting at a rendezvous (call when a rank failed outside an exchange)
+ *   aero_local_group_stats .... {all_to_all calls, all_gather calls, all_reduce calls, bytes sent} of a rank
+ * aero_prove_fib_sharded_local: the whole thing in one call - a context and a thread per rank on device_ids[r] (ids may repeat),
+ * trace in host memory (aero_prove_fib_sharded_host per rank); proofs[r] / proof_lens[r] per rank (aero_free each), rank_ms and
+ * bytes_sent (may be NULL) per rank. */
+typedef struct aero_local_group aero_local_group;
+int32_t aero_local_group_create(uint32_t world, aero_local_group** out);
+int32_t aero_local_group_comm(aero_local_group* group, aero_ctx* ctx, int32_t rank, uint32_t min_peer_digests, aero_comm* out);
+int32_t aero_local_group_stats(const aero_local_group* group, int32_t rank, uint64_t out[4]);
+const char* aero_local_group_last_error(const aero_local_group* group, int32_t rank);
+void aero_local_group_abort(aero_local_group* group);
+void aero_local_group_destroy(aero_local_group* group);
+int32_t aero_prove_fib_sharded_local(const int32_t* device_ids, uint32_t world, const uint64_t* trace_col_major, uint32_t width, uint32_t log_n,
+                                     const aero_fib_air* air, const aero_proof_options* options, uint32_t min_peer_digests, uint8_t** proofs,
+                                     size_t* proof_lens, uint64_t* pub_out, double* rank_ms, uint64_t* bytes_sent, char* err, size_t err_cap);
+
 /* ---- auxiliary trace segment ---------------------------------------------------------------------------------------------------- */
 /* `Prover::prove` for FibAir extended by ONE auxiliary segment, the step the fork's `commit_to_trace_and_validate`
  * (proving_worker.rs:323-332) performs per aux segment: after the main commitment `aux_rands` elements are drawn from the

@@ -1,0 +1,83 @@
+"""One proof sharded over the ranks of ONE process: the library's in-process communicator (stream-ordered device copies between
+the ranks' contexts, event hand-shakes, no RCCL / gloo / Python in the exchange) and the host-memory hand-over of the sharded
+proof (every rank copies only its width / world columns; coefficients all-gathered; rows exchanged instead of digests where a
+row is shorter than its digest). Every rank's bytes must equal the single-GPU proof's (the reference's own gather
+steps: proving_worker.rs:302-310,428-437)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import aero_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = aero_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("width,log_n,aux,opt,worlds", [
+    (2, 12, (0, 0, 2), [27, 8, 16, 4, 1, 8, 8], (2, 4, 8)),          # width < world for 4 and 8: whole-trace copy; rows exchanged (16 B < 32 B)
+    (8, 13, (0, 0, 2), [27, 8, 8, 4, 1, 8, 6], (2, 4, 8)),           # column-partitioned hand-over
+    (16, 12, (4, 3, 5), [27, 8, 8, 4, 1, 4, 7], (2, 4, 8)),          # aux segment of degree 5 (8 composition columns), fold 4
+    (8, 12, (0, 0, 2), [20, 8, 8, 4, 2, 8, 6], (2, 8)),              # quadratic extension
+    (72, 10, (9, 16, 8), [27, 8, 8, 4, 1, 4, 7], (8,)),              # Miden's shape
+    (4, 14, (0, 0, 2), [27, 16, 8, 4, 1, 2, 6], (4, 16)),            # blowup 16: world 16
+])
+def test_local_group_proofs_equal_the_single_gpu_proof(ctx, oracle, width, log_n, aux, opt, worlds):
+    trace = aero_amd.fib_trace(width, log_n)
+    o = aero_amd.ProofOptions(*opt)
+    want, pub = ctx.prove_fib_aux(trace, aux[0], aux[1], o, aux_degree=aux[2])
+    ref, _, _ = oracle.prove_fib_aux(width, log_n, aux[0], aux[1], opt, D=aux[2]) if aux[0] else oracle.prove_fib(width, log_n, opt)
+    assert want == ref
+    for world in worlds:
+        proofs, pub2, ms, sent = aero_amd.prove_fib_sharded_local(trace, o, world, aux)
+        assert pub2 == pub
+        assert all(p == want for p in proofs), f"world {world}"
+        assert all(s > 0 for s in sent)
+
+
+def test_rows_travel_instead_of_digests_when_they_are_shorter(ctx):
+    trace = aero_amd.fib_trace(2, 16)
+    o = aero_amd.ProofOptions.with_96_bit_security()
+    want, _ = ctx.prove_fib(trace, o)
+    sent = {}
+    for flag in ("1", "0"):
+        os.environ["AERO_EXCHANGE_ROWS"] = flag
+        try:
+            proofs, _, _, s = aero_amd.prove_fib_sharded_local(trace, o, 8)
+        finally:
+            os.environ.pop("AERO_EXCHANGE_ROWS", None)
+        assert all(p == want for p in proofs)
+        sent[flag] = s[0]
+    # trace and composition commitments: 16-byte rows instead of 32-byte digests
+    assert sent["1"] < sent["0"] - 1.5e6, sent           # 2 commitments x 16 B x 2^16 rows x 7/8 less per rank
+
+
+def test_non_canonical_trace_is_refused_by_every_rank():
+    trace = aero_amd.fib_trace(8, 12)
+    trace[5][100] = 0xFFFFFFFF00000001 + 1           # rank 2 of 4 copies this column: the verdict is all-reduced
+    with pytest.raises(aero_amd.AeroError) as e:
+        aero_amd.prove_fib_sharded_local(trace, aero_amd.ProofOptions.with_96_bit_security(), 4)
+    assert e.value.code == -1 and "non-canonical" in str(e.value)
+
+
+def test_plain_c_host_shards_a_proof_without_python(tmp_path):
+    exe = str(tmp_path / "sharded_local")
+    lib_dir = os.path.join(ROOT, "aero_amd")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "sharded_local.c"),
+           "-L", lib_dir, "-laero_stark", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for args in (["14", "8", "4"], ["12", "16", "8", "4", "3", "5"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        assert res["identical"] and res["world"] == int(args[2]) and res["bytes_sent_rank0"] > 0

@@ -1,6 +1,8 @@
 """Per-rank compute time of a sharded proof, measured on ONE GPU with loopback exchanges (aero_amd.shard.LoopbackComm).
 usage: python tools/shard_sim.py [log_n ...]   -> JSON lines (one per log_n / world)
-       AERO_SIM_SHAPE=width,aux_width,aux_rands,aux_degree,fold selects another trace shape (default 2,0,0,2,8)"""
+       AERO_SIM_SHAPE=width,aux_width,aux_rands,aux_degree,fold selects another trace shape (default 2,0,0,2,8)
+       AERO_SIM_HOST=1: the trace is handed over in pinned HOST memory (aero_prove_fib_sharded_host): the rank's share of the
+       host-to-device copy is inside the clock (width / world columns when world divides the width, else the whole trace)"""
 import json
 import os
 import sys
@@ -19,8 +21,14 @@ def main():
     ctx = aero_amd.Context(0)
     opts = aero_amd.ProofOptions.with_96_bit_security()
     opts.fri_folding_factor = fold
+    host = os.environ.get("AERO_SIM_HOST", "0") == "1"
     for log_n in logs:
-        trace = ctx.trace_upload(aero_amd.fib_trace(W, log_n))
+        trace = aero_amd.PinnedTrace(aero_amd.fib_trace(W, log_n)) if host else ctx.trace_upload(aero_amd.fib_trace(W, log_n))
+
+        def prove(comm):
+            if host:
+                return ctx.prove_fib_sharded_host(comm, trace, opts, (A, R, D))
+            return ctx.prove_fib_aux(trace, A, R, opts, comm=comm, aux_degree=D)
         reps = 7 if log_n <= 20 else 3
         base = None
         for world in (1, 2, 4, 8):
@@ -29,20 +37,20 @@ def main():
                 ts = []
                 for i in range(reps + 1):
                     t0 = time.perf_counter()
-                    ctx.prove_fib_aux(trace, A, R, opts, comm=comm, aux_degree=D)
+                    prove(comm)
                     ts.append((time.perf_counter() - t0) * 1e3)
                 ts = sorted(ts[1:])
                 ms = ts[len(ts) // 2]
                 ctx.set_stage_timing(True)
-                ctx.prove_fib_aux(trace, A, R, opts, comm=comm, aux_degree=D)
+                prove(comm)
                 st = ctx.last_stage_ms()
                 ctx.set_stage_timing(False)
                 if world == 1:
                     base = ms
-                print(json.dumps({"log_n": log_n, "shape": [W, A, R, D, fold], "world": world, "rank": rank, "ms": round(ms, 3), "speedup_vs_1": round(base / ms, 2),
+                print(json.dumps({"log_n": log_n, "shape": [W, A, R, D, fold], "host_handover": host, "world": world, "rank": rank, "ms": round(ms, 3), "speedup_vs_1": round(base / ms, 2),
                                   "exchanges": dict(comm.calls), "bytes_sent_per_proof": comm.bytes_sent // (reps + 2),
                                   "stages_ms": {k: round(v, 3) for k, v in st.items()}}), flush=True)
-        trace.free()
+        trace.release() if host else trace.free()
     ctx.close()
 
 
