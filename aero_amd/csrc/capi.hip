@@ -530,7 +530,7 @@ static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, i
         REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "prove_fib_sharded: missing exchange callback");
         ShardComm sc;
         sc.rank = comm->rank; sc.world = comm->world; sc.user = comm->user;
-        sc.all_to_all = comm->all_to_all; sc.all_gather = comm->all_gather; sc.all_reduce_sum_u64 = comm->all_reduce_sum_u64;
+        sc.all_to_all = comm->all_to_all; sc.all_gather = comm->all_gather; sc.all_reduce_sum_u64 = comm->all_reduce_sum_u64; sc.send_recv = comm->send_recv;
         sc.min_peer_digests = comm->min_peer_digests ? comm->min_peer_digests : 2048;
         sc.stream_ordered = (comm->flags & AERO_COMM_STREAM_ORDERED) != 0;
         p.set_comm(sc);

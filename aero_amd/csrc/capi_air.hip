@@ -99,7 +99,7 @@ static void prove_program(aero_ctx* ctx, const aero_comm* comm, const aero_air* 
         REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "prove_air: missing exchange callback");
         ShardComm sc;
         sc.rank = comm->rank; sc.world = comm->world; sc.user = comm->user;
-        sc.all_to_all = comm->all_to_all; sc.all_gather = comm->all_gather; sc.all_reduce_sum_u64 = comm->all_reduce_sum_u64;
+        sc.all_to_all = comm->all_to_all; sc.all_gather = comm->all_gather; sc.all_reduce_sum_u64 = comm->all_reduce_sum_u64; sc.send_recv = comm->send_recv;
         sc.min_peer_digests = comm->min_peer_digests ? comm->min_peer_digests : 2048;
         sc.stream_ordered = (comm->flags & AERO_COMM_STREAM_ORDERED) != 0;
         pr.set_comm(sc);

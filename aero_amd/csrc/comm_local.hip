@@ -100,6 +100,26 @@ int32_t exchange(aero_local_group::Slot* s, const void* send, void* recv, uint64
 }
 int32_t local_all_to_all(void* user, const void* send, void* recv, uint64_t bytes) { return exchange(static_cast<aero_local_group::Slot*>(user), send, recv, bytes, 0); }
 int32_t local_all_gather(void* user, const void* send, void* recv, uint64_t bytes) { return exchange(static_cast<aero_local_group::Slot*>(user), send, recv, bytes, 1); }
+// one chunk to `to`, one chunk from `from`: the peer that reads this rank's buffer is `to`
+int32_t local_send_recv(void* user, const void* send, int32_t to, void* recv, int32_t from, uint64_t bytes) {
+    aero_local_group::Slot* s = static_cast<aero_local_group::Slot*>(user);
+    aero_local_group* g = s->g;
+    if (hipSetDevice(s->device) != hipSuccess) { s->err = "hipSetDevice failed"; return 1; }
+    if (to < 0 || from < 0 || (uint32_t)to >= g->world || (uint32_t)from >= g->world) { s->err = "send_recv: bad peer"; return 1; }
+    s->send = send; s->bytes = bytes;
+    LOCAL_HIP(hipEventRecord(s->ready, s->stream));
+    if (!g->rendezvous()) { s->err = "the group was aborted (a peer failed)"; return 1; }
+    const aero_local_group::Slot& peer = g->slots[from];
+    if (peer.bytes != bytes) { s->err = "peers disagree on the send_recv size"; g->rendezvous(); return 1; }
+    if (from != s->rank) LOCAL_HIP(hipStreamWaitEvent(s->stream, peer.ready, 0));
+    LOCAL_HIP(hipMemcpyAsync(recv, peer.send, bytes, hipMemcpyDeviceToDevice, s->stream));
+    LOCAL_HIP(hipEventRecord(s->done, s->stream));
+    if (!g->rendezvous()) { s->err = "the group was aborted (a peer failed)"; return 1; }
+    if (to != s->rank) LOCAL_HIP(hipStreamWaitEvent(s->stream, g->slots[to].done, 0));
+    s->calls[0] += 1;
+    s->bytes_sent += bytes;
+    return 0;
+}
 int32_t local_all_reduce(void* user, void* buf, uint64_t count) {
     aero_local_group::Slot* s = static_cast<aero_local_group::Slot*>(user);
     aero_local_group* g = s->g;
@@ -169,7 +189,7 @@ int32_t aero_local_group_comm(aero_local_group* g, aero_ctx* ctx, int32_t rank, 
     }
     out->rank = rank; out->world = (int32_t)g->world; out->user = &s;
     out->all_to_all = local_all_to_all; out->all_gather = local_all_gather; out->all_reduce_sum_u64 = local_all_reduce;
-    out->min_peer_digests = min_peer_digests; out->flags = AERO_COMM_STREAM_ORDERED;
+    out->min_peer_digests = min_peer_digests; out->flags = AERO_COMM_STREAM_ORDERED; out->send_recv = local_send_recv;
     return AERO_OK;
 }
 int32_t aero_local_group_stats(const aero_local_group* g, int32_t rank, uint64_t out[4]) {
@@ -238,7 +258,12 @@ int32_t aero_prove_fib_sharded_local(const int32_t* device_ids, uint32_t world, 
         for (auto& t : th) t.join();
         for (uint32_t r = 0; r < world; r++) {
             if (bytes_sent) { uint64_t st[4]; aero_local_group_stats(g, (int32_t)r, st); bytes_sent[r] = st[3]; }
-            if (status[r] != AERO_OK && rc == AERO_OK) { rc = status[r]; put("rank " + std::to_string(r) + ": " + msgs[r]); }
+            if (status[r] != AERO_OK && rc == AERO_OK) rc = status[r];
+        }
+        if (rc != AERO_OK) {
+            std::string all;
+            for (uint32_t r = 0; r < world; r++) if (status[r] != AERO_OK) all += "rank " + std::to_string(r) + " (" + std::to_string(status[r]) + "): " + msgs[r] + "; ";
+            put(all);
         }
         if (rc != AERO_OK) for (uint32_t r = 0; r < world; r++) { free(proofs[r]); proofs[r] = nullptr; proof_lens[r] = 0; }
     }

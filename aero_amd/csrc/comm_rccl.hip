@@ -13,7 +13,16 @@
 // librccl is bound at run time (dlopen), not at link time: libaero_stark.so loads on a box without RCCL as long as no sharded
 // proof is requested, and the copy that is bound is the one living next to the HIP runtime this library itself uses (see rccl_api).
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// librccl is bound with dlopen; without its headers the few types of its C API this file names are declared here (NCCL 2.x ABI)
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 
 #include <cstring>
 #include <mutex>
@@ -125,6 +134,18 @@ static int32_t rccl_all_to_all(void* user, const void* send, void* recv, uint64_
     r->bytes_sent += bytes * (uint64_t)(r->world - 1);
     return 0;
 }
+static int32_t rccl_send_recv(void* user, const void* send, int32_t to, void* recv, int32_t from, uint64_t bytes) {
+    aero_rccl* r = static_cast<aero_rccl*>(user);
+    if (hipSetDevice(r->device) != hipSuccess) { r->err = "send_recv: hipSetDevice failed"; return 1; }
+    if (!r->ok(r->api->GroupStart(), "send_recv: ncclGroupStart")) return 1;
+    const bool good = r->ok(r->api->Send(send, bytes, ncclUint8, to, r->comm, r->stream), "send_recv: ncclSend") &&
+                      r->ok(r->api->Recv(recv, bytes, ncclUint8, from, r->comm, r->stream), "send_recv: ncclRecv");
+    const bool ended = r->ok(r->api->GroupEnd(), "send_recv: ncclGroupEnd");
+    if (!good || !ended) return 1;
+    r->calls[0] += 1;
+    r->bytes_sent += bytes;
+    return 0;
+}
 static int32_t rccl_all_gather(void* user, const void* send, void* recv, uint64_t bytes) {
     aero_rccl* r = static_cast<aero_rccl*>(user);
     if (hipSetDevice(r->device) != hipSuccess) { r->err = "all_gather: hipSetDevice failed"; return 1; }
@@ -189,6 +210,7 @@ int32_t aero_rccl_comm(aero_rccl* r, uint32_t min_peer_digests, aero_comm* out) 
     out->all_to_all = rccl_all_to_all; out->all_gather = rccl_all_gather; out->all_reduce_sum_u64 = rccl_all_reduce;
     out->min_peer_digests = min_peer_digests;
     out->flags = AERO_COMM_STREAM_ORDERED;
+    out->send_recv = rccl_send_recv;
     return AERO_OK;
 }
 

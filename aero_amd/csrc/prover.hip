@@ -515,6 +515,10 @@ void Prover::comm_all_reduce(uint64_t* buf, size_t count) {
     if (!comm_.stream_ordered) ctx_->sync();
     if (!comm_.all_reduce_sum_u64 || comm_.all_reduce_sum_u64(comm_.user, buf, count) != 0) fail("sharded prove: all_reduce exchange failed", ST_COMM);
 }
+void Prover::comm_send_recv(const void* send, int to, void* recv, int from, size_t bytes) {
+    if (!comm_.stream_ordered) ctx_->sync();
+    if (!comm_.send_recv || comm_.send_recv(comm_.user, send, to, recv, from, bytes) != 0) fail("sharded prove: send_recv exchange failed", ST_COMM);
+}
 // Leaf digests of this rank's coset (local leaf t = global leaf t*G + rank) -> every rank ends up with the digests of the
 // contiguous global range [rank*L, (rank+1)*L), builds that subtree, and the G subtree roots are all-gathered; the top
 // log2 G levels are hashed on the host by every rank.
@@ -579,6 +583,20 @@ void Prover::finish_exchange(Commitment& c) {
     for (int i = G - 1; i >= 1; i--) c.top[i] = b2s::merge(c.top[2 * i], c.top[2 * i + 1]);
     c.root = c.top[1];
     c.tree.root_host = c.top[G + comm_.rank];
+}
+
+// The constraint evaluations this rank needs from its peers: its constraint domain h_k<w_ce> is the union of `q` cosets, owned by
+// the ranks (rank + t * step) mod G, t < q. With a pairwise exchange only those q - 1 pieces travel (2^24 x 2 over 8 GPUs: one
+// piece of 128 MiB instead of seven); a communicator without one all-gathers. all[owner * bytes ...] holds the pieces.
+void Prover::gather_h_cosets(const uint64_t* mine, uint64_t* all, size_t bytes, int q, int step) {
+    const int G = comm_.world, rank = comm_.rank;
+    if (!comm_.send_recv || q >= G) { comm_all_gather(mine, all, bytes); return; }
+    uint8_t* base = reinterpret_cast<uint8_t*>(all);
+    AERO_HIP(hipMemcpyAsync(base + (size_t)rank * bytes, mine, bytes, hipMemcpyDeviceToDevice, ctx_->stream));
+    for (int t = 1; t < q; t++) {
+        const int from = (rank + t * step) % G, to = ((rank - t * step) % G + G) % G;
+        comm_send_recv(mine, to, base + (size_t)from * bytes, from, bytes);
+    }
 }
 
 // ---- stage functions shared by prove_impl and the C ABI ---------------------------------------------------
@@ -908,7 +926,18 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             AERO_HIP(hipMemcpyAsync(A ? land + (size_t)c0 * n : mine, host_trace + (size_t)c0 * n, (size_t)cpr * col_bytes, hipMemcpyHostToDevice, ctx->stream));
             if (A) {
                 AERO_HIP(hipMemcpyAsync(mine, land + (size_t)c0 * n, (size_t)cpr * col_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-                comm_all_gather(land + (size_t)c0 * n, land, (size_t)cpr * col_bytes);
+                // the main columns the auxiliary builders read: few of them (9 of 72 for the stand-in) come straight from the host,
+                // otherwise the evaluations are all-gathered over the GPU links
+                std::vector<uint8_t> need(W, 0);
+                if (prog) { for (uint32_t d : prog->aux_desc) if (!(d & 0x40000000u)) need[d & 0xffff] = 1; }
+                else for (uint32_t c = 0; c < A; c++) need[c % W] = 1;
+                uint32_t extra = 0;
+                for (uint32_t c = 0; c < W; c++) extra += need[c] && (c < c0 || c >= c0 + cpr);
+                if (extra * 2 <= W) {
+                    for (uint32_t c = 0; c < W; c++)
+                        if (need[c] && (c < c0 || c >= c0 + cpr))
+                            AERO_HIP(hipMemcpyAsync(land + (size_t)c * n, host_trace + (size_t)c * n, col_bytes, hipMemcpyHostToDevice, ctx->stream));
+                } else comm_all_gather(land + (size_t)c0 * n, land, (size_t)cpr * col_bytes);
             }
             ctx->ntt_inverse(mine, n, (int)cpr, log_n, 1, 1, 1, 0, d_bad);          // plain coefficients: no coset yet
             comm_all_gather(mine, polys.data.get(), (size_t)cpr * col_bytes);
@@ -953,7 +982,14 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             }
             ms.interpolate = 0;
         }
-        if (G > 1) comm_all_reduce(reinterpret_cast<uint64_t*>(d_bad), 1);       // every rank checked its own columns: one verdict for all
+        if (G > 1) {
+            // every rank checked its own columns: one verdict for all, and known BEFORE the ranks go on exchanging data derived
+            // from values the field arithmetic is not defined on (their transcripts could part ways mid-proof)
+            comm_all_reduce(reinterpret_cast<uint64_t*>(d_bad), 1);
+            uint64_t bad = 0;
+            ctx->fetch(&bad, d_bad, 8);
+            if (bad) { *host_verdict_ = 1; fail("prove: the trace holds a non-canonical field element (>= p)"); }
+        }
         AERO_HIP(hipMemcpyAsync(host_verdict_, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
         trace_src = A ? trace_keep.get() : nullptr;
     } else {
@@ -1042,7 +1078,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
                 DevBuf<uint64_t> hloc(ctx, (size_t)F::DEG * M), hall(ctx, (size_t)F::DEG * N);
                 uint64_t* oh[2] = {hloc.get(), hloc.get() + (F::DEG > 1 ? M : 0)};
                 air_eval_constraints<F>(ctx, *prog, pinst, ge, cc, air.results.data(), rands.data(), 1, nullptr, oh);
-                comm_all_gather(hloc.get(), hall.get(), (size_t)F::DEG * M * 8);          // [rank][component][t]
+                gather_h_cosets(hloc.get(), hall.get(), (size_t)F::DEG * M * 8, (int)(ceN / M), (int)((N / ceN) % (size_t)G));          // [rank][component][t]
                 for (int d = 0; d < F::DEG; d++)
                     launch_select_coset_u64(ctx, hall.get() + (size_t)d * M, (size_t)F::DEG * M, hbuf.get() + (size_t)d * ceN, ceN, (uint32_t)rank,
                                             N / ceN, N, (uint32_t)G);
@@ -1080,7 +1116,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
                 DevBuf<uint64_t> hloc(ctx, (size_t)F::DEG * M), hall(ctx, (size_t)F::DEG * N);
                 for (int d = 0; d < F::DEG; d++) a.out_h[d] = hloc.get() + (size_t)d * M;
                 launch_fib_constraints<F>(ctx, a, 1);
-                comm_all_gather(hloc.get(), hall.get(), (size_t)F::DEG * M * 8);          // [rank][component][t]
+                gather_h_cosets(hloc.get(), hall.get(), (size_t)F::DEG * M * 8, (int)(ceN / M), (int)((N / ceN) % (size_t)G));          // [rank][component][t]
                 for (int d = 0; d < F::DEG; d++)
                     launch_select_coset_u64(ctx, hall.get() + (size_t)d * M, (size_t)F::DEG * M, hbuf.get() + (size_t)d * ceN, ceN, (uint32_t)rank,
                                             N / ceN, N, (uint32_t)G);

@@ -132,6 +132,7 @@ struct ShardComm {
     int32_t (*all_to_all)(void*, const void*, void*, uint64_t) = nullptr;
     int32_t (*all_gather)(void*, const void*, void*, uint64_t) = nullptr;
     int32_t (*all_reduce_sum_u64)(void*, void*, uint64_t) = nullptr;
+    int32_t (*send_recv)(void*, const void*, int32_t, void*, int32_t, uint64_t) = nullptr;   // optional
     uint32_t min_peer_digests = 2048;
     bool stream_ordered = false;   // the callbacks enqueue on the context's stream (aero_comm flag AERO_COMM_STREAM_ORDERED)
 };
@@ -228,6 +229,8 @@ private:
     void comm_all_to_all(const void* send, void* recv, size_t bytes);
     void comm_all_gather(const void* send, void* recv, size_t bytes);
     void comm_all_reduce(uint64_t* buf, size_t count);
+    void comm_send_recv(const void* send, int to, void* recv, int from, size_t bytes);
+    void gather_h_cosets(const uint64_t* mine, uint64_t* all, size_t bytes, int q, int step);
     Context* ctx_;
     ProofOptions opt_;
     ShardComm comm_;

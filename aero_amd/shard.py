@@ -10,11 +10,12 @@ import ctypes as C
 _A2A = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 _AG = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 _AR = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64)
+_SR = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint64)
 
 
 class CommStruct(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("all_to_all", _A2A), ("all_gather", _AG),
-                ("all_reduce_sum_u64", _AR), ("min_peer_digests", C.c_uint32), ("flags", C.c_uint32)]
+                ("all_reduce_sum_u64", _AR), ("min_peer_digests", C.c_uint32), ("flags", C.c_uint32), ("send_recv", _SR)]   # send_recv: NULL = all_gather fallback
 
 
 class _DevPtr:
@@ -168,11 +169,19 @@ class LoopbackComm:
         self.calls = {"all_to_all": 0, "all_gather": 0, "all_reduce": 0}
         self.bytes_sent = 0
         self.last_error = None
-        self._a2a, self._ag, self._ar = _A2A(self._all_to_all), _AG(self._all_gather), _AR(self._all_reduce)
-        self.struct = CommStruct(rank, world, None, self._a2a, self._ag, self._ar, min_peer_digests)
+        self._a2a, self._ag, self._ar, self._sr = _A2A(self._all_to_all), _AG(self._all_gather), _AR(self._all_reduce), _SR(self._send_recv)
+        self.struct = CommStruct(rank, world, None, self._a2a, self._ag, self._ar, min_peer_digests, 0, self._sr)
 
     def _t(self, ptr, nbytes):
         return self.torch.as_tensor(_DevPtr(ptr, nbytes), device=self.device)
+
+    def _send_recv(self, _user, send, _to, recv, _from, nbytes):
+        n = int(nbytes)
+        self._t(recv, n).copy_(self._t(send, n))
+        self.torch.cuda.synchronize(self.device)
+        self.calls["all_to_all"] += 1
+        self.bytes_sent += n
+        return 0
 
     def _all_to_all(self, _user, send, recv, nbytes):
         n = int(nbytes) * self.world

@@ -246,6 +246,7 @@ int32_t aero_host_unregister(void* p);
  *   all_to_all ........ send = world chunks of `bytes` (chunk r goes to rank r); recv = world chunks (chunk r came from rank r)
  *   all_gather ........ send = `bytes`; recv = world chunks of `bytes` in rank order
  *   all_reduce_sum_u64  in-place wrapping sum of `count` u64 over all ranks
+ *   send_recv ......... (optional) one chunk to one peer, one chunk from another - see the struct
  * min_peer_digests: a FRI layer stays sharded while every rank still sends at least this many leaf digests to every peer;
  * smaller layers are all-gathered once and finished redundantly on every rank (0 = default 2048 = 64 KiB messages). */
 typedef struct aero_comm {
@@ -256,6 +257,10 @@ typedef struct aero_comm {
     int32_t (*all_reduce_sum_u64)(void* user, void* buf, uint64_t count);
     uint32_t min_peer_digests;
     uint32_t flags;      /* 0, or AERO_COMM_STREAM_ORDERED */
+    /* optional (NULL: the library falls back to all_gather): `bytes` from `send` go to rank send_to while `bytes` from rank recv_from
+     * arrive in `recv` - every rank calls it with the same shift (send_to - rank = rank - recv_from mod world). Used where a rank
+     * needs the data of one or two peers only (the constraint evaluations of the cosets that make up its constraint domain). */
+    int32_t (*send_recv)(void* user, const void* send, int32_t send_to, void* recv, int32_t recv_from, uint64_t bytes);
 } aero_comm;
 #define AERO_COMM_STREAM_ORDERED 1u
 
