@@ -39,14 +39,18 @@ GL_HD uint64_t add(uint64_t a, uint64_t b) {
     return s >= P ? s - P : s;
 #endif
 }
-// NOTE: the carry-chain form of sub is disabled: combined with the carry-chain mul it produced wrong DEEP evaluations
-// inside deep_kernel on ROCm 7.2 (each alone is bit-exact; tools/ubench_field.hip finds no mismatch) - parity tests caught it.
+// NOTE: the carry-chain form of sub is NOT the default: ROCm 7.2's LLVM folds its high limb `d1 - borrow` into the high limb of a
+// following carry-chain add as `d1 + sext(borrow) + carry` and keeps using THAT instruction's carry-out, which is a different
+// function of the operands (profiles/r3_carry_sub_miscompile.md has the instruction-level account). GL_CARRY_SUB selects it with an
+// optimisation barrier on the high limb that keeps the combiner from looking through the subtraction.
 GL_HD uint64_t sub(uint64_t a, uint64_t b) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(GL_CARRY_SUB)
     uint32_t c, c1;
     uint32_t d0 = __builtin_subc((uint32_t)a, (uint32_t)b, 0u, &c), d1 = __builtin_subc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &c1);
     uint32_t t0 = __builtin_subc(d0, 0xFFFFFFFFu, 0u, &c), t1 = __builtin_subc(d1, 0u, c, &c);   // d + p = d - EPS (mod 2^64)
-    return c1 ? mk64(t0, t1) : mk64(d0, d1);
+    uint32_t hi = c1 ? t1 : d1;
+    asm volatile("" : "+v"(hi));
+    return mk64(c1 ? t0 : d0, hi);
 #else
     uint64_t d = a - b;
     return a < b ? d + P : d;                     // a - b + p, computed mod 2^64

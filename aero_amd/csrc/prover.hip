@@ -896,6 +896,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         return ctx->ntt_forward(polys.data.get() + (size_t)c0 * n, n, tlde.data.get() + (size_t)c0 * M, M, (int)nc, log_M, log_Bl, &co);
     };
     DevBuf<uint64_t> trace_keep;              // device copy of a HOST trace, kept when the AIR reads the main segment again (aux builders)
+    bool aux_columns_pending = false;         // some of its columns are still travelling on the copy stream (event 1)
     const uint64_t* trace_src = trace_dev;
     if (host_trace) {
         // Direct hand-over: the columns are copied straight into the buffer the interpolation works in; the canonical-form check
@@ -934,9 +935,15 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
                 uint32_t extra = 0;
                 for (uint32_t c = 0; c < W; c++) extra += need[c] && (c < c0 || c >= c0 + cpr);
                 if (extra * 2 <= W) {
+                    // on the copy stream: they are not needed before the main segment is committed
+                    hipStream_t cs = ctx->get_copy_stream();
+                    AERO_HIP(hipEventRecord(ctx->sync_event(0), ctx->stream));
+                    AERO_HIP(hipStreamWaitEvent(cs, ctx->sync_event(0), 0));
                     for (uint32_t c = 0; c < W; c++)
                         if (need[c] && (c < c0 || c >= c0 + cpr))
-                            AERO_HIP(hipMemcpyAsync(land + (size_t)c * n, host_trace + (size_t)c * n, col_bytes, hipMemcpyHostToDevice, ctx->stream));
+                            AERO_HIP(hipMemcpyAsync(land + (size_t)c * n, host_trace + (size_t)c * n, col_bytes, hipMemcpyHostToDevice, cs));
+                    AERO_HIP(hipEventRecord(ctx->sync_event(1), cs));
+                    aux_columns_pending = true;
                 } else comm_all_gather(land + (size_t)c0 * n, land, (size_t)cpr * col_bytes);
             }
             ctx->ntt_inverse(mine, n, (int)cpr, log_n, 1, 1, 1, 0, d_bad);          // plain coefficients: no coset yet
@@ -1020,6 +1027,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         pp.commit();
         d_rands = pp.ptr<T>(ir);
         apolys = Matrix(ctx, (int)(A * F::DEG), n);
+        if (aux_columns_pending) AERO_HIP(hipStreamWaitEvent(ctx->stream, ctx->sync_event(1), 0));
         if (prog) air_build_aux<F>(ctx, *prog, trace_src, log_n, air.results.data(), rands.data(), apolys.data.get());
         else launch_aux_columns<F>(ctx, trace_src, n, W, A, R, D, d_rands, apolys.data.get());
         trace_keep.release();

@@ -599,11 +599,22 @@ def main():
         s_achieved = (s_bytes / (s_ms * 1e-3)) / 1e9 if s_ms > 0 else 0.0
         comp_per_launch = (1 << log_n) * opt.blowup_factor * ((width + 1) // 2 + 7 / 8)
         is_hash = dominant.startswith("merkle_") or dominant.startswith("hash_")
+        # measured ceilings of this chip, from the tracked raw outputs of the microbenchmarks (tools/ceilings.sh -> profiles/)
+        ceilings = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "ceilings.json")) as f:
+                ceilings = json.load(f)
+        except Exception:
+            ceilings = {}
+        blake_ceiling = ceilings.get("blake2s_in_register_ceiling_Gcomp_per_s")
+        # nominal VALU rate: 256 CUs x 128 lanes x 2.4 GHz; one compression = 957 VALU instructions (profiles/r2_isa_merkle_leaf8_rows2.json)
+        blake_nominal = 256 * 128 * 2.4e9 / 957 / 1e9
         out["roofline"] = {
             # contract numbers: HIP events on the launch stream INSIDE the timed region (stream 0's launches of this kernel; with
             # several proofs in flight a launch shares the CUs with the other streams, so this duration is a property of the
             # mix, not of the kernel - the kernel alone is reported under "one_proof_in_flight")
-            "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound` names what limits the kernel; achieved / peak / frac stay the HBM figures the contract defines
+            "bound": "valu" if is_hash else "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "limiter": ("valu: BLAKE2s is 32-bit integer issue-bound (957 VALU instructions = about 1208 full-rate issue slots per 64-byte block, 16 of which bytes come from HBM; profiles/r2_isa_merkle_leaf8_rows2.json); "
                         "the HBM fraction is priced as the contract asks but is not what limits this kernel - see valu_view") if is_hash
@@ -616,7 +627,11 @@ def main():
                                     "measured": "HIP events, 3 traced proofs with nothing else on the GPU (right before the timed region)"},
             "valu_view": ({"what": "BLAKE2s compressions/s of this kernel (8 leaves + 7 nodes per thread)",
                            "achieved_Gcomp_per_s": comp_per_launch / (1e-3 * s_ms / max(s_calls, 1)) / 1e9,
-                           "in_register_ceiling_Gcomp_per_s": 41.0, "ceiling_source": "tools/ubench_valu.hip on MI355X; ISA histogram of one compression in profiles/"}
+                           "in_register_ceiling_Gcomp_per_s": blake_ceiling,
+                           "frac_of_in_register_ceiling": (comp_per_launch / (1e-3 * s_ms / max(s_calls, 1)) / 1e9 / blake_ceiling) if blake_ceiling else None,
+                           "nominal_valu_ceiling_Gcomp_per_s": blake_nominal,
+                           "frac_of_nominal_valu_rate": comp_per_launch / (1e-3 * s_ms / max(s_calls, 1)) / 1e9 / blake_nominal,
+                           "ceiling_source": "profiles/ceilings.json + profiles/r3_ubench_valu.txt (tools/ceilings.sh: the register-only BLAKE2s loops of tools/ubench_valu.hip on this chip); nominal = 256 CUs x 128 lanes x 2.4 GHz / 957 VALU instructions per compression (profiles/r2_isa_merkle_leaf8_rows2.json)"}
                           if dominant == "merkle_leaf8_kernel" else None),
             "next_kernels": [{"kernel": k, "share_of_kernel_time": v[1] / total_ms if total_ms else None,
                               "achieved": (v[2] / (v[1] * 1e-3)) / 1e9 if v[1] > 0 else 0.0,
