@@ -759,6 +759,27 @@ def prove_fib_sharded_local(trace, options: ProofOptions, world, aux=(0, 0, 2), 
     return out, pub[:w // 2].tolist(), list(ms), list(sent)
 
 
+def synth_vm_program(log_n, pairs, aux=0, rands=4) -> bytes:
+    """The VM-shaped synthetic AIR as an AEROAIR program (aero_air_synth_vm_program); pairs = 26, aux = 9, rands = 16: Miden's shape."""
+    out, n = u8p(), C.c_size_t(0)
+    rc = lib().aero_air_synth_vm_program(C.c_uint32(log_n), C.c_uint32(pairs), C.c_uint32(aux), C.c_uint32(rands), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise AeroError(rc, lib().aero_last_error(None).decode())
+    data = C.string_at(out, n.value)
+    lib().aero_free(out)
+    return data
+
+
+def synth_vm_trace(log_n, pairs):
+    """A trace that satisfies synth_vm_program: ((20 + 2 pairs, 2^log_n) uint64, public inputs)."""
+    t = np.zeros((20 + 2 * pairs, 1 << log_n), np.uint64)
+    pub = np.zeros(pairs + 1, np.uint64)
+    rc = lib().aero_air_synth_vm_trace(C.c_uint32(log_n), C.c_uint32(pairs), _p64(t), _p64(pub))
+    if rc != 0:
+        raise AeroError(rc, "synth_vm_trace: bad shape")
+    return t, pub.tolist()
+
+
 class VerifyPolicy(C.Structure):
     """aero_verify_policy (include/aero_stark.h)."""
     _fields_ = [("min_query_security_bits", C.c_uint32), ("expected_log_n", C.c_uint32), ("allow_unknown_air", C.c_uint32),

@@ -192,6 +192,7 @@ public:
     template <class Src> void merkle_recompute(const Src& src, size_t n, const uint64_t* idx_dev, int count, Digest* out_dev);
 
     // internal state
+    bool fri_tail_attr_set = false;   // the opt-in for > 64 KiB of dynamic LDS was made on this context's device
     std::map<int, NttTables> ntt_tabs;
     std::map<uint64_t, uint64_t*> pass_tabs;
     std::map<std::vector<uint64_t>, uint64_t*> ktab_cache;

@@ -837,6 +837,154 @@ inline std::vector<uint8_t> fib_program(uint32_t width, uint32_t aux_width, uint
     return e.bytes();
 }
 
+
+// ---- a synthetic AIR in the SHAPE of a VM's, with a trace that satisfies it (include/aero_air.h: aero_air_synth_vm_*) -----------------
+// Miden's ProcessorAir is absent from the reference mount; this is the stand-in for BASELINE configs[4] that
+// goes through the program path: 20 + 2 * pairs main columns - clock, 4-bit binary counter, its low 3 bits as a number, 8 state
+// columns under power maps of degree 2..7 gated by a periodic selector with periodic round constants (cycle 8), 4 accumulators of
+// degree 5..8, two columns that are cyclic shifts of state columns (permutation arguments), Fibonacci pairs; `aux` auxiliary running
+// products (two of them with denominators, periodic gating, boundary values that depend on the random elements); two transition
+// exemptions; assertions at the first, last, an interior step and periodic ones. 24 + 2 * pairs main and `aux` auxiliary transition
+// constraints in 10+ degree groups; 8 composition columns. tests/air_examples.py: synth_vm builds the SAME system in Python.
+struct SynthVm {
+    static constexpr uint32_t CLK = 0, BIT = 1, M8 = 5, S = 6, ACC = 14, B1 = 18, B2 = 19, FIB = 20;
+    static uint64_t sel(uint32_t i) { static const uint64_t v[8] = {1, 1, 1, 0, 1, 0, 0, 1}; return v[i & 7]; }
+    static uint64_t rc(uint32_t j, uint32_t i) {
+        const unsigned __int128 v = (unsigned __int128)0x9E3779B97F4A7C15ull * (8 * j + (i & 7) + 1) + 12345;
+        return (uint64_t)(v % gl::P);
+    }
+    static uint32_t deg_s(uint32_t j) { static const uint32_t d[8] = {2, 3, 4, 5, 6, 7, 2, 3}; return d[j]; }
+    static uint32_t deg_acc(uint32_t k) { return 5 + k; }
+    static uint32_t width(uint32_t pairs) { return 20 + 2 * pairs; }
+};
+// column-major width x 2^log_n; pub (pairs + 1 values): the Fibonacci results, then the last value of the degree-8 accumulator
+inline void synth_vm_trace(uint32_t log_n, uint32_t pairs, uint64_t* t, uint64_t* pub) {
+    typedef SynthVm V;
+    const size_t n = (size_t)1 << log_n;
+    auto col = [&](uint32_t c) { return t + (size_t)c * n; };
+    for (uint32_t j = 0; j < 8; j++) col(V::S + j)[0] = 3 + j;
+    for (uint32_t k = 0; k < 4; k++) col(V::ACC + k)[0] = 11 + k;
+    for (uint32_t k = 0; k < pairs; k++) { col(V::FIB + 2 * k)[0] = 1 + 2 * k; col(V::FIB + 2 * k + 1)[0] = 2 + 2 * k; }
+    for (size_t i = 0; i < n; i++) {
+        col(V::CLK)[i] = i;
+        for (uint32_t q = 0; q < 4; q++) col(V::BIT + q)[i] = (i >> q) & 1;
+        col(V::M8)[i] = i & 7;
+        if (i + 1 == n) break;
+        uint64_t s[8];
+        for (uint32_t j = 0; j < 8; j++) s[j] = col(V::S + j)[i];
+        for (uint32_t j = 0; j < 8; j++)
+            col(V::S + j)[i + 1] = V::sel((uint32_t)i) ? gl::add(gl::pow(s[j], V::deg_s(j)), V::rc(j, (uint32_t)i)) : gl::add(s[j], s[(j + 1) & 7]);
+        for (uint32_t k = 0; k < 4; k++) col(V::ACC + k)[i + 1] = gl::add(gl::pow(col(V::ACC + k)[i], V::deg_acc(k)), s[k]);
+        for (uint32_t k = 0; k < pairs; k++) {
+            const uint64_t a = col(V::FIB + 2 * k)[i], b = col(V::FIB + 2 * k + 1)[i], na = gl::add(a, b);
+            col(V::FIB + 2 * k)[i + 1] = na;
+            col(V::FIB + 2 * k + 1)[i + 1] = gl::add(b, na);
+        }
+    }
+    for (size_t i = 0; i + 1 < n; i++) {      // cyclic shift by one step over the first n - 1 rows
+        col(V::B1)[i] = col(V::S)[(i + 1) % (n - 1)];
+        col(V::B2)[i] = col(V::S + 5)[(i + 1) % (n - 1)];
+    }
+    col(V::B1)[n - 1] = 0; col(V::B2)[n - 1] = 0;
+    if (pub) {
+        for (uint32_t k = 0; k < pairs; k++) pub[k] = col(V::FIB + 2 * k + 1)[n - 1];
+        pub[pairs] = col(V::ACC + 3)[n - 1];
+    }
+}
+// the program for a trace of 2^log_n rows (an interior assertion sits at step n / 2, two values are read off the trace's first row)
+inline std::vector<uint8_t> synth_vm_program(uint32_t log_n, uint32_t pairs, uint32_t aux, uint32_t rands) {
+    typedef SynthVm V;
+    if (log_n < 4 || log_n > 29 || pairs < 1 || V::width(pairs) > 254 || aux > 255 - V::width(pairs) || (aux && (rands < 3 || rands > 255)))
+        fail("synth_vm_program: log_n in [4, 29], 1 <= pairs <= 117, an auxiliary segment needs at least 3 random elements");
+    const uint64_t n = 1ull << log_n;
+    Emitter e{};
+    e.W = V::width(pairs); e.A = aux; e.R = aux ? rands : 0; e.num_pub = pairs + 1; e.exemptions = 2;
+    auto cur = [](uint32_t c) { return mk_ref(K_MAIN_CUR, c); };
+    auto nxt = [](uint32_t c) { return mk_ref(K_MAIN_NXT, c); };
+    std::vector<uint64_t> selv(8), rcv(8);
+    for (uint32_t i = 0; i < 8; i++) selv[i] = V::sel(i);
+    const uint32_t selp = e.per(selv);
+    uint32_t rcp[8];
+    for (uint32_t j = 0; j < 8; j++) { for (uint32_t i = 0; i < 8; i++) rcv[i] = V::rc(j, i); rcp[j] = e.per(rcv); }
+    const uint32_t one = e.cst(1), two = e.cst(2);
+    auto T = [&](uint32_t root, uint32_t base, std::vector<uint32_t> cyc = {}) { e.mtrans.push_back({root, base, cyc}); };
+    T(e.sub(e.sub(nxt(V::CLK), cur(V::CLK)), one), 1);
+    uint32_t bits[4];
+    for (uint32_t i = 0; i < 4; i++) { bits[i] = cur(V::BIT + i); T(e.mul(bits[i], e.sub(bits[i], one)), 2); }
+    uint32_t carry = REF_NONE;
+    for (uint32_t i = 0; i < 4; i++) {                        // bit_i' = bit_i XOR (bit_0 ... bit_(i-1))
+        const uint32_t t = carry == REF_NONE ? one : carry;
+        T(e.sub(nxt(V::BIT + i), e.sub(e.add(bits[i], t), e.mul(two, e.mul(bits[i], t)))), i ? i + 1 : 1);
+        carry = carry == REF_NONE ? bits[i] : e.mul(carry, bits[i]);
+    }
+    T(e.sub(cur(V::M8), e.add(e.add(bits[0], e.mul(two, bits[1])), e.mul(e.cst(4), bits[2]))), 1);
+    uint32_t s[8];
+    for (uint32_t j = 0; j < 8; j++) s[j] = cur(V::S + j);
+    const uint32_t nsel = e.sub(one, selp);
+    for (uint32_t j = 0; j < 8; j++)                          // s_j' = sel (s_j^d + rc_j) + (1 - sel)(s_j + s_(j+1))
+        T(e.sub(nxt(V::S + j), e.add(e.mul(selp, e.add(e.pow(s[j], V::deg_s(j)), rcp[j])), e.mul(nsel, e.add(s[j], s[(j + 1) & 7])))), V::deg_s(j), {8});
+    for (uint32_t k = 0; k < 4; k++) T(e.sub(nxt(V::ACC + k), e.add(e.pow(cur(V::ACC + k), V::deg_acc(k)), s[k])), V::deg_acc(k));
+    T(e.sub(cur(V::B1), nxt(V::S)), 1);
+    T(e.sub(cur(V::B2), nxt(V::S + 5)), 1);
+    for (uint32_t k = 0; k < pairs; k++) {
+        const uint32_t a = cur(V::FIB + 2 * k), b = cur(V::FIB + 2 * k + 1), na = nxt(V::FIB + 2 * k), nb = nxt(V::FIB + 2 * k + 1);
+        T(e.sub(na, e.add(a, b)), 1);
+        T(e.sub(nb, e.add(b, na)), 1);
+    }
+    auto Am = [&](uint32_t c, int64_t step, uint32_t stride, uint32_t val) { e.masserts.push_back(Assertion{c, step, stride, val}); };
+    Am(V::CLK, 0, 0, e.cst(0));
+    Am(V::CLK, (int64_t)(n / 2), 0, e.cst(n / 2));
+    Am(V::B1, -2, 0, e.cst(3));                               // where the cyclic shift wraps: s_0(0) = 3, s_5(0) = 8
+    Am(V::B2, -2, 0, e.cst(8));
+    for (uint32_t j = 0; j < 8; j++) Am(V::S + j, 0, 0, e.cst(3 + j));
+    for (uint32_t k = 0; k < 4; k++) Am(V::ACC + k, 0, 0, e.cst(11 + k));
+    Am(V::ACC + 3, -1, 0, mk_ref(K_PUB, pairs));
+    for (uint32_t k = 0; k < pairs; k++) {
+        Am(V::FIB + 2 * k, 0, 0, e.cst(1 + 2 * k));
+        Am(V::FIB + 2 * k + 1, 0, 0, e.cst(2 + 2 * k));
+        Am(V::FIB + 2 * k + 1, -1, 0, mk_ref(K_PUB, k));
+    }
+    Am(V::M8, 0, 8, e.cst(0));
+    Am(V::M8, 3, 8, e.cst(3));
+    Am(V::BIT, 1, 2, one);
+    if (aux) {
+        auto r = [&](uint32_t i) { return mk_ref(K_RAND, i % rands); };
+        auto ac = [](uint32_t c) { return mk_ref(K_AUX_CUR, c); };
+        auto an = [](uint32_t c) { return mk_ref(K_AUX_NXT, c); };
+        // p0: permutation argument s_0 <-> b1 over the first n - 1 rows: p' (r0 + b1) = p (r0 + s_0); it returns to 1
+        {
+            const uint32_t num = e.add(r(0), s[0]), den = e.add(r(0), cur(V::B1));
+            e.atrans.push_back({e.sub(e.mul(an(0), den), e.mul(ac(0), num)), 2, {}});
+            e.builders.push_back(Builder{one, num, den});
+            e.aasserts.push_back(Assertion{0, 0, 0, one});
+            e.aasserts.push_back(Assertion{0, -1, 0, one});
+        }
+        for (uint32_t c = 1; c < aux; c++) {
+            if (c == 1) {                                     // a second argument with a denominator, tuples compressed with r1, r2
+                const uint32_t rc2 = e.mul(r(2), cur(V::CLK));
+                const uint32_t num = e.add(e.add(r(1), s[5]), rc2), den = e.add(e.add(r(1), cur(V::B2)), rc2);
+                const uint32_t init = e.add(e.mul(r(0), r(0)), one);
+                e.atrans.push_back({e.sub(e.mul(an(c), den), e.mul(ac(c), num)), 2, {}});
+                e.builders.push_back(Builder{init, num, den});
+                e.aasserts.push_back(Assertion{c, 0, 0, init});        // a boundary value that depends on the random elements
+                continue;
+            }
+            const uint32_t ex = 1 + c % 3;
+            const uint32_t colv = e.add(s[(c + 1) & 7], e.mul(r(c + 1), cur(V::CLK)));
+            uint32_t f = e.pow(e.add(r(c), colv), ex);
+            if (c % 2 == 0) {                                 // gated by the periodic selector
+                f = e.add(e.mul(selp, f), nsel);
+                e.atrans.push_back({e.sub(an(c), e.mul(ac(c), f)), ex + 1, {8}});
+            } else {
+                e.atrans.push_back({e.sub(an(c), e.mul(ac(c), f)), ex + 1, {}});
+            }
+            e.builders.push_back(Builder{one, f, REF_NONE});
+            e.aasserts.push_back(Assertion{c, 0, 0, one});
+        }
+    }
+    return e.bytes();
+}
+
 }  // namespace air
 }  // namespace aero
 

@@ -65,6 +65,20 @@ int32_t aero_air_fib_program(uint32_t width, const aero_fib_air* desc, uint8_t**
     } catch (const Error& e) { g_create_err = e.what(); return e.code; }
     catch (const std::bad_alloc&) { return AERO_E_OOM; }
 }
+int32_t aero_air_synth_vm_program(uint32_t log_n, uint32_t pairs, uint32_t aux, uint32_t rands, uint8_t** program, size_t* len) {
+    if (!program || !len) return AERO_E_BAD_ARG;
+    try {
+        const std::vector<uint8_t> b = air::synth_vm_program(log_n, pairs, aux, rands);
+        *program = to_malloc(b, len);
+        return AERO_OK;
+    } catch (const Error& e) { g_create_err = e.what(); return e.code; }
+    catch (const std::bad_alloc&) { return AERO_E_OOM; }
+}
+int32_t aero_air_synth_vm_trace(uint32_t log_n, uint32_t pairs, uint64_t* trace_out, uint64_t* pub_out) {
+    if (!trace_out || log_n < 4 || log_n > 29 || pairs < 1 || 20 + 2 * pairs > 254) return AERO_E_BAD_ARG;
+    air::synth_vm_trace(log_n, pairs, trace_out, pub_out);
+    return AERO_OK;
+}
 int32_t aero_air_info(const aero_air* air, uint32_t out[16]) {
     if (!air || !out) return AERO_E_BAD_ARG;
     const air::Program& p = air->prog;

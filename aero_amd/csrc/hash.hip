@@ -494,13 +494,12 @@ void Context::fri_tail(const FriTailArgs& a, int fold) {
     if (a.dom0 > (uint32_t)FRI_TAIL_MAX_DOM || a.dom0 / (uint32_t)fold > (uint32_t)FRI_TAIL_MAX_ROWS || a.n_layers < 1 || a.n_layers > FRI_TAIL_MAX_LAYERS)
         fail("fri_tail: bad shape", ST_INTERNAL);
     const size_t lds = (size_t)a.deg * a.dom0 * 8 + 513 * sizeof(Digest);
-    static bool attr_set = false;
-    if (!attr_set) {   // up to 2 x 4096 evaluations + 513 digests: above the 64 KiB default limit of dynamic LDS
+    if (!fri_tail_attr_set) {   // per context (= per device, per host thread): up to 2 x 4096 evaluations + 513 digests, above the 64 KiB default of dynamic LDS
         const int cap = 2 * FRI_TAIL_MAX_DOM * 8 + 513 * (int)sizeof(Digest);
         AERO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fri_tail_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         AERO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fri_tail_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         AERO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fri_tail_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        attr_set = true;
+        fri_tail_attr_set = true;
     }
     if (fold == 8) AERO_LAUNCH(this, "fri_tail_kernel", 0, fri_tail_kernel<3>, dim3(1), dim3(512), lds, a);
     else if (fold == 4) AERO_LAUNCH(this, "fri_tail_kernel", 0, fri_tail_kernel<2>, dim3(1), dim3(512), lds, a);

@@ -95,16 +95,21 @@ class RcclComm:
         self.lib.aero_rccl_last_error.argtypes = [C.c_void_p]
         self.rank, self.world = rank, world
         self.h = None
-        uid = None
+        uid, failure = None, None
         if rank == 0:
             buf = (C.c_uint8 * 128)()
             rc = self.lib.aero_rccl_unique_id(buf)
             if rc != 0:
-                raise aero_amd.AeroError(rc, self.lib.aero_rccl_last_error(None).decode())
-            uid = bytes(buf)
+                # the peers are waiting for the id: hand them the failure instead of leaving them in the broadcast for ever
+                failure = (rc, self.lib.aero_rccl_last_error(None).decode())
+                uid = b"FAIL" + repr(failure).encode()
+            else:
+                uid = bytes(buf)
         if share_id is None:
             share_id = _share_over_torch_dist if world > 1 else (lambda b: b)
         uid = share_id(uid)
+        if isinstance(uid, (bytes, bytearray)) and bytes(uid[:4]) == b"FAIL":
+            raise aero_amd.AeroError(failure[0] if failure else -4, "rank 0 could not create the RCCL id: " + bytes(uid[4:]).decode(errors="replace"))
         assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
         self.h = C.c_void_p()
         rc = self.lib.aero_rccl_create(ctx.h, C.c_int32(rank), C.c_int32(world), (C.c_uint8 * 128)(*uid), C.byref(self.h))

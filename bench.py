@@ -124,6 +124,54 @@ def prove_call(ctx, dev, opt, over, comm=None):
     return ctx.prove_fib(dev, opt)
 
 
+def kernel_times(ctx, fn, names, reps):
+    """Per-kernel HIP-event ms per proof over `reps` calls of fn (one untimed call first) + the wall-clock per call."""
+    fn()
+    ctx.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    rep = ctx.kernel_timing_report()
+    ctx.set_kernel_timing(False)
+    out = {k: round(rep[k][1] / reps, 4) for k in names if k in rep}
+    out["proof_wall_ms"] = round(wall, 3)
+    return out
+
+
+def air_program_leg(aero_amd, ctx, log_n=20, reps=3):
+    """The AIR-as-data path (include/aero_air.h) beside the hard-wired kernels: (1) FibAir(72) as a program vs fib_constraints_kernel
+    on the same trace, same proof bytes; (2) a VM-shaped program (72 + 9 columns, 76 + 9 transition constraints, degree <= 8) proven
+    and verified. Resident traces, one proof at a time."""
+    opt = aero_amd.ProofOptions(27, 8, 16, 4, 1, 8, 8)
+    out = {}
+    dev = ctx.trace_upload(aero_amd.fib_trace(72, log_n))
+    air = aero_amd.Air(aero_amd.fib_program(72))
+    want, pub = ctx.prove_fib(dev, opt)
+    assert ctx.prove_air(air, dev, pub, opt) == want, "program proof differs from the hard-wired proof"
+    hard = kernel_times(ctx, lambda: ctx.prove_fib(dev, opt), ["fib_constraints_kernel"], reps)
+    prog = kernel_times(ctx, lambda: ctx.prove_air(air, dev, pub, opt), ["air_constraints_kernel"], reps)
+    dev.free()
+    out["fibair_72_as_program"] = {"workload": f"fib_2^{log_n}x72", "hard_wired_ms": hard, "program_ms": prog,
+                                   "constraint_kernel_ratio": round(prog["air_constraints_kernel"] / hard["fib_constraints_kernel"], 3)}
+    pairs, A, R = 26, 9, 16
+    fold4 = aero_amd.ProofOptions(27, 8, 16, 4, 1, 4, 8)
+    program = aero_amd.synth_vm_program(log_n, pairs, A, R)
+    trace, vpub = aero_amd.synth_vm_trace(log_n, pairs)
+    vair = aero_amd.Air(program)
+    vdev = ctx.trace_upload(trace)
+    proof = ctx.prove_air(vair, vdev, vpub, fold4)
+    aero_amd.verify_air(proof, vpub, vair, expected_log_n=log_n)
+    vm = kernel_times(ctx, lambda: ctx.prove_air(vair, vdev, vpub, fold4), ["air_constraints_kernel", "air_aux_factors_kernel"], reps)
+    vdev.free()
+    info = vair.info()
+    out["vm_shaped_program"] = {"workload": f"synth_vm_2^{log_n}x(72+9aux)_fold4", "ms": vm, "verified": True, "proof_bytes": len(proof),
+                                "transition_constraints": info["main_transition"] + info["aux_transition"],
+                                "cells_per_s_single_proof": round((81 << log_n) / (vm["proof_wall_ms"] * 1e-3)),
+                                "constraint_stage_share": round(vm["air_constraints_kernel"] / vm["proof_wall_ms"], 3)}
+    return out
+
+
 def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch, comm_kind="auto"):
     """ONE proof of `workload` proven cooperatively by all ranks of the default process group: `warmup` untimed proofs, then
     exactly `steps` timed ones (barrier + synchronize on both sides, max over ranks). Every rank checks its proof bytes
@@ -133,7 +181,11 @@ def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch, c
     log_n, width, over = WORKLOADS[workload]
     opt = make_options(aero_amd, over)
     ctx = aero_amd.Context(device)
-    dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
+    # the metric's hand-over: the trace lies in (pinned) HOST memory; a rank copies its width / world columns inside the clock
+    # (aero_prove_fib_sharded_host). One process per GPU: every rank holds the synthetic trace in its own host memory.
+    host = aero_amd.PinnedTrace(aero_amd.fib_trace(width, log_n))
+    aux = over.get("aux") or (0, 0, 2)
+    dev = ctx.trace_upload(host.array)
     # data plane: the library's native RCCL communicator when every rank has its own GPU; torch.distributed collectives on the
     # device buffers (gloo) when the ranks share one GPU (RCCL refuses two ranks on one device)
     native = comm_kind == "rccl" or (comm_kind == "auto" and torch.cuda.device_count() >= world)
@@ -143,29 +195,33 @@ def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch, c
         dist.barrier()
         torch.cuda.synchronize()
 
+    def sharded_proof():
+        return ctx.prove_fib_sharded_host(comm, host, opt, aux)
+
     proof = None
     for _ in range(max(1, warmup)):
-        proof, _ = prove_call(ctx, dev, opt, over, comm)
+        proof, _ = sharded_proof()
     single, _ = prove_call(ctx, dev, opt, over)
     identical = proof == single
     calls0, sent0 = dict(comm.calls), comm.bytes_sent
-    dt = timed_steps(lambda: prove_call(ctx, dev, opt, over, comm), steps, barrier)
+    dt = timed_steps(sharded_proof, steps, barrier)
     ctl = torch.device("cuda", device) if dist.get_backend() == "nccl" else "cpu"     # control-plane tensors
     dt = max_over_ranks(dt, dist, ctl)
     calls1, sent1 = dict(comm.calls), comm.bytes_sent
     flag = torch.tensor([1 if identical else 0], dtype=torch.int32, device=ctl)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     ctx.set_stage_timing(True)
-    prove_call(ctx, dev, opt, over, comm)
+    sharded_proof()
     stages = ctx.last_stage_ms()
     ctx.set_stage_timing(False)
     t1 = time.perf_counter()
     for _ in range(3):
-        prove_call(ctx, dev, opt, over)
+        ctx.prove_fib_aux(host, aux[0], aux[1], opt, aux_degree=aux[2])      # one GPU, same hand-over (whole trace copied in)
     single_ms = (time.perf_counter() - t1) * 1e3 / 3
     res = {
         "workload": workload, "world": world, "exchange": ("native RCCL (aero_rccl_*), stream-ordered" if native else f"torch.distributed {dist.get_backend()} on device buffers"),
         "control_plane": dist.get_backend(), "gpus_visible": torch.cuda.device_count(),
+        "h2d_included": True, "hand_over": "trace in pinned host memory; every rank copies its share of the columns inside the timed region",
         "steps": steps, "ms_per_proof": 1e3 * dt / steps, "value": (1 << log_n) * trace_cols(width, over) * steps / dt, "unit": "cells/s",
         "single_gpu_ms_same_process": single_ms, "speedup_vs_single_gpu": single_ms / (1e3 * dt / steps),
         "proof_identical_to_single_gpu_on_every_rank": bool(flag.item() == 1), "proof_bytes": len(proof),
@@ -174,6 +230,7 @@ def sharded_measure(workload, steps, warmup, rank, world, device, dist, torch, c
         "rank0_stage_ms": {k: round(v, 3) for k, v in stages.items()},
     }
     dev.free()
+    host.release()
     if native:
         comm.close()
     ctx.close()
@@ -397,6 +454,7 @@ def main():
     ap.add_argument("--sharded-check-world", type=int, default=-1,
                     help="ranks of the sharded-proof side measurement run after the timed region (default: N when N > 1, else "
                          "off; on a 1-GPU box the ranks share the GPU over gloo, which checks the path but not its speed)")
+    ap.add_argument("--no-air-program", action="store_true", help="skip the AIR-as-data leg (interpreter vs hard-wired constraint kernel)")
     ap.add_argument("--sharded-workloads", default="fib_2^20x2_blowup8_blake2s_base,fib_2^24x2_blowup8_blake2s_base,"
                                                      "standin_miden_shape_2^22x(72+9aux)_deg8_fold4")
     ap.add_argument("--sharded-timeout", type=float, default=300.0)
@@ -658,6 +716,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sys.stdout.flush()
             out["cpu_baseline"] = cpu_baseline_leg(args, log_n, width, over, opt, first_proof)
+        if world == 1 and not args.no_air_program:
+            try:
+                out["air_program"] = air_program_leg(aero_amd, ctx)
+            except Exception as e:
+                out["air_program"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         check_world = args.sharded_check_world if args.sharded_check_world >= 0 else (world if world > 1 else 0)
         if check_world > 1:
             sys.stdout.flush()

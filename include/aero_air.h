@@ -94,6 +94,14 @@ void aero_air_free(aero_air* air);
 /* The built-in AIRs as programs (so that a host without the Python helpers can obtain them): FibAir(width) with its optional
  * auxiliary segment (desc may be NULL) - byte-for-byte the constraint set aero_prove_fib_air hard-wires. *program is malloc'd. */
 int32_t aero_air_fib_program(uint32_t width, const aero_fib_air* desc, uint8_t** program, size_t* len);
+/* A synthetic AIR in the SHAPE of a VM's, as a program, and a trace that satisfies it (the role aero_fib_trace plays for FibAir;
+ * Miden's own AIR and traces are absent from the reference mount): 20 + 2 * pairs main columns (clock, binary counter, state
+ * under power maps of degree 2..7 gated by a periodic selector, degree 5..8 accumulators, permutation columns, Fibonacci pairs),
+ * `aux` auxiliary running products over `rands` random elements (two with denominators), 2 transition exemptions, first / last /
+ * interior / periodic assertions, 8 composition columns. pairs = 26, aux = 9, rands = 16 is Miden's 72 + 9 shape (BASELINE
+ * configs[4]). trace_out: column-major (20 + 2 pairs) x 2^log_n; pub_out: the pairs + 1 public inputs. */
+int32_t aero_air_synth_vm_program(uint32_t log_n, uint32_t pairs, uint32_t aux, uint32_t rands, uint8_t** program, size_t* len);
+int32_t aero_air_synth_vm_trace(uint32_t log_n, uint32_t pairs, uint64_t* trace_out, uint64_t* pub_out);
 /* out = { main_width, aux_width, aux_rands, num_pub, num_exemptions, num_main_transition, num_aux_transition,
  *         num_main_assertions, num_aux_assertions, ce_blowup (= composition columns), num_periodic, num_nodes,
  *         device instructions, base-field registers, extension-field registers, has_aux_builders }

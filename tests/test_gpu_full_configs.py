@@ -80,3 +80,36 @@ def test_config5_standin_2p18_bytes_identical(ctx, oracle):
     want, want_pub, _ = oracle.prove_fib_aux(W, log_n, A, R, MIDEN_SHAPE, D=D)
     assert pub == want_pub
     assert got == want, "config-5-shaped proof differs from the oracle's"
+
+
+# ---- configs[4] through the AIR-as-data path: a VM-SHAPED program (20 + 2 * 26 = 72 main columns, 9 auxiliary running products
+# over 16 random elements, 76 main + 9 auxiliary transition constraints in > 10 degree groups up to degree 8, periodic columns,
+# two exemptions, first / last / interior / periodic assertions) instead of the hard-wired stand-in ------------------------------
+def test_config5_vm_shaped_program_2p18_bytes_identical(ctx, oracle):
+    log_n, pairs, A, R = 18, 26, 9, 16
+    program = aero_amd.synth_vm_program(log_n, pairs, A, R)
+    trace, pub = aero_amd.synth_vm_trace(log_n, pairs)
+    air = aero_amd.Air(program)
+    info = air.info()
+    assert info["main_width"] == 72 and info["aux_width"] == 9 and info["main_transition"] == 76 and info["aux_transition"] == 9
+    got = ctx.prove_air(air, trace, pub, aero_amd.ProofOptions(*MIDEN_SHAPE))
+    want, _ = oracle.prove_air(program, trace, pub, MIDEN_SHAPE)
+    assert got == want, "VM-shaped program proof differs from the oracle's"
+    aero_amd.verify_air(got, pub, air, expected_log_n=log_n)
+
+
+def test_config5_vm_shaped_program_2p22_verifies(ctx, oracle):
+    log_n, pairs, A, R = 22, 26, 9, 16
+    program = aero_amd.synth_vm_program(log_n, pairs, A, R)
+    trace, pub = aero_amd.synth_vm_trace(log_n, pairs)
+    air = aero_amd.Air(program)
+    dev = ctx.trace_upload(trace)
+    got = ctx.prove_air(air, dev, pub, aero_amd.ProofOptions(*MIDEN_SHAPE))
+    dev.free()
+    again = ctx.prove_air(air, trace, pub, aero_amd.ProofOptions(*MIDEN_SHAPE))      # handed over in host memory this time
+    assert again == got, "resident and host hand-over proofs differ"
+    assert got[:4] == bytes([72, A, R, log_n]) and got[15:22] == bytes(MIDEN_SHAPE)
+    oracle.verify_air(got, program, pub, log_n)               # every check of src/stark_verifier + the OOD constraint check over the program
+    aero_amd.verify_air(got, pub, air, expected_log_n=log_n)
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.verify_air(got, pub[:-1] + [pub[-1] ^ 1], air, expected_log_n=log_n)

@@ -64,3 +64,61 @@ def test_bad_arguments(env):
     assert L.aero_rccl_create(ctx.h, C.c_int32(2), C.c_int32(2), uid, C.byref(h)) == -1      # rank out of range
     assert L.aero_rccl_create(None, C.c_int32(0), C.c_int32(1), uid, C.byref(h)) == -1
     assert L.aero_rccl_unique_id(None) == -1
+
+
+def test_pairwise_exchange_with_itself(env):
+    ctx, comm = env
+    cs = comm.struct
+    n = 1 << 12
+    data = np.arange(n, dtype=np.uint64).reshape(1, n)
+    src, dst = ctx.trace_upload(data), ctx.trace_upload(np.zeros((1, n), np.uint64))
+    assert cs.send_recv(cs.user, src.device_ptr, 0, dst.device_ptr, 0, 8 * n) == 0, comm.error_text()
+    assert (dst.download() == data).all()
+
+
+RANK_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+import aero_amd
+from aero_amd.shard import RcclComm
+rank, world, idfile, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+def share(uid):
+    if rank == 0:
+        with open(idfile + ".tmp", "wb") as f: f.write(uid)
+        os.replace(idfile + ".tmp", idfile)
+        return uid
+    for _ in range(600):
+        if os.path.exists(idfile): return open(idfile, "rb").read()
+        time.sleep(0.1)
+    raise SystemExit("no id from rank 0")
+ctx = aero_amd.Context(rank)
+comm = RcclComm(ctx, rank, world, share_id=share)
+opt = aero_amd.ProofOptions.with_96_bit_security()
+for (w, log_n, aux) in ((2, 14, (0, 0, 2)), (8, 13, (0, 0, 2)), (16, 12, (4, 3, 5))):
+    trace = aero_amd.PinnedTrace(aero_amd.fib_trace(w, log_n))
+    proof, pub = ctx.prove_fib_sharded_host(comm, trace, opt, aux)
+    open(out + f".{w}.{log_n}", "wb").write(proof)
+print("ok", comm.calls, comm.bytes_sent)
+'''
+
+
+@pytest.mark.skipif(aero_amd.device_count() < 2, reason="RCCL refuses two ranks on one device: needs >= 2 GPUs")
+def test_two_ranks_over_rccl_give_the_single_gpu_proof(tmp_path):
+    """world = 2 through the NATIVE communicator (ncclSend / ncclRecv groups, all-gather, all-reduce, pairwise exchange on the
+    contexts' streams, AERO_COMM_STREAM_ORDERED), one process per GPU, trace in host memory."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_WORKER % {"root": root})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(tmp_path / "id"), str(tmp_path / f"proof{r}")], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, cwd=root) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    ctx = aero_amd.Context(0)
+    opt = aero_amd.ProofOptions.with_96_bit_security()
+    for (w, log_n, aux) in ((2, 14, (0, 0, 2)), (8, 13, (0, 0, 2)), (16, 12, (4, 3, 5))):
+        want, _ = ctx.prove_fib_aux(aero_amd.fib_trace(w, log_n), aux[0], aux[1], opt, aux_degree=aux[2])
+        for r in range(2):
+            assert (tmp_path / f"proof{r}.{w}.{log_n}").read_bytes() == want
+    ctx.close()

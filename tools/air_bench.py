@@ -3,6 +3,7 @@ aero_prove_fib_air (fib_constraints_kernel) and through aero_prove_air with the 
 (air_constraints_kernel), per-kernel HIP-event times of the constraint stage.
 
     python tools/air_bench.py [--width 72] [--log-n 20] [--aux 0,0,2] [--ext 1] [--reps 5]
+    python tools/air_bench.py --vm 26,9,16 [--log-n 20] [--fold 4]      # the VM-shaped program (aero_air_synth_vm_*), no hard-wired twin
 """
 import argparse
 import json
@@ -35,7 +36,23 @@ def main():
     ap.add_argument("--aux", default="0,0,2")
     ap.add_argument("--ext", type=int, default=1)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--vm", default="", help="pairs,aux,rands: prove the VM-shaped synthetic program instead")
+    ap.add_argument("--fold", type=int, default=8)
     a = ap.parse_args()
+    if a.vm:
+        pairs, A, R = (int(x) for x in a.vm.split(","))
+        opt = aero_amd.ProofOptions(27, 8, 16, 4, a.ext, a.fold, 8)
+        ctx = aero_amd.Context(0)
+        air = aero_amd.Air(aero_amd.synth_vm_program(a.log_n, pairs, A, R))
+        trace, pub = aero_amd.synth_vm_trace(a.log_n, pairs)
+        dev = ctx.trace_upload(trace)
+        proof = ctx.prove_air(air, dev, pub, opt)
+        aero_amd.verify_air(proof, pub, air, expected_log_n=a.log_n)
+        ms = kernel_ms(ctx, lambda: ctx.prove_air(air, dev, pub, opt), ["air_constraints_kernel", "air_aux_factors_kernel", "air_divide_kernel"], a.reps)
+        host_ms = kernel_ms(ctx, lambda: ctx.prove_air(air, trace, pub, opt), [], a.reps)["proof_wall_ms"]
+        print(json.dumps({"workload": f"synth_vm_2^{a.log_n}x({20 + 2 * pairs}+{A}aux)_fold{a.fold}" + ("_quadratic" if a.ext == 2 else ""), "ms": ms,
+                          "proof_wall_ms_pageable_host_trace": host_ms, "program_info": air.info(), "proof_bytes": len(proof), "verified": True}))
+        return
     aux = tuple(int(x) for x in a.aux.split(","))
     opt = aero_amd.ProofOptions(27, 8, 16, 4, a.ext, 8, 8)
     ctx = aero_amd.Context(0)
