@@ -373,6 +373,9 @@ template <class F, int MODE> static bool air_launch_mode(Context* ctx, const Air
     if (wide && r_env == 4 && F::DEG == 1 && a.n_bgroups <= 2 && air_launch_variant<F, MODE, 4, 2>(ctx, a, abytes)) return true;
     if (wide && r_env != 1 && a.n_bgroups <= 2 && air_launch_variant<F, MODE, RW, 2>(ctx, a, abytes)) return true;
     if (wide && r_env != 1 && a.n_bgroups <= 4 && air_launch_variant<F, MODE, RW, 4>(ctx, a, abytes)) return true;
+    // a VM's assertions (first / last / interior steps, a few periodic strides) make 5 - 8 divisor groups: their accumulators still fit
+    // the registers (2 rows x 8 groups x 2 sums), which keeps the read-modify-write of every BOUND out of the LDS
+    if (wide && r_env != 1 && a.n_bgroups <= 8 && air_launch_variant<F, MODE, RW, 8>(ctx, a, abytes)) return true;
     return air_launch_variant<F, MODE, 1, 0>(ctx, a, abytes);
 }
 template <class F> bool launch_air_constraints(Context* ctx, const AirConsArgs<F>& a, int mode) {

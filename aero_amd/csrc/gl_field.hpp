@@ -26,7 +26,14 @@ constexpr int TWO_ADICITY = 32;
 // (tools/ubench_field.hip) add 6.7 T/s vs 4.8, sub 7.7 vs 6.2, mul 1.65 vs 1.34 T/s for the plain u64 formulation.
 GL_HD uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 GL_HD uint64_t add(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_PLAIN_ADD)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_LAZY_ADD_UNSAFE)
+    // MEASUREMENT ONLY (tools/ubench_dft.hip): one wrap correction, no canonicalisation, a second wrap goes unnoticed - not a field add.
+    uint32_t c, c1;
+    uint32_t s0 = __builtin_addc((uint32_t)a, (uint32_t)b, 0u, &c), s1 = __builtin_addc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &c1);
+    const uint32_t m = 0u - c1;
+    s0 = __builtin_addc(s0, m, 0u, &c); s1 = __builtin_addc(s1, 0u, c, &c);
+    return mk64(s0, s1);
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(GL_PLAIN_ADD)
     // a + b < 2p. Result is s + EPS (mod 2^64) iff the sum wrapped past 2^64 or s >= p (<=> s + EPS wraps).
     uint32_t c, c1, c2;
     uint32_t s0 = __builtin_addc((uint32_t)a, (uint32_t)b, 0u, &c), s1 = __builtin_addc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &c1);

@@ -11,6 +11,10 @@ for t in ubench_valu ubench_rates ubench_field bench_hash; do
   { echo "# $t on $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//') / $(cat /opt/rocm/.info/version 2>/dev/null) / $(date -u +%FT%TZ)"; "/tmp/$t"; } > "$OUT/$t.txt" 2>&1
   rm -f "$OUT/$t.build.log"
 done
+# lazy-reduction bound for the NTT's register transforms (canonical vs uncanonicalised add)
+{ echo "# ubench_dft on $(rocminfo 2>/dev/null | grep -m1 'Marketing Name' | sed 's/.*: *//') / $(cat /opt/rocm/.info/version 2>/dev/null) / $(date -u +%FT%TZ)";
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I "$ROOT/aero_amd/csrc" "$ROOT/tools/ubench_dft.hip" -o /tmp/ubench_dft && /tmp/ubench_dft;
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGL_LAZY_ADD_UNSAFE -I "$ROOT/aero_amd/csrc" "$ROOT/tools/ubench_dft.hip" -o /tmp/ubench_dft_lazy && /tmp/ubench_dft_lazy; } > "$OUT/ubench_dft.txt" 2>&1
 python3 - "$OUT" <<'PY'
 import json, re, sys, os
 out = sys.argv[1]
