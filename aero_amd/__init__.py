@@ -705,6 +705,21 @@ class Air:
         lib().aero_air_info(self.h, out)
         return dict(zip(self.INFO, list(out)))
 
+    def jit_compile(self, log_n, field_extension=1, fused=True):
+        """Build the run-time compiled evaluation kernel ahead of the first proof (aero_air_jit_compile; no GPU needed)."""
+        rc = lib().aero_air_jit_compile(self.h, C.c_uint32(log_n), C.c_uint32(field_extension), C.c_int32(1 if fused else 0))
+        if rc != 0:
+            raise AeroError(rc, lib().aero_last_error(None).decode())
+
+    def jit_source(self, log_n, field_extension=1, fused=True) -> str:
+        out, n = u8p(), C.c_size_t(0)
+        rc = lib().aero_air_jit_source(self.h, C.c_uint32(log_n), C.c_uint32(field_extension), C.c_int32(1 if fused else 0), C.byref(out), C.byref(n))
+        if rc != 0:
+            raise AeroError(rc, lib().aero_last_error(None).decode())
+        data = C.string_at(out, n.value)
+        lib().aero_free(out)
+        return data.decode()
+
     def num_divisors(self, log_n):
         v = C.c_uint32(0)
         rc = lib().aero_air_num_divisors(self.h, C.c_uint32(log_n), C.byref(v))

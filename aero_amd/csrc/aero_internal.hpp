@@ -192,6 +192,10 @@ public:
     template <class Src> void merkle_recompute(const Src& src, size_t n, const uint64_t* idx_dev, int count, Digest* out_dev);
 
     // internal state
+    // AIR programs compiled at run time (air_jit.hip): AERO_AIR_JIT=0 keeps the interpreter; modules loaded on this context's device
+    bool air_jit = true;
+    std::map<uint64_t, void*> jit_funcs;
+    std::vector<hipModule_t> jit_modules;
     bool fri_tail_attr_set = false;   // the opt-in for > 64 KiB of dynamic LDS was made on this context's device
     std::map<int, NttTables> ntt_tabs;
     std::map<uint64_t, uint64_t*> pass_tabs;

@@ -31,6 +31,7 @@ PeriodicTables periodic_tables(const Program& p, uint64_t n, uint64_t rows, uint
 template <class F> struct Pool {
     std::vector<uint64_t> words;
     std::vector<Insn> code;
+    uint32_t oSE = 0, oT = 0, oB = 0;         // where the E scalars, the transition and the boundary coefficient pairs start
 };
 template <class F>
 Pool<F> build_pool(const Program& p, const std::vector<Insn>& code, const std::vector<uint32_t>& desc, const Scalars<F>& sc, const PeriodicTables& pt,
@@ -56,6 +57,7 @@ Pool<F> build_pool(const Program& p, const std::vector<Insn>& code, const std::v
     }
     for (int i = 0; i < 8; i++) w.push_back(0);
     if (w.size() >= (1ull << 31)) fail("air program: scalar pool too large", ST_UNSUPPORTED);
+    pool.oSE = oSE; pool.oT = oT; pool.oB = oB;
     pool.code = code;
     for (Insn& I : pool.code) {
         switch (I.pk) {
@@ -126,9 +128,11 @@ void air_eval_constraints(Context* ctx, const Program& p, const Instance& in, co
     const PeriodicTables pt = periodic_tables(p, in.n, rows, h);
     const DivisorTables dv = divisor_tables(p, in, rows, h);
     const Pool<F> pool = build_pool<F>(p, p.cons_code, p.cons_desc, sc, pt, cc.ta, tb, nm ? ba : std::vector<T>(), nm ? bb : std::vector<T>(), mem_group);
+    std::vector<uint64_t> pdesc;               // the run-time compiled kernel's view of the periodic tables: offset | mask << 32
+    for (size_t k = 0; k < pt.off.size(); k++) pdesc.push_back((uint64_t)pt.off[k] | ((uint64_t)pt.mask[k] << 32));
     ParamPack pp(ctx);
     const size_t i_code = pp.add(pool.code), i_pool = pp.add(pool.words), i_pt = pp.add(pt.tab), i_dg = pp.add(dg_exp), i_bg = pp.add(dv.groups),
-                 i_ga = pp.add(gA), i_gb = pp.add(gB), i_zn = pp.add(dv.zn_inv), i_ex = pp.add(dv.exempt);
+                 i_ga = pp.add(gA), i_gb = pp.add(gB), i_zn = pp.add(dv.zn_inv), i_ex = pp.add(dv.exempt), i_pd = pp.add(pdesc);
     pp.commit();
     NttTables* tw = ctx->ntt_tables(ilog2z(rows));
     AirConsArgs<F> a{};
@@ -144,6 +148,8 @@ void air_eval_constraints(Context* ctx, const Program& p, const Instance& in, co
     a.exempt = pp.ptr<uint64_t>(i_ex); a.n_exempt = p.exemptions;
     a.out_cols = out_cols;
     if (out_h) { a.out_h[0] = out_h[0]; a.out_h[1] = out_h[1]; }
+    // the program as a kernel of its own, compiled when it is first met (air_jit.hip); the interpreter otherwise
+    if (launch_air_jit<F>(ctx, p, in, a, pp.ptr<uint64_t>(i_pd), pool.oSE, pool.oT, pool.oB, mode)) return;
     if (mode == 0) { launch_air_constraints<F>(ctx, a, 0); return; }
     if (launch_air_constraints<F>(ctx, a, 1)) return;
     // too many boundary divisors for the fused form: numerator columns, then the division

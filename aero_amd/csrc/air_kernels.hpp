@@ -56,6 +56,15 @@ template <class F> struct AirConsArgs {
 // for the LDS): the caller then evaluates mode 0 and divides with launch_air_divide.
 template <class F> bool launch_air_constraints(Context* ctx, const AirConsArgs<F>& a, int mode);
 
+// The same evaluation by a kernel generated from the program and compiled at run time (air_jit.hip). Returns false when the context
+// runs with the interpreter (AERO_AIR_JIT=0) or the kernel could not be built (air_jit_last_error() says why): the caller then
+// interprets. pdesc: per periodic column offset | mask << 32 into ptab; oSE / oT / oB: layout of `pool` (air_host.hip: build_pool).
+template <class F> bool launch_air_jit(Context* ctx, const air::Program& p, const air::Instance& in, const AirConsArgs<F>& a, const uint64_t* pdesc, uint64_t oSE,
+                                       uint64_t oT, uint64_t oB, int mode);
+std::string air_jit_last_error();
+std::string air_jit_source(const air::Program& p, const air::Instance& in, int deg, int mode);     // the generated HIP source (diagnosis, tests)
+bool air_jit_compile_only(const air::Program& p, const air::Instance& in, int deg, int mode, std::string* err);   // no device needed
+
 // H = sum_j column_j / divisor_j over the evaluation domain (the unfused `ConstraintEvaluationTable::into_poly` division)
 template <class F> struct AirDivideArgs {
     const uint64_t* cols;        // ((1 + n_bgroups) * DEG) x rows numerators, column-major

@@ -30,6 +30,8 @@
 
 #include "aero_internal.hpp"
 
+#include <memory>
+
 namespace aero {
 namespace air {
 
@@ -101,6 +103,7 @@ struct Program {
     std::vector<uint32_t> cons_desc, aux_desc;       // LOAD descriptors
     uint32_t cons_slotsB = 0, cons_slotsE = 0, aux_slotsB = 0, aux_slotsE = 0;
     std::vector<uint8_t> has_den;             // per aux column
+    mutable std::shared_ptr<void> jit_cache;  // code objects of the run-time compiled evaluation kernels (air_jit.hip), shared by copies
 
     size_t num_transition() const { return trans.size(); }
     size_t num_assertions() const { return masserts.size() + aasserts.size(); }

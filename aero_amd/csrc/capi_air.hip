@@ -94,6 +94,27 @@ int32_t aero_air_num_divisors(const aero_air* air, uint32_t log_n, uint32_t* out
     catch (const Error& e) { g_create_err = e.what(); return e.code; }
 }
 
+int32_t aero_air_jit_compile(const aero_air* air, uint32_t log_n, uint32_t field_extension, int32_t fused) {
+    if (!air || (field_extension != 1 && field_extension != 2)) return AERO_E_BAD_ARG;
+    try {
+        const air::Instance in = air::instantiate(air->prog, (int)log_n);
+        std::string err;
+        if (air_jit_compile_only(air->prog, in, (int)field_extension, fused ? 1 : 0, &err)) return AERO_OK;
+        g_create_err = err;
+        return AERO_E_UNSUPPORTED;
+    } catch (const Error& e) { g_create_err = e.what(); return e.code; }
+    catch (const std::bad_alloc&) { return AERO_E_OOM; }
+}
+int32_t aero_air_jit_source(const aero_air* air, uint32_t log_n, uint32_t field_extension, int32_t fused, uint8_t** source, size_t* len) {
+    if (!air || !source || !len || (field_extension != 1 && field_extension != 2)) return AERO_E_BAD_ARG;
+    try {
+        const std::string s = air_jit_source(air->prog, air::instantiate(air->prog, (int)log_n), (int)field_extension, fused ? 1 : 0);
+        *source = to_malloc(std::vector<uint8_t>(s.begin(), s.end()), len);
+        return AERO_OK;
+    } catch (const Error& e) { g_create_err = e.what(); return e.code; }
+    catch (const std::bad_alloc&) { return AERO_E_OOM; }
+}
+
 }  // extern "C"
 
 // ---- whole proof -----------------------------------------------------------------------------------------------------------

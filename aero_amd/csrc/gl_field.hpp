@@ -9,8 +9,16 @@
 // 2^64 = 2^32 - 1 (mod p) fold. MFMA is deliberately not used: 64-bit modular mul-add is not a dense fp
 // contraction. All values are kept canonical (< p) between operations so results are bit-exact by construction.
 #pragma once
+#ifndef __HIPCC_RTC__          // compiled at run time too (air_jit.hip embeds this file): hiprtc brings the HIP built-ins itself
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+typedef unsigned long long uint64_t;
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned char uint8_t;
+typedef unsigned long size_t;
+#endif
 
 #define GL_HD __host__ __device__ __forceinline__
 

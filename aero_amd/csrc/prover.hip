@@ -28,6 +28,7 @@ Context::Context(int dev) : device(dev) {
     if (const char* e = getenv("AERO_NTT_NAMES")) pass_names = e[0] != '0';
     if (const char* e = getenv("AERO_NTT_2PHASE")) two_phase = e[0] != '0';
     if (const char* e = getenv("AERO_QUAD_TOPS")) quad_tops = e[0] != '0';
+    if (const char* e = getenv("AERO_AIR_JIT")) air_jit = e[0] != '0';
 }
 Context::~Context() {
     (void)hipSetDevice(device);
@@ -35,6 +36,7 @@ Context::~Context() {
     for (auto& kv : free_blocks) (void)hipFree(kv.second);
     for (auto& kv : live_blocks) (void)hipFree(kv.first);
     for (void* p : persistent) (void)hipFree(p);
+    for (hipModule_t m : jit_modules) (void)hipModuleUnload(m);
     if (stage_base) (void)hipHostFree(stage_base);
     if (pinned_flag) (void)hipHostFree(pinned_flag);
     for (auto& r : kt_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }

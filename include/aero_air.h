@@ -111,6 +111,14 @@ int32_t aero_air_info(const aero_air* air, uint32_t out[16]);
 /* Number of numerator columns (= distinct divisors) for a trace of 2^log_n rows: 1 + boundary divisor groups. */
 int32_t aero_air_num_divisors(const aero_air* air, uint32_t log_n, uint32_t* out);
 
+/* The evaluation kernel the library generates from the program and compiles at run time (hiprtc, gfx950) when the first proof of a
+ * (program, trace length, field) arrives - straight-line HIP over the expression DAG, same arithmetic as the interpreter, same
+ * bytes; AERO_AIR_JIT=0 in the environment of aero_create keeps the interpreter. aero_air_jit_compile builds (and caches in the
+ * handle) the kernel ahead of the first proof; it needs no GPU. field_extension 1 | 2; fused 1 = the proving path (numerators
+ * divided and summed), 0 = the numerator-column form of aero_eval_constraints_program. source: malloc'ed text (aero_free). */
+int32_t aero_air_jit_compile(const aero_air* air, uint32_t log_n, uint32_t field_extension, int32_t fused);
+int32_t aero_air_jit_source(const aero_air* air, uint32_t log_n, uint32_t field_extension, int32_t fused, uint8_t** source, size_t* len);
+
 /* `Prover::prove(trace)` + `to_bytes()` for a program AIR (proving_worker.rs:465-467 with the generic `Air`): trace = device
  * matrix of main_width columns; pub = the num_pub public-input elements - they seed the coin (`hash_elements` of the elements,
  * crypto/random.cairo:254-280) and are what PUB operands read. comm may be NULL (one GPU). */

@@ -1,0 +1,46 @@
+"""The run-time compiled evaluation kernel of an AIR program (aero_amd/csrc/air_jit.hip) needs no GPU to be BUILT: hiprtc
+cross-compiles for gfx950 like hipcc does. Checked here: the generated source is what the program says (one definition per node it
+needs, literals for constants, the boundary divisors as one fraction per row) and it compiles, for both fields and both output forms."""
+import re
+
+import pytest
+
+import aero_amd
+from tests import air_examples as ex
+
+
+@pytest.mark.parametrize("ext,fused", [(1, True), (2, True), (1, False)])
+def test_fibair_program_compiles_for_gfx950(ext, fused):
+    air = aero_amd.Air(aero_amd.fib_program(4, (2, 3, 2)))
+    src = air.jit_source(10, ext, fused)
+    assert 'extern "C" __global__' in src and ("typedef gl::FQ F;" if ext == 2 else "typedef gl::FB F;") in src
+    assert ("sh_d[q][threadIdx.x] = run;" in src) == fused          # one inversion per thread over its rows, fused form only
+    assert ("a.out_cols[" in src) == (not fused)
+    air.jit_compile(10, ext, fused)
+    air.jit_compile(10, ext, fused)                                 # cached in the handle
+
+
+def test_vm_shaped_program_source_and_build():
+    b, _, _ = ex.synth_vm(6, 2, 3)
+    air = aero_amd.Air(b.to_bytes())
+    info = air.info()
+    src = air.jit_source(6, 1, True)
+    body = src[src.index('extern "C" __global__'):]
+    nt = info["main_transition"] + info["aux_transition"]
+    assert len(re.findall(r"^\s+acc = F::add\(acc, F::mulb?\(F::make\(pool\[oT", body, re.M)) == nt
+    assert len(re.findall(r"pool\[oB \+ \d+\]", body)) == 2 * (info["main_assertions"] + info["aux_assertions"])
+    assert len(re.findall(r"const uint64_t d\d+ = ", body)) == air.num_divisors(6) - 1
+    defs = re.findall(r"const (?:uint64_t|T) ([te]\d+) = ", body)
+    assert len(defs) == len(set(defs)) <= info["num_nodes"]          # every node at most once
+    assert "0x9e3779b97f4a7c15" not in body                           # (no stray literals: constants appear as written in the program)
+    air.jit_compile(6, 1, True)
+
+
+def test_a_program_without_assertion_groups_needs_no_inversion():
+    b = aero_amd.air.AirBuilder(1)
+    b.transition(b.main_next(0) - 2 * b.main(0), 1)
+    b.assert_single(0, 0, b.const(1))
+    air = aero_amd.Air(b.to_bytes())
+    src = air.jit_source(5, 1, True)
+    assert "gl::inv(tot)" in src                                       # one divisor group: one fraction per row
+    air.jit_compile(5, 1, True)

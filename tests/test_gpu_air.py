@@ -32,6 +32,23 @@ def ctx():
     c.close()
 
 
+# ---- the program as a run-time compiled kernel (air_jit.hip, the default) and as interpreted code (AERO_AIR_JIT=0) ----------------
+@pytest.fixture(scope="module")
+def ctx_interp():
+    import os
+    old = os.environ.get("AERO_AIR_JIT")
+    os.environ["AERO_AIR_JIT"] = "0"
+    try:
+        c = aero_amd.Context(0)
+    finally:
+        if old is None:
+            del os.environ["AERO_AIR_JIT"]
+        else:
+            os.environ["AERO_AIR_JIT"] = old
+    yield c
+    c.close()
+
+
 @pytest.mark.parametrize("width,log_n,aux,opt", [
     (2, 5, (0, 0, 2), [6, 4, 0, 4, 1, 2, 3]),
     (2, 10, (0, 0, 2), OPT),
@@ -137,8 +154,10 @@ def test_smallest_program_and_a_degree_nine_constraint(ctx, oracle):
         ctx.prove_air(air, tr, [c0[-1]], options([27, 8, 8, 4, 1, 4, 6]))
 
 
+@pytest.mark.parametrize("evaluator", ["compiled", "interpreted"])
 @pytest.mark.parametrize("ext,nfrag", [(1, 1), (1, 8), (2, 4)])
-def test_stage_entry_points_against_the_oracle_intermediates(ctx, oracle, ext, nfrag):
+def test_stage_entry_points_against_the_oracle_intermediates(ctx, ctx_interp, oracle, ext, nfrag, evaluator):
+    ctx = ctx if evaluator == "compiled" else ctx_interp
     log_n, pairs, aux = 9, 3, 4
     deg = 2 if ext == 2 else 1
     opt = [27, 8, 8, 4, ext, 8, 6]
@@ -200,3 +219,35 @@ def test_constraint_worker_message_with_a_program(ctx, oracle):
         assert fn == 4 and cols.shape == (ncols, C * n // 4)
         got[:, fi:fi + cols.shape[1]] = cols
     assert (got == want).all()
+
+
+def _kernels_of(c, fn):
+    c.set_kernel_timing(True)
+    out = fn()
+    names = set(c.kernel_timing_report())
+    c.set_kernel_timing(False)
+    return out, names
+
+
+@pytest.mark.parametrize("case", ["fib8_aux", "vm_small", "vm_quadratic", "vm_72_9", "no_groups"])
+def test_compiled_kernel_and_interpreter_give_the_same_bytes(ctx, ctx_interp, oracle, case):
+    if case == "fib8_aux":
+        program, trace, opt = aero_amd.fib_program(8, (3, 4, 2)), aero_amd.fib_trace(8, 12), [27, 8, 8, 4, 1, 4, 7]
+        _, pub = ctx.prove_fib_aux(ctx.trace_upload(trace), 3, 4, options(opt), aux_degree=2)
+    elif case == "no_groups":
+        b, trace, pub = ex.tiny_no_assertion_groups(6) if hasattr(ex, "tiny_no_assertion_groups") else ex.synth_vm(6, 1, 0)
+        program, opt = b.to_bytes(), [6, 8, 0, 4, 1, 2, 4]
+    else:
+        log_n, pairs, aux, opt = {"vm_small": (8, 2, 3, [27, 8, 8, 4, 1, 8, 6]), "vm_quadratic": (9, 4, 4, [20, 8, 8, 4, 2, 8, 6]),
+                                  "vm_72_9": (12, 26, 9, [27, 8, 16, 4, 1, 4, 8])}[case]
+        program = aero_amd.synth_vm_program(log_n, pairs, aux, 16 if pairs == 26 else 4)
+        trace, pub = aero_amd.synth_vm_trace(log_n, pairs)
+    air = aero_amd.Air(program)
+    got, names = _kernels_of(ctx, lambda: ctx.prove_air(air, trace, pub, options(opt)))
+    ref, names_i = _kernels_of(ctx_interp, lambda: ctx_interp.prove_air(air, trace, pub, options(opt)))
+    assert "air_jit_kernel" in names and "air_constraints_kernel" not in names, names
+    assert "air_constraints_kernel" in names_i and "air_jit_kernel" not in names_i, names_i
+    assert got == ref
+    want, _ = oracle.prove_air(program, trace, pub, opt)
+    assert got == want
+    aero_amd.verify_air(got, pub, air, min_query_security_bits=0)

@@ -48,7 +48,7 @@ def main():
         dev = ctx.trace_upload(trace)
         proof = ctx.prove_air(air, dev, pub, opt)
         aero_amd.verify_air(proof, pub, air, expected_log_n=a.log_n)
-        ms = kernel_ms(ctx, lambda: ctx.prove_air(air, dev, pub, opt), ["air_constraints_kernel", "air_aux_factors_kernel", "air_divide_kernel"], a.reps)
+        ms = kernel_ms(ctx, lambda: ctx.prove_air(air, dev, pub, opt), ["air_jit_kernel", "air_constraints_kernel", "air_aux_factors_kernel", "air_divide_kernel"], a.reps)
         host_ms = kernel_ms(ctx, lambda: ctx.prove_air(air, trace, pub, opt), [], a.reps)["proof_wall_ms"]
         print(json.dumps({"workload": f"synth_vm_2^{a.log_n}x({20 + 2 * pairs}+{A}aux)_fold{a.fold}" + ("_quadratic" if a.ext == 2 else ""), "ms": ms,
                           "proof_wall_ms_pageable_host_trace": host_ms, "program_info": air.info(), "proof_bytes": len(proof), "verified": True}))
@@ -61,10 +61,11 @@ def main():
     want, pub = ctx.prove_fib_aux(dev, aux[0], aux[1], opt, aux_degree=aux[2])
     assert ctx.prove_air(air, dev, pub, opt) == want, "program proof differs from the hard-wired proof"
     hard = kernel_ms(ctx, lambda: ctx.prove_fib_aux(dev, aux[0], aux[1], opt, aux_degree=aux[2]), ["fib_constraints_kernel", "aux_columns_kernel"], a.reps)
-    prog = kernel_ms(ctx, lambda: ctx.prove_air(air, dev, pub, opt), ["air_constraints_kernel", "air_aux_kernel"], a.reps)
+    prog = kernel_ms(ctx, lambda: ctx.prove_air(air, dev, pub, opt), ["air_jit_kernel", "air_constraints_kernel", "air_aux_factors_kernel"], a.reps)
     res = {"workload": f"fib_2^{a.log_n}x{a.width}" + (f"+aux{aux}" if aux[0] else "") + ("_quadratic" if a.ext == 2 else ""),
            "hard_wired_ms": hard, "program_ms": prog, "program_info": air.info(),
-           "constraint_kernel_ratio": round(prog["air_constraints_kernel"] / hard["fib_constraints_kernel"], 3)}
+           "evaluator": "compiled at run time (air_jit_kernel)" if "air_jit_kernel" in prog else "interpreter (air_constraints_kernel; AERO_AIR_JIT=0)",
+           "constraint_kernel_ratio": round(prog.get("air_jit_kernel", prog.get("air_constraints_kernel", 0.0)) / hard["fib_constraints_kernel"], 3)}
     print(json.dumps(res))
 
 
