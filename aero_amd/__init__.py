@@ -846,7 +846,7 @@ def proof_security_bits(proof: bytes):
     return q.value, f.value
 
 
-AIR_FIB, AIR_MIDEN_PROCESSOR = 0, 1
+AIR_FIB, AIR_MIDEN_PROCESSOR, AIR_PROGRAM = 0, 1, 2     # AIR_PROGRAM: the constraint set travels as an AEROAIR program next to the trace file
 
 
 def trace_file_write(path, trace: np.ndarray, air=(0, 0, 2), air_id=AIR_FIB):

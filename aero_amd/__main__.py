@@ -3,6 +3,8 @@
 
     python -m aero_amd prove  --width 2 --log-n 20 --out proofs/fib_gpu.bin [--aux 9,16,8] [--quadratic] [--fold 8] [--blowup 8]
     python -m aero_amd prove  --trace dump.aerotrc --out proofs/p.bin    # a trace produced elsewhere (AEROTRC file: include/aero_stark.h)
+    python -m aero_amd program --log-n 12 --out /tmp/vm       # VM-shaped constraint program + a trace that satisfies it + public inputs (no GPU)
+    python -m aero_amd prove  --trace /tmp/vm.aerotrc --air /tmp/vm.aeroair --pub /tmp/vm.pub --fold 4 --out /tmp/vm.bin ; python -m aero_amd verify /tmp/vm.bin --air /tmp/vm.aeroair
     python -m aero_amd trace  --width 2 --log-n 20 --out dump.aerotrc [--aux 9,16,8]   # write the synthetic trace in that format (no GPU)
     python -m aero_amd cairo  proofs/p.bin proof | public-inputs | trace-queries '[5207,...]' | constraint-queries '[..]' | fri-queries '[..]'
                                                                          # = bin/stark_parser <file> <command> (miden-to-cairo-parser/src/main.rs:42-113)
@@ -13,6 +15,7 @@
 The container is `u64 len || input_bytes || u64 len || proof_bytes` (miden-proof-generator/src/lib.rs:1-6); for the built-in
 AIR input_bytes = the public results as little-endian u64."""
 import argparse
+import os
 import struct
 import sys
 import time
@@ -55,6 +58,14 @@ def main():
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--out", required=True)
     p.add_argument("--trace", default=None, help="AEROTRC file holding the trace (and its AIR parameters) instead of the synthetic one")
+    p.add_argument("--air", default=None, help="AEROAIR constraint program (include/aero_air.h) the trace satisfies: proves through aero_prove_air")
+    p.add_argument("--pub", default="", help="--air: the program's public-input elements, comma separated")
+    g = sub.add_parser("program", help="write the VM-shaped synthetic constraint program, a trace that satisfies it and its public inputs (no GPU)")
+    g.add_argument("--log-n", type=int, default=10)
+    g.add_argument("--pairs", type=int, default=26)
+    g.add_argument("--aux", type=int, default=9)
+    g.add_argument("--rands", type=int, default=16)
+    g.add_argument("--out", required=True, help="prefix: <out>.aeroair, <out>.aerotrc, <out>.pub")
     t = sub.add_parser("trace")
     t.add_argument("--width", type=int, default=2)
     t.add_argument("--log-n", type=int, default=10)
@@ -76,6 +87,7 @@ def main():
     v.add_argument("--min-security", type=int, default=96, help="reject proofs whose num_queries * log2(blowup) + grinding is below this")
     v.add_argument("--log-n", type=int, default=0, help="trace length the statement is about (0 = accept the proof's own)")
     v.add_argument("--cairo-compat", action="store_true", help="also require the shape the reference's Cairo verifier hard-codes")
+    v.add_argument("--air", default=None, help="AEROAIR constraint program the proof is about (out-of-domain check over the program)")
     args = ap.parse_args()
     if args.cmd == "cairo":
         import json
@@ -88,6 +100,18 @@ def main():
         with open(args.out, "wb") as f:
             f.write(data)
         print(f"{len(data)} protobuf bytes -> {args.out}")
+        return
+    if args.cmd == "program":
+        program = aero_amd.synth_vm_program(args.log_n, args.pairs, args.aux, args.rands)
+        trace, pub = aero_amd.synth_vm_trace(args.log_n, args.pairs)
+        with open(args.out + ".aeroair", "wb") as f:
+            f.write(program)
+        aero_amd.trace_file_write(args.out + ".aerotrc", trace, (args.aux, args.rands, 2), air_id=aero_amd.AIR_PROGRAM)
+        with open(args.out + ".pub", "w") as f:
+            f.write(",".join(str(x) for x in pub))
+        info = aero_amd.Air(program).info()
+        print(f"{info['main_width']} + {info['aux_width']} columns, {info['main_transition'] + info['aux_transition']} transition constraints, "
+              f"{info['main_assertions'] + info['aux_assertions']} assertions, 2^{args.log_n} rows -> {args.out}.aeroair / .aerotrc / .pub")
         return
     aux = tuple(int(x) for x in args.aux.split(","))
     if args.cmd == "trace":
@@ -107,7 +131,12 @@ def main():
         else:
             dev = ctx.trace_upload(aero_amd.fib_trace(args.width, args.log_n))
         t0 = time.perf_counter()
-        proof, pub = ctx.prove_fib_aux(dev, aux[0], aux[1], opt, aux_degree=aux[2])
+        if args.air:
+            air = aero_amd.Air(open(args.air, "rb").read())
+            pub = [int(x) for x in (open(args.pub).read() if os.path.exists(args.pub) else args.pub).split(",") if x.strip()]
+            proof = ctx.prove_air(air, dev, pub, opt)
+        else:
+            proof, pub = ctx.prove_fib_aux(dev, aux[0], aux[1], opt, aux_degree=aux[2])
         ms = (time.perf_counter() - t0) * 1e3
         blob = aero_amd.proof_container(b"".join(struct.pack("<Q", int(x)) for x in pub), proof)
         with open(args.out, "wb") as f:
@@ -116,7 +145,10 @@ def main():
     else:
         inputs, proof = split_container(open(args.file, "rb").read())
         pol = dict(min_query_security_bits=args.min_security, expected_log_n=args.log_n, cairo_compat=args.cairo_compat)
-        if args.miden:
+        if args.air:
+            pol.pop("cairo_compat")
+            aero_amd.verify_air(proof, list(struct.unpack(f"<{len(inputs) // 8}Q", inputs)), aero_amd.Air(open(args.air, "rb").read()), **pol)
+        elif args.miden:
             aero_amd.verify_fib(proof, miden_pub_elements(inputs), None, allow_unknown_air=True, **pol)
         else:
             aero_amd.verify_fib(proof, list(struct.unpack(f"<{len(inputs) // 8}Q", inputs)), aux, **pol)

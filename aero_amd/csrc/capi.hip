@@ -698,9 +698,11 @@ int32_t aero_trace_file_load(aero_ctx* ctx, const char* path, aero_matrix** trac
         if (!fc.f) fail(std::string("trace file: cannot open ") + path);
         TraceHeader h;
         read_header(fc.f, path, &h);
-        if (h.air_id != AERO_AIR_FIB)
-            fail("trace file: AIR id " + std::to_string(h.air_id) + " is not built into this library (0 = FibAir; Miden's ProcessorAir, id 1, needs the "
-                 "constraint set of the miden-air crate, which the reference mount does not contain)", ST_UNSUPPORTED);
+        // 0 = the built-in FibAir; 2 = the constraint set travels as an AEROAIR program next to the file (include/aero_air.h:
+        // aero_prove_air takes the matrix); 1 = Miden's ProcessorAir by name, whose constraint set this library does not contain
+        if (h.air_id != AERO_AIR_FIB && h.air_id != 2u /* AERO_AIR_PROGRAM */)
+            fail("trace file: AIR id " + std::to_string(h.air_id) + " is not built into this library (0 = FibAir, 2 = a constraint program handed to "
+                 "aero_prove_air; Miden's ProcessorAir, id 1, is not in the reference mount: export it as a program and write the file with id 2)", ST_UNSUPPORTED);
         const size_t count = (size_t)h.width << h.log_n;
         std::unique_ptr<aero_matrix> m(new aero_matrix(ctx));
         m->m = Matrix(c, (int)h.width, (size_t)1 << h.log_n);

@@ -139,7 +139,7 @@ def kernel_times(ctx, fn, names, reps):
     return out
 
 
-def air_program_leg(aero_amd, ctx, log_n=20, reps=3):
+def air_program_leg(aero_amd, ctx, device=0, log_n=20, reps=3):
     """The AIR-as-data path (include/aero_air.h) beside the hard-wired kernels: (1) FibAir(72) as a program vs fib_constraints_kernel
     on the same trace, same proof bytes; (2) a VM-shaped program (72 + 9 columns, 76 + 9 transition constraints, degree <= 8) proven
     and verified. Resident traces, one proof at a time."""
@@ -167,10 +167,29 @@ def air_program_leg(aero_amd, ctx, log_n=20, reps=3):
     vm = kernel_times(ctx, lambda: ctx.prove_air(vair, vdev, vpub, fold4), ["air_jit_kernel", "air_constraints_kernel", "air_aux_factors_kernel"], reps)
     vk = "air_jit_kernel" if "air_jit_kernel" in vm else "air_constraints_kernel"
     vdev.free()
+    # the same program with 3 proofs in flight (one context and host thread each; the C calls release the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    ctxs = [aero_amd.Context(device) for _ in range(3)]
+    devs = [c.trace_upload(trace) for c in ctxs]
+    rounds = 3
+
+    def worker(i):
+        for _ in range(rounds):
+            ctxs[i].prove_air(vair, devs[i], vpub, fold4)
+
+    with ThreadPoolExecutor(3) as ex:
+        list(ex.map(worker, range(3)))                   # warm: modules loaded on every context
+        t0 = time.perf_counter()
+        list(ex.map(worker, range(3)))
+        dt3 = time.perf_counter() - t0
+    for d_, c_ in zip(devs, ctxs):
+        d_.free()
+        c_.close()
     info = vair.info()
     out["vm_shaped_program"] = {"workload": f"synth_vm_2^{log_n}x(72+9aux)_fold4", "ms": vm, "verified": True, "proof_bytes": len(proof),
                                 "transition_constraints": info["main_transition"] + info["aux_transition"],
                                 "cells_per_s_single_proof": round((81 << log_n) / (vm["proof_wall_ms"] * 1e-3)),
+                                "cells_per_s_3_in_flight": round(3 * rounds * (81 << log_n) / dt3),
                                 "constraint_stage_share": round(vm[vk] / vm["proof_wall_ms"], 3)}
     return out
 
@@ -721,7 +740,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline_leg(args, log_n, width, over, opt, first_proof)
         if world == 1 and not args.no_air_program:
             try:
-                out["air_program"] = air_program_leg(aero_amd, ctx)
+                out["air_program"] = air_program_leg(aero_amd, ctx, local_rank)
             except Exception as e:
                 out["air_program"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         check_world = args.sharded_check_world if args.sharded_check_world >= 0 else (world if world > 1 else 0)

@@ -95,3 +95,41 @@ def test_load_and_prove_from_a_trace_file(tmp_path, oracle):
     r = subprocess.run([sys.executable, "-m", "aero_amd", "verify", str(out), "--aux", "3,2,5", "--log-n", "9"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0 and "accepted" in r.stdout, r.stderr
     ctx.close()
+
+
+def test_command_line_writes_a_constraint_program_with_its_trace(tmp_path):
+    # `python -m aero_amd program`: the VM-shaped program, a trace file with the "AIR travels as a program" id and the public inputs
+    pre = tmp_path / "vm"
+    r = subprocess.run([sys.executable, "-m", "aero_amd", "program", "--log-n", "7", "--pairs", "2", "--aux", "3", "--rands", "4", "--out", str(pre)],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    assert aero_amd.trace_file_info(str(pre) + ".aerotrc")[:3] == (24, 7, aero_amd.AIR_PROGRAM)
+    air = aero_amd.Air(open(str(pre) + ".aeroair", "rb").read())
+    assert air.info()["main_width"] == 24 and len(open(str(pre) + ".pub").read().split(",")) == air.info()["num_pub"]
+
+
+@pytest.mark.gpu
+def test_prove_a_foreign_trace_with_its_constraint_program_from_the_command_line(tmp_path, oracle):
+    # what a Miden build would do: dump the trace (AIR id 2) and the AIR as a program, prove, verify with the OOD check over the program
+    pre = tmp_path / "vm"
+    run = lambda *a: subprocess.run([sys.executable, "-m", "aero_amd", *a], capture_output=True, text=True, cwd=ROOT)
+    r = run("program", "--log-n", "10", "--pairs", "3", "--aux", "4", "--rands", "4", "--out", str(pre))
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / "vm.bin"
+    r = run("prove", "--trace", str(pre) + ".aerotrc", "--air", str(pre) + ".aeroair", "--pub", str(pre) + ".pub", "--fold", "4", "--out", str(out))
+    assert r.returncode == 0, r.stderr
+    r = run("verify", str(out), "--air", str(pre) + ".aeroair", "--log-n", "10")
+    assert r.returncode == 0 and "accepted" in r.stdout, r.stderr
+    # the same bytes as the oracle's proof of that program and trace
+    program = open(str(pre) + ".aeroair", "rb").read()
+    trace, pub = aero_amd.synth_vm_trace(10, 3)
+    opt = aero_amd.ProofOptions.with_96_bit_security()
+    opt.fri_folding_factor = 4
+    want, _ = oracle.prove_air(program, trace, pub, opt.to_list())
+    blob = open(out, "rb").read()
+    assert blob.endswith(want)
+    # another program does not accept it
+    other = tmp_path / "other.aeroair"
+    other.write_bytes(aero_amd.synth_vm_program(10, 3, 4, 5))
+    r = run("verify", str(out), "--air", str(other), "--log-n", "10")
+    assert r.returncode != 0

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--vm", default="", help="pairs,aux,rands: prove the VM-shaped synthetic program instead")
     ap.add_argument("--fold", type=int, default=8)
+    ap.add_argument("--table", action="store_true", help="--vm: also print the whole per-kernel table of one proof (HIP events) to stderr")
     a = ap.parse_args()
     if a.vm:
         pairs, A, R = (int(x) for x in a.vm.split(","))
@@ -50,6 +51,12 @@ def main():
         aero_amd.verify_air(proof, pub, air, expected_log_n=a.log_n)
         ms = kernel_ms(ctx, lambda: ctx.prove_air(air, dev, pub, opt), ["air_jit_kernel", "air_constraints_kernel", "air_aux_factors_kernel", "air_divide_kernel"], a.reps)
         host_ms = kernel_ms(ctx, lambda: ctx.prove_air(air, trace, pub, opt), [], a.reps)["proof_wall_ms"]
+        if a.table:
+            ctx.set_kernel_timing(True)
+            ctx.prove_air(air, dev, pub, opt)
+            for name, (c, m, b) in sorted(ctx.kernel_timing_report().items(), key=lambda kv: -kv[1][1]):
+                print(f"  {name:28s} calls {c:5.0f}  ms {m:8.3f}  alg GB/s {(b / (m * 1e-3) / 1e9 if m > 0 else 0.0):8.1f}", file=sys.stderr)
+            ctx.set_kernel_timing(False)
         print(json.dumps({"workload": f"synth_vm_2^{a.log_n}x({20 + 2 * pairs}+{A}aux)_fold{a.fold}" + ("_quadratic" if a.ext == 2 else ""), "ms": ms,
                           "proof_wall_ms_pageable_host_trace": host_ms, "program_info": air.info(), "proof_bytes": len(proof), "verified": True}))
         return
