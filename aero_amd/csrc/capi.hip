@@ -876,6 +876,8 @@ static int32_t pool_run(aero_pool* pool, const aero_matrix* const* traces, const
     {
         std::unique_lock<std::mutex> lk(pool->mu);
         pool->cv_done.wait(lk, [&] { return pool->pending == 0; });
+        // the batch is over: a proof proven on one of these contexts on its own (single-proof latency) pipelines its copy again
+        for (uint32_t i = 0; i < count; i++) pool->slots[i]->ctx->concurrent_peers = false;
     }
     int32_t first = AERO_OK;
     size_t poff = 0;

@@ -208,3 +208,57 @@ class LoopbackComm:
         self.calls["all_reduce"] += 1
         self.bytes_sent += int(count) * 8
         return 0
+
+
+class LocalGroup:
+    """aero_local_group_* (comm_local.hip): the ranks of ONE sharded proof as threads of this process, exchanges = stream-ordered peer
+    copies inside the library (no torch, no RCCL). `run(fn)` calls fn(rank, ctx, comm) on one Python thread per rank (the C calls
+    release the GIL) and returns the per-rank results; a failing rank aborts the group so that nobody waits at a rendezvous."""
+
+    class _Comm:
+        def __init__(self, struct):
+            self.struct = struct
+            self.last_error = None
+
+    def __init__(self, world, devices=None, min_peer_digests=0):
+        import aero_amd
+        self.aero, self.world = aero_amd, world
+        self.h = C.c_void_p()
+        rc = aero_amd.lib().aero_local_group_create(C.c_uint32(world), C.byref(self.h))
+        if rc != 0:
+            raise aero_amd.AeroError(rc, "aero_local_group_create")
+        self.ctxs = [aero_amd.Context((devices or [0] * world)[r]) for r in range(world)]
+        self.comms = []
+        for r in range(world):
+            s = CommStruct()
+            rc = aero_amd.lib().aero_local_group_comm(self.h, self.ctxs[r].h, C.c_int32(r), C.c_uint32(min_peer_digests), C.byref(s))
+            if rc != 0:
+                raise aero_amd.AeroError(rc, "aero_local_group_comm")
+            self.comms.append(LocalGroup._Comm(s))
+
+    def stats(self, rank):
+        out = (C.c_uint64 * 4)()
+        self.aero.lib().aero_local_group_stats(self.h, C.c_int32(rank), out)
+        return {"all_to_all": out[0], "all_gather": out[1], "all_reduce": out[2], "bytes_sent": out[3]}
+
+    def run(self, fn):
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(r):
+            try:
+                return fn(r, self.ctxs[r], self.comms[r])
+            except BaseException:
+                self.aero.lib().aero_local_group_abort(self.h)
+                raise
+
+        with ThreadPoolExecutor(self.world) as ex:
+            futs = [ex.submit(one, r) for r in range(self.world)]
+            return [f.result() for f in futs]
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+        if self.h:
+            self.aero.lib().aero_local_group_destroy(self.h)
+            self.h = None

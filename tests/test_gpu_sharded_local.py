@@ -81,3 +81,35 @@ def test_plain_c_host_shards_a_proof_without_python(tmp_path):
         assert r.returncode == 0, (r.stdout, r.stderr)
         res = json.loads(r.stdout.strip().splitlines()[-1])
         assert res["identical"] and res["world"] == int(args[2]) and res["bytes_sent_rank0"] > 0
+
+
+# ---- AIR programs sharded over thread ranks (aero_prove_air with a communicator) -----------------------------------------------
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("case", ["vm_small", "vm_quadratic", "vm_72_9", "fib_program"])
+def test_program_air_sharded_over_thread_ranks_gives_the_single_gpu_bytes(world, case, oracle):
+    from aero_amd.shard import LocalGroup
+    if case == "fib_program":
+        program, (log_n, opt) = aero_amd.fib_program(8, (3, 4, 2)), (12, [27, 8, 8, 4, 1, 4, 7])
+        trace = aero_amd.fib_trace(8, log_n)
+        pub = [int(trace[2 * k + 1][-1]) for k in range(4)]
+    else:
+        log_n, pairs, aux, opt = {"vm_small": (10, 2, 3, [27, 8, 8, 4, 1, 8, 6]), "vm_quadratic": (9, 4, 4, [20, 8, 8, 4, 2, 8, 6]),
+                                  "vm_72_9": (12, 26, 9, [27, 8, 16, 4, 1, 4, 8])}[case]
+        program = aero_amd.synth_vm_program(log_n, pairs, aux, 16 if pairs == 26 else 4)
+        trace, pub = aero_amd.synth_vm_trace(log_n, pairs)
+    air = aero_amd.Air(program)
+    options = aero_amd.ProofOptions(*opt)
+    single = aero_amd.Context(0)
+    want = single.prove_air(air, single.trace_upload(trace), pub, options)
+    single.close()
+    ref, _ = oracle.prove_air(program, trace, pub, opt)
+    assert want == ref
+    g = LocalGroup(world, min_peer_digests=64)
+    try:
+        proofs = g.run(lambda r, ctx, comm: ctx.prove_air(air, ctx.trace_upload(trace), pub, options, comm=comm))
+        stats = g.stats(0)
+    finally:
+        g.close()
+    for r, p in enumerate(proofs):
+        assert p == want, f"rank {r} of {world}"
+    assert stats["all_to_all"] >= 2 and stats["bytes_sent"] > 0
