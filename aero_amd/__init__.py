@@ -672,6 +672,34 @@ class Pool:
             out.append((data, pubs[i * (w // 2):(i + 1) * (w // 2)].tolist()))
         return out
 
+    def prove_air(self, air: "Air", traces, pub, options: ProofOptions, rounds=1):
+        """The same for an AIR given as a constraint program: traces[i] = Matrix resident on slot i's context, or (all of them) host
+        arrays / PinnedTrace of one shape; one program and one statement for the whole batch. Returns the proof bytes per slot."""
+        n = len(traces)
+        pb = np.array(pub, dtype=np.uint64, ndmin=1) if len(pub) else np.zeros(1, np.uint64)
+        proofs = (u8p * n)()
+        lens = (C.c_size_t * n)()
+        if isinstance(traces[0], Matrix):
+            arr = (C.c_void_p * n)(*[t.h for t in traces])
+            rc = lib().aero_pool_prove_air(self.h, air.h, arr, C.c_uint32(n), _p64(pb), C.c_uint32(len(pub)), C.byref(options), C.c_uint32(rounds), proofs, lens)
+        else:
+            arrs = [t.array if isinstance(t, PinnedTrace) else np.ascontiguousarray(t, np.uint64) for t in traces]
+            assert all(a.shape == arrs[0].shape for a in arrs), "host traces of one batch must have one shape"
+            ptrs = (u64p * n)(*[_p64(a) for a in arrs])
+            rc = lib().aero_pool_prove_air_host(self.h, air.h, ptrs, C.c_uint32(int(arrs[0].shape[1]).bit_length() - 1), C.c_uint32(n), _p64(pb),
+                                                C.c_uint32(len(pub)), C.byref(options), C.c_uint32(rounds), proofs, lens)
+        if rc != 0:
+            msgs = [lib().aero_last_error(c.h).decode() for c in self.ctxs[:n]]
+            for i in range(n):
+                if proofs[i]:
+                    lib().aero_free(proofs[i])
+            raise AeroError(rc, "; ".join(m for m in msgs if m))
+        out = []
+        for i in range(n):
+            out.append(C.string_at(proofs[i], lens[i]))
+            lib().aero_free(proofs[i])
+        return out
+
     def close(self):
         if self.h:
             lib().aero_pool_destroy(self.h)

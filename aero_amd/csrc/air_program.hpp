@@ -17,8 +17,14 @@
 //      by group, each constraint's expression tree in post-order with common sub-expressions computed once, followed by an EMIT
 //      that folds the value into the group's two accumulators (sum alpha_k t_k and sum beta_k t_k); GROUP_END multiplies the
 //      second by x^adj - ONE power per group and row, obtained as a twiddle-table lookup, not an exponentiation;
-//   4. register allocation: a linear scan over the emitted stream assigns every live node a slot of the per-lane register file
+//   4. lowering: every frame access becomes explicit - LOAD instructions fetch 8 frame values (4 of the auxiliary segment) at a time,
+//      looking ahead in the stream; the assertions on a column are bound right behind the load of its current-row value; the last one
+//      or two nodes of a constraint are folded into its EMIT (EMIT_ADD/SUB/MUL_B, EMIT3_B); a value whose next use is far is re-loaded;
+//   5. register allocation: a linear scan over the lowered stream assigns every live value a slot of the per-lane register file
 //      (LDS on the device), reusing slots after the last use.
+// The SAME parsed program (nodes, types, folded scalars, degree and boundary groups) also feeds the run-time code generator of
+// air_jit.hip, which is the default evaluator on the device; the instruction stream above is what the interpreter (air_kernels.hip)
+// and the host evaluation of the verifier (`host_evaluate`) run.
 #pragma once
 #include <algorithm>
 #include <cstring>

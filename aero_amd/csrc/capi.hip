@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "capi_internal.hpp"
+#include "../../include/aero_air.h"
 #include "proof_format.hpp"
 #include "stark_kernels.hpp"
 #include "worker_messages.hpp"
@@ -790,6 +791,8 @@ struct aero_pool {
     bool stop = false;
     // batch parameters
     aero_fib_air air{0, 0, 2};
+    const aero_air* program = nullptr;     // batch of a program AIR (aero_pool_prove_air*): proven through aero_prove_air[_host]
+    std::vector<uint64_t> program_pub;
     aero_proof_options opt{};
     uint32_t rounds = 1;
     uint32_t host_width = 0, host_log_n = 0;
@@ -809,7 +812,12 @@ struct aero_pool {
             std::vector<uint64_t> pub((size_t)(s->host_trace ? host_width : (uint32_t)s->trace->m.cols) / 2);
             for (uint32_t r = 0; r < rounds && rc == AERO_OK; r++) {
                 if (out) { free(out); out = nullptr; }
-                if (s->host_trace) rc = aero_prove_fib_air_host(s->ctx, s->host_trace, host_width, host_log_n, &air, &opt, &out, &len, pub.data());
+                if (program) {
+                    const uint32_t np = (uint32_t)program_pub.size();
+                    if (s->host_trace) rc = aero_prove_air_host(s->ctx, program, s->host_trace, host_log_n, program_pub.data(), np, &opt, &out, &len);
+                    else rc = aero_prove_air(s->ctx, nullptr, program, s->trace, program_pub.data(), np, &opt, &out, &len);
+                }
+                else if (s->host_trace) rc = aero_prove_fib_air_host(s->ctx, s->host_trace, host_width, host_log_n, &air, &opt, &out, &len, pub.data());
                 else rc = aero_prove_fib_air(s->ctx, nullptr, s->trace, &air, &opt, &out, &len, pub.data());
             }
             {
@@ -856,9 +864,11 @@ uint32_t aero_pool_slots(const aero_pool* pool) { return pool ? (uint32_t)pool->
 aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot) { return (pool && slot < pool->slots.size()) ? pool->slots[slot]->ctx : nullptr; }
 static int32_t pool_run(aero_pool* pool, const aero_matrix* const* traces, const uint64_t* const* host_traces, uint32_t width, uint32_t log_n,
                         uint32_t count, const aero_fib_air* air, const aero_proof_options* options, uint32_t rounds, uint8_t** proofs,
-                        size_t* proof_lens, uint64_t* pubs) {
+                        size_t* proof_lens, uint64_t* pubs, const aero_air* program = nullptr, const uint64_t* program_pub = nullptr, uint32_t n_pub = 0) {
     {
         std::lock_guard<std::mutex> lk(pool->mu);
+        pool->program = program;
+        pool->program_pub.assign(program_pub, program_pub + (program ? n_pub : 0));
         pool->air = air ? *air : aero_fib_air{0, 0, 2};
         pool->opt = *options;
         pool->rounds = rounds;
@@ -905,6 +915,22 @@ int32_t aero_pool_prove_fib_host(aero_pool* pool, const uint64_t* const* host_tr
     if (width < 2 || width > 254 || log_n < 3 || log_n > 29) return AERO_E_BAD_ARG;
     for (uint32_t i = 0; i < count; i++) if (!host_traces[i]) return AERO_E_BAD_ARG;
     return pool_run(pool, nullptr, host_traces, width, log_n, count, air, options, rounds, proofs, proof_lens, pubs);
+}
+// the same for an AIR given as a constraint program (include/aero_air.h): one program and one statement for the whole batch
+int32_t aero_pool_prove_air(aero_pool* pool, const aero_air* air, const aero_matrix* const* traces, uint32_t count, const uint64_t* pub, uint32_t n_pub,
+                            const aero_proof_options* options, uint32_t rounds, uint8_t** proofs, size_t* proof_lens) {
+    if (!pool || !air || !traces || !options || !proofs || !proof_lens || (n_pub && !pub) || count == 0 || count > pool->slots.size() || rounds == 0) return AERO_E_BAD_ARG;
+    for (uint32_t i = 0; i < count; i++)
+        if (!traces[i] || traces[i]->keep.get() != pool->slots[i]->ctx->c) return AERO_E_BAD_ARG;
+    return pool_run(pool, traces, nullptr, 0, 0, count, nullptr, options, rounds, proofs, proof_lens, nullptr, air, pub, n_pub);
+}
+int32_t aero_pool_prove_air_host(aero_pool* pool, const aero_air* air, const uint64_t* const* host_traces, uint32_t log_n, uint32_t count,
+                                 const uint64_t* pub, uint32_t n_pub, const aero_proof_options* options, uint32_t rounds, uint8_t** proofs,
+                                 size_t* proof_lens) {
+    if (!pool || !air || !host_traces || !options || !proofs || !proof_lens || (n_pub && !pub) || count == 0 || count > pool->slots.size() || rounds == 0) return AERO_E_BAD_ARG;
+    if (log_n < 3 || log_n > 29) return AERO_E_BAD_ARG;
+    for (uint32_t i = 0; i < count; i++) if (!host_traces[i]) return AERO_E_BAD_ARG;
+    return pool_run(pool, nullptr, host_traces, 2, log_n, count, nullptr, options, rounds, proofs, proof_lens, nullptr, air, pub, n_pub);
 }
 // ---- the reference's worker seam at the message level (worker_messages.hpp) ------------------------------------------------------
 // hashing_worker.rs:12-26: every row of the work item -> Blake2s_256::hash_elements, answered in row order with the batch index.

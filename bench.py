@@ -167,24 +167,18 @@ def air_program_leg(aero_amd, ctx, device=0, log_n=20, reps=3):
     vm = kernel_times(ctx, lambda: ctx.prove_air(vair, vdev, vpub, fold4), ["air_jit_kernel", "air_constraints_kernel", "air_aux_factors_kernel"], reps)
     vk = "air_jit_kernel" if "air_jit_kernel" in vm else "air_constraints_kernel"
     vdev.free()
-    # the same program with 3 proofs in flight (one context and host thread each; the C calls release the GIL)
-    from concurrent.futures import ThreadPoolExecutor
-    ctxs = [aero_amd.Context(device) for _ in range(3)]
-    devs = [c.trace_upload(trace) for c in ctxs]
+    # the same program with 3 proofs in flight: one C call, a context + stream + worker thread per slot inside the library
+    vpool = aero_amd.Pool(device, 3)
+    vdevs = [vpool.ctx(i).trace_upload(trace) for i in range(3)]
     rounds = 3
-
-    def worker(i):
-        for _ in range(rounds):
-            ctxs[i].prove_air(vair, devs[i], vpub, fold4)
-
-    with ThreadPoolExecutor(3) as ex:
-        list(ex.map(worker, range(3)))                   # warm: modules loaded on every context
-        t0 = time.perf_counter()
-        list(ex.map(worker, range(3)))
-        dt3 = time.perf_counter() - t0
-    for d_, c_ in zip(devs, ctxs):
+    proofs3 = vpool.prove_air(vair, vdevs, vpub, fold4, rounds=1)          # warm: modules loaded on every context
+    assert all(p_ == proof for p_ in proofs3), "pool proofs differ from the single proof"
+    t0 = time.perf_counter()
+    vpool.prove_air(vair, vdevs, vpub, fold4, rounds=rounds)
+    dt3 = time.perf_counter() - t0
+    for d_ in vdevs:
         d_.free()
-        c_.close()
+    vpool.close()
     info = vair.info()
     out["vm_shaped_program"] = {"workload": f"synth_vm_2^{log_n}x(72+9aux)_fold4", "ms": vm, "verified": True, "proof_bytes": len(proof),
                                 "transition_constraints": info["main_transition"] + info["aux_transition"],

@@ -111,6 +111,16 @@ int32_t aero_air_info(const aero_air* air, uint32_t out[16]);
 /* Number of numerator columns (= distinct divisors) for a trace of 2^log_n rows: 1 + boundary divisor groups. */
 int32_t aero_air_num_divisors(const aero_air* air, uint32_t log_n, uint32_t* out);
 
+/* Several program-AIR proofs in flight on one GPU (aero_pool_* of aero_stark.h: one context, stream and worker thread per slot):
+ * slot i proves traces[i] / host_traces[i] (column-major main_width x 2^log_n) `rounds` times, all with the same program and
+ * public inputs; the last proof of each slot is returned (malloc'ed, aero_free). Returns the first non-zero status of any slot. */
+struct aero_pool;
+int32_t aero_pool_prove_air(struct aero_pool* pool, const aero_air* air, const aero_matrix* const* traces, uint32_t count, const uint64_t* pub,
+                            uint32_t n_pub, const aero_proof_options* options, uint32_t rounds, uint8_t** proofs, size_t* proof_lens);
+int32_t aero_pool_prove_air_host(struct aero_pool* pool, const aero_air* air, const uint64_t* const* host_traces, uint32_t log_n, uint32_t count,
+                                 const uint64_t* pub, uint32_t n_pub, const aero_proof_options* options, uint32_t rounds, uint8_t** proofs,
+                                 size_t* proof_lens);
+
 /* The evaluation kernel the library generates from the program and compiles at run time (hiprtc, gfx950) when the first proof of a
  * (program, trace length, field) arrives - straight-line HIP over the expression DAG, same arithmetic as the interpreter, same
  * bytes; AERO_AIR_JIT=0 in the environment of aero_create keeps the interpreter. aero_air_jit_compile builds (and caches in the

@@ -251,3 +251,23 @@ def test_compiled_kernel_and_interpreter_give_the_same_bytes(ctx, ctx_interp, or
     want, _ = oracle.prove_air(program, trace, pub, opt)
     assert got == want
     aero_amd.verify_air(got, pub, air, min_query_security_bits=0)
+
+
+def test_pool_proves_program_airs_in_flight(oracle):
+    # aero_pool_prove_air / aero_pool_prove_air_host: several proofs of one program in flight on one GPU, resident and host traces
+    log_n, pairs, aux = 9, 3, 4
+    program = aero_amd.synth_vm_program(log_n, pairs, aux, 4)
+    trace, pub = aero_amd.synth_vm_trace(log_n, pairs)
+    air = aero_amd.Air(program)
+    opt = [27, 8, 8, 4, 1, 4, 6]
+    want, _ = oracle.prove_air(program, trace, pub, opt)
+    pool = aero_amd.Pool(0, 3)
+    try:
+        devs = [pool.ctx(i).trace_upload(trace) for i in range(3)]
+        assert pool.prove_air(air, devs, pub, options(opt), rounds=2) == [want] * 3
+        assert pool.prove_air(air, [trace, trace.copy()], pub, options(opt)) == [want] * 2
+        with pytest.raises(aero_amd.AeroError):                      # a statement the trace does not satisfy is not detected by the prover,
+            pool.prove_air(air, devs, pub[:-1], options(opt))        # a wrong NUMBER of public inputs is
+        assert pool.prove_air(air, devs[:1], pub, options(opt)) == [want]      # the pool is still usable
+    finally:
+        pool.close()
