@@ -196,6 +196,7 @@ public:
     bool air_jit = true;
     std::map<uint64_t, void*> jit_funcs;
     std::vector<hipModule_t> jit_modules;
+    std::vector<std::shared_ptr<void>> jit_blobs;
     bool fri_tail_attr_set = false;   // the opt-in for > 64 KiB of dynamic LDS was made on this context's device
     std::map<int, NttTables> ntt_tabs;
     std::map<uint64_t, uint64_t*> pass_tabs;

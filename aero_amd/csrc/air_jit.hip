@@ -397,6 +397,9 @@ bool air_jit_compile_only(const air::Program& p, const air::Instance& in, int de
 template <class F> bool launch_air_jit(Context* ctx, const air::Program& p, const air::Instance& in, const AirConsArgs<F>& c, const uint64_t* pdesc, uint64_t oSE,
                                        uint64_t oT, uint64_t oB, int mode) {
     if (!ctx->air_jit) return false;
+    // a kernel body grows with the program: beyond this many nodes + constraints + assertions (minutes of compilation, a code object of
+    // several MB) the interpreter, whose cost per proof does not depend on a compiler, is the better evaluator
+    if (p.nodes.size() + p.num_transition() + p.num_assertions() > 20000) return false;
     const int R = jit_rows(p, c.count, mode, in.bgroups.size());
     auto blob = get_blob(p, in, F::DEG, mode, R);
     if (!blob->error.empty()) return false;
@@ -408,6 +411,7 @@ template <class F> bool launch_air_jit(Context* ctx, const air::Program& p, cons
         hipModule_t mod;
         if (hipModuleLoadData(&mod, blob->code.data()) != hipSuccess) { (void)hipGetLastError(); return false; }
         ctx->jit_modules.push_back(mod);
+        ctx->jit_blobs.push_back(blob);          // the image stays alive as long as the module that was loaded from it
         if (hipModuleGetFunction(&fn, mod, "air_jit_kernel") != hipSuccess) { (void)hipGetLastError(); return false; }
         ctx->jit_funcs[blob->id] = (void*)fn;
     }

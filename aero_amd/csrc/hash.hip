@@ -544,10 +544,37 @@ void Context::hash_message_rows(const MsgSrc& src, size_t rows, Digest* leaves) 
     AERO_LAUNCH(this, "hash_message_rows_kernel", 0, (hash_rows_kernel<MsgSrc>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, src, rows, leaves);
     check_launch("hash_message_rows");
 }
+// FRI rows with a compile-time shape: the FOLD * DEG values of a row (each in its own line, FOLD rows apart) are fetched up front,
+// then hashed - with the loads left next to the compression that consumes them a lane waits for memory FOLD * DEG / 2 times per row.
+template <int FOLD, int DEG> __global__ __launch_bounds__(256) void hash_fri_rows_fixed_kernel(FriSrc s, Digest* leaves) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= s.rows) return;
+    uint64_t e[FOLD * DEG];
+#pragma unroll
+    for (int j = 0; j < FOLD; j++) {
+        e[j * DEG] = s.c0[i + (size_t)j * s.rows];
+        if (DEG > 1) e[j * DEG + DEG - 1] = s.c1[i + (size_t)j * s.rows];
+    }
+    b2s::State st;
+    b2s::init(st);
+#pragma unroll
+    for (int q = 0; q < FOLD * DEG; q += 2) b2s::compress_elems(st, e[q], e[q + 1], true, (uint32_t)(q + 2) * 32, q + 2 == FOLD * DEG);
+    store_digest(&leaves[i], state_digest(st));
+}
 void Context::hash_fri_rows(const FriSrc& src, Digest* leaves) {
     if ((src.fold * src.deg) & 1) fail("hash_fri_rows: odd element count");
-    AERO_LAUNCH(this, "hash_fri_rows_kernel", src.rows * ((size_t)src.fold * src.deg * 8 + 32), (hash_rows_kernel<FriSrc>),
-                dim3((unsigned)((src.rows + 255) / 256)), dim3(256), 0, src, src.rows, leaves);
+    const size_t abytes = src.rows * ((size_t)src.fold * src.deg * 8 + 32);
+    const dim3 grid((unsigned)((src.rows + 255) / 256));
+    const int shape = src.fold * 4 + src.deg;
+    switch (shape) {
+        case 8 * 4 + 1: AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_fri_rows_fixed_kernel<8, 1>), grid, dim3(256), 0, src, leaves); break;
+        case 8 * 4 + 2: AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_fri_rows_fixed_kernel<8, 2>), grid, dim3(256), 0, src, leaves); break;
+        case 4 * 4 + 1: AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_fri_rows_fixed_kernel<4, 1>), grid, dim3(256), 0, src, leaves); break;
+        case 4 * 4 + 2: AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_fri_rows_fixed_kernel<4, 2>), grid, dim3(256), 0, src, leaves); break;
+        case 2 * 4 + 1: AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_fri_rows_fixed_kernel<2, 1>), grid, dim3(256), 0, src, leaves); break;
+        case 2 * 4 + 2: AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_fri_rows_fixed_kernel<2, 2>), grid, dim3(256), 0, src, leaves); break;
+        default: AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_rows_kernel<FriSrc>), grid, dim3(256), 0, src, src.rows, leaves);
+    }
     check_launch("hash_fri_rows");
 }
 

@@ -82,3 +82,34 @@ def test_cpp_prover_trait_flow_matches_the_oracle(tmp_path, oracle, width, log_n
     want, want_pub, _ = oracle.prove_fib(width, log_n, [27, 8, 16, 4, 1, 8, 8])
     assert proof == want and len(proof) == res["proof_bytes"]
     assert inputs == b"".join(int(v).to_bytes(8, "little") for v in want_pub)
+
+
+# ---- a foreign AIR as a constraint program from plain C (include/aero_air.h) -------------------------------------------------------
+def build_air_demo(tmp_path):
+    exe = str(tmp_path / "air_demo")
+    lib_dir = os.path.join(ROOT, "aero_amd")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "air_demo.c"),
+           "-L", lib_dir, "-laero_stark", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_air_header_is_plain_c(tmp_path):
+    exe = build_air_demo(tmp_path)
+    r = subprocess.run([exe, "8", "2", "3", str(tmp_path / "p.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 2), (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_host_proves_a_constraint_program(tmp_path, oracle):
+    import aero_amd
+    exe = build_air_demo(tmp_path)
+    out = tmp_path / "vm.proof"
+    r = subprocess.run([exe, "10", "3", "4", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "27 + 4 columns" not in r.stdout and "26 + 4 columns" in r.stdout and "proved and verified" in r.stdout
+    program = aero_amd.synth_vm_program(10, 3, 4, 4)
+    trace, pub = aero_amd.synth_vm_trace(10, 3)
+    want, _ = oracle.prove_air(program, trace, pub, [27, 8, 16, 4, 1, 4, 8])
+    assert out.read_bytes() == want
