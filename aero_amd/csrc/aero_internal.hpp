@@ -61,7 +61,7 @@ struct CompactOut {
     int log_step = 0;
     int log_split = 0;
 };
-std::vector<NttPass> plan_passes(int log_n, bool reg_passes, int first_bits = 12);
+std::vector<NttPass> plan_passes(int log_n, bool reg_passes, int first_bits = 12, bool radix128 = false);
 
 typedef b2s::Digest Digest;   // 8 x u32, byte order = digest byte order (little-endian words)
 
@@ -163,6 +163,7 @@ public:
     bool pass_names = false;   // AERO_NTT_NAMES=1: forward passes are timed under per-variant names (diagnosis)
     bool two_phase = true;     // contiguous pass of the blowup-8 LDE as two register transforms around one LDS exchange (AERO_NTT_2PHASE=0: LDS rounds)
     bool reg_passes = true;    // strided passes of radix 16..64 run entirely in registers (AERO_NTT_REG=0: LDS passes only)
+    bool radix128 = true;      // forward transforms take radix-128 two-lane passes where that saves a pass (AERO_NTT_R128=0: radix <= 64)
     bool fwd_two_phase(int log_out, int log_pad) const;
     // returns true when `compact` was requested AND written (the last pass must be a strided register pass: transforms that fit the
     // contiguous pass alone do not produce it and the caller falls back to strided reads of the full matrix)

@@ -578,6 +578,54 @@ __global__ __launch_bounds__(256) void ntt_fwd_strided_reg6x2(PassArgs a) {
         }
     }
 }
+// Radix-128 pass, each 128-point transform shared by two lanes (l and l + 32), 64 values per lane: lane half h holds rows 64 h + i, the
+// first six stages are the 64-point register transform of each half (shift twiddles), the last stage pairs row j with row j + 64
+// across the halves (V_PERMLANE32_SWAP: rows (i, 64 + i) end up in the lower half, (32 + i, 96 + i) in the upper) with the
+// twiddle w_128^j = w_128^(j mod 32) * (w_4 = 2^48 in the upper half): w_128 is not a power of two (2 has order 192), so this one
+// stage multiplies by 31 table constants (w_4096^(32 i), uniform over the wavefront) - half a multiplication per element. Used where
+// it saves a whole pass: a 2^25-point LDE (2^22-row traces, BASELINE configs[4]) is 11 + 7 + 7 bits instead of 11 + 5 + 5 + 4.
+__global__ __launch_bounds__(256, 3) void ntt_fwd_strided_reg7x2(PassArgs a) {
+    const uint32_t lane = threadIdx.x & 63, half = lane >> 5;
+    const size_t p = (((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) << 5) + (lane & 31);    // over 2^(log_n - 7) positions per column
+    const size_t lo = p & (((size_t)1 << a.log_s) - 1);
+    const uint32_t b = (uint32_t)(((size_t)blockIdx.x * 128) >> a.log_s);                  // S >= 128: uniform over the workgroup
+    const size_t base = lo + (((size_t)b << 7) << a.log_s);
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    uint64_t y[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) y[i] = in[base + ((size_t)(64 * half + i) << a.log_s)];
+    __builtin_amdgcn_sched_barrier(0);
+    dft_dit_reg<6>(y);
+#pragma unroll
+    for (int i = 0; i < 32; i++) swap_halves(y[i], y[32 + i]);
+    // y[i] = row 32 half + i, y[32 + i] = row 64 + 32 half + i: (u, v) of the last stage, twiddle w_128^(32 half + i). Every pair is
+    // finished - butterfly, pass-boundary twiddle, stores - before the next one is touched: its registers are free again at once.
+    const uint32_t r0 = 32 * half;
+    const bool twiddle = !a.first && b;
+    const uint64_t* tw = a.tw_pass + ((size_t)b << 7) + r0;
+    const bool compact = a.compact && (lo & (((size_t)1 << a.compact_log) - 1)) == 0;
+    uint64_t* co = a.compact + (size_t)blockIdx.y * a.compact_col_stride;
+    const size_t part_len = (((size_t)1 << a.log_n) >> a.compact_log) >> a.compact_split, pmask = ((size_t)1 << a.compact_split) - 1;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        uint64_t v = y[32 + i];
+        const uint64_t t = mul_w4(v);
+        v = half ? t : v;
+        if (i) v = mul(v, a.tw_r[32 * i]);
+        const uint64_t u = y[i];
+        uint64_t lo_row = add(u, v), hi_row = sub(u, v);
+        if (twiddle) { lo_row = mul(lo_row, tw[i]); hi_row = mul(hi_row, tw[64 + i]); }
+        const size_t p0 = base + ((size_t)(r0 + i) << a.log_s), p1 = base + ((size_t)(r0 + 64 + i) << a.log_s);
+        out[p0] = lo_row;
+        out[p1] = hi_row;
+        if (compact) {
+            const size_t j0 = p0 >> a.compact_log, j1 = p1 >> a.compact_log;
+            co[(j0 & pmask) * part_len + (j0 >> a.compact_split)] = lo_row;
+            co[(j1 & pmask) * part_len + (j1 >> a.compact_split)] = hi_row;
+        }
+    }
+}
 template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_inv_strided_reg(PassArgs a) {
     constexpr int R = 1 << LOGR;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -685,13 +733,15 @@ void Context::ensure_small_twiddles() {
 // passes every strided pass has radix <= 64 (one more pass over HBM beats a radix-128/256 pass through LDS: measured 2^25
 // points, 4 columns: 1162 us for the LDS radix-128 pass against 550 us for a register radix-64 pass); without them the
 // strided passes take up to 8 bits each through LDS tiles of R x TL = 4096 elements.
-std::vector<NttPass> plan_passes(int L, bool reg, int first_bits) {
+std::vector<NttPass> plan_passes(int L, bool reg, int first_bits, bool radix128) {
     std::vector<NttPass> p;
     int r1 = L < first_bits ? L : first_bits;
     p.push_back(NttPass{0, r1, 0});
     int rem = L - r1, s = r1;
     if (rem == 0) return p;
-    const int max_r = reg ? 6 : 8;
+    int max_r = reg ? 6 : 8;
+    // forward register passes: radix 128 (two lanes per transform) where it saves a whole pass over radix <= 64
+    if (reg && radix128 && (rem + 6) / 7 < (rem + 5) / 6) max_r = 7;
     int npass = (rem + max_r - 1) / max_r;
     for (int i = 0; i < npass; i++) {
         int r = (rem + (npass - 1 - i)) / (npass - i);   // split as evenly as possible, larger radices first
@@ -714,7 +764,7 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
     ensure_small_twiddles();
     bool compact_written = false;
     NttTables* t = ntt_tables(log_out);
-    std::vector<NttPass> plan = plan_passes(log_out, reg_passes, fwd_two_phase(log_out, log_pad) ? 11 : 12);
+    std::vector<NttPass> plan = plan_passes(log_out, reg_passes, fwd_two_phase(log_out, log_pad) ? 11 : 12, radix128);
     if (plan[0].log_r < log_pad) fail("ntt_forward: transform too small for the requested padding");
     for (size_t q = 0; q < plan.size(); q++) {
         PassArgs a{};
@@ -736,6 +786,9 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
             dim3 rgrid((unsigned)((((size_t)1 << log_out) >> a.log_r) / 256), ncols);
             const char* nm = pass_names ? (a.log_r == 6 ? (a.first ? "ntt_fwd_reg6_last" : "ntt_fwd_reg6_mid") : a.log_r == 5 ? "ntt_fwd_reg5" : a.log_r == 4 ? "ntt_fwd_reg4" : "ntt_fwd_reg123") : "ntt_fwd_pass";
             switch (a.log_r) {
+                case 7:
+                    AERO_LAUNCH(this, pass_names ? "ntt_fwd_reg7" : nm, abytes, ntt_fwd_strided_reg7x2, dim3((unsigned)((((size_t)1 << log_out) >> 6) / 256), ncols), dim3(256), 0, a);
+                    break;
                 case 6:
                     if (a.log_s >= 7)    // two lanes per transform: 32 values per lane (the block index stays uniform over a workgroup)
                         AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg6x2, dim3((unsigned)((((size_t)1 << log_out) >> 5) / 256), ncols), dim3(256), 0, a);
@@ -778,7 +831,7 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
     // (measured: -20 % on 72 columns x 2^20 and on 2 x 2^24, -7 % on 2 x 2^21; on 2 x 2^20 - one wave per SIMD, pure latency - it
     // equals the LDS rounds, which keep the smaller launches)
     const bool inv2p = inv2p_env && reg_passes && log_n >= 13 && ((size_t)ncols << log_n) >= ((size_t)1 << 22);
-    std::vector<NttPass> plan = plan_passes(log_n, reg_passes, inv2p ? 11 : 12);
+    std::vector<NttPass> plan = plan_passes(log_n, reg_passes, inv2p ? 11 : 12, false);
     const int r1 = plan[0].log_r;
     // per-k table for the final (contiguous) pass
     uint64_t ninv = gl::inv((uint64_t)1 << log_n);

@@ -29,6 +29,7 @@ Context::Context(int dev) : device(dev) {
     if (const char* e = getenv("AERO_NTT_2PHASE")) two_phase = e[0] != '0';
     if (const char* e = getenv("AERO_QUAD_TOPS")) quad_tops = e[0] != '0';
     if (const char* e = getenv("AERO_AIR_JIT")) air_jit = e[0] != '0';
+    if (const char* e = getenv("AERO_NTT_R128")) radix128 = e[0] != '0';
 }
 Context::~Context() {
     (void)hipSetDevice(device);
