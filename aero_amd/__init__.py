@@ -393,10 +393,13 @@ class Context:
             rc = lib().aero_prove_air(self.h, C.byref(comm.struct) if comm is not None else None, air.h, trace.h, _p64(pb), C.c_uint32(len(pub)),
                                       C.byref(options), C.byref(proof), C.byref(plen))
         else:
-            assert comm is None, "sharded proofs take a device-resident trace"
             t = trace.array if isinstance(trace, PinnedTrace) else np.ascontiguousarray(trace, np.uint64)
-            rc = lib().aero_prove_air_host(self.h, air.h, _p64(t), C.c_uint32(int(t.shape[1]).bit_length() - 1), _p64(pb), C.c_uint32(len(pub)),
-                                           C.byref(options), C.byref(proof), C.byref(plen))
+            if comm is not None:      # one proof over the communicator's ranks, each copying its share of the columns from host memory
+                rc = lib().aero_prove_air_sharded_host(self.h, C.byref(comm.struct), air.h, _p64(t), C.c_uint32(int(t.shape[1]).bit_length() - 1), _p64(pb),
+                                                       C.c_uint32(len(pub)), C.byref(options), C.byref(proof), C.byref(plen))
+            else:
+                rc = lib().aero_prove_air_host(self.h, air.h, _p64(t), C.c_uint32(int(t.shape[1]).bit_length() - 1), _p64(pb), C.c_uint32(len(pub)),
+                                               C.byref(options), C.byref(proof), C.byref(plen))
         if rc != 0 and getattr(comm, "last_error", None) is not None:
             raise AeroError(rc, f"{lib().aero_last_error(self.h).decode()} ({comm.last_error!r})")
         self._ck(rc)

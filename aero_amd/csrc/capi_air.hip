@@ -156,8 +156,21 @@ int32_t aero_prove_air(aero_ctx* ctx, const aero_comm* comm, const aero_air* air
         prove_program(ctx, comm, air, trace->m.data.get(), nullptr, nullptr, (uint32_t)trace->m.cols, ilog2u(trace->m.rows), pub, n_pub, options, proof, proof_len);
     });
 }
+static int32_t prove_air_from_host(aero_ctx* ctx, const aero_comm* comm, const aero_air* air, const uint64_t* trace_col_major, uint32_t log_n,
+                                   const uint64_t* pub, uint32_t n_pub, const aero_proof_options* options, uint8_t** proof, size_t* proof_len);
 int32_t aero_prove_air_host(aero_ctx* ctx, const aero_air* air, const uint64_t* trace_col_major, uint32_t log_n, const uint64_t* pub, uint32_t n_pub,
                             const aero_proof_options* options, uint8_t** proof, size_t* proof_len) {
+    return prove_air_from_host(ctx, nullptr, air, trace_col_major, log_n, pub, n_pub, options, proof, proof_len);
+}
+// one proof over the ranks of `comm`, every rank holding (or mapping) the same host trace: rank k copies only its share of the
+// main columns (and the few the auxiliary builders read), as aero_prove_fib_sharded_host does
+int32_t aero_prove_air_sharded_host(aero_ctx* ctx, const aero_comm* comm, const aero_air* air, const uint64_t* trace_col_major, uint32_t log_n,
+                                    const uint64_t* pub, uint32_t n_pub, const aero_proof_options* options, uint8_t** proof, size_t* proof_len) {
+    if (!comm) return AERO_E_BAD_ARG;
+    return prove_air_from_host(ctx, comm, air, trace_col_major, log_n, pub, n_pub, options, proof, proof_len);
+}
+static int32_t prove_air_from_host(aero_ctx* ctx, const aero_comm* comm, const aero_air* air, const uint64_t* trace_col_major, uint32_t log_n,
+                                   const uint64_t* pub, uint32_t n_pub, const aero_proof_options* options, uint8_t** proof, size_t* proof_len) {
     return guard(ctx, [&] {
         REQUIRE(air && trace_col_major && proof && proof_len, "prove_air_host: null argument");
         REQUIRE(log_n >= 3 && log_n <= 29, "prove_air_host: log_n must be in [3, 29]");
@@ -169,7 +182,7 @@ int32_t aero_prove_air_host(aero_ctx* ctx, const aero_air* air, const uint64_t* 
         // the columns go straight into the interpolation buffer (Prover::set_host_trace); with auxiliary builders a device copy of the
         // main segment is kept until the auxiliary columns are built
         (void)n; (void)c;
-        prove_program(ctx, nullptr, air, nullptr, trace_col_major, verdict, W, (int)log_n, pub, n_pub, options, proof, proof_len);
+        prove_program(ctx, comm, air, nullptr, trace_col_major, verdict, W, (int)log_n, pub, n_pub, options, proof, proof_len);
         if (*verdict != 0) {
             free(*proof);
             *proof = nullptr; *proof_len = 0;

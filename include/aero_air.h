@@ -138,6 +138,11 @@ int32_t aero_prove_air(aero_ctx* ctx, const aero_comm* comm, const aero_air* air
 int32_t aero_prove_air_host(aero_ctx* ctx, const aero_air* air, const uint64_t* trace_col_major, uint32_t log_n, const uint64_t* pub,
                             uint32_t n_pub, const aero_proof_options* options, uint8_t** proof, size_t* proof_len);
 
+/* ONE proof over the ranks of `comm` from host memory (aero_prove_fib_sharded_host for a program AIR): every rank passes the same
+ * column-major trace and copies only its share of the main columns over PCIe; every rank returns the identical proof bytes. */
+int32_t aero_prove_air_sharded_host(aero_ctx* ctx, const aero_comm* comm, const aero_air* air, const uint64_t* trace_col_major, uint32_t log_n,
+                                    const uint64_t* pub, uint32_t n_pub, const aero_proof_options* options, uint8_t** proof, size_t* proof_len);
+
 /* The constraint seam (ConstraintComputeWorkItem -> ConstraintComputeResult, utils.rs:302-347,417-422; constraints_worker.rs:14-79)
  * for a program AIR: numerator columns of fragment `fragment_offset` of `num_fragments` over the C * n-point constraint domain.
  * aux_lde = (A * deg) component columns (NULL when A = 0), rands = R elements, coeffs = (alpha, beta) pairs in draw order (above),

@@ -113,3 +113,29 @@ def test_config5_vm_shaped_program_2p22_verifies(ctx, oracle):
     aero_amd.verify_air(got, pub, air, expected_log_n=log_n)
     with pytest.raises(aero_amd.AeroError):
         aero_amd.verify_air(got, pub[:-1] + [pub[-1] ^ 1], air, expected_log_n=log_n)
+
+
+def test_config5_vm_shaped_program_2p22_sharded_8_ways_from_host(ctx):
+    # configs[4] "... 8 x MI355X": ONE proof of the VM-shaped program over 8 ranks (threads of this process sharing the test GPU,
+    # exchanges = the library's local group), every rank copying only its 9 of the 72 main columns (+ the ones the auxiliary builders
+    # read) from host memory; every rank's bytes = the single-GPU proof (which test_config5_vm_shaped_program_2p22_verifies verifies)
+    from aero_amd.shard import LocalGroup
+    log_n, pairs, A, R = 22, 26, 9, 16
+    program = aero_amd.synth_vm_program(log_n, pairs, A, R)
+    trace, pub = aero_amd.synth_vm_trace(log_n, pairs)
+    air = aero_amd.Air(program)
+    opt = aero_amd.ProofOptions(*MIDEN_SHAPE)
+    want = ctx.prove_air(air, trace, pub, opt)
+    aero_amd.verify_air(want, pub, air, expected_log_n=log_n)
+    pinned = aero_amd.PinnedTrace(trace)
+    del trace
+    g = LocalGroup(8)
+    try:
+        proofs = g.run(lambda r, c, comm: c.prove_air(air, pinned, pub, opt, comm=comm))
+        sent = g.stats(0)["bytes_sent"]
+    finally:
+        g.close()
+        pinned.release()
+    for r, p in enumerate(proofs):
+        assert p == want, f"rank {r} of 8"
+    assert sent < 4.0e9

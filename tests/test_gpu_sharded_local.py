@@ -113,3 +113,12 @@ def test_program_air_sharded_over_thread_ranks_gives_the_single_gpu_bytes(world,
     for r, p in enumerate(proofs):
         assert p == want, f"rank {r} of {world}"
     assert stats["all_to_all"] >= 2 and stats["bytes_sent"] > 0
+    # the same from HOST memory: every rank copies its share of the main columns (+ what the auxiliary builders read)
+    g = LocalGroup(world, min_peer_digests=64)
+    try:
+        pinned = aero_amd.PinnedTrace(trace)
+        proofs = g.run(lambda r, ctx, comm: ctx.prove_air(air, pinned, pub, options, comm=comm))
+    finally:
+        g.close()
+    for r, p in enumerate(proofs):
+        assert p == want, f"host hand-over, rank {r} of {world}"
