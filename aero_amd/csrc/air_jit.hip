@@ -19,6 +19,7 @@
 #include "air_kernels.hpp"
 
 #include <hip/hiprtc.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <mutex>
@@ -330,6 +331,29 @@ std::shared_ptr<Blob> compile(const Program& p, const Instance& in, int DEG, int
     if (const char* dump = getenv("AERO_AIR_JIT_DUMP")) {
         if (FILE* f = fopen(dump, "w")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
     }
+    // optional on-disk cache of code objects (AERO_AIR_JIT_CACHE=<directory>): a prover process that restarts does not pay the
+    // compilation again. Keyed by the generated source (which contains the field arithmetic and every switch) + the hiprtc version.
+    std::string cache_path;
+    if (const char* dir = getenv("AERO_AIR_JIT_CACHE")) {
+        int major = 0, minor = 0;
+        (void)hiprtcVersion(&major, &minor);
+        uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull ^ ((uint64_t)major << 32 | (uint32_t)minor);
+        for (unsigned char ch : src) { h1 = (h1 ^ ch) * 0x100000001b3ull; h2 = (h2 + ch) * 0x9E3779B97F4A7C15ull; h2 ^= h2 >> 29; }
+        char name[64];
+        snprintf(name, sizeof name, "/aero_air_%016llx%016llx.co", (unsigned long long)h1, (unsigned long long)h2);
+        cache_path = std::string(dir) + name;
+        if (FILE* f = fopen(cache_path.c_str(), "rb")) {
+            fseek(f, 0, SEEK_END);
+            const long sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            if (sz > 0) {
+                blob->code.resize((size_t)sz);
+                if (fread(blob->code.data(), 1, (size_t)sz, f) != (size_t)sz) blob->code.clear();
+            }
+            fclose(f);
+            if (!blob->code.empty()) return blob;
+        }
+    }
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "air_jit_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         blob->error = "hiprtcCreateProgram failed";
@@ -351,6 +375,14 @@ std::shared_ptr<Blob> compile(const Program& p, const Instance& in, int DEG, int
         if (!cs) blob->error = "hiprtc produced no code object";
     }
     hiprtcDestroyProgram(&prog);
+    if (!cache_path.empty() && blob->error.empty()) {         // written under a temporary name, then renamed: readers never see a partial file
+        const std::string tmp = cache_path + ".tmp" + std::to_string((unsigned long long)blob->id) + "_" + std::to_string((long)getpid());
+        if (FILE* f = fopen(tmp.c_str(), "wb")) {
+            const bool ok = fwrite(blob->code.data(), 1, blob->code.size(), f) == blob->code.size();
+            fclose(f);
+            if (!ok || rename(tmp.c_str(), cache_path.c_str()) != 0) remove(tmp.c_str());
+        }
+    }
     return blob;
 }
 

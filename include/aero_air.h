@@ -125,7 +125,9 @@ int32_t aero_pool_prove_air_host(struct aero_pool* pool, const aero_air* air, co
  * (program, trace length, field) arrives - straight-line HIP over the expression DAG, same arithmetic as the interpreter, same
  * bytes; AERO_AIR_JIT=0 in the environment of aero_create keeps the interpreter. aero_air_jit_compile builds (and caches in the
  * handle) the kernel ahead of the first proof; it needs no GPU. field_extension 1 | 2; fused 1 = the proving path (numerators
- * divided and summed), 0 = the numerator-column form of aero_eval_constraints_program. source: malloc'ed text (aero_free). */
+ * divided and summed), 0 = the numerator-column form of aero_eval_constraints_program. source: malloc'ed text (aero_free).
+ * AERO_AIR_JIT_CACHE=<directory> in the environment keeps the compiled code objects on disk (keyed by the generated source and the
+ * hiprtc version), so that a restarted prover does not compile again. */
 int32_t aero_air_jit_compile(const aero_air* air, uint32_t log_n, uint32_t field_extension, int32_t fused);
 int32_t aero_air_jit_source(const aero_air* air, uint32_t log_n, uint32_t field_extension, int32_t fused, uint8_t** source, size_t* len);
 

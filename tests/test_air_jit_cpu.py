@@ -44,3 +44,19 @@ def test_a_program_without_assertion_groups_needs_no_inversion():
     src = air.jit_source(5, 1, True)
     assert "gl::inv(tot)" in src                                       # one divisor group: one fraction per row
     air.jit_compile(5, 1, True)
+
+
+def test_code_objects_are_cached_on_disk_when_asked(tmp_path, monkeypatch):
+    import time
+    monkeypatch.setenv("AERO_AIR_JIT_CACHE", str(tmp_path))
+    program = aero_amd.fib_program(6, (2, 3, 3))
+    t0 = time.perf_counter()
+    aero_amd.Air(program).jit_compile(9, 1, True)
+    first = time.perf_counter() - t0
+    files = [f for f in tmp_path.iterdir() if f.suffix == ".co"]
+    assert len(files) == 1 and files[0].stat().st_size > 1000 and not [f for f in tmp_path.iterdir() if ".tmp" in f.name]
+    t0 = time.perf_counter()
+    aero_amd.Air(program).jit_compile(9, 1, True)          # a fresh handle: served from the directory
+    assert time.perf_counter() - t0 < first / 2
+    aero_amd.Air(program).jit_compile(9, 2, True)          # another field: another kernel
+    assert len([f for f in tmp_path.iterdir() if f.suffix == ".co"]) == 2
