@@ -407,6 +407,19 @@ class Context:
         lib().aero_free(proof)
         return data
 
+    def validate_trace(self, air: "Air", trace: Matrix, pub, aux: Matrix = None, rands=None, field_extension=1):
+        """`Trace::validate(&air)` on the device (aero_air_validate_trace). Returns None when the trace satisfies the program, else
+        (row, "transition" | "assertion", index) of the first failing check; without `aux` only the main segment is checked."""
+        pb = np.array(pub, dtype=np.uint64, ndmin=1) if len(pub) else np.zeros(1, np.uint64)
+        rv = np.ascontiguousarray(rands, np.uint64) if rands is not None else None
+        out = C.c_uint64(0)
+        self._ck(lib().aero_air_validate_trace(self.h, air.h, trace.h, aux.h if aux is not None else None, _p64(pb), C.c_uint32(len(pub)),
+                                               _p64(rv) if rv is not None else None, C.c_uint8(field_extension), C.byref(out)))
+        if out.value == 0xFFFFFFFFFFFFFFFF:
+            return None
+        row, ident = out.value >> 16, out.value & 0xFFFF
+        return (row, "assertion", ident & 0x7FFF) if ident & 0x8000 else (row, "transition", ident)
+
     def eval_constraints_program(self, air: "Air", lde: Matrix, aux_lde, log_blowup, pub, rands, coeffs, field_extension=1, fragment_offset=0,
                                  num_fragments=1):
         """ConstraintComputeWorkItem -> ConstraintComputeResult for a program AIR. Returns (frag_index, cols (divisors*deg, rows))."""

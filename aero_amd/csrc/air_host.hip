@@ -211,4 +211,34 @@ void air_build_aux(Context* ctx, const Program& p, const uint64_t* trace_dev, in
 template void air_build_aux<FB>(Context*, const Program&, const uint64_t*, int, const uint64_t*, const uint64_t*, uint64_t*);
 template void air_build_aux<FQ>(Context*, const Program&, const uint64_t*, int, const uint64_t*, const gl::E2*, uint64_t*);
 
+template <class F>
+uint64_t air_validate_trace(Context* ctx, const Program& p, const Instance& in, const uint64_t* trace_dev, const uint64_t* aux_dev, const uint64_t* pub,
+                            const typename F::T* rands) {
+    const uint64_t n = in.n;
+    const Scalars<F> sc = fold_scalars<F>(p, pub, rands);
+    const PeriodicTables pt = periodic_tables(p, n, n, 1);       // on the trace domain the tables are the cycles themselves
+    std::vector<uint64_t> words(sc.b.begin(), sc.b.end()), pdesc;
+    const uint64_t oSE = words.size();
+    for (auto& v : sc.e) for (int d = 0; d < F::DEG; d++) words.push_back(F::comp(v, d));
+    words.push_back(0);
+    for (size_t k = 0; k < pt.off.size(); k++) pdesc.push_back((uint64_t)pt.off[k] | ((uint64_t)pt.mask[k] << 32));
+    const std::vector<uint64_t> init{~0ull};
+    ParamPack pp(ctx);
+    const size_t i_pool = pp.add(words), i_pt = pp.add(pt.tab), i_pd = pp.add(pdesc), i_flag = pp.add(init);
+    pp.commit();
+    AirConsArgs<F> a{};
+    a.lde = trace_dev; a.aux = aux_dev; a.N = n; a.W = p.W; a.A = aux_dev ? p.A : 0; a.blowup = 1; a.ce_step = 1; a.split_log = 0;
+    a.rows = n; a.first = 0; a.count = n;
+    a.pool = pp.ptr<uint64_t>(i_pool); a.ptab = pp.ptr<uint64_t>(i_pt);
+    a.out_h[0] = const_cast<uint64_t*>(pp.ptr<uint64_t>(i_flag));
+    // mode 2: every constraint; mode 3: without auxiliary columns only the main segment's constraints and assertions
+    if (!launch_air_jit<F>(ctx, p, in, a, pp.ptr<uint64_t>(i_pd), oSE, 0, 0, (aux_dev || !p.A) ? 2 : 3))
+        fail("air program: trace validation needs the run-time compiled kernel (" + air_jit_last_error() + ")", ST_UNSUPPORTED);
+    uint64_t flag = 0;
+    ctx->fetch(&flag, a.out_h[0], 8);
+    return flag;
+}
+template uint64_t air_validate_trace<FB>(Context*, const Program&, const Instance&, const uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*);
+template uint64_t air_validate_trace<FQ>(Context*, const Program&, const Instance&, const uint64_t*, const uint64_t*, const uint64_t*, const gl::E2*);
+
 }  // namespace aero

@@ -56,4 +56,11 @@ void air_divide_columns(Context* ctx, const air::Program& p, const air::Instance
 template <class F>
 void air_build_aux(Context* ctx, const air::Program& p, const uint64_t* trace_dev, int log_n, const uint64_t* pub, const typename F::T* rands, uint64_t* out);
 
+// `Trace::validate(&air)` on the device (run-time compiled kernel, air_jit.hip mode 2): trace = W x n main segment, aux = (A * DEG) x n
+// component columns or null (then only the main constraints and assertions are checked). Returns ~0 when every constraint holds, else
+// row << 16 | id of the first failure (id = transition index in the program's order, or 0x8000 | assertion index, main first).
+template <class F>
+uint64_t air_validate_trace(Context* ctx, const air::Program& p, const air::Instance& in, const uint64_t* trace_dev, const uint64_t* aux_dev,
+                            const uint64_t* pub, const typename F::T* rands);
+
 }  // namespace aero

@@ -229,7 +229,52 @@ struct Gen {
     // (N = sum_j num_j prod_(i != j) d_i, D = prod_j d_j), and a thread inverts the D of its R rows with one field inversion
     // (~95 multiplications, as much as a few hundred constraint terms). The rows run through a real loop - the body is emitted
     // once - and wait for the inversion in LDS (2 DEG + 1 words per row and thread).
+    // mode 2: `Trace::validate(&air)` of a debug-mode Winterfell prover (the "(debug) validate" of commit_to_trace_and_validate,
+    // proving_worker.rs:323-332) on the TRACE domain: every transition constraint on every row but the exempted last ones, every
+    // assertion on the steps it names; the smallest (row << 16 | id) that fails is left in out_h0[0] (id = transition index, or
+    // 0x8000 | assertion index in the program's order, main first).
+    std::string validate_source(size_t args_size) {
+        o << GL_FIELD_SRC << "\n" << ARGS_SRC;
+        o << "static_assert(sizeof(Args) == " << args_size << ", \"argument block\");\n";
+        o << "typedef gl::" << (DEG == 1 ? "FB" : "FQ") << " F;\ntypedef F::T T;\nconstexpr int DEG = " << DEG << ";\n";
+        o << "__device__ __forceinline__ bool nz(uint64_t v) { return v != 0; }\n__device__ __forceinline__ bool nz(gl::E2 v) { return (v.a0 | v.a1) != 0; }\n";
+        o << "__device__ __forceinline__ bool ne(uint64_t a, uint64_t b) { return a != b; }\n__device__ __forceinline__ bool ne(gl::E2 a, gl::E2 b) { return a.a0 != b.a0 || a.a1 != b.a1; }\n";
+        o << "extern \"C\" __global__ __launch_bounds__(256) void air_jit_kernel(Args a) {\n";
+        o << "    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;\n    if (s >= a.count) return;\n";
+        o << "    const uint64_t* pool = a.pool;\n    const uint64_t oSE = a.oSE;\n";
+        o << "    const size_t r = s, rn = (s + 1) & (a.N - 1);\n";
+        o << "    unsigned long long bad = ~0ull;\n";
+        const bool early = g_tune.early;
+        for (auto& v : asserts_main) v.clear();          // assertions are checked explicitly below, not accumulated
+        for (auto& v : asserts_aux) v.clear();
+        (void)early;
+        o << "    if (s + " << p.exemptions << " < a.count) {\n";
+        for (size_t k = 0; k < (mode == 3 ? (size_t)p.n_main_trans : p.num_transition()); k++) {
+            need(p.trans[k].root);
+            const auto v = operand(p.trans[k].root);
+            o << "    if (nz(" << v.first << ")) { const unsigned long long e = (s << 16) | " << k << "ull; bad = e < bad ? e : bad; }\n";
+        }
+        o << "    }\n";
+        for (uint32_t m = 0; m < in.members.size(); m++) {
+            const BoundaryMember& bm = in.members[m];
+            if (mode == 3 && bm.aux) continue;
+            const BoundaryGroup& bg = in.bgroups[bm.group];
+            std::string cond = bg.stride ? "(s & " + std::to_string(bg.stride - 1) + ") == " + std::to_string(bg.first) : "s == " + std::to_string(bg.first);
+            o << "    if (" << cond << ") {\n";
+            const std::string col = bm.aux ? "F::make(a.aux[" + std::to_string((uint64_t)bm.col * DEG) + "ull * a.N + r], " +
+                                                 (DEG > 1 ? "a.aux[" + std::to_string((uint64_t)bm.col * DEG + 1) + "ull * a.N + r])" : std::string("0)"))
+                                           : "a.lde[" + std::to_string(bm.col) + "ull * a.N + r]";
+            std::string want;
+            if (bm.val_ext) want = pool_e("oSE", bm.val_idx);
+            else want = bm.aux ? "F::from(pool[" + std::to_string(bm.val_idx) + "])" : "pool[" + std::to_string(bm.val_idx) + "]";
+            o << "        if (ne(" << col << ", " << want << ")) { const unsigned long long e = (s << 16) | " << (0x8000u | m) << "ull; bad = e < bad ? e : bad; }\n    }\n";
+        }
+        o << "    if (bad != ~0ull) atomicMin((unsigned long long*)a.out_h0, bad);\n}\n";
+        return o.str();
+    }
+
     std::string source(size_t args_size, int R) {
+        if (mode >= 2) return validate_source(args_size);
         const size_t nt = p.num_transition(), ng = in.bgroups.size(), ndg = p.dgroups.size();
         const bool batch = mode == 1 && ng > 0;
         if (!batch) R = 1;
@@ -432,7 +477,7 @@ template <class F> bool launch_air_jit(Context* ctx, const air::Program& p, cons
     // a kernel body grows with the program: beyond this many nodes + constraints + assertions (minutes of compilation, a code object of
     // several MB) the interpreter, whose cost per proof does not depend on a compiler, is the better evaluator
     if (p.nodes.size() + p.num_transition() + p.num_assertions() > 20000) return false;
-    const int R = jit_rows(p, c.count, mode, in.bgroups.size());
+    const int R = mode >= 2 ? 1 : jit_rows(p, c.count, mode, in.bgroups.size());
     auto blob = get_blob(p, in, F::DEG, mode, R);
     if (!blob->error.empty()) return false;
     hipFunction_t fn;

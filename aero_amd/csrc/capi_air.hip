@@ -284,6 +284,28 @@ int32_t aero_aux_columns_program(aero_ctx* ctx, const aero_air* air, const aero_
         else fail("aux_columns: field extension must be 1 (None) or 2 (Quadratic)", ST_UNSUPPORTED);
     });
 }
+// `Trace::validate(&air)` (what a debug build of the reference's prover runs inside commit_to_trace_and_validate, proving_worker.rs:323-332)
+int32_t aero_air_validate_trace(aero_ctx* ctx, const aero_air* air, const aero_matrix* trace, const aero_matrix* aux, const uint64_t* pub, uint32_t n_pub,
+                                const uint64_t* rands, uint8_t field_extension, uint64_t* first_failure) {
+    return guard(ctx, [&] {
+        REQUIRE(air && trace && first_failure, "validate_trace: null argument");
+        const air::Program& p = air->prog;
+        const std::vector<uint64_t> pubv = read_pub(p, pub, n_pub, "validate_trace");
+        REQUIRE((uint32_t)trace->m.cols == p.W, "validate_trace: the trace does not have the program's main width");
+        REQUIRE(trace->m.rows >= 8 && (trace->m.rows & (trace->m.rows - 1)) == 0, "validate_trace: trace length must be a power of two >= 8");
+        const int deg = field_extension == EXT_QUADRATIC ? 2 : 1;
+        REQUIRE(field_extension == EXT_NONE || field_extension == EXT_QUADRATIC, "validate_trace: field extension must be 1 (None) or 2 (Quadratic)");
+        if (aux) {
+            REQUIRE(p.A > 0 && (uint32_t)aux->m.cols == p.A * (uint32_t)deg && aux->m.rows == trace->m.rows, "validate_trace: auxiliary matrix must hold aux_width * degree component columns of the trace's length");
+            REQUIRE(rands, "validate_trace: the auxiliary constraints need the random elements");
+        }
+        const air::Instance in = air::instantiate(p, ilog2u(trace->m.rows));
+        std::vector<uint64_t> zero((size_t)p.R * 2 + 2, 0);
+        const uint64_t* rv = rands ? rands : zero.data();
+        if (deg == 1) *first_failure = air_validate_trace<gl::FB>(ctx->c, p, in, trace->m.data.get(), aux ? aux->m.data.get() : nullptr, pubv.data(), rv);
+        else *first_failure = air_validate_trace<gl::FQ>(ctx->c, p, in, trace->m.data.get(), aux ? aux->m.data.get() : nullptr, pubv.data(), reinterpret_cast<const gl::E2*>(rv));
+    });
+}
 int32_t aero_composition_poly_program(aero_ctx* ctx, const aero_air* air, const uint64_t* numer_cols, uint32_t log_n, uint8_t field_extension,
                                       aero_matrix** comp_polys) {
     return guard(ctx, [&] {

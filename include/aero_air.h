@@ -156,6 +156,14 @@ int32_t aero_eval_constraints_program(aero_ctx* ctx, const aero_air* air, const 
 /* `Trace::build_aux_segment(rand_elements)` from the program's builders: (A * deg) x n component columns. */
 int32_t aero_aux_columns_program(aero_ctx* ctx, const aero_air* air, const aero_matrix* trace, const uint64_t* pub, uint32_t n_pub,
                                  const uint64_t* rands, uint8_t field_extension, aero_matrix** aux_out);
+/* `Trace::validate(&air)` - the check a DEBUG build of the reference's prover runs inside commit_to_trace_and_validate
+ * (proving_worker.rs:323-332): every transition constraint on every row but the exempted last ones, every assertion on the steps it
+ * names, evaluated on the trace itself by a kernel compiled from the program (needs hiprtc). aux = the (aux_width * degree) x n
+ * component columns of aero_aux_columns_program with the same `rands`, or NULL: then only the main segment is checked.
+ * *first_failure = UINT64_MAX when the trace satisfies the program, else row << 16 | id of the first failing check (id = index of the
+ * transition constraint, main first, or 0x8000 | index of the assertion, main first). The prover itself never validates a trace. */
+int32_t aero_air_validate_trace(aero_ctx* ctx, const aero_air* air, const aero_matrix* trace, const aero_matrix* aux, const uint64_t* pub,
+                                uint32_t n_pub, const uint64_t* rands, uint8_t field_extension, uint64_t* first_failure);
 /* `ConstraintEvaluationTable::into_poly` -> `CompositionPoly` for a program AIR: numer_cols = the num_divisors * deg numerator
  * columns over the whole constraint domain (host); result as aero_composition_poly_air. */
 int32_t aero_composition_poly_program(aero_ctx* ctx, const aero_air* air, const uint64_t* numer_cols, uint32_t log_n,

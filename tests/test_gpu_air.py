@@ -271,3 +271,33 @@ def test_pool_proves_program_airs_in_flight(oracle):
         assert pool.prove_air(air, devs[:1], pub, options(opt)) == [want]      # the pool is still usable
     finally:
         pool.close()
+
+
+@pytest.mark.parametrize("ext", [1, 2])
+def test_trace_validation_on_the_device(ctx, oracle, ext):
+    # aero_air_validate_trace = Trace::validate of a debug-mode prover: silent on a good trace, names the first bad row otherwise
+    log_n, pairs, aux = 9, 3, 4
+    b, trace, pub = ex.synth_vm(log_n, pairs, aux)
+    air = aero_amd.Air(b.to_bytes())
+    info = air.info()
+    dev = ctx.trace_upload(trace)
+    assert ctx.validate_trace(air, dev, pub) is None                                   # main segment only
+    rands = np.arange(7, 7 + 4 * ext, dtype=np.uint64)
+    auxm = ctx.aux_columns_program(air, dev, pub, rands, ext)
+    assert ctx.validate_trace(air, dev, pub, aux=auxm, rands=rands, field_extension=ext) is None
+    # a flipped cell in a state column (column 7 = s_1): the transition constraints of row 99 -> 100 and 100 -> 101 fail; the first is reported
+    bad = trace.copy()
+    bad[7][100] ^= 1
+    row, kind, idx = ctx.validate_trace(air, ctx.trace_upload(bad), pub)
+    assert (row, kind) == (99, "transition") and idx < info["main_transition"]
+    with pytest.raises(RuntimeError):                                                  # the oracle's own check agrees
+        oracle.air_check_trace(b.to_bytes(), bad, pub)
+    # a wrong public input: an assertion at the last step
+    wrong = [pub[0] ^ 1] + pub[1:]
+    row, kind, idx = ctx.validate_trace(air, dev, wrong)
+    assert kind == "assertion" and row == (1 << log_n) - 1
+    # a corrupted auxiliary column is found only when the auxiliary segment is handed over
+    a = auxm.download()
+    a[0][5] ^= 1
+    got = ctx.validate_trace(air, dev, pub, aux=ctx.trace_upload(a), rands=rands, field_extension=ext)
+    assert got is not None and got[0] in (4, 5) and got[1] == "transition" and got[2] >= info["main_transition"]
