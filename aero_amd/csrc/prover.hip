@@ -914,7 +914,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         uint64_t* const land = A ? trace_keep.get() : polys.data.get();
         const size_t col_bytes = n * 8;
         uint32_t gw = W;
-        if (h2d_pipeline && W >= 16 && G == 1) {
+        if (h2d_pipeline && G == 1 && (W >= 16 || (W >= 2 && col_bytes >= ((size_t)64 << 20)))) {     // wide traces, or few but long columns (2^24 x 2: one column per group)
             gw = (W + 15) / 16;                                                   // at most 16 groups ...
             const uint32_t min_cols = (uint32_t)(((size_t)32 << 20) / col_bytes);   // ... of at least 32 MiB
             if (gw < min_cols) gw = min_cols;
