@@ -914,9 +914,9 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         uint64_t* const land = A ? trace_keep.get() : polys.data.get();
         const size_t col_bytes = n * 8;
         uint32_t gw = W;
-        if (h2d_pipeline && G == 1 && (W >= 16 || (W >= 2 && col_bytes >= ((size_t)64 << 20)))) {     // wide traces, or few but long columns (2^24 x 2: one column per group)
+        if (h2d_pipeline && G == 1 && (W >= 16 || (W >= 2 && col_bytes >= ((size_t)4 << 20)))) {     // wide traces, or few but long columns (2^24 x 2: one column per group)
             gw = (W + 15) / 16;                                                   // at most 16 groups ...
-            const uint32_t min_cols = (uint32_t)(((size_t)32 << 20) / col_bytes);   // ... of at least 32 MiB
+            const uint32_t min_cols = (uint32_t)(((size_t)(W >= 16 ? 32 : 8) << 20) / col_bytes);   // ... of at least 32 MiB (8 MiB for narrow traces)
             if (gw < min_cols) gw = min_cols;
             if (gw > W) gw = W;
         }
