@@ -757,7 +757,9 @@ std::vector<NttPass> plan_passes(int L, bool reg, int first_bits, bool radix128)
 // The two-phase contiguous pass covers 11 bits instead of 12: it is used where that does not cost an extra strided pass.
 bool Context::fwd_two_phase(int log_out, int log_pad) const {
     if (!reg_passes || !two_phase || log_pad != 3 || log_out < 13) return false;
-    return (log_out - 11 + 5) / 6 == (log_out - 12 + 5) / 6 || log_out - 12 <= 0;
+    // strided passes behind an 11-bit and behind a 12-bit first pass (radix 128 where it saves a pass, as plan_passes decides)
+    auto strided = [&](int rem) { const int r6 = (rem + 5) / 6, r7 = (rem + 6) / 7; return radix128 && r7 < r6 ? r7 : r6; };
+    return strided(log_out - 11) == strided(log_out - 12) || log_out - 12 <= 0;
 }
 bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad,
                           const CompactOut* compact) {

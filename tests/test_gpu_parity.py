@@ -116,10 +116,10 @@ def test_lde_matches_oracle(ctx, oracle, log_n, width, log_blowup):
     assert (ctx.hash_matrix_rows(lde) == oracle.hash_rows(got)).all()
 
 
-@pytest.mark.parametrize("log_n", [18, 20, 22])
+@pytest.mark.parametrize("log_n", [18, 20, 21, 22])
 def test_lde_large_properties(ctx, oracle, log_n):
     # full-size case: the oracle finishes a single 2^20 -> 2^23 column in seconds; also check linearity on the device
-    # (2^22 -> 2^25: the forward transform takes two radix-128 two-lane passes, ntt_fwd_strided_reg7x2)
+    # (2^22 -> 2^25: the forward transform takes two radix-128 two-lane passes, ntt_fwd_strided_reg7x2; 2^21 -> 2^24: two-phase first pass + radix 128 + radix 64)
     rng = np.random.default_rng(log_n)
     a = rand_felts(rng, (1, 1 << log_n))
     b = rand_felts(rng, (1, 1 << log_n))
