@@ -104,3 +104,23 @@ def test_malformed_programs_are_refused_on_the_host():
         with pytest.raises(aero_amd.AeroError) as e:
             aero_amd.Air(data)
         assert e.value.code == -1, name
+
+
+def test_loader_survives_mutated_programs_under_sanitizers(tmp_path):
+    # tests/c_abi/fuzz_air_load.cpp: the AEROAIR loader (host code of the library, it parses bytes a host hands over) built with
+    # g++ -fsanitize=address,undefined; bit flips, truncations, insertions and wild counts must end in aero::Error or a clean load
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "fuzz_air_load")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I", os.path.join(root, "aero_amd", "csrc"), "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "fuzz_air_load.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitizer" in r.stderr.lower():
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, "4000", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "no memory error" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
