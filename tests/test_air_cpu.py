@@ -124,3 +124,38 @@ def test_loader_survives_mutated_programs_under_sanitizers(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe, "4000", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "no memory error" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_message_and_proof_parsers_survive_mutations_under_sanitizers(tmp_path, oracle):
+    # tests/c_abi/fuzz_parsers.cpp: the worker-message, proof-layout and public-input parsers (host-only headers of the library) built
+    # with g++ -fsanitize=address,undefined, fed mutated copies of well-formed inputs
+    import os
+    import shutil
+    import subprocess
+    from aero_amd import messages
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "fuzz_parsers")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I", os.path.join(root, "aero_amd", "csrc"), "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "fuzz_parsers.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitizer" in r.stderr.lower():
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    opt, width, log_n = [8, 8, 4, 4, 1, 8, 5], 2, 5
+    n = 1 << log_n
+    proof, pub, _ = oracle.prove_fib(width, log_n, opt)
+    pub_bytes = messages.miden_public_inputs([1, 2, 3, 4], [0, 1], pub)
+    lde = [np.arange(8 * n, dtype=np.uint64) + c for c in range(width)]
+    coeffs = np.arange(2 * (width + width + width // 2), dtype=np.uint64).reshape(-1, 2)
+    files = {"hash": messages.encode_hashing_work_item([[1, 2, 3], [4, 5], [], [7, 8, 9, 10, 11]], 3),
+             "cons": messages.encode_constraint_work_item((width, 0, 0), n, pub_bytes, opt, [], coeffs[:width], coeffs[width:], lde, [], 8, 0, 2),
+             "proof": proof, "pub": pub_bytes}
+    paths = []
+    for k, v in files.items():
+        p = tmp_path / (k + ".bin")
+        p.write_bytes(v)
+        paths.append(str(p))
+    r = subprocess.run([exe, *paths, "6000", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "no memory error" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
