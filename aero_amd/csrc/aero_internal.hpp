@@ -120,6 +120,16 @@ public:
 
     explicit Context(int dev);
     ~Context();
+    // Several contexts of one pool copy their traces from host memory over the same PCIe link. Left alone, proofs that start together
+    // copy together (each at 1 / k of the link) and then compute together: the copies hide behind nothing. The gate orders the copies
+    // on the device - a context's copy waits for the previous context's copy - so the proofs fall out of phase and every copy runs
+    // under the other proofs' kernels (2^22 x (72 + 9), 3 in flight: 420 -> 3xx ms per round).
+    struct CopyGate {
+        std::mutex mu;
+        hipEvent_t last = nullptr;
+    };
+    CopyGate* copy_gate = nullptr;
+    hipEvent_t gate_event = nullptr;       // this context's last gated copy
     // second stream + events for the host-to-device copy of a wide trace: column group g + 1 travels while group g is transformed
     hipStream_t copy_stream = nullptr;
     hipStream_t get_copy_stream();

@@ -784,6 +784,7 @@ struct aero_pool {
         bool has_job = false;
     };
     std::vector<std::unique_ptr<Slot>> slots;
+    Context::CopyGate gate;        // orders the slots' host-to-device copies (aero_internal.hpp)
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
     uint64_t generation = 0;       // bumped per batch
@@ -844,6 +845,7 @@ int32_t aero_pool_create(int32_t device_id, uint32_t slots, aero_pool** out) {
         }
         p->slots.emplace_back(new aero_pool::Slot());
         p->slots.back()->ctx = c;
+        c->c->copy_gate = &p->gate;
     }
     for (auto& s : p->slots) s->th = std::thread(&aero_pool::worker, p.get(), s.get());
     *out = p.release();

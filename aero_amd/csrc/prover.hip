@@ -43,6 +43,10 @@ Context::~Context() {
     for (auto& r : kt_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (hipEvent_t e : kt_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : sync_events) (void)hipEventDestroy(e);
+    if (gate_event) {
+        if (copy_gate) { std::lock_guard<std::mutex> lk(copy_gate->mu); if (copy_gate->last == gate_event) copy_gate->last = nullptr; }
+        (void)hipEventDestroy(gate_event);
+    }
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -967,6 +971,15 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             ms.interpolate = clk.lap();
             have_tc = extend_columns(0, W);
         } else if (gw == W) {
+            if (ctx->copy_gate) {
+                // one copy at a time per pool (Context::CopyGate): behind the previous context's copy, in front of this proof's kernels
+                std::lock_guard<std::mutex> lk(ctx->copy_gate->mu);
+                if (ctx->copy_gate->last) AERO_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_gate->last, 0));
+                AERO_HIP(hipMemcpyAsync(land, host_trace, (size_t)W * col_bytes, hipMemcpyHostToDevice, ctx->stream));
+                if (!ctx->gate_event) AERO_HIP(hipEventCreateWithFlags(&ctx->gate_event, hipEventDisableTiming));
+                AERO_HIP(hipEventRecord(ctx->gate_event, ctx->stream));
+                ctx->copy_gate->last = ctx->gate_event;
+            } else
             AERO_HIP(hipMemcpyAsync(land, host_trace, (size_t)W * col_bytes, hipMemcpyHostToDevice, ctx->stream));
             if (A) AERO_HIP(hipMemcpyAsync(polys.data.get(), land, (size_t)W * col_bytes, hipMemcpyDeviceToDevice, ctx->stream));
             ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0, d_bad);

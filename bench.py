@@ -64,6 +64,11 @@ WORKLOADS = {
     "standin_miden_shape_2^22x(72+9aux)_deg8_fold4": (22, 72, {"fri_folding_factor": 4, "aux": (9, 16, 8)}),
     "standin_miden_shape_2^18x(72+9aux)_deg8_fold4": (18, 72, {"fri_folding_factor": 4, "aux": (9, 16, 8)}),
     "standin_miden_shape_2^22x(72+9aux)_fold4": (22, 72, {"fri_folding_factor": 4, "aux": (9, 16, 2)}),
+    # the same shape through the AIR-as-data path (include/aero_air.h): the VM-shaped constraint PROGRAM of aero_air_synth_vm_* -
+    # 76 + 9 transition constraints up to degree 8, periodic columns, interior / periodic assertions, two exemptions - proven by
+    # aero_pool_prove_air*. program = (Fibonacci pairs, aux columns, random elements); aux = (columns, -, -) only counts the cells.
+    "program_vm_shape_2^22x(72+9aux)_fold4": (22, 72, {"fri_folding_factor": 4, "aux": (9, 16, 8), "program": (26, 9, 16)}),
+    "program_vm_shape_2^20x(72+9aux)_fold4": (20, 72, {"fri_folding_factor": 4, "aux": (9, 16, 8), "program": (26, 9, 16)}),
     "standin_miden_shape_2^18x(72+9aux)_fold4": (18, 72, {"fri_folding_factor": 4, "aux": (9, 16, 2)}),
 }
 
@@ -106,7 +111,7 @@ def cpu_thread_candidates(cores):
 def make_options(aero_amd, over):
     opt = aero_amd.ProofOptions.with_96_bit_security()
     for k, v in over.items():
-        if k != "aux":
+        if k not in ("aux", "program"):
             setattr(opt, k, v)
     return opt
 
@@ -117,7 +122,10 @@ def trace_cols(width, over):
 
 
 def prove_call(ctx, dev, opt, over, comm=None):
-    """One proof of the workload: plain FibAir, or FibAir + auxiliary segment when the workload names one."""
+    """One proof of the workload: plain FibAir, FibAir + auxiliary segment when the workload names one, or a constraint program.
+    Returns (proof bytes, public inputs)."""
+    if over.get("_air") is not None:
+        return ctx.prove_air(over["_air"], dev, over["_pub"], opt, comm=comm), over["_pub"]
     aux = over.get("aux")
     if aux or comm is not None:
         return ctx.prove_fib_aux(dev, aux[0] if aux else 0, aux[1] if aux else 0, opt, comm=comm, aux_degree=aux[2] if aux else 2)
@@ -398,6 +406,27 @@ def cpu_baseline_leg(args, log_n, width, over, opt, first_proof):
     ncpu = os.cpu_count() or 1
     aux = over.get("aux") or (0, 0, 2)
     cols = trace_cols(width, over)
+    if over.get("program"):
+        import aero_amd
+        pairs, pa, pr = over["program"]
+
+        real = orc
+
+        class _ProgramOracle:                         # the oracle's ProgramAir prover behind the call shape used below
+            def __init__(self):
+                self.cache = {}
+
+            def prove_fib_aux(self, width_, ln, a_, r_, o_, D=2):
+                if ln not in self.cache:
+                    self.cache = {ln: (aero_amd.synth_vm_program(ln, pairs, pa, pr),) + aero_amd.synth_vm_trace(ln, pairs)}
+                prog_, tr_, pub_ = self.cache[ln]
+                proof_, times_ = real.prove_air(prog_, tr_, pub_, o_)
+                return proof_, pub_, times_
+
+            def set_threads(self, t):
+                real.set_threads(t)
+
+        orc = _ProgramOracle()
     probe_log = min(14 if width > 8 else 16, log_n)
     best = None
     for t in cpu_thread_candidates(ncpu):
@@ -554,7 +583,13 @@ def main():
     # S contexts on this GPU, each driven by its own worker thread INSIDE the library (aero_pool_*): the whole timed region is one C call
     pool = aero_amd.Pool(local_rank, S)
     ctxs = [pool.ctx(i) for i in range(S)]
-    trace = aero_amd.fib_trace(width, log_n)          # synthetic data, pure function of (width, log_n)
+    program = over.get("program")
+    if program:
+        over["_air"] = aero_amd.Air(aero_amd.synth_vm_program(log_n, *program))
+        trace, over["_pub"] = aero_amd.synth_vm_trace(log_n, program[0])
+        assert trace.shape[0] == width
+    else:
+        trace = aero_amd.fib_trace(width, log_n)      # synthetic data, pure function of (width, log_n)
     # the hand-over the metric is defined on: trace in (pinned) HOST memory -> proof bytes in
     # host memory; every proof starts with the host-to-device copy of its trace on its own stream. One pinned buffer per slot.
     hosts = [aero_amd.PinnedTrace(trace.copy()) for _ in range(S)]
@@ -565,6 +600,8 @@ def main():
     h2d = not args.resident
 
     def run_rounds(rounds, from_host):
+        if program:
+            return [(p_, over["_pub"]) for p_ in pool.prove_air(over["_air"], hosts if from_host else devs, over["_pub"], opt, rounds=rounds)]
         if from_host:
             return pool.prove_fib_host(hosts, opt, aux, rounds=rounds)
         return pool.prove_fib(devs, opt, aux, rounds=rounds)
@@ -592,7 +629,7 @@ def main():
         ts = []
         for _ in range(reps):
             t1 = time.perf_counter()
-            ctx.prove_fib_aux(src, aux[0], aux[1], opt, aux_degree=aux[2])
+            prove_call(ctx, src, opt, over) if program else ctx.prove_fib_aux(src, aux[0], aux[1], opt, aux_degree=aux[2])
             ts.append((time.perf_counter() - t1) * 1e3)
         return median(ts)
 
@@ -639,7 +676,9 @@ def main():
                    "num_queries": opt.num_queries, "grinding": opt.grinding_factor, "fri_fold": opt.fri_folding_factor,
                    "field_extension": "quadratic" if opt.field_extension == 2 else "none", "hash": "blake2s_256",
                    "aux_segment": ({"columns": over["aux"][0], "random_elements": over["aux"][1], "constraint_degree": over["aux"][2],
-                                    "composition_columns": 2 if over["aux"][2] <= 2 else (4 if over["aux"][2] <= 4 else 8), "air": "synthetic stand-in (prefix-product columns); the Miden AIR is not in the reference mount"}
+                                    "composition_columns": 2 if over["aux"][2] <= 2 else (4 if over["aux"][2] <= 4 else 8),
+                                    "air": ("VM-shaped constraint PROGRAM (aero_air_synth_vm_*: 76 + 9 transition constraints up to degree 8, periodic columns, interior / periodic assertions, auxiliary running products with denominators), evaluated by a kernel compiled from it at run time; the Miden AIR is not in the reference mount"
+                                            if program else "synthetic stand-in (prefix-product columns); the Miden AIR is not in the reference mount")}
                                    if over.get("aux") else None),
                    "h2d_included": h2d,
                    "hand_over": ("trace in pinned host memory -> proof bytes in host memory; the host-to-device copy of every trace is inside the timed region"
