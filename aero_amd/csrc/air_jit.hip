@@ -64,6 +64,26 @@ struct Args {
     uint64_t *out_cols, *out_h0, *out_h1;
 };
 __device__ __forceinline__ uint64_t tw(const Args& a, uint64_t e) { return gl::mul(a.tw_lo[e & ((1ull << a.tw_h) - 1)], a.tw_hi[e >> a.tw_h]); }
+// Sum of products as an integer of 160 bits (up to 2^32 terms), reduced once: 2^64 = 2^32 - 1 and 2^128 = -2^32 (mod p).
+struct Wide { uint32_t l0, l1, l2, l3, l4; };
+__device__ __forceinline__ Wide wzero() { return Wide{0u, 0u, 0u, 0u, 0u}; }
+__device__ __forceinline__ void wmac(Wide& w, uint64_t x, uint64_t y) {
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32);
+    const uint64_t t = (uint64_t)x0 * y0;
+    const uint64_t u = (uint64_t)x0 * y1 + (t >> 32);
+    const uint64_t v = (uint64_t)x1 * y0 + (uint32_t)u;
+    const uint64_t z = (uint64_t)x1 * y1 + ((u >> 32) + (v >> 32));
+    uint32_t c;
+    w.l0 = __builtin_addc(w.l0, (uint32_t)t, 0u, &c);
+    w.l1 = __builtin_addc(w.l1, (uint32_t)v, c, &c);
+    w.l2 = __builtin_addc(w.l2, (uint32_t)z, c, &c);
+    w.l3 = __builtin_addc(w.l3, (uint32_t)(z >> 32), c, &c);
+    w.l4 += c;
+}
+__device__ __forceinline__ uint64_t wreduce(const Wide& w) {
+    const uint64_t r = gl::reduce128(gl::mk64(w.l0, w.l1), gl::mk64(w.l2, w.l3));
+    return gl::sub(r, gl::mul((uint64_t)w.l4, 1ull << 32));
+}
 )SRC";
 
 struct Blob {
@@ -90,6 +110,8 @@ struct Tune {
     int early = 1;         // a column's assertions are evaluated where its current-row value is first loaded, not after all transition constraints
     int minblocks = 2;     // __launch_bounds__(256, minblocks)
     int rows = 0;          // rows per thread of the fused form; 0 = by program size: 4 for small programs (the inversion dominates), 2 otherwise
+    int wide = 1;          // products coefficient x base-field value are summed as 160-bit integers and reduced once per sum (4 multiply-adds + 5
+                           // carry adds per term instead of a whole field multiplication + addition)
 };
 Tune read_tune() {
     Tune t;
@@ -103,7 +125,7 @@ Tune read_tune() {
         if (eq != std::string::npos && eq < end) {
             const std::string k = str.substr(pos, eq - pos);
             const int v = atoi(str.substr(eq + 1, end - eq - 1).c_str());
-            if (k == "barrier") t.barrier = v; else if (k == "early") t.early = v; else if (k == "minblocks") t.minblocks = v; else if (k == "rows") t.rows = v;
+            if (k == "barrier") t.barrier = v; else if (k == "early") t.early = v; else if (k == "minblocks") t.minblocks = v; else if (k == "rows") t.rows = v; else if (k == "wide") t.wide = v;
         }
         pos = end + 1;
     }
@@ -130,9 +152,20 @@ struct Gen {
         if (member_done[m]) return;
         member_done[m] = 1;
         const BoundaryMember& bm = in.members[m];
+        if (!bm.aux && use_wide()) {
+            for (int d = 0; d < DEG; d++) {
+                o << "    wmac(wsa" << bm.group << "_" << d << ", pool[oB + " << (2 * m) * DEG + d << "], " << v << ");\n";
+                o << "    wmac(wsb" << bm.group << "_" << d << ", pool[oB + " << (2 * m + 1) * DEG + d << "], " << v << ");\n";
+            }
+            return;
+        }
         const char* mf = bm.aux ? "F::mul" : "F::mulb";
         o << "    sa" << bm.group << " = F::add(sa" << bm.group << ", " << mf << "(" << pool_e("oB", 2 * m) << ", " << v << "));\n";
         o << "    sb_" << bm.group << " = F::add(sb_" << bm.group << ", " << mf << "(" << pool_e("oB", 2 * m + 1) << ", " << v << "));\n";
+    }
+    bool use_wide() const { return g_tune.wide && mode <= 1; }
+    std::string wide_value(const std::string& name) const {       // the E element whose components were summed in <name>_0 (, <name>_1)
+        return "F::make(wreduce(" + name + "_0), " + (DEG > 1 ? "wreduce(" + name + "_1))" : std::string("0)"));
     }
 
     static std::string lit(uint64_t v) { char b[40]; snprintf(b, sizeof b, "0x%llxull", (unsigned long long)v); return b; }
@@ -295,14 +328,37 @@ struct Gen {
         o << "    T acc = F::zero();\n";
         for (size_t g = 0; g < ndg; g++) o << "    T gb" << g << " = F::zero();\n";
         for (size_t j = 0; j < ng; j++) o << "    T sa" << j << " = F::zero(), sb_" << j << " = F::zero();\n";
-        // transition constraints: acc += alpha c, gb[group] += beta' c
-        for (size_t k = 0; k < nt; k++) {
+        const bool wide = use_wide();
+        if (wide) {
+            for (int d = 0; d < DEG; d++) o << "    Wide wacc_" << d << " = wzero();\n";
+            for (size_t j = 0; j < ng; j++)
+                for (int d = 0; d < DEG; d++) o << "    Wide wsa" << j << "_" << d << " = wzero(), wsb" << j << "_" << d << " = wzero();\n";
+        }
+        // transition constraints: acc += alpha c, gb[group] += beta' c; one degree group after the other (a single wide gb is live)
+        std::vector<size_t> order(nt);
+        for (size_t k = 0; k < nt; k++) order[k] = k;
+        if (wide) std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return p.trans[x].group < p.trans[y].group; });
+        for (size_t q = 0; q < nt; q++) {
+            const size_t k = order[q];
+            const uint32_t g = p.trans[k].group;
             need(p.trans[k].root);
             const auto v = operand(p.trans[k].root);
-            const char* m = v.second ? "F::mul" : "F::mulb";
-            o << "    acc = F::add(acc, " << m << "(" << pool_e("oT", 2 * k) << ", " << v.first << "));\n";
-            o << "    gb" << p.trans[k].group << " = F::add(gb" << p.trans[k].group << ", " << m << "(" << pool_e("oT", 2 * k + 1) << ", " << v.first << "));\n";
+            if (wide && (q == 0 || p.trans[order[q - 1]].group != g))
+                for (int d = 0; d < DEG; d++) o << "    Wide wgb" << g << "_" << d << " = wzero();\n";
+            if (wide && !v.second) {
+                for (int d = 0; d < DEG; d++) {
+                    o << "    wmac(wacc_" << d << ", pool[oT + " << (2 * k) * DEG + d << "], " << v.first << ");\n";
+                    o << "    wmac(wgb" << g << "_" << d << ", pool[oT + " << (2 * k + 1) * DEG + d << "], " << v.first << ");\n";
+                }
+            } else {
+                const char* m = v.second ? "F::mul" : "F::mulb";
+                o << "    acc = F::add(acc, " << m << "(" << pool_e("oT", 2 * k) << ", " << v.first << "));\n";
+                o << "    gb" << g << " = F::add(gb" << g << ", " << m << "(" << pool_e("oT", 2 * k + 1) << ", " << v.first << "));\n";
+            }
+            if (wide && (q + 1 == nt || p.trans[order[q + 1]].group != g))
+                o << "    gb" << g << " = F::add(gb" << g << ", " << wide_value("wgb" + std::to_string(g)) << ");\n";
         }
+        if (wide) o << "    acc = F::add(acc, " << wide_value("wacc") << ");\n";
         for (size_t g = 0; g < ndg; g++) o << "    acc = F::add(acc, F::mulb(gb" << g << ", tw(a, (s * a.dg_exp[" << g << "]) & rmask)));\n";
         // assertions not met on the way (their column is in no transition constraint, or early = 0)
         for (uint32_t m = 0; m < in.members.size(); m++) {
@@ -314,6 +370,11 @@ struct Gen {
             s2 << "F::make(a." << arr << "[" << j * DEG << "], " << (DEG > 1 ? std::string("a.") + arr + "[" + std::to_string(j * DEG + 1) + "]" : std::string("0")) << ")";
             return s2.str();
         };
+        if (wide)
+            for (size_t j = 0; j < ng; j++) {
+                o << "    sa" << j << " = F::add(sa" << j << ", " << wide_value("wsa" + std::to_string(j)) << ");\n";
+                o << "    sb_" << j << " = F::add(sb_" << j << ", " << wide_value("wsb" + std::to_string(j)) << ");\n";
+            }
         for (size_t j = 0; j < ng; j++)
             o << "    const T num" << j << " = F::add(F::sub(sa" << j << ", " << gpair("gA", j) << "), F::mulb(F::sub(sb_" << j << ", " << gpair("gB", j)
               << "), tw(a, (s * a.bgroups[" << j << "].adj_exp) & rmask)));\n";

@@ -27,7 +27,8 @@ def test_vm_shaped_program_source_and_build():
     src = air.jit_source(6, 1, True)
     body = src[src.index('extern "C" __global__'):]
     nt = info["main_transition"] + info["aux_transition"]
-    assert len(re.findall(r"^\s+acc = F::add\(acc, F::mulb?\(F::make\(pool\[oT", body, re.M)) == nt
+    # one accumulation per transition constraint: base-field values as 160-bit sums (wmac), E-valued ones as field multiplications
+    assert len(re.findall(r"^\s+acc = F::add\(acc, F::mulb?\(F::make\(pool\[oT", body, re.M)) + len(re.findall(r"^\s+wmac\(wacc_0, pool\[oT", body, re.M)) == nt
     assert len(re.findall(r"pool\[oB \+ \d+\]", body)) == 2 * (info["main_assertions"] + info["aux_assertions"])
     assert len(re.findall(r"const uint64_t d\d+ = ", body)) == air.num_divisors(6) - 1
     defs = re.findall(r"const (?:uint64_t|T) ([te]\d+) = ", body)

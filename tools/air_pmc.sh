@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the AIR-program interpreter (air_constraints_kernel) on the VM-shaped program, four separate --pmc passes
+# SQ counters of the AIR-program evaluator on the VM-shaped program (air_jit_kernel by default, the interpreter air_constraints_kernel with AERO_AIR_JIT=0), four separate --pmc passes
 # (counters only, no other trace domain). usage: bash tools/air_pmc.sh <tag> [log_n]   -> gpurun_out/<tag>/air_pmc_pass{1..4}.csv
 TAG=${1:-rX}; LOGN=${2:-18}
 OUT=$(pwd)/gpurun_out/$TAG; mkdir -p "$OUT"
@@ -14,7 +14,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CY
   rm -rf "/tmp/air_pmc_$i"
   rocprofv3 --pmc $set -d "/tmp/air_pmc_$i" --output-format csv -- python3 "$REPO/tools/air_bench.py" --vm 26,9,16 --log-n "$LOGN" --fold 4 --reps 1 > "$OUT/air_pmc_pass$i.log" 2>&1
   f=$(find "/tmp/air_pmc_$i" -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && { head -1 "$f"; grep air_constraints_kernel "$f"; } > "$OUT/air_pmc_pass$i.csv"
+  [ -n "$f" ] && { head -1 "$f"; grep -E "air_constraints_kernel|air_jit_kernel" "$f"; } > "$OUT/air_pmc_pass$i.csv"
 done
 python3 - "$OUT" <<'PY'
 import csv, sys, glob, collections
