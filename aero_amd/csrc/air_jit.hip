@@ -64,26 +64,7 @@ struct Args {
     uint64_t *out_cols, *out_h0, *out_h1;
 };
 __device__ __forceinline__ uint64_t tw(const Args& a, uint64_t e) { return gl::mul(a.tw_lo[e & ((1ull << a.tw_h) - 1)], a.tw_hi[e >> a.tw_h]); }
-// Sum of products as an integer of 160 bits (up to 2^32 terms), reduced once: 2^64 = 2^32 - 1 and 2^128 = -2^32 (mod p).
-struct Wide { uint32_t l0, l1, l2, l3, l4; };
-__device__ __forceinline__ Wide wzero() { return Wide{0u, 0u, 0u, 0u, 0u}; }
-__device__ __forceinline__ void wmac(Wide& w, uint64_t x, uint64_t y) {
-    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32);
-    const uint64_t t = (uint64_t)x0 * y0;
-    const uint64_t u = (uint64_t)x0 * y1 + (t >> 32);
-    const uint64_t v = (uint64_t)x1 * y0 + (uint32_t)u;
-    const uint64_t z = (uint64_t)x1 * y1 + ((u >> 32) + (v >> 32));
-    uint32_t c;
-    w.l0 = __builtin_addc(w.l0, (uint32_t)t, 0u, &c);
-    w.l1 = __builtin_addc(w.l1, (uint32_t)v, c, &c);
-    w.l2 = __builtin_addc(w.l2, (uint32_t)z, c, &c);
-    w.l3 = __builtin_addc(w.l3, (uint32_t)(z >> 32), c, &c);
-    w.l4 += c;
-}
-__device__ __forceinline__ uint64_t wreduce(const Wide& w) {
-    const uint64_t r = gl::reduce128(gl::mk64(w.l0, w.l1), gl::mk64(w.l2, w.l3));
-    return gl::sub(r, gl::mul((uint64_t)w.l4, 1ull << 32));
-}
+using gl::Wide; using gl::wzero; using gl::wmac; using gl::wreduce;      // 160-bit sums of products (gl_field.hpp)
 )SRC";
 
 struct Blob {

@@ -120,6 +120,38 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) {
 #endif
 }
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
+
+// Sum of products as a 160-bit integer (up to 2^32 terms), reduced ONCE: the constraint and DEEP kernels spend most of their
+// multiplications on sum_k coefficient_k * value_k, and a term costs 4 multiply-adds + 5 carry adds here against a whole field
+// multiplication + addition (about 27 instructions) when every product is reduced. 2^64 = 2^32 - 1, 2^128 = -2^32 (mod p).
+struct Wide { uint32_t l0, l1, l2, l3, l4; };
+GL_HD Wide wzero() { return Wide{0u, 0u, 0u, 0u, 0u}; }
+GL_HD void wmac(Wide& w, uint64_t x, uint64_t y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32);
+    const uint64_t t = (uint64_t)x0 * y0;
+    const uint64_t u = (uint64_t)x0 * y1 + (t >> 32);
+    const uint64_t v = (uint64_t)x1 * y0 + (uint32_t)u;
+    const uint64_t z = (uint64_t)x1 * y1 + ((u >> 32) + (v >> 32));
+    uint32_t c;
+    w.l0 = __builtin_addc(w.l0, (uint32_t)t, 0u, &c);
+    w.l1 = __builtin_addc(w.l1, (uint32_t)v, c, &c);
+    w.l2 = __builtin_addc(w.l2, (uint32_t)z, c, &c);
+    w.l3 = __builtin_addc(w.l3, (uint32_t)(z >> 32), c, &c);
+    w.l4 += c;
+#else
+    uint64_t lo, hi;
+    mul_wide(x, y, lo, hi);
+    unsigned __int128 s = ((unsigned __int128)mk64(w.l2, w.l3) << 64 | mk64(w.l0, w.l1));
+    const unsigned __int128 q = ((unsigned __int128)hi << 64) | lo, r = s + q;
+    w.l4 += r < s ? 1u : 0u;
+    w.l0 = (uint32_t)r; w.l1 = (uint32_t)(r >> 32); w.l2 = (uint32_t)(r >> 64); w.l3 = (uint32_t)(r >> 96);
+#endif
+}
+GL_HD uint64_t wreduce(const Wide& w) {
+    const uint64_t r = reduce128(mk64(w.l0, w.l1), mk64(w.l2, w.l3));
+    return sub(r, mul((uint64_t)w.l4, 1ULL << 32));
+}
 GL_HD uint64_t pow(uint64_t b, uint64_t e) {
     uint64_t r = 1;
     while (e) {

@@ -31,7 +31,9 @@ template <class F> __device__ __forceinline__ typename F::T ld(const uint64_t* c
 // s*ce_step, x = 7 w_ce^s). Frame = (LDE row r, LDE row r + blowup mod N).
 //   MODE 0: write the three per-divisor numerator columns (the reference's ConstraintEvaluationTable seam)
 //   MODE 1: additionally divide by the divisors and write H(x) = sum_i col_i / div_i (fused; columns not stored)
-template <class F, int MODE, int K>
+// WIDE: the sums over the columns as 160-bit integers reduced once (gl::Wide) - pays from a few columns on (2^20 x 72: 0.87 -> 0.81 ms,
+// F_p^2 0.50 -> 0.27 ms at 2^18 x 72) and costs registers that a 2-column trace has better use for (0.093 -> 0.126 ms).
+template <class F, int MODE, int K, bool WIDE>
 __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) {
     typedef typename F::T T;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -60,16 +62,43 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
         const uint64_t xt = gl::mul(a.k7, xinv);
         const uint64_t xb = gl::mul(gl::mul(a.k7, x), a.xn_inv[s & a.xmask]);
         T acc = F::zero(), g0 = F::zero(), g1 = F::zero();
-        for (uint32_t k = 0; k < a.W / 2; k++) {
-            const uint64_t ca = a.lde[(size_t)(2 * k) * a.N + r], cb = a.lde[(size_t)(2 * k + 1) * a.N + r];
-            const uint64_t na = a.lde[(size_t)(2 * k) * a.N + rn], nb = a.lde[(size_t)(2 * k + 1) * a.N + rn];
-            const uint64_t t0 = gl::sub(na, gl::add(ca, cb));
-            const uint64_t t1 = gl::sub(nb, gl::add(cb, na));
-            acc = F::add(acc, F::mulb(F::add(a.ta[2 * k], F::mulb(a.tb[2 * k], xt)), t0));
-            acc = F::add(acc, F::mulb(F::add(a.ta[2 * k + 1], F::mulb(a.tb[2 * k + 1], xt)), t1));
-            g0 = F::add(g0, F::mulb(F::add(a.ba[2 * k], F::mulb(a.bb[2 * k], xb)), gl::sub(ca, 1 + 2 * (uint64_t)k)));
-            g0 = F::add(g0, F::mulb(F::add(a.ba[2 * k + 1], F::mulb(a.bb[2 * k + 1], xb)), gl::sub(cb, 2 + 2 * (uint64_t)k)));
-            g1 = F::add(g1, F::mulb(F::add(a.ba[a.W + k], F::mulb(a.bb[a.W + k], xb)), gl::sub(cb, a.results[k])));
+        if (WIDE) {
+            // sum_k (alpha_k + beta_k x^adj) c_k = sum alpha_k c_k + x^adj sum beta_k c_k: the two sums per divisor are accumulated as
+            // 160-bit integers (gl::Wide) and reduced once - 9 instructions per term and sum instead of two field multiplications and additions
+            gl::Wide wa[F::DEG], wb[F::DEG], w0a[F::DEG], w0b[F::DEG], w1a[F::DEG], w1b[F::DEG];
+#pragma unroll
+            for (int d = 0; d < F::DEG; d++) wa[d] = wb[d] = w0a[d] = w0b[d] = w1a[d] = w1b[d] = gl::wzero();
+            for (uint32_t k = 0; k < a.W / 2; k++) {
+                const uint64_t ca = a.lde[(size_t)(2 * k) * a.N + r], cb = a.lde[(size_t)(2 * k + 1) * a.N + r];
+                const uint64_t na = a.lde[(size_t)(2 * k) * a.N + rn], nb = a.lde[(size_t)(2 * k + 1) * a.N + rn];
+                const uint64_t t0 = gl::sub(na, gl::add(ca, cb));
+                const uint64_t t1 = gl::sub(nb, gl::add(cb, na));
+                const uint64_t b0 = gl::sub(ca, 1 + 2 * (uint64_t)k), b1 = gl::sub(cb, 2 + 2 * (uint64_t)k), b2 = gl::sub(cb, a.results[k]);
+#pragma unroll
+                for (int d = 0; d < F::DEG; d++) {
+                    gl::wmac(wa[d], F::comp(a.ta[2 * k], d), t0);      gl::wmac(wb[d], F::comp(a.tb[2 * k], d), t0);
+                    gl::wmac(wa[d], F::comp(a.ta[2 * k + 1], d), t1);  gl::wmac(wb[d], F::comp(a.tb[2 * k + 1], d), t1);
+                    gl::wmac(w0a[d], F::comp(a.ba[2 * k], d), b0);     gl::wmac(w0b[d], F::comp(a.bb[2 * k], d), b0);
+                    gl::wmac(w0a[d], F::comp(a.ba[2 * k + 1], d), b1); gl::wmac(w0b[d], F::comp(a.bb[2 * k + 1], d), b1);
+                    gl::wmac(w1a[d], F::comp(a.ba[a.W + k], d), b2);   gl::wmac(w1b[d], F::comp(a.bb[a.W + k], d), b2);
+                }
+            }
+            auto folded = [](const gl::Wide (&w)[F::DEG]) { return F::make(gl::wreduce(w[0]), F::DEG > 1 ? gl::wreduce(w[F::DEG - 1]) : 0); };
+            acc = F::add(folded(wa), F::mulb(folded(wb), xt));
+            g0 = F::add(folded(w0a), F::mulb(folded(w0b), xb));
+            g1 = F::add(folded(w1a), F::mulb(folded(w1b), xb));
+        } else {
+            for (uint32_t k = 0; k < a.W / 2; k++) {
+                const uint64_t ca = a.lde[(size_t)(2 * k) * a.N + r], cb = a.lde[(size_t)(2 * k + 1) * a.N + r];
+                const uint64_t na = a.lde[(size_t)(2 * k) * a.N + rn], nb = a.lde[(size_t)(2 * k + 1) * a.N + rn];
+                const uint64_t t0 = gl::sub(na, gl::add(ca, cb));
+                const uint64_t t1 = gl::sub(nb, gl::add(cb, na));
+                acc = F::add(acc, F::mulb(F::add(a.ta[2 * k], F::mulb(a.tb[2 * k], xt)), t0));
+                acc = F::add(acc, F::mulb(F::add(a.ta[2 * k + 1], F::mulb(a.tb[2 * k + 1], xt)), t1));
+                g0 = F::add(g0, F::mulb(F::add(a.ba[2 * k], F::mulb(a.bb[2 * k], xb)), gl::sub(ca, 1 + 2 * (uint64_t)k)));
+                g0 = F::add(g0, F::mulb(F::add(a.ba[2 * k + 1], F::mulb(a.bb[2 * k + 1], xb)), gl::sub(cb, 2 + 2 * (uint64_t)k)));
+                g1 = F::add(g1, F::mulb(F::add(a.ba[a.W + k], F::mulb(a.bb[a.W + k], xb)), gl::sub(cb, a.results[k])));
+            }
         }
         if (a.A) {
             // auxiliary transition constraints (degree 2): adjustment x^n, constant on each of the C cosets of <w_n>
@@ -127,12 +156,17 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
 template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F>& a, int mode) {
     size_t cnt = a.count;
     const size_t in_cols = (size_t)a.W + (size_t)a.A * F::DEG;
+    const bool wide = a.W >= 8;
+    const dim3 g1((unsigned)((cnt + 255) / 256)), g4((unsigned)((cnt / 4 + 255) / 256));
     if (mode == 0) {
-        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + 3 * F::DEG), (fib_constraints_kernel<F, 0, 1>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, a);
+        if (wide) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + 3 * F::DEG), (fib_constraints_kernel<F, 0, 1, true>), g1, dim3(256), 0, a);
+        else AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + 3 * F::DEG), (fib_constraints_kernel<F, 0, 1, false>), g1, dim3(256), 0, a);
     } else if (cnt % 4 == 0) {   // 4 rows per thread share one batched inversion (measured best of 4 / 2 / 1 in both fields)
-        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 4>), dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, a);
+        if (wide) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 4, true>), g4, dim3(256), 0, a);
+        else AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 4, false>), g4, dim3(256), 0, a);
     } else {
-        AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 1>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, a);
+        if (wide) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 1, true>), g1, dim3(256), 0, a);
+        else AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 1, false>), g1, dim3(256), 0, a);
     }
     ctx->check_launch("fib_constraints");
 }
