@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void field_selftest_kernel(const uint64_t* __r
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint64_t x = a[i], y = b[i];
-    uint64_t* o = out + i * 16;
+    uint64_t* o = out + i * 17;
     o[0] = gl::add(x, y);
     o[1] = gl::sub(x, y);
     o[2] = gl::mul(x, y);
@@ -643,6 +643,11 @@ __global__ __launch_bounds__(256) void field_selftest_kernel(const uint64_t* __r
     const gl::E2 e = gl::mul(gl::E2{x, y}, gl::E2{y, gl::add(x, 1)});
     o[13] = e.a0; o[14] = e.a1;
     o[15] = (i & 63) == 0 ? gl::mul(gl::inv(x), x) : 1;              // inversion on a sample (x != 0 by construction)
+    // 160-bit sum of products (gl::Wide): 40 terms that make the limbs carry, reduced once
+    gl::Wide w = gl::wzero();
+    uint64_t u = x, v = y;
+    for (int k = 0; k < 40; k++) { gl::wmac(w, u, v); u = gl::sub(gl::P - 1, mul_2_24(u)); v = gl::add(v, x); }
+    o[16] = gl::wreduce(w);
 }
 static uint64_t ref_mulmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % gl::P); }
 static uint64_t ref_addmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + b) % gl::P); }
@@ -659,19 +664,20 @@ void field_selftest(Context* ctx, size_t n, uint64_t seed) {
     // edge values: 0 / 1 / p - 1 / 2^32 - 1 / 2^32 / 2^63 around the carry boundaries of the limb arithmetic
     const uint64_t edge[] = {1, gl::P - 1, 0xFFFFFFFFull, 0x100000000ull, 0xFFFFFFFF00000000ull, 1ull << 63, gl::P - 0xFFFFFFFFull, 2};
     for (size_t i = 0; i < 64 && i < n; i++) { a[i] = edge[i & 7]; b[i] = i < 8 ? 0 : edge[(i >> 3) & 7]; }
-    DevBuf<uint64_t> da(ctx, n), db(ctx, n), dout(ctx, n * 16);
+    DevBuf<uint64_t> da(ctx, n), db(ctx, n), dout(ctx, n * 17);
     AERO_HIP(hipMemcpyAsync(da.get(), a.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
     AERO_HIP(hipMemcpyAsync(db.get(), b.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
     AERO_LAUNCH(ctx, "field_selftest_kernel", 0, field_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, da.get(), db.get(), n, dout.get());
     ctx->check_launch("field_selftest");
-    std::vector<uint64_t> out(n * 16);
-    AERO_HIP(hipMemcpyAsync(out.data(), dout.get(), n * 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint64_t> out(n * 17);
+    AERO_HIP(hipMemcpyAsync(out.data(), dout.get(), n * 17 * 8, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
-    static const char* names[16] = {"add", "sub", "mul", "sqr", "neg", "mul(sub, add)", "sub(mul, mul)", "mul_2_24", "mul_w4 (2^48)", "mul_2_72",
-                                    "add(pow2<39>, pow2<78>)", "sub(pow2<60>, pow2<7>)", "pow2<95>", "E2 mul (component 0)", "E2 mul (component 1)", "inv"};
+    static const char* names[17] = {"add", "sub", "mul", "sqr", "neg", "mul(sub, add)", "sub(mul, mul)", "mul_2_24", "mul_w4 (2^48)", "mul_2_72",
+                                    "add(pow2<39>, pow2<78>)", "sub(pow2<60>, pow2<7>)", "pow2<95>", "E2 mul (component 0)", "E2 mul (component 1)", "inv",
+                                    "160-bit sum of 40 products (Wide)"};
     for (size_t i = 0; i < n; i++) {
         const uint64_t x = a[i], y = b[i];
-        uint64_t want[16];
+        uint64_t want[17];
         want[0] = ref_addmod(x, y); want[1] = ref_submod(x, y); want[2] = ref_mulmod(x, y); want[3] = ref_mulmod(x, x); want[4] = ref_submod(0, x);
         want[5] = ref_mulmod(ref_submod(x, y), ref_addmod(x, y));
         want[6] = ref_submod(ref_mulmod(x, y), ref_mulmod(y, y));
@@ -685,11 +691,16 @@ void field_selftest(Context* ctx, size_t n, uint64_t seed) {
             want[14] = ref_submod(ref_mulmod(ref_addmod(x, y), ref_addmod(y, b1)), a0b0);
         }
         want[15] = 1;
-        for (int k = 0; k < 16; k++)
-            if (out[i * 16 + k] != want[k]) {
+        {
+            uint64_t acc = 0, u = x, v = y;
+            for (int k = 0; k < 40; k++) { acc = ref_addmod(acc, ref_mulmod(u, v)); u = ref_submod(gl::P - 1, ref_pow2(u, 24)); v = ref_addmod(v, x); }
+            want[16] = acc;
+        }
+        for (int k = 0; k < 17; k++)
+            if (out[i * 17 + k] != want[k]) {
                 char msg[256];
                 snprintf(msg, sizeof msg, "field self-test: device %s is wrong for x = %llu, y = %llu: got %llu, expected %llu", names[k],
-                         (unsigned long long)x, (unsigned long long)y, (unsigned long long)out[i * 16 + k], (unsigned long long)want[k]);
+                         (unsigned long long)x, (unsigned long long)y, (unsigned long long)out[i * 17 + k], (unsigned long long)want[k]);
                 fail(msg, ST_INTERNAL);
             }
     }
