@@ -132,7 +132,7 @@ def test_lde_large_properties(ctx, oracle, log_n):
 
 
 # a10: constraint evaluation seam (constraints_worker.rs:14-79), fragments stitched like proving_worker.rs:428-437
-@pytest.mark.parametrize("log_n,width,ext", [(6, 2, 1), (8, 4, 1), (8, 2, 2), (10, 6, 2)])
+@pytest.mark.parametrize("log_n,width,ext", [(6, 2, 1), (8, 4, 1), (8, 2, 2), (10, 6, 2), (8, 8, 1), (7, 10, 2), (9, 16, 1)])      # >= 8 columns: the 160-bit-sum form of the kernel
 def test_constraint_fragments_match_oracle(ctx, oracle, log_n, width, ext):
     o = [27, 8, 16, 4, ext, 8, 5 if log_n < 8 else 8]
     proof, pub, _ = oracle.prove_fib(width, log_n, o, keep_artifacts=True)
