@@ -753,6 +753,32 @@ def main():
                               "avg_launch_us": 1e3 * v[1] / max(v[0], 1)}
                              for k, v in sorted(table.items(), key=lambda kv: -kv[1][1])[1:4]],
         }
+        # the NTT family is VALU-bound as well: its register transforms against their in-register rate on this chip
+        # (tools/ubench_dft.hip, raw output tracked under profiles/): a contiguous first pass = 3 shift stages + phase B, a strided
+        # radix-64 pass = 6 shift stages + one multiplication; the forward passes of an LDE are 1 first + 2 strided per element
+        try:
+            dft = {}
+            variant = None
+            for line in open(os.path.join(ROOT, "profiles", "r3_ubench_dft.txt")):
+                if line.startswith("variant:"):
+                    variant = "lazy" if "WITHOUT" in line else "canonical"
+                elif variant == "canonical" and "Gelem/s" in line:
+                    dft[line.split("  ")[0].strip()] = float(line.split()[-2])
+            mul_rate = ceilings.get("valu_Gop_per_s", {}).get("goldilocks mul")
+            pb, d32, d8 = dft["phase B (mul + dft32 + 2 mul) per element"], dft["dft32 shift-twiddle stages only"], dft["dft8 (radix-8 butterfly of the LDS rounds)"]
+            first_pass = 1.0 / (1.0 / pb + 1.0 / d8)
+            strided = 1.0 / (6.0 / (5.0 * d32) + (1.0 / mul_rate if mul_rate else 0.0))
+            lde_mix = 3.0 / (1.0 / first_pass + 2.0 / strided)
+            if "ntt_fwd_pass" in table and table["ntt_fwd_pass"][1] > 0:
+                c_, ms_, b_ = table["ntt_fwd_pass"]
+                passes = (b_ * 3.0 / 41.0) / (ms_ * 1e-3) / 1e9          # 9 + 16 + 16 algorithmic bytes per element over the three passes
+                out["roofline"]["ntt_valu_view"] = {
+                    "what": "forward NTT passes (one proof in flight): element-passes per second against the register transforms' own rate",
+                    "achieved_Gelem_passes_per_s": passes, "in_register_ceiling_Gelem_passes_per_s": lde_mix, "frac_of_in_register_ceiling": passes / lde_mix,
+                    "ceilings_Gelem_per_s": {"contiguous_first_pass": first_pass, "strided_radix64_pass": strided},
+                    "source": "profiles/r3_ubench_dft.txt (tools/ubench_dft.hip, canonical variant) + profiles/ceilings.json (goldilocks mul)"}
+        except Exception:
+            pass
         # whole-proof view: SURVEY 8d algorithmic bytes per cell
         E = 2
         bpc = 168 + 8 * E + (1259 + 176 * E) / width
