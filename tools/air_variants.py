@@ -1,3 +1,6 @@
+"""Ablation of the AIR-program INTERPRETER on FibAir(72) (which instruction classes cost what): programs with / without transition
+constraints, boundary assertions, fused EMIT forms. Run with AERO_AIR_JIT=0 (the default evaluator is the run-time compiled kernel).
+usage: AERO_AIR_JIT=0 python tools/air_variants.py"""
 import sys, json
 sys.path.insert(0, '.')
 import aero_amd
