@@ -77,6 +77,8 @@ struct Cache {
     std::map<std::string, std::shared_ptr<Blob>> blobs;
 };
 std::mutex g_mu;
+std::mutex g_rtc_mu;          // hiprtc / comgr and hipModuleLoadData are entered by one thread at a time (pool workers and thread ranks meet their
+                              // first proof of a program together; neither library promises re-entrancy)
 std::string g_last_error;
 std::atomic<uint64_t> g_next_id{1};
 
@@ -441,6 +443,7 @@ std::shared_ptr<Blob> compile(const Program& p, const Instance& in, int DEG, int
             if (!blob->code.empty()) return blob;
         }
     }
+    std::lock_guard<std::mutex> rtc_lock(g_rtc_mu);
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "air_jit_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         blob->error = "hiprtcCreateProgram failed";
@@ -527,6 +530,7 @@ template <class F> bool launch_air_jit(Context* ctx, const air::Program& p, cons
     if (it != ctx->jit_funcs.end()) {
         fn = (hipFunction_t)it->second;
     } else {
+        std::lock_guard<std::mutex> rtc_lock(g_rtc_mu);
         hipModule_t mod;
         if (hipModuleLoadData(&mod, blob->code.data()) != hipSuccess) { (void)hipGetLastError(); return false; }
         ctx->jit_modules.push_back(mod);
