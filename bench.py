@@ -561,8 +561,10 @@ def main():
                 "warmup": args.warmup, "ms_per_step": res["ms_per_proof"], "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": args.workload, "trace_rows": 1 << log_n, "trace_cols": width, "blowup": opt.blowup_factor,
-                           "parallelism": f"ONE proof sharded over {world} GPUs by LDE coset; per commitment: all-to-all of leaf "
-                                          "digests + all-gather of subtree roots (RCCL); one all-reduce for the openings"},
+                           "h2d_included": True,
+                           "hand_over": "trace in pinned host memory; every rank copies its share of the columns inside the timed region (aero_prove_fib_sharded_host)",
+                           "parallelism": f"ONE proof sharded over {world} GPUs by LDE coset; every rank copies and interpolates W / {world} columns, all-gather of the "
+                                          "coefficients; per commitment: all-to-all of rows or leaf digests + all-gather of subtree roots; one all-reduce for the openings"},
                 "sharded_proof": res,
                 "path_roofline": {"bytes_per_cell": bpc, "achieved_GBps": res["value"] * bpc / 1e9 / world,
                                   "frac_of_hbm_peak": res["value"] * bpc / 1e9 / world / HBM_PEAK_GBS},
