@@ -77,6 +77,13 @@ int32_t aero_ctx_synchronize(aero_ctx* ctx);
 /* Text of the last error on this context; ctx may be NULL for errors of aero_ctx_create itself. */
 const char* aero_last_error(const aero_ctx* ctx);
 void aero_free(void* p); /* releases buffers returned through uint8_t** out-parameters */
+/* Crash diagnostics for the hosting process (opt-in; also installed at load time when AERO_CRASH_TRACE=1 is in the environment).
+ * Installs a std::terminate handler and SIGABRT / SIGSEGV / SIGBUS handlers that write the escaping exception's what(), the
+ * thread and a native backtrace with write(2) to the stderr that existed at install time, to the current fd 2 and, when
+ * AERO_CRASH_LOG names a file, to that file - then chain to the previous handlers (core dumps, Python's faulthandler). A host that
+ * drives the prover repeatedly from one long-lived worker (proving_worker.rs:124-223) gets the cause of a native abort even
+ * when a harness has redirected its descriptors. Idempotent. */
+int32_t aero_install_crash_diagnostics(void);
 
 /* ---- matrices -------------------------------------------------------------------------------------------------- */
 /* Trace hand-over. Replaces `trace.main_segment()` handed to the prover: proving_worker.rs:272. */
