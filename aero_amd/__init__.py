@@ -417,8 +417,8 @@ class Context:
                                                _p64(rv) if rv is not None else None, C.c_uint8(field_extension), C.byref(out)))
         if out.value == 0xFFFFFFFFFFFFFFFF:
             return None
-        row, ident = out.value >> 16, out.value & 0xFFFF
-        return (row, "assertion", ident & 0x7FFF) if ident & 0x8000 else (row, "transition", ident)
+        row, ident = out.value >> 24, out.value & 0xFFFFFF
+        return (row, "assertion", ident & 0x7FFFFF) if ident & 0x800000 else (row, "transition", ident)
 
     def eval_constraints_program(self, air: "Air", lde: Matrix, aux_lde, log_blowup, pub, rands, coeffs, field_extension=1, fragment_offset=0,
                                  num_fragments=1):

@@ -128,7 +128,7 @@ public:
         std::mutex mu;
         hipEvent_t last = nullptr;
     };
-    CopyGate* copy_gate = nullptr;
+    std::shared_ptr<CopyGate> copy_gate;   // shared with the pool: a context kept alive by one of its matrices may outlive aero_pool_destroy
     hipEvent_t gate_event = nullptr;       // this context's last gated copy
     // second stream + events for the host-to-device copy of a wide trace: column group g + 1 travels while group g is transformed
     hipStream_t copy_stream = nullptr;
@@ -207,6 +207,7 @@ public:
     bool air_jit = true;
     std::map<uint64_t, void*> jit_funcs;
     std::vector<hipModule_t> jit_modules;
+    static void unload_jit_modules(Context* ctx);   // air_jit.hip: hipModuleUnload under the lock that serialises module loading
     std::vector<std::shared_ptr<void>> jit_blobs;
     bool fri_tail_attr_set = false;   // the opt-in for > 64 KiB of dynamic LDS was made on this context's device
     std::map<int, NttTables> ntt_tabs;

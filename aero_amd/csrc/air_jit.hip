@@ -247,8 +247,8 @@ struct Gen {
     // once - and wait for the inversion in LDS (2 DEG + 1 words per row and thread).
     // mode 2: `Trace::validate(&air)` of a debug-mode Winterfell prover (the "(debug) validate" of commit_to_trace_and_validate,
     // proving_worker.rs:323-332) on the TRACE domain: every transition constraint on every row but the exempted last ones, every
-    // assertion on the steps it names; the smallest (row << 16 | id) that fails is left in out_h0[0] (id = transition index, or
-    // 0x8000 | assertion index in the program's order, main first).
+    // assertion on the steps it names; the smallest (row << 24 | id) that fails is left in out_h0[0] (id = transition index, or
+    // 0x800000 | assertion index in the program's order, main first; the loader admits at most 2^20 of either, rows < 2^29).
     std::string validate_source(size_t args_size) {
         o << GL_FIELD_SRC << "\n" << ARGS_SRC;
         o << "static_assert(sizeof(Args) == " << args_size << ", \"argument block\");\n";
@@ -268,7 +268,7 @@ struct Gen {
         for (size_t k = 0; k < (mode == 3 ? (size_t)p.n_main_trans : p.num_transition()); k++) {
             need(p.trans[k].root);
             const auto v = operand(p.trans[k].root);
-            o << "    if (nz(" << v.first << ")) { const unsigned long long e = (s << 16) | " << k << "ull; bad = e < bad ? e : bad; }\n";
+            o << "    if (nz(" << v.first << ")) { const unsigned long long e = (s << 24) | " << k << "ull; bad = e < bad ? e : bad; }\n";
         }
         o << "    }\n";
         for (uint32_t m = 0; m < in.members.size(); m++) {
@@ -283,7 +283,7 @@ struct Gen {
             std::string want;
             if (bm.val_ext) want = pool_e("oSE", bm.val_idx);
             else want = bm.aux ? "F::from(pool[" + std::to_string(bm.val_idx) + "])" : "pool[" + std::to_string(bm.val_idx) + "]";
-            o << "        if (ne(" << col << ", " << want << ")) { const unsigned long long e = (s << 16) | " << (0x8000u | m) << "ull; bad = e < bad ? e : bad; }\n    }\n";
+            o << "        if (ne(" << col << ", " << want << ")) { const unsigned long long e = (s << 24) | " << (0x800000u | m) << "ull; bad = e < bad ? e : bad; }\n    }\n";
         }
         o << "    if (bad != ~0ull) atomicMin((unsigned long long*)a.out_h0, bad);\n}\n";
         return o.str();
@@ -409,6 +409,9 @@ std::string structure_key(const Program& p, const Instance& in, int DEG, int mod
     std::ostringstream k;
     k << DEG << ":" << mode << ":" << R << ":" << in.bgroups.size() << ":";
     for (auto& m : in.members) k << m.group << ",";
+    // the validation kernels carry each boundary group's (stride, first step) as literals, and `first` follows the trace length for
+    // steps counted from the end: a second aero_air_validate_trace with another length must not meet the first one's kernel
+    if (mode >= 2) for (auto& g : in.bgroups) k << "|" << g.stride << "@" << g.first;
     return k.str();
 }
 
@@ -514,6 +517,14 @@ bool air_jit_compile_only(const air::Program& p, const air::Instance& in, int de
     auto blob = get_blob(p, in, deg, mode, jit_rows(p, (size_t)1 << 20, mode, in.bgroups.size()));
     if (err) *err = blob->error;
     return blob->error.empty();
+}
+
+void Context::unload_jit_modules(Context* ctx) {
+    if (ctx->jit_modules.empty()) return;
+    std::lock_guard<std::mutex> rtc_lock(g_rtc_mu);
+    for (hipModule_t m : ctx->jit_modules) (void)hipModuleUnload(m);
+    ctx->jit_modules.clear();
+    ctx->jit_funcs.clear();
 }
 
 template <class F> bool launch_air_jit(Context* ctx, const air::Program& p, const air::Instance& in, const AirConsArgs<F>& c, const uint64_t* pdesc, uint64_t oSE,

@@ -784,7 +784,7 @@ struct aero_pool {
         bool has_job = false;
     };
     std::vector<std::unique_ptr<Slot>> slots;
-    Context::CopyGate gate;        // orders the slots' host-to-device copies (aero_internal.hpp)
+    std::shared_ptr<Context::CopyGate> gate = std::make_shared<Context::CopyGate>();   // orders the slots' host-to-device copies (aero_internal.hpp)
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
     uint64_t generation = 0;       // bumped per batch
@@ -810,7 +810,11 @@ struct aero_pool {
             int32_t rc = AERO_OK;
             uint8_t* out = nullptr;
             size_t len = 0;
-            std::vector<uint64_t> pub((size_t)(s->host_trace ? host_width : (uint32_t)s->trace->m.cols) / 2);
+            std::vector<uint64_t> pub;
+            // an exception that leaves a thread body ends the whole host process (std::terminate): whatever is thrown here
+            // (the entry points below catch their own) becomes the slot's status
+            try {
+            pub.resize((size_t)(s->host_trace ? host_width : (uint32_t)s->trace->m.cols) / 2);
             for (uint32_t r = 0; r < rounds && rc == AERO_OK; r++) {
                 if (out) { free(out); out = nullptr; }
                 if (program) {
@@ -821,6 +825,8 @@ struct aero_pool {
                 else if (s->host_trace) rc = aero_prove_fib_air_host(s->ctx, s->host_trace, host_width, host_log_n, &air, &opt, &out, &len, pub.data());
                 else rc = aero_prove_fib_air(s->ctx, nullptr, s->trace, &air, &opt, &out, &len, pub.data());
             }
+            } catch (const std::bad_alloc&) { rc = AERO_E_OOM; s->ctx->err = "pool worker: host allocation failed"; }
+            catch (...) { rc = AERO_E_INTERNAL; s->ctx->err = "pool worker: unexpected exception"; }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 s->status = rc; s->proof = out; s->proof_len = len; s->pub = std::move(pub); s->has_job = false;
@@ -845,7 +851,7 @@ int32_t aero_pool_create(int32_t device_id, uint32_t slots, aero_pool** out) {
         }
         p->slots.emplace_back(new aero_pool::Slot());
         p->slots.back()->ctx = c;
-        c->c->copy_gate = &p->gate;
+        c->c->copy_gate = p->gate;
     }
     for (auto& s : p->slots) s->th = std::thread(&aero_pool::worker, p.get(), s.get());
     *out = p.release();

@@ -41,6 +41,16 @@ struct aero_fri {
 extern thread_local std::string g_create_err;
 
 
+// Work enqueued before a failure may still read the caller's (pinned) buffers and the scratch blocks: whatever went wrong, the
+// streams drain before the scratch blocks return to the pool and the caller gets its memory back.
+static inline void drain_after_failure(aero_ctx* ctx) {
+    (void)hipGetLastError();   // leave no stale HIP error behind for the next call's launch checks
+    if (!ctx || !ctx->c) return;
+    if (ctx->c->copy_stream) (void)hipStreamSynchronize(ctx->c->copy_stream);
+    (void)hipStreamSynchronize(ctx->c->stream);
+    (void)hipGetLastError();
+    ctx->c->scratch_reset();
+}
 template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
     try {
         if (!ctx || !ctx->c) { g_create_err = "null context"; return AERO_E_BAD_ARG; }
@@ -48,16 +58,20 @@ template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
         fn();
         return AERO_OK;
     } catch (const Error& e) {
-        (void)hipGetLastError();   // leave no stale HIP error behind for the next call's launch checks
-        // work enqueued before the failure may still read the caller's (pinned) buffers and the scratch blocks: let the stream drain
-        // before the scratch blocks return to the pool and the caller gets its memory back
-        if (ctx) { ctx->err = e.what(); if (ctx->c) { if (ctx->c->copy_stream) (void)hipStreamSynchronize(ctx->c->copy_stream); (void)hipStreamSynchronize(ctx->c->stream); (void)hipGetLastError(); ctx->c->scratch_reset(); } }
+        ctx->err = e.what();
+        drain_after_failure(ctx);
         return e.code;
     } catch (const std::bad_alloc&) {
-        if (ctx) ctx->err = "host allocation failed";
+        ctx->err = "host allocation failed";
+        drain_after_failure(ctx);
         return AERO_E_OOM;
     } catch (const std::exception& e) {
-        if (ctx) ctx->err = e.what();
+        ctx->err = e.what();
+        drain_after_failure(ctx);
+        return AERO_E_INTERNAL;
+    } catch (...) {   // nothing may cross the C boundary
+        ctx->err = "unknown exception";
+        drain_after_failure(ctx);
         return AERO_E_INTERNAL;
     }
 }

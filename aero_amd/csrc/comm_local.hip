@@ -244,6 +244,7 @@ int32_t aero_prove_fib_sharded_local(const int32_t* device_ids, uint32_t world, 
         for (uint32_t r = 0; r < world; r++) {
             proofs[r] = nullptr; proof_lens[r] = 0;
             th.emplace_back([&, r] {
+                try {
                 aero_comm comm{};
                 int32_t st = aero_local_group_comm(g, ctxs[r], (int32_t)r, min_peer_digests, &comm);
                 const auto t0 = std::chrono::steady_clock::now();
@@ -253,6 +254,11 @@ int32_t aero_prove_fib_sharded_local(const int32_t* device_ids, uint32_t world, 
                 status[r] = st;
                 if (st != AERO_OK) { msgs[r] = std::string(aero_last_error(ctxs[r])) + " " + aero_local_group_last_error(g, (int32_t)r); aero_local_group_abort(g); }
                 else if (r == 0 && pub_out) memcpy(pub_out, pub.data(), (width / 2) * 8);
+                } catch (...) {   // never out of a thread body (std::terminate would take the host process down); peers must not wait for this rank
+                    status[r] = AERO_E_INTERNAL;
+                    try { msgs[r] = "unexpected exception in the rank's thread"; } catch (...) {}
+                    aero_local_group_abort(g);
+                }
             });
         }
         for (auto& t : th) t.join();

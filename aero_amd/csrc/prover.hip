@@ -37,7 +37,7 @@ Context::~Context() {
     for (auto& kv : free_blocks) (void)hipFree(kv.second);
     for (auto& kv : live_blocks) (void)hipFree(kv.first);
     for (void* p : persistent) (void)hipFree(p);
-    for (hipModule_t m : jit_modules) (void)hipModuleUnload(m);
+    unload_jit_modules(this);   // may run on whichever host thread drops the last handle: not while another thread loads a module
     if (stage_base) (void)hipHostFree(stage_base);
     if (pinned_flag) (void)hipHostFree(pinned_flag);
     for (auto& r : kt_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
@@ -939,9 +939,18 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
                 std::vector<uint8_t> need(W, 0);
                 if (prog) { for (uint32_t d : prog->aux_desc) if (!(d & 0x40000000u)) need[d & 0xffff] = 1; }
                 else for (uint32_t c = 0; c < A; c++) need[c % W] = 1;
-                uint32_t extra = 0;
-                for (uint32_t c = 0; c < W; c++) extra += need[c] && (c < c0 || c >= c0 + cpr);
-                if (extra * 2 <= W) {
+                // The choice must be the SAME on every rank (the all-gather is a collective): it is made from the largest number of
+                // foreign needed columns any rank would have to fetch, computed here for all ranks alike - not from this rank's own count
+                // (W = 8, G = 4, A = 5: ranks 0-2 need 3 or 4 foreign columns, rank 3 needs 5).
+                uint32_t total_need = 0, min_own = W;
+                for (uint32_t c = 0; c < W; c++) total_need += need[c];
+                for (uint32_t r = 0; r < (uint32_t)G; r++) {
+                    uint32_t own = 0;
+                    for (uint32_t c = r * cpr; c < (r + 1) * cpr; c++) own += need[c];
+                    min_own = std::min(min_own, own);
+                }
+                const uint32_t extra_max = total_need - min_own;
+                if (extra_max * 2 <= W) {
                     // on the copy stream: they are not needed before the main segment is committed
                     hipStream_t cs = ctx->get_copy_stream();
                     AERO_HIP(hipEventRecord(ctx->sync_event(0), ctx->stream));

@@ -160,8 +160,8 @@ int32_t aero_aux_columns_program(aero_ctx* ctx, const aero_air* air, const aero_
  * (proving_worker.rs:323-332): every transition constraint on every row but the exempted last ones, every assertion on the steps it
  * names, evaluated on the trace itself by a kernel compiled from the program (needs hiprtc). aux = the (aux_width * degree) x n
  * component columns of aero_aux_columns_program with the same `rands`, or NULL: then only the main segment is checked.
- * *first_failure = UINT64_MAX when the trace satisfies the program, else row << 16 | id of the first failing check (id = index of the
- * transition constraint, main first, or 0x8000 | index of the assertion, main first). The prover itself never validates a trace. */
+ * *first_failure = UINT64_MAX when the trace satisfies the program, else row << 24 | id of the first failing check (id = index of the
+ * transition constraint, main first, or 0x800000 | index of the assertion, main first). The prover itself never validates a trace. */
 int32_t aero_air_validate_trace(aero_ctx* ctx, const aero_air* air, const aero_matrix* trace, const aero_matrix* aux, const uint64_t* pub,
                                 uint32_t n_pub, const uint64_t* rands, uint8_t field_extension, uint64_t* first_failure);
 /* `ConstraintEvaluationTable::into_poly` -> `CompositionPoly` for a program AIR: numer_cols = the num_divisors * deg numerator

@@ -301,3 +301,15 @@ def test_trace_validation_on_the_device(ctx, oracle, ext):
     a[0][5] ^= 1
     got = ctx.validate_trace(air, dev, pub, aux=ctx.trace_upload(a), rands=rands, field_extension=ext)
     assert got is not None and got[0] in (4, 5) and got[1] == "transition" and got[2] >= info["main_transition"]
+
+
+def test_one_program_handle_validates_traces_of_different_lengths(ctx):
+    # the validation kernel carries the steps of the assertions as literals; "last step" follows the trace length, so a second
+    # length on the same aero_air handle must get its own kernel (round-3 advice: the cache key ignored the length)
+    air = aero_amd.Air(aero_amd.fib_program(4))
+    for log_n in (8, 10, 8, 9):
+        trace = aero_amd.fib_trace(4, log_n)
+        pub = [int(trace[2 * k + 1][-1]) for k in range(2)]
+        assert ctx.validate_trace(air, ctx.trace_upload(trace), pub) is None, log_n
+        row, kind, _ = ctx.validate_trace(air, ctx.trace_upload(trace), [pub[0] ^ 1, pub[1]])
+        assert (row, kind) == ((1 << log_n) - 1, "assertion"), log_n

@@ -29,6 +29,7 @@ def ctx():
     (16, 12, (4, 3, 5), [27, 8, 8, 4, 1, 4, 7], (2, 4, 8)),          # aux segment of degree 5 (8 composition columns), fold 4
     (8, 12, (0, 0, 2), [20, 8, 8, 4, 2, 8, 6], (2, 8)),              # quadratic extension
     (72, 10, (9, 16, 8), [27, 8, 8, 4, 1, 4, 7], (8,)),              # Miden's shape
+    (8, 12, (5, 3, 5), [27, 8, 8, 4, 1, 4, 7], (4, 2)),              # needed main columns straddle W / 2: ranks 0-2 would fetch 3-4 foreign columns, rank 3 five - one decision for all
     (4, 14, (0, 0, 2), [27, 16, 8, 4, 1, 2, 6], (4, 16)),            # blowup 16: world 16
 ])
 def test_local_group_proofs_equal_the_single_gpu_proof(ctx, oracle, width, log_n, aux, opt, worlds):
