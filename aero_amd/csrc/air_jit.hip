@@ -19,6 +19,7 @@
 #include "air_kernels.hpp"
 
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -71,6 +72,7 @@ struct Blob {
     uint64_t id;
     std::vector<char> code;
     std::string error;       // non-empty: compilation failed, the interpreter runs instead
+    std::string cache_file;  // non-empty: the code object was read from this cache entry
 };
 struct Cache {
     std::mutex mu;
@@ -405,6 +407,36 @@ struct Gen {
     }
 };
 
+// BLAKE2s-256 of a byte string (host): integrity of the on-disk code-object cache
+b2s::Digest hash_bytes(const void* data, size_t len) {
+    b2s::State st; b2s::init(st);
+    const unsigned char* p = (const unsigned char*)data;
+    size_t off = 0;
+    do {
+        uint32_t m[16] = {0};
+        const size_t take = std::min<size_t>(64, len - off);
+        memcpy(m, p + off, take);
+        off += take;
+        b2s::compress(st, m, (uint32_t)off, (uint32_t)((uint64_t)off >> 32), off == len);
+    } while (off < len);
+    b2s::Digest d;
+    for (int i = 0; i < 8; i++) d.w[i] = st.h[i];
+    return d;
+}
+// Cache file = header + code object. The header binds the file to the generated source (a strong hash, not the file name's) and
+// to its own payload, so a truncated, foreign or tampered file is recompiled instead of being handed to hipModuleLoadData.
+struct CacheHeader {
+    char magic[8];            // "AEROJIT1"
+    uint64_t src_len, code_len;
+    b2s::Digest src_hash, code_hash;
+};
+// a cache directory that others can write to is a way to inject kernels into the prover: refused
+bool cache_dir_trusted(const char* dir) {
+    struct stat st;
+    if (stat(dir, &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    return (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+
 std::string structure_key(const Program& p, const Instance& in, int DEG, int mode, int R) {
     std::ostringstream k;
     k << DEG << ":" << mode << ":" << R << ":" << in.bgroups.size() << ":";
@@ -426,7 +458,13 @@ std::shared_ptr<Blob> compile(const Program& p, const Instance& in, int DEG, int
     // optional on-disk cache of code objects (AERO_AIR_JIT_CACHE=<directory>): a prover process that restarts does not pay the
     // compilation again. Keyed by the generated source (which contains the field arithmetic and every switch) + the hiprtc version.
     std::string cache_path;
-    if (const char* dir = getenv("AERO_AIR_JIT_CACHE")) {
+    const char* dir = getenv("AERO_AIR_JIT_CACHE");
+    if (dir && *dir && !cache_dir_trusted(dir)) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_last_error = std::string("AERO_AIR_JIT_CACHE ignored: ") + dir + " is not a directory or is group/world-writable";
+        dir = nullptr;
+    }
+    if (dir && *dir) {
         int major = 0, minor = 0;
         (void)hiprtcVersion(&major, &minor);
         uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull ^ ((uint64_t)major << 32 | (uint32_t)minor);
@@ -438,12 +476,22 @@ std::shared_ptr<Blob> compile(const Program& p, const Instance& in, int DEG, int
             fseek(f, 0, SEEK_END);
             const long sz = ftell(f);
             fseek(f, 0, SEEK_SET);
-            if (sz > 0) {
-                blob->code.resize((size_t)sz);
-                if (fread(blob->code.data(), 1, (size_t)sz, f) != (size_t)sz) blob->code.clear();
+            CacheHeader hd;
+            bool ok = sz > (long)sizeof hd && fread(&hd, 1, sizeof hd, f) == sizeof hd && memcmp(hd.magic, "AEROJIT1", 8) == 0 &&
+                      hd.src_len == src.size() && hd.code_len == (uint64_t)sz - sizeof hd;
+            if (ok) {
+                blob->code.resize((size_t)hd.code_len);
+                ok = fread(blob->code.data(), 1, blob->code.size(), f) == blob->code.size();
             }
             fclose(f);
-            if (!blob->code.empty()) return blob;
+            if (ok) {
+                const b2s::Digest hs = hash_bytes(src.data(), src.size()), hc = hash_bytes(blob->code.data(), blob->code.size());
+                ok = memcmp(&hs, &hd.src_hash, sizeof hs) == 0 && memcmp(&hc, &hd.code_hash, sizeof hc) == 0 &&
+                     blob->code.size() > 4 && memcmp(blob->code.data(), "\x7f" "ELF", 4) == 0;
+            }
+            if (ok) { blob->cache_file = cache_path; return blob; }
+            blob->code.clear();
+            remove(cache_path.c_str());          // unusable entry: compiled again below and rewritten
         }
     }
     std::lock_guard<std::mutex> rtc_lock(g_rtc_mu);
@@ -471,7 +519,11 @@ std::shared_ptr<Blob> compile(const Program& p, const Instance& in, int DEG, int
     if (!cache_path.empty() && blob->error.empty()) {         // written under a temporary name, then renamed: readers never see a partial file
         const std::string tmp = cache_path + ".tmp" + std::to_string((unsigned long long)blob->id) + "_" + std::to_string((long)getpid());
         if (FILE* f = fopen(tmp.c_str(), "wb")) {
-            const bool ok = fwrite(blob->code.data(), 1, blob->code.size(), f) == blob->code.size();
+            CacheHeader hd;
+            memcpy(hd.magic, "AEROJIT1", 8);
+            hd.src_len = src.size(); hd.code_len = blob->code.size();
+            hd.src_hash = hash_bytes(src.data(), src.size()); hd.code_hash = hash_bytes(blob->code.data(), blob->code.size());
+            const bool ok = fwrite(&hd, 1, sizeof hd, f) == sizeof hd && fwrite(blob->code.data(), 1, blob->code.size(), f) == blob->code.size();
             fclose(f);
             if (!ok || rename(tmp.c_str(), cache_path.c_str()) != 0) remove(tmp.c_str());
         }
@@ -541,9 +593,32 @@ template <class F> bool launch_air_jit(Context* ctx, const air::Program& p, cons
     if (it != ctx->jit_funcs.end()) {
         fn = (hipFunction_t)it->second;
     } else {
+        // Lock order everywhere: a program's cache mutex (get_blob) BEFORE g_rtc_mu (compile, module load) - so the retry after a
+        // cache entry that does not load re-enters get_blob with g_rtc_mu released.
+        hipModule_t mod = nullptr;
+        auto load = [&](const std::shared_ptr<Blob>& b) {
+            std::lock_guard<std::mutex> rtc_lock(g_rtc_mu);
+            const bool ok = hipModuleLoadData(&mod, b->code.data()) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            return ok;
+        };
+        if (!load(blob)) {
+            // not retried on every launch; a cache entry that does not load (built for another chip or runtime) is dropped and the
+            // program compiled afresh, once (the entry is gone, so this cannot loop)
+            const bool from_cache = !blob->cache_file.empty();
+            if (from_cache) remove(blob->cache_file.c_str());
+            blob->error = "hipModuleLoadData refused the code object";
+            { std::lock_guard<std::mutex> lk(g_mu); g_last_error = blob->error; }
+            if (!from_cache) return false;
+            {
+                auto cache = std::static_pointer_cast<Cache>(p.jit_cache);
+                std::lock_guard<std::mutex> lk(cache->mu);
+                cache->blobs.erase(structure_key(p, in, F::DEG, mode, R));
+            }
+            blob = get_blob(p, in, F::DEG, mode, R);
+            if (!blob->error.empty() || !load(blob)) return false;
+        }
         std::lock_guard<std::mutex> rtc_lock(g_rtc_mu);
-        hipModule_t mod;
-        if (hipModuleLoadData(&mod, blob->code.data()) != hipSuccess) { (void)hipGetLastError(); return false; }
         ctx->jit_modules.push_back(mod);
         ctx->jit_blobs.push_back(blob);          // the image stays alive as long as the module that was loaded from it
         if (hipModuleGetFunction(&fn, mod, "air_jit_kernel") != hipSuccess) { (void)hipGetLastError(); return false; }

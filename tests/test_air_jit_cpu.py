@@ -61,3 +61,29 @@ def test_code_objects_are_cached_on_disk_when_asked(tmp_path, monkeypatch):
     assert time.perf_counter() - t0 < first / 2
     aero_amd.Air(program).jit_compile(9, 2, True)          # another field: another kernel
     assert len([f for f in tmp_path.iterdir() if f.suffix == ".co"]) == 2
+
+
+def test_a_corrupt_or_foreign_cache_entry_is_recompiled_not_loaded(tmp_path, monkeypatch):
+    monkeypatch.setenv("AERO_AIR_JIT_CACHE", str(tmp_path))
+    program = aero_amd.fib_program(4, (1, 1, 2))
+    aero_amd.Air(program).jit_compile(8, 1, True)
+    (entry,) = [f for f in tmp_path.iterdir() if f.suffix == ".co"]
+    good = entry.read_bytes()
+    assert good[:8] == b"AEROJIT1" and good[8 + 16 + 64:][:4] == b"\x7fELF"       # header (magic, lengths, two BLAKE2s digests) + code object
+    for bad in (good[:-100],                                                     # truncated
+                good[:200] + bytes([good[200] ^ 1]) + good[201:],                # one flipped bit in the code object
+                good[88:],                                                       # a bare code object under the right name (the old format)
+                b"AEROJIT1" + bytes(80) + good[88:]):                            # header that does not match
+        entry.write_bytes(bad)
+        aero_amd.Air(program).jit_compile(8, 1, True)                            # fresh handle: reads the directory, rejects, recompiles
+        assert entry.read_bytes() == good
+
+
+def test_a_cache_directory_others_can_write_to_is_ignored(tmp_path, monkeypatch):
+    import os
+    d = tmp_path / "shared"
+    d.mkdir()
+    os.chmod(d, 0o777)
+    monkeypatch.setenv("AERO_AIR_JIT_CACHE", str(d))
+    aero_amd.Air(aero_amd.fib_program(4)).jit_compile(8, 1, True)                # still compiles ...
+    assert not list(d.iterdir())                                                 # ... but neither reads nor writes there
