@@ -755,6 +755,13 @@ class Air:
         if rc != 0:
             raise AeroError(rc, lib().aero_last_error(None).decode())
 
+    def prepare(self, log_n, options: "ProofOptions", world=1):
+        """Build exactly the kernel a proof of 2^log_n rows under `options` will ask for, ahead of that proof (aero_air_prepare):
+        the cold start (hiprtc) moves off the first proof's clock; pools and sharded entry points do this themselves."""
+        rc = lib().aero_air_prepare(self.h, C.c_uint32(log_n), C.byref(options), C.c_uint32(world))
+        if rc != 0:
+            raise AeroError(rc, lib().aero_last_error(None).decode())
+
     def jit_source(self, log_n, field_extension=1, fused=True) -> str:
         out, n = u8p(), C.c_size_t(0)
         rc = lib().aero_air_jit_source(self.h, C.c_uint32(log_n), C.c_uint32(field_extension), C.c_int32(1 if fused else 0), C.byref(out), C.byref(n))

@@ -571,6 +571,16 @@ bool air_jit_compile_only(const air::Program& p, const air::Instance& in, int de
     return blob->error.empty();
 }
 
+// The kernel a PROOF of 2^log_n rows will ask for (mode 1, rows per thread chosen from the rows one launch evaluates), built ahead of
+// the proof: pools and sharded entry points call this once before their workers / ranks start, so no worker meets a compilation.
+bool air_jit_prepare(const air::Program& p, int log_n, int deg, size_t rows_per_launch, std::string* err) {
+    if (p.nodes.size() + p.num_transition() + p.num_assertions() > 20000) { if (err) *err = "program too large for the compiled evaluator (interpreter)"; return false; }
+    const air::Instance in = air::instantiate(p, log_n);
+    auto blob = get_blob(p, in, deg, 1, jit_rows(p, rows_per_launch, 1, in.bgroups.size()));
+    if (err) *err = blob->error;
+    return blob->error.empty();
+}
+
 void Context::unload_jit_modules(Context* ctx) {
     if (ctx->jit_modules.empty()) return;
     std::lock_guard<std::mutex> rtc_lock(g_rtc_mu);

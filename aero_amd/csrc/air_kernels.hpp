@@ -63,6 +63,7 @@ template <class F> bool launch_air_jit(Context* ctx, const air::Program& p, cons
                                        uint64_t oT, uint64_t oB, int mode);
 std::string air_jit_last_error();
 std::string air_jit_source(const air::Program& p, const air::Instance& in, int deg, int mode);     // the generated HIP source (diagnosis, tests)
+bool air_jit_prepare(const air::Program& p, int log_n, int deg, size_t rows_per_launch, std::string* err);   // the kernel a proof will use, ahead of it
 bool air_jit_compile_only(const air::Program& p, const air::Instance& in, int deg, int mode, std::string* err);   // no device needed
 
 // H = sum_j column_j / divisor_j over the evaluation domain (the unfused `ConstraintEvaluationTable::into_poly` division)

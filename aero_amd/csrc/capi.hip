@@ -873,6 +873,9 @@ aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot) { return (pool && slot <
 static int32_t pool_run(aero_pool* pool, const aero_matrix* const* traces, const uint64_t* const* host_traces, uint32_t width, uint32_t log_n,
                         uint32_t count, const aero_fib_air* air, const aero_proof_options* options, uint32_t rounds, uint8_t** proofs,
                         size_t* proof_lens, uint64_t* pubs, const aero_air* program = nullptr, const uint64_t* program_pub = nullptr, uint32_t n_pub = 0) {
+    // a program's evaluation kernel is built HERE, once, before the workers start: no slot meets a compilation inside its proof
+    // (a refusal by hiprtc is not an error: the proofs run interpreted)
+    if (program) (void)aero_air_prepare(program, traces ? (uint32_t)ilog2u(traces[0]->m.rows) : log_n, options, 1);
     {
         std::lock_guard<std::mutex> lk(pool->mu);
         pool->program = program;

@@ -105,6 +105,21 @@ int32_t aero_air_jit_compile(const aero_air* air, uint32_t log_n, uint32_t field
     } catch (const Error& e) { g_create_err = e.what(); return e.code; }
     catch (const std::bad_alloc&) { return AERO_E_OOM; }
 }
+int32_t aero_air_prepare(const aero_air* air, uint32_t log_n, const aero_proof_options* options, uint32_t world) {
+    if (!air || !options || world == 0 || (world & (world - 1)) || log_n < 3 || log_n > 29) return AERO_E_BAD_ARG;
+    if (options->field_extension != 1 && options->field_extension != 2) return AERO_E_BAD_ARG;
+    if (const char* e = getenv("AERO_AIR_JIT")) if (e[0] == '0') return AERO_OK;      // interpreter: nothing to build
+    try {
+        // rows of one evaluation launch: the constraint domain (ce_blowup * n), or a rank's coset of the LDE when that is smaller
+        const size_t n = (size_t)1 << log_n, ce = (size_t)air->prog.ce_blowup * n, shard = (size_t)options->blowup_factor * n / world;
+        std::string err;
+        if (air_jit_prepare(air->prog, (int)log_n, (int)options->field_extension, world > 1 && shard < ce ? shard : ce, &err)) return AERO_OK;
+        g_create_err = err;
+        return AERO_E_UNSUPPORTED;
+    } catch (const Error& e) { g_create_err = e.what(); return e.code; }
+    catch (const std::bad_alloc&) { return AERO_E_OOM; }
+    catch (const std::exception& e) { g_create_err = e.what(); return AERO_E_INTERNAL; }
+}
 int32_t aero_air_jit_source(const aero_air* air, uint32_t log_n, uint32_t field_extension, int32_t fused, uint8_t** source, size_t* len) {
     if (!air || !source || !len || (field_extension != 1 && field_extension != 2)) return AERO_E_BAD_ARG;
     try {
@@ -167,6 +182,7 @@ int32_t aero_prove_air_host(aero_ctx* ctx, const aero_air* air, const uint64_t* 
 int32_t aero_prove_air_sharded_host(aero_ctx* ctx, const aero_comm* comm, const aero_air* air, const uint64_t* trace_col_major, uint32_t log_n,
                                     const uint64_t* pub, uint32_t n_pub, const aero_proof_options* options, uint8_t** proof, size_t* proof_len) {
     if (!comm) return AERO_E_BAD_ARG;
+    if (air && options && comm->world >= 1 && log_n >= 3 && log_n <= 29) (void)aero_air_prepare(air, log_n, options, (uint32_t)comm->world);   // the ranks' kernel, once, ahead of the proof
     return prove_air_from_host(ctx, comm, air, trace_col_major, log_n, pub, n_pub, options, proof, proof_len);
 }
 static int32_t prove_air_from_host(aero_ctx* ctx, const aero_comm* comm, const aero_air* air, const uint64_t* trace_col_major, uint32_t log_n,

@@ -88,33 +88,56 @@ class RcclComm:
     moves the 128-byte id from rank 0 to the other ranks - `share_id` is any callable(bytes_or_None) -> bytes that broadcasts
     rank 0's value (default: torch.distributed.broadcast_object_list on the default group, any backend)."""
 
-    def __init__(self, ctx, rank, world, share_id=None, min_peer_digests=0):
+    def __init__(self, ctx, rank, world, share_id=None, min_peer_digests=0, agree=None):
+        """share_id(bytes_or_None) -> bytes broadcasts rank 0's value; agree(int) -> int returns the most negative status over all
+        ranks (0 = every rank is fine). Defaults: torch.distributed on the default group. With `agree`, a rank that cannot take
+        part (no librccl, a refused `ncclCommInitRank`) makes EVERY rank raise - before the collective initialisation where that
+        is knowable, after it otherwise - instead of leaving its peers inside RCCL's bootstrap for ever."""
         import aero_amd
         self.lib = aero_amd.lib()
         self.lib.aero_rccl_last_error.restype = C.c_char_p
         self.lib.aero_rccl_last_error.argtypes = [C.c_void_p]
         self.rank, self.world = rank, world
         self.h = None
+        if share_id is None:
+            share_id = _share_over_torch_dist if world > 1 else (lambda b: b)
+            if agree is None and world > 1:
+                agree = _agree_over_torch_dist
+        # pre-flight on every rank (binds librccl, asks it for an id that only rank 0's copy of is used): a rank without a usable RCCL
+        # is known BEFORE anybody enters ncclCommInitRank
+        buf = (C.c_uint8 * 128)()
+        rc0 = self.lib.aero_rccl_unique_id(buf)
+        text0 = self.lib.aero_rccl_last_error(None).decode() if rc0 != 0 else ""
+        if agree is not None:
+            worst = agree(rc0)
+            if worst != 0:
+                raise aero_amd.AeroError(rc0 if rc0 != 0 else worst, "RCCL communicator not created: " + (text0 or f"a peer rank reported status {worst} before initialisation"))
         uid, failure = None, None
         if rank == 0:
-            buf = (C.c_uint8 * 128)()
-            rc = self.lib.aero_rccl_unique_id(buf)
-            if rc != 0:
+            if rc0 != 0:
                 # the peers are waiting for the id: hand them the failure instead of leaving them in the broadcast for ever
-                failure = (rc, self.lib.aero_rccl_last_error(None).decode())
+                failure = (rc0, text0)
                 uid = b"FAIL" + repr(failure).encode()
             else:
                 uid = bytes(buf)
-        if share_id is None:
-            share_id = _share_over_torch_dist if world > 1 else (lambda b: b)
         uid = share_id(uid)
         if isinstance(uid, (bytes, bytearray)) and bytes(uid[:4]) == b"FAIL":
             raise aero_amd.AeroError(failure[0] if failure else -4, "rank 0 could not create the RCCL id: " + bytes(uid[4:]).decode(errors="replace"))
+        if rc0 != 0:
+            raise aero_amd.AeroError(rc0, text0)
         assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
-        self.h = C.c_void_p()
-        rc = self.lib.aero_rccl_create(ctx.h, C.c_int32(rank), C.c_int32(world), (C.c_uint8 * 128)(*uid), C.byref(self.h))
-        if rc != 0:
-            raise aero_amd.AeroError(rc, self.lib.aero_rccl_last_error(None).decode())
+        h = C.c_void_p()
+        rc = self.lib.aero_rccl_create(ctx.h, C.c_int32(rank), C.c_int32(world), (C.c_uint8 * 128)(*uid), C.byref(h))
+        text = self.lib.aero_rccl_last_error(None).decode() if rc != 0 else ""
+        if agree is not None:
+            worst = agree(rc)
+            if worst != 0:
+                if rc == 0:
+                    self.lib.aero_rccl_destroy(h)
+                raise aero_amd.AeroError(rc if rc != 0 else worst, "RCCL communicator not created: " + (text or f"a peer rank failed in aero_rccl_create (status {worst})"))
+        elif rc != 0:
+            raise aero_amd.AeroError(rc, text)
+        self.h = h
         self.struct = CommStruct()
         rc = self.lib.aero_rccl_comm(self.h, C.c_uint32(min_peer_digests), C.byref(self.struct))
         assert rc == 0
@@ -151,6 +174,13 @@ class RcclComm:
             self.close()
         except Exception:
             pass
+
+
+def _agree_over_torch_dist(status):
+    import torch.distributed as dist
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, int(status))
+    return min(box)
 
 
 def _share_over_torch_dist(uid):

@@ -53,6 +53,17 @@ def test_replica_mode_two_ranks_with_sharded_side_measurement():
     assert res["exchanges_per_proof"]["all_reduce"] == 2 and res["h2d_included"] is True
 
 
+def test_refused_native_communicator_is_reported_and_the_replica_line_still_printed():
+    """`--shard-comm rccl` with both ranks on the one GPU: RCCL refuses the communicator (two ranks on one device). The side
+    measurement must say so in `sharded_proof`, the replica measurement and its JSON line must be unaffected, exit code 0."""
+    out = _run(["--concurrent", "2", "--sharded-workloads", SMALL, "--sharded-timeout", "300", "--shard-comm", "rccl"])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    sp = out["sharded_proof"]
+    err = sp.get("error") or (sp.get("results") or [{}])[0].get("error")
+    assert err, sp
+    assert "RCCL" in err or "rccl" in err or "nccl" in err.lower(), err
+
+
 def test_sharded_mode_two_ranks():
     out = _run(["--mode", "sharded"])
     assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["value"] > 0

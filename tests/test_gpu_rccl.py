@@ -122,3 +122,69 @@ def test_two_ranks_over_rccl_give_the_single_gpu_proof(tmp_path):
         for r in range(2):
             assert (tmp_path / f"proof{r}.{w}.{log_n}").read_bytes() == want
     ctx.close()
+
+
+NEGATIVE_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+import aero_amd
+from aero_amd.shard import RcclComm
+rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+def share(uid):
+    path = os.path.join(d, "id")
+    if rank == 0:
+        with open(path + ".tmp", "wb") as f: f.write(uid)
+        os.replace(path + ".tmp", path)
+        return uid
+    for _ in range(600):
+        if os.path.exists(path): return open(path, "rb").read()
+        time.sleep(0.1)
+    raise SystemExit("no id from rank 0")
+stage = [0]
+def agree(status):            # all-gather of one integer through files: every rank reads every rank's status
+    stage[0] += 1
+    mine = os.path.join(d, f"st{stage[0]}.{rank}")
+    with open(mine + ".tmp", "w") as f: f.write(str(int(status)))
+    os.replace(mine + ".tmp", mine)
+    vals = []
+    for r in range(world):
+        p = os.path.join(d, f"st{stage[0]}.{r}")
+        for _ in range(1200):
+            if os.path.exists(p): break
+            time.sleep(0.1)
+        else:
+            raise SystemExit("peer status missing")
+        vals.append(int(open(p).read()))
+    return min(vals)
+ctx = aero_amd.Context(0)                     # BOTH ranks on device 0
+try:
+    RcclComm(ctx, rank, world, share_id=share, agree=agree)
+except aero_amd.AeroError as e:
+    print("REFUSED", e.code, str(e)[:300], flush=True)
+    ctx.close()
+    sys.exit(0)
+print("CREATED", flush=True)
+sys.exit(3)
+'''
+
+
+def test_two_ranks_on_one_device_are_refused_cleanly_on_both_ranks(tmp_path):
+    """RCCL refuses two ranks of one communicator on the same device. First contact with a multi-GPU node must not find out what
+    a refusal does: both ranks get an AeroError (status + RCCL's text), nobody hangs, the contexts stay usable and close."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "neg.py"
+    script.write_text(NEGATIVE_WORKER % {"root": root})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              cwd=root, stdin=subprocess.DEVNULL) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=240)[0])
+    finally:
+        for p in procs:                                # exactly the processes started here, by handle
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("REFUSED" in o for o in outs), outs

@@ -119,3 +119,64 @@ def test_shard_identities_under_gloo(tmp_path, world):
     assert r["world"] == world
     for rank, checks in enumerate(r["checks"]):
         assert all(checks), f"rank {rank}: (coset LDE, root, subtree, fold locality, constraint-coset selection) = {checks}"
+
+
+# ---- RcclComm's failure agreement (host logic only; the library is replaced by a stand-in: there is no GPU and no second rank here) -----
+class _FakeRcclLib:
+    def __init__(self, preflight_rc=0, create_rc=0):
+        self.preflight_rc, self.create_rc = preflight_rc, create_rc
+        self.created = self.destroyed = 0
+
+        class _Fn:
+            restype = argtypes = None
+
+            def __call__(_self, *_a):
+                return b"stand-in error text"
+        self.aero_rccl_last_error = _Fn()
+
+    def aero_rccl_unique_id(self, buf):
+        return self.preflight_rc
+
+    def aero_rccl_create(self, *a):
+        self.created += 1
+        return self.create_rc
+
+    def aero_rccl_destroy(self, h):
+        self.destroyed += 1
+
+    def aero_rccl_comm(self, *a):
+        return 0
+
+    def aero_rccl_stats(self, h, out):
+        return 0
+
+
+@pytest.mark.parametrize("mine,peer,when", [(0, -4, "preflight"), (-4, 0, "preflight"), (0, -4, "create"), (-5, 0, "create"), (0, 0, None)])
+def test_rccl_comm_raises_on_every_rank_when_one_rank_cannot_join(monkeypatch, mine, peer, when):
+    """A rank that cannot take part (no librccl: status before the collective initialisation; refused ncclCommInitRank: after it)
+    must make its PEERS raise too, instead of leaving them inside RCCL's bootstrap."""
+    import aero_amd
+    from aero_amd import shard
+
+    class Ctx:
+        h = None
+    fake = _FakeRcclLib(preflight_rc=mine if when == "preflight" else 0, create_rc=mine if when == "create" else 0)
+    monkeypatch.setattr(aero_amd, "lib", lambda: fake)
+    calls = []
+
+    def agree(status):            # this rank's status and the peer's: the worst of the two, as an all-gather would give
+        calls.append(status)
+        stage = "preflight" if len(calls) == 1 else "create"
+        return min(status, peer if stage == when else 0)
+    share = lambda uid: uid if uid is not None else bytes(128)
+    if when is None:
+        c = shard.RcclComm(Ctx(), 0, 2, share_id=share, agree=agree)
+        assert calls == [0, 0] and fake.created == 1 and c.h is not None
+        return
+    with pytest.raises(aero_amd.AeroError) as e:
+        shard.RcclComm(Ctx(), 0, 2, share_id=share, agree=agree)
+    assert "not created" in str(e.value)
+    if when == "preflight":
+        assert fake.created == 0 and calls == [mine]              # nobody entered the collective initialisation
+    else:
+        assert fake.created == 1 and fake.destroyed == (1 if mine == 0 else 0)    # a communicator that did come up is released
