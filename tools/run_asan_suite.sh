@@ -6,10 +6,10 @@ mkdir -p $OUT
 export AERO_LIB_PATH=$PWD/build/asan/libaero_stark.so AERO_ORACLE_PATH=$PWD/build/asan/liboracle.so
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=1:abort_on_error=0:log_path=$OUT/report:print_stats=0:handle_abort=1
 export AERO_CRASH_TRACE=1 AERO_CRASH_LOG=$OUT/crash.log AERO_TEST_ORDER=${AERO_TEST_ORDER:-alpha}
-RT=/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so
+RT="/usr/lib/x86_64-linux-gnu/libasan.so.6 /usr/lib/x86_64-linux-gnu/libstdc++.so.6"
 t0=$(date +%s)
 if [ $# -eq 0 ]; then set -- tests/ -q -m gpu -p no:cacheprovider; fi
-LD_PRELOAD=$RT python3 -m pytest "$@" > $OUT/pytest.log 2>&1
+LD_PRELOAD="$RT" python3 -m pytest "$@" > $OUT/pytest.log 2>&1
 echo "rc=$? secs=$(( $(date +%s) - t0 ))" | tee $OUT/summary.txt
 ls -la $OUT
 tail -40 $OUT/pytest.log
