@@ -3,7 +3,9 @@
 
 The surface follows winter-air's `Air` (whose implementation for Miden, ProcessorAir, the reference instantiates at
 aero-sdk/miden-wasm/src/constraints_worker.rs:32-36): transition constraints with a declared `TransitionConstraintDegree`,
-`Assertion::single / periodic`, periodic columns, one auxiliary segment with random elements.
+`Assertion::single / periodic / sequence`, periodic columns, one auxiliary segment with random elements (winter-air 0.4's
+`TraceLayout` holds exactly one auxiliary segment: NUM_AUX_SEGMENTS = 1, and its proof bytes one (width, rands) pair). Programs
+that use a sequence assertion or an affine auxiliary builder are written as AEROAIR version 2, everything else as version 1.
 
     b = AirBuilder(main_width=2, num_pub=1)
     a, bb, na, nb = b.main(0), b.main(1), b.main_next(0), b.main_next(1)
@@ -17,7 +19,7 @@ import struct
 P = 0xFFFFFFFF00000001
 MAGIC = b"AEROAIR\x01"
 OP_ADD, OP_SUB, OP_MUL = 1, 2, 3
-NODE, MAIN_CUR, MAIN_NXT, AUX_CUR, AUX_NXT, PERIODIC, CONST, PUB, RAND = range(9)
+NODE, MAIN_CUR, MAIN_NXT, AUX_CUR, AUX_NXT, PERIODIC, CONST, PUB, RAND, SEQ = range(10)
 NONE = 0xFFFFFFFF
 
 
@@ -60,7 +62,8 @@ class AirBuilder:
         self.nodes, self._node_idx = [], {}
         self.main_trans, self.aux_trans = [], []       # (root ref, degree_base, cycles)
         self.main_asserts, self.aux_asserts = [], []   # (column, first_step, stride, value ref)
-        self.builders = {}                             # aux column -> (init ref, num ref, den ref)
+        self.builders = {}                             # aux column -> (init ref, num ref, den ref, add_num ref, add_den ref)
+        self.sequences = []                            # value lists of the sequence assertions
 
     # ---- operands
     def _ref(self, kind, idx): return Expr(self, (kind << 24) | idx)
@@ -113,6 +116,21 @@ class AirBuilder:
         assert stride >= 2 and stride & (stride - 1) == 0 and 0 <= first_step < stride
         self.main_asserts.append((column, first_step, stride, self._e(value).ref))
 
+    def _sequence(self, first_step, stride, values):
+        vals = [int(v) % P for v in values]
+        assert len(vals) >= 2 and len(vals) & (len(vals) - 1) == 0, "a sequence needs a power-of-two number of values >= 2"
+        assert stride >= 2 and stride & (stride - 1) == 0 and 0 <= first_step < stride
+        self.sequences.append(vals)
+        return (SEQ << 24) | (len(self.sequences) - 1)
+
+    def assert_sequence(self, column, first_step, stride, values):
+        """`Assertion::sequence(column, first_step, stride, values)`: the column equals values[i] at step first_step + i * stride;
+        the trace length must be stride * len(values)."""
+        self.main_asserts.append((column, first_step, stride, self._sequence(first_step, stride, values)))
+
+    def aux_assert_sequence(self, column, first_step, stride, values):
+        self.aux_asserts.append((column, first_step, stride, self._sequence(first_step, stride, values)))
+
     def aux_assert_single(self, column, step, value):
         self.aux_asserts.append((column, step, 0, self._e(value).ref))
 
@@ -120,19 +138,26 @@ class AirBuilder:
         assert stride >= 2 and stride & (stride - 1) == 0 and 0 <= first_step < stride
         self.aux_asserts.append((column, first_step, stride, self._e(value).ref))
 
-    def aux_builder(self, column, init, num, den=None):
-        """aux column(0) = init, column(i+1) = column(i) * num(row i, row i+1) / den(row i, row i+1)."""
-        self.builders[column] = (self._e(init).ref, self._e(num).ref, NONE if den is None else self._e(den).ref)
+    def aux_builder(self, column, init, num=1, den=None, add=None, add_den=None):
+        """aux column(0) = init, column(i+1) = column(i) * num / den + add / add_den, every term evaluated on (row i, row i+1) of the
+        main segment: running products (multiset / permutation arguments), running sums (log-derivative arguments: num = 1,
+        add = multiplicity, add_den = alpha + value) and mixed forms. add / add_den make the program version 2."""
+        assert add is not None or add_den is None
+        self.builders[column] = (self._e(init).ref, self._e(num).ref, NONE if den is None else self._e(den).ref,
+                                 NONE if add is None else self._e(add).ref, NONE if add_den is None else self._e(add_den).ref)
 
     def to_bytes(self):
         nb = len(self.builders)
         assert nb in (0, self.A) and sorted(self.builders) == list(range(nb)), "one aux builder per aux column, or none"
-        out = bytearray(MAGIC)
+        v2 = bool(self.sequences) or any(b[3] != NONE for b in self.builders.values())
+        out = bytearray(b"AEROAIR\x02" if v2 else MAGIC)
         out += struct.pack("<16I", self.W, self.A, self.R, self.num_pub, self.exemptions, len(self.consts), len(self.periodics),
                            len(self.nodes), len(self.main_trans), len(self.aux_trans), len(self.main_asserts), len(self.aux_asserts),
-                           nb, 0, 0, 0)
+                           nb, len(self.sequences), 0, 0)
         out += struct.pack(f"<{len(self.consts)}Q", *self.consts)
         for vals in self.periodics:
+            out += struct.pack(f"<I{len(vals)}Q", len(vals), *vals)
+        for vals in self.sequences:
             out += struct.pack(f"<I{len(vals)}Q", len(vals), *vals)
         for op, a, b in self.nodes:
             out += struct.pack("<3I", op, a, b)
@@ -141,7 +166,7 @@ class AirBuilder:
         for col, first, stride, val in self.main_asserts + self.aux_asserts:
             out += struct.pack("<IiII", col, first, stride, val)
         for c in range(nb):
-            out += struct.pack("<3I", *self.builders[c])
+            out += struct.pack("<5I", *self.builders[c]) if v2 else struct.pack("<3I", *self.builders[c][:3])
         return bytes(out)
 
 

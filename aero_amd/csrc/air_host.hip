@@ -89,6 +89,64 @@ DivisorTables divisor_tables(const Program& p, const Instance& in, uint64_t rows
     if (d.groups.empty()) d.groups.push_back(AirBGroupDev{});
     return d;
 }
+// Sequence assertions (`Assertion::sequence`): the value an asserted column must take varies with the row - it is the polynomial
+// P_m(x w_n^-first) (P_m = interpolant of the assertion's values; winter-air 0.4 BoundaryConstraint, "poly_offset"). For every divisor
+// group that holds such assertions ONE E-valued table over the evaluation domain is built per proof,
+//     T_g(x) = sum_m (alpha_m + beta_m x^adj_g) P_m(x w_n^-first_g),
+// which the evaluation kernels subtract from the group's numerator: deg T_g < ce_n, so it is the transform of a coefficient vector
+// with at most 2 (n / stride) non-zero entries per component (folded modulo x^rows - offset^rows when a rank evaluates a domain
+// smaller than ce_n). groups[j].seq = 1 + index of the group's table (0 = none); returns DEG * (#tables) columns of `rows` entries.
+template <class F>
+const uint64_t* seq_tables(Context* ctx, const Program& p, const Instance& in, uint64_t rows, uint64_t h, const std::vector<typename F::T>& ba,
+                           const std::vector<typename F::T>& bb, std::vector<AirBGroupDev>& groups) {
+    typedef typename F::T T;
+    uint32_t ntab = 0;
+    for (size_t j = 0; j < in.bgroups.size(); j++) if (in.bgroups[j].has_seq) groups[j].seq = ++ntab;
+    if (!ntab) return nullptr;
+    const int lg = ilog2z(rows);
+    std::vector<uint64_t> pos, val;                    // scatter list: destination (bit-reversed index within its column) and value
+    for (size_t j = 0; j < in.bgroups.size(); j++) {
+        if (!in.bgroups[j].has_seq) continue;
+        const BoundaryGroup& bg = in.bgroups[j];
+        std::map<uint64_t, T> bucket;                  // coefficient index mod rows -> sum of c_k offset^k
+        for (size_t m = 0; m < in.members.size(); m++) {
+            const BoundaryMember& bm = in.members[m];
+            if (bm.seq < 0 || bm.group != j) continue;
+            const std::vector<uint64_t> co = sequence_poly(p, (uint32_t)bm.seq, in.log_n, bg.first);
+            uint64_t hk = 1;                                           // offset^k
+            const uint64_t hadj = gl::pow(h, bg.adj);
+            for (size_t k = 0; k < co.size(); k++) {
+                if (co[k]) {
+                    const uint64_t c = gl::mul(co[k], hk);
+                    auto add_to = [&](uint64_t idx, T v) { auto it = bucket.find(idx); if (it == bucket.end()) bucket[idx] = v; else it->second = F::add(it->second, v); };
+                    add_to(k & (rows - 1), F::mulb(ba[bm.coef], c));
+                    add_to((k + bg.adj) & (rows - 1), F::mulb(bb[bm.coef], gl::mul(c, hadj)));
+                }
+                hk = gl::mul(hk, h);
+            }
+        }
+        const uint64_t col0 = (uint64_t)(groups[j].seq - 1) * F::DEG;
+        for (auto& kv : bucket)
+            for (int d = 0; d < F::DEG; d++) {
+                pos.push_back((col0 + d) * rows + gl::bitrev((uint32_t)kv.first, lg));
+                val.push_back(F::comp(kv.second, d));
+            }
+    }
+    const size_t ncols = (size_t)ntab * F::DEG;
+    uint64_t* tab = (uint64_t*)ctx->scratch_alloc(ncols * rows * 8);
+    AERO_HIP(hipMemsetAsync(tab, 0, ncols * rows * 8, ctx->stream));
+    if (!pos.empty()) {
+        // the lists travel through a staging copy of their own (they can exceed the parameter staging block)
+        uint64_t* d_pos = (uint64_t*)ctx->scratch_alloc(pos.size() * 16);
+        uint64_t* d_val = d_pos + pos.size();
+        AERO_HIP(hipMemcpyAsync(d_pos, pos.data(), pos.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        AERO_HIP(hipMemcpyAsync(d_val, val.data(), val.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        launch_air_scatter(ctx, tab, d_pos, d_val, pos.size());
+        ctx->sync();                                   // pos / val are pageable host vectors that die with this frame
+    }
+    ctx->ntt_forward(tab, rows, tab, rows, (int)ncols, lg, 0);       // plain transform: bit-reversed coefficients in, natural order out
+    return tab;
+}
 }  // namespace
 
 template <class F>
@@ -120,13 +178,15 @@ void air_eval_constraints(Context* ctx, const Program& p, const Instance& in, co
             ba[m] = cc.ba[bm.coef];
             bb[m] = F::mulb(cc.bb[bm.coef], hadj[bm.group]);
             mem_group[m] = bm.group;
+            if (bm.seq >= 0) continue;                   // a sequence assertion's value varies with the row: seq_tables() below
             const T val = bm.val_ext ? sc.e[bm.val_idx] : F::from(sc.b[bm.val_idx]);
             gA[bm.group] = F::add(gA[bm.group], F::mul(ba[m], val));
             gB[bm.group] = F::add(gB[bm.group], F::mul(bb[m], val));
         }
     }
     const PeriodicTables pt = periodic_tables(p, in.n, rows, h);
-    const DivisorTables dv = divisor_tables(p, in, rows, h);
+    DivisorTables dv = divisor_tables(p, in, rows, h);
+    const uint64_t* seq_tab = seq_tables<F>(ctx, p, in, rows, h, cc.ba, cc.bb, dv.groups);
     const Pool<F> pool = build_pool<F>(p, p.cons_code, p.cons_desc, sc, pt, cc.ta, tb, nm ? ba : std::vector<T>(), nm ? bb : std::vector<T>(), mem_group);
     std::vector<uint64_t> pdesc;               // the run-time compiled kernel's view of the periodic tables: offset | mask << 32
     for (size_t k = 0; k < pt.off.size(); k++) pdesc.push_back((uint64_t)pt.off[k] | ((uint64_t)pt.mask[k] << 32));
@@ -142,7 +202,7 @@ void air_eval_constraints(Context* ctx, const Program& p, const Instance& in, co
     a.code = pp.ptr<Insn>(i_code); a.pool = pp.ptr<uint64_t>(i_pool); a.slotsB = p.cons_slotsB; a.slotsE = p.cons_slotsE;
     a.ptab = pp.ptr<uint64_t>(i_pt); a.dg_exp = pp.ptr<uint64_t>(i_dg);
     a.bgroups = pp.ptr<AirBGroupDev>(i_bg); a.n_bgroups = (uint32_t)in.bgroups.size();
-    a.gA = pp.ptr<T>(i_ga); a.gB = pp.ptr<T>(i_gb);
+    a.gA = pp.ptr<T>(i_ga); a.gB = pp.ptr<T>(i_gb); a.seq_tab = seq_tab;
     a.tw_lo = tw->lo_fwd; a.tw_hi = tw->hi_fwd; a.tw_h = tw->h; a.offset = h;
     a.zn_inv = pp.ptr<uint64_t>(i_zn); a.xmask = (uint32_t)(rows / in.n) - 1;
     a.exempt = pp.ptr<uint64_t>(i_ex); a.n_exempt = p.exemptions;
@@ -222,9 +282,13 @@ uint64_t air_validate_trace(Context* ctx, const Program& p, const Instance& in, 
     for (auto& v : sc.e) for (int d = 0; d < F::DEG; d++) words.push_back(F::comp(v, d));
     words.push_back(0);
     for (size_t k = 0; k < pt.off.size(); k++) pdesc.push_back((uint64_t)pt.off[k] | ((uint64_t)pt.mask[k] << 32));
+    // the values of the sequence assertions, raw, behind the periodic tables (the validation kernel reads entry (step - first) / stride)
+    std::vector<uint64_t> ptab = pt.tab;
+    for (auto& seq : p.sequences) { pdesc.push_back(ptab.size()); ptab.insert(ptab.end(), seq.begin(), seq.end()); }
+    if (ptab.size() >= (1ull << 32)) fail("air program: tables too large", ST_UNSUPPORTED);
     const std::vector<uint64_t> init{~0ull};
     ParamPack pp(ctx);
-    const size_t i_pool = pp.add(words), i_pt = pp.add(pt.tab), i_pd = pp.add(pdesc), i_flag = pp.add(init);
+    const size_t i_pool = pp.add(words), i_pt = pp.add(ptab), i_pd = pp.add(pdesc), i_flag = pp.add(init);
     pp.commit();
     AirConsArgs<F> a{};
     a.lde = trace_dev; a.aux = aux_dev; a.N = n; a.W = p.W; a.A = aux_dev ? p.A : 0; a.blowup = 1; a.ce_step = 1; a.split_log = 0;

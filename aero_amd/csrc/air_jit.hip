@@ -47,9 +47,10 @@ struct AirJitArgs {      // mirrored in the generated source; every member 8 byt
     uint64_t xmask;
     const uint64_t* exempt;
     uint64_t *out_cols, *out_h0, *out_h1;
+    const uint64_t* seq_tab;
 };
 const char* const ARGS_SRC = R"SRC(
-struct BG { uint64_t a_exp, ha, b, adj_exp; };
+struct BG { uint64_t a_exp, ha, b, adj_exp, seq; };
 struct Args {
     const uint64_t *lde, *aux;
     uint64_t N, blowup, ce_step, split_log, rows, first, count;
@@ -63,6 +64,7 @@ struct Args {
     uint64_t xmask;
     const uint64_t* exempt;
     uint64_t *out_cols, *out_h0, *out_h1;
+    const uint64_t* seq_tab;
 };
 __device__ __forceinline__ uint64_t tw(const Args& a, uint64_t e) { return gl::mul(a.tw_lo[e & ((1ull << a.tw_h) - 1)], a.tw_hi[e >> a.tw_h]); }
 using gl::Wide; using gl::wzero; using gl::wmac; using gl::wreduce;      // 160-bit sums of products (gl_field.hpp)
@@ -283,7 +285,14 @@ struct Gen {
                                                  (DEG > 1 ? "a.aux[" + std::to_string((uint64_t)bm.col * DEG + 1) + "ull * a.N + r])" : std::string("0)"))
                                            : "a.lde[" + std::to_string(bm.col) + "ull * a.N + r]";
             std::string want;
-            if (bm.val_ext) want = pool_e("oSE", bm.val_idx);
+            if (bm.seq >= 0) {
+                // raw values behind the periodic tables (air_validate_trace): entry (s - first) / stride
+                int lgs = 0; while ((1u << lgs) < bg.stride) lgs++;
+                const size_t pd = std::max<size_t>(1, p.periodic.size()) + (size_t)bm.seq;
+                want = "a.ptab[(a.pdesc[" + std::to_string(pd) + "] & 0xffffffffull) + ((s - " + std::to_string(bg.first) + "ull) >> " + std::to_string(lgs) + ")]";
+                if (bm.aux) want = "F::from(" + want + ")";
+            }
+            else if (bm.val_ext) want = pool_e("oSE", bm.val_idx);
             else want = bm.aux ? "F::from(pool[" + std::to_string(bm.val_idx) + "])" : "pool[" + std::to_string(bm.val_idx) + "]";
             o << "        if (ne(" << col << ", " << want << ")) { const unsigned long long e = (s << 24) | " << (0x800000u | m) << "ull; bad = e < bad ? e : bad; }\n    }\n";
         }
@@ -360,9 +369,17 @@ struct Gen {
                 o << "    sa" << j << " = F::add(sa" << j << ", " << wide_value("wsa" + std::to_string(j)) << ");\n";
                 o << "    sb_" << j << " = F::add(sb_" << j << ", " << wide_value("wsb" + std::to_string(j)) << ");\n";
             }
-        for (size_t j = 0; j < ng; j++)
-            o << "    const T num" << j << " = F::add(F::sub(sa" << j << ", " << gpair("gA", j) << "), F::mulb(F::sub(sb_" << j << ", " << gpair("gB", j)
-              << "), tw(a, (s * a.bgroups[" << j << "].adj_exp) & rmask)));\n";
+        for (size_t j = 0, t = 0; j < ng; j++) {
+            std::ostringstream e;
+            e << "F::add(F::sub(sa" << j << ", " << gpair("gA", j) << "), F::mulb(F::sub(sb_" << j << ", " << gpair("gB", j) << "), tw(a, (s * a.bgroups[" << j << "].adj_exp) & rmask)))";
+            if (in.bgroups[j].has_seq) {
+                // sequence assertions of this group: minus the row's entry of the group's value table (air_host.hip: seq_tables)
+                std::ostringstream v;
+                v << "F::make(a.seq_tab[" << t * DEG << "ull * a.rows + s], " << (DEG > 1 ? "a.seq_tab[" + std::to_string(t * DEG + 1) + "ull * a.rows + s]" : std::string("0")) << ")";
+                o << "    const T num" << j << " = F::sub(" << e.str() << ", " << v.str() << ");\n";
+                t++;
+            } else o << "    const T num" << j << " = " << e.str() << ";\n";
+        }
         if (mode == 0) {
             for (int d = 0; d < DEG; d++) o << "    a.out_cols[" << d << "ull * a.count + (s - a.first)] = F::comp(acc, " << d << ");\n";
             for (size_t j = 0; j < ng; j++)
@@ -440,7 +457,7 @@ bool cache_dir_trusted(const char* dir) {
 std::string structure_key(const Program& p, const Instance& in, int DEG, int mode, int R) {
     std::ostringstream k;
     k << DEG << ":" << mode << ":" << R << ":" << in.bgroups.size() << ":";
-    for (auto& m : in.members) k << m.group << ",";
+    for (auto& m : in.members) k << m.group << (m.seq >= 0 ? "s" : "") << ",";
     // the validation kernels carry each boundary group's (stride, first step) as literals, and `first` follows the trace length for
     // steps counted from the end: a second aero_air_validate_trace with another length must not meet the first one's kernel
     if (mode >= 2) for (auto& g : in.bgroups) k << "|" << g.stride << "@" << g.first;
@@ -643,6 +660,7 @@ template <class F> bool launch_air_jit(Context* ctx, const air::Program& p, cons
     a.tw_lo = c.tw_lo; a.tw_hi = c.tw_hi; a.tw_h = (uint64_t)c.tw_h; a.offset = c.offset;
     a.zn_inv = c.zn_inv; a.xmask = c.xmask; a.exempt = c.exempt;
     a.out_cols = c.out_cols; a.out_h0 = c.out_h[0]; a.out_h1 = c.out_h[1];
+    a.seq_tab = c.seq_tab;
     size_t size = sizeof(a);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     const size_t in_cols = (size_t)c.W + (size_t)c.A * F::DEG;

@@ -316,7 +316,11 @@ template <class F, int MODE, int R, int NB> __global__ __launch_bounds__(AIR_WG)
             for (int j = 0; j < NBR; j++) {
                 if ((uint32_t)j >= nb) continue;
                 const T sa = F::sub(gsa[q][j], a.gA[j]), sb = F::sub(gsb[q][j], a.gB[j]);
-                const T gnum = F::add(sa, F::mulb(sb, air_tw(a.tw_lo, a.tw_hi, (s * a.bgroups[j].adj_exp) & rmask, a.tw_h)));
+                T gnum = F::add(sa, F::mulb(sb, air_tw(a.tw_lo, a.tw_hi, (s * a.bgroups[j].adj_exp) & rmask, a.tw_h)));
+                if (a.bgroups[j].seq && active) {      // sequence assertions: the row's share of the values (air_host.hip: seq_tables)
+                    const uint64_t* tp = a.seq_tab + (size_t)(a.bgroups[j].seq - 1) * F::DEG * a.rows + s;
+                    gnum = F::sub(gnum, F::make(tp[0], F::DEG > 1 ? tp[a.rows] : 0));
+                }
                 if (MODE == 0) { if (active) for (int d = 0; d < F::DEG; d++) a.out_cols[(size_t)((1 + j) * F::DEG + d) * a.count + o] = F::comp(gnum, d); }
                 else h = F::add(h, F::mulb(gnum, dinv[q][j]));
             }
@@ -339,7 +343,11 @@ template <class F, int MODE, int R, int NB> __global__ __launch_bounds__(AIR_WG)
                 const uint64_t* gp = ldsG + (size_t)j * 2 * F::DEG * AIR_WG;
                 const T sa = F::sub(F::make(gp[0], F::DEG > 1 ? gp[AIR_WG] : 0), a.gA[j]);
                 const T sb = F::sub(F::make(gp[F::DEG * AIR_WG], F::DEG > 1 ? gp[(F::DEG + 1) * AIR_WG] : 0), a.gB[j]);
-                const T gnum = F::add(sa, F::mulb(sb, air_tw(a.tw_lo, a.tw_hi, (s * a.bgroups[j].adj_exp) & rmask, a.tw_h)));
+                T gnum = F::add(sa, F::mulb(sb, air_tw(a.tw_lo, a.tw_hi, (s * a.bgroups[j].adj_exp) & rmask, a.tw_h)));
+                if (a.bgroups[j].seq && active) {      // sequence assertions: the row's share of the values (air_host.hip: seq_tables)
+                    const uint64_t* tp = a.seq_tab + (size_t)(a.bgroups[j].seq - 1) * F::DEG * a.rows + s;
+                    gnum = F::sub(gnum, F::make(tp[0], F::DEG > 1 ? tp[a.rows] : 0));
+                }
                 if (MODE == 0) { if (active) for (int d = 0; d < F::DEG; d++) a.out_cols[(size_t)((1 + j) * F::DEG + d) * a.count + o] = F::comp(gnum, d); }
                 else { h = F::add(h, F::mulb(gnum, gl::mul(ia, ldsP[j * AIR_WG]))); ia = gl::mul(ia, ldsD[j * AIR_WG]); }
             }
@@ -419,6 +427,16 @@ template <class F> __global__ __launch_bounds__(256) void air_divide_kernel(AirD
     }
     for (int d = 0; d < F::DEG; d++) a.out_h[d][s] = F::comp(h, d);
 }
+__global__ __launch_bounds__(256) void air_scatter_kernel(uint64_t* __restrict__ dst, const uint64_t* __restrict__ pos, const uint64_t* __restrict__ val, size_t count) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) dst[pos[i]] = val[i];
+}
+void launch_air_scatter(Context* ctx, uint64_t* dst, const uint64_t* pos, const uint64_t* val, size_t count) {
+    if (!count) return;
+    AERO_LAUNCH(ctx, "air_scatter_kernel", count * 24, air_scatter_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, dst, pos, val, count);
+    ctx->check_launch("air_scatter");
+}
+
 template <class F> void launch_air_divide(Context* ctx, const AirDivideArgs<F>& a) {
     if (a.n_bgroups > AIR_MAX_BGROUPS) fail("air program: more than 64 boundary divisors", ST_UNSUPPORTED);
     AERO_LAUNCH(ctx, "air_divide_kernel", a.rows * 8 * F::DEG * (2 + a.n_bgroups), (air_divide_kernel<F>), dim3((unsigned)((a.rows + 255) / 256)), dim3(256), 0, a);

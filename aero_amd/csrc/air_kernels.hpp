@@ -13,6 +13,7 @@ struct AirBGroupDev {
     uint64_t ha;         // offset^a
     uint64_t b;
     uint64_t adj_exp;    // adj mod rows (offset^adj is folded into the beta coefficients)
+    uint64_t seq;        // 0, or 1 + index of the group's sequence-assertion table in AirConsArgs::seq_tab (DEG columns of `rows` entries each)
 };
 
 // LOAD descriptor on the device (one u64): bits 0-31 column index (main / aux) or offset into the periodic tables, bits 32-43
@@ -40,6 +41,7 @@ template <class F> struct AirConsArgs {
     const AirBGroupDev* bgroups;
     uint32_t n_bgroups;
     const T *gA, *gB;            // per group: sum alpha_m value_m, sum beta'_m value_m (the assertions' constant parts)
+    const uint64_t* seq_tab;     // row-dependent parts (sequence assertions): table t, component d at seq_tab[((t * DEG) + d) * rows + s]
     // domain
     const uint64_t *tw_lo, *tw_hi;   // two-level table of w_rows
     int tw_h;
@@ -82,6 +84,8 @@ template <class F> struct AirDivideArgs {
     uint64_t* out_h[2];
 };
 template <class F> void launch_air_divide(Context* ctx, const AirDivideArgs<F>& a);
+// dst[pos[i]] = val[i]
+void launch_air_scatter(Context* ctx, uint64_t* dst, const uint64_t* pos, const uint64_t* val, size_t count);
 
 // Auxiliary segment from the program's builders: column c(0) = init_c, c(i+1) = c(i) * num_c(i) / den_c(i).
 template <class F> struct AirAuxArgs {

@@ -41,7 +41,7 @@
 namespace aero {
 namespace air {
 
-enum Kind : uint32_t { K_NODE = 0, K_MAIN_CUR, K_MAIN_NXT, K_AUX_CUR, K_AUX_NXT, K_PERIODIC, K_CONST, K_PUB, K_RAND, K_COUNT };
+enum Kind : uint32_t { K_NODE = 0, K_MAIN_CUR, K_MAIN_NXT, K_AUX_CUR, K_AUX_NXT, K_PERIODIC, K_CONST, K_PUB, K_RAND, K_COUNT, K_SEQ = K_COUNT };   // K_SEQ: value of a sequence assertion only
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
 inline uint32_t ref_kind(uint32_t r) { return r >> 24; }
 inline uint32_t ref_index(uint32_t r) { return r & 0xFFFFFFu; }
@@ -84,13 +84,14 @@ inline bool dkind_is_scalar(uint32_t k) { return k == D_SCAL_B || k == D_SCAL_E;
 struct Node { uint32_t op, a, b; };
 struct Transition { uint32_t root, base; std::vector<uint32_t> cycles; uint32_t group; };
 struct Assertion { uint32_t col; int64_t first; uint32_t stride, value; };
-struct Builder { uint32_t init, num, den; };
+struct Builder { uint32_t init, num, den, add_num = REF_NONE, add_den = REF_NONE; };   // column(i+1) = column(i) * num / den + add_num / add_den
 
 struct Program {
     // ---- as written
     uint32_t W = 0, A = 0, R = 0, num_pub = 0, exemptions = 1;
     std::vector<uint64_t> consts;
     std::vector<std::vector<uint64_t>> periodic;
+    std::vector<std::vector<uint64_t>> sequences;   // version 2: the value lists of `Assertion::sequence` (an assertion's value = K_SEQ | index)
     std::vector<Node> nodes;
     std::vector<Transition> trans;            // main first
     uint32_t n_main_trans = 0;
@@ -407,7 +408,8 @@ struct CodeGen {
 
 inline Program load(const uint8_t* bytes, size_t len) {
     if (!bytes || len < 8 + 64) fail("air program: too short");
-    if (memcmp(bytes, "AEROAIR\x01", 8) != 0) fail("air program: not an AEROAIR version-1 program");
+    if (memcmp(bytes, "AEROAIR", 7) != 0 || (bytes[7] != 1 && bytes[7] != 2)) fail("air program: not an AEROAIR version-1 or version-2 program");
+    const int version = bytes[7];
     detail::Reader rd{bytes, len, 8};
     uint32_t h[16];
     for (auto& v : h) v = rd.u32();
@@ -419,7 +421,9 @@ inline Program load(const uint8_t* bytes, size_t len) {
     if ((p.A == 0) != (p.R == 0) || p.R > 255) fail("air program: an auxiliary segment needs 1..255 random elements (and none without one)");
     if (p.num_pub > 4096) fail("air program: at most 4096 public inputs");
     if (p.exemptions < 1 || p.exemptions > 64) fail("air program: 1..64 transition exemptions");
-    if (h[13] || h[14] || h[15]) fail("air program: reserved header words must be zero");
+    const uint32_t nseq = version >= 2 ? h[13] : 0;
+    if ((version < 2 && h[13]) || h[14] || h[15]) fail("air program: reserved header words must be zero");
+    if (nseq > 4096) fail("air program: at most 4096 sequences", ST_UNSUPPORTED);
     if (nb != 0 && nb != p.A) fail("air program: one aux builder per auxiliary column, or none");
     if (nn > (1u << 22) || nc > (1u << 22) || np > 4096 || (uint64_t)nmt + nat > (1u << 20) || (uint64_t)nma + naa > (1u << 20)) fail("air program: section too large", ST_UNSUPPORTED);
     if (nmt + nat == 0) fail("air program: no transition constraints");
@@ -433,6 +437,14 @@ inline Program load(const uint8_t* bytes, size_t len) {
         std::vector<uint64_t> v(cl);
         for (auto& x : v) x = rd.felt();
         p.periodic.push_back(std::move(v));
+    }
+    for (uint32_t i = 0; i < nseq; i++) {
+        const uint32_t cnt = rd.u32();
+        if (cnt < 2 || (cnt & (cnt - 1)) || cnt > (1u << 28)) fail("air program: a sequence needs a power-of-two number of values >= 2");
+        rd.need((size_t)cnt * 8);
+        std::vector<uint64_t> v(cnt);
+        for (auto& x : v) x = rd.felt();
+        p.sequences.push_back(std::move(v));
     }
     auto check_ref = [&](uint32_t ref, uint32_t node_limit, const char* what) {
         const uint32_t k = ref_kind(ref), i = ref_index(ref);
@@ -483,19 +495,30 @@ inline Program load(const uint8_t* bytes, size_t len) {
         Assertion s;
         s.col = rd.u32(); s.first = (int32_t)rd.u32(); s.stride = rd.u32(); s.value = rd.u32();
         const bool aux = i >= nma;
-        check_ref(s.value, nn, "an assertion");
         if (s.col >= (aux ? p.A : p.W)) fail("air program: assertion column out of range");
-        if (ref_row_dep(p, s.value)) fail("air program: an assertion's value must not depend on the trace or a periodic column");
-        if (!aux && ref_is_ext(p, s.value)) fail("air program: a main assertion's value must be a base-field quantity (constant or public input)");
         if (s.stride && (s.stride < 2 || (s.stride & (s.stride - 1)))) fail("air program: an assertion's stride must be 0 or a power of two >= 2");
+        if (ref_kind(s.value) == K_SEQ) {
+            // `Assertion::sequence(column, first_step, stride, values)`: the column equals values[i] at first_step + i * stride
+            if (ref_index(s.value) >= nseq) fail("air program: sequence index out of range in an assertion");
+            if (!s.stride) fail("air program: a sequence assertion needs a stride");
+        } else {
+            check_ref(s.value, nn, "an assertion");
+            if (ref_row_dep(p, s.value)) fail("air program: an assertion's value must not depend on the trace or a periodic column");
+            if (!aux && ref_is_ext(p, s.value)) fail("air program: a main assertion's value must be a base-field quantity (constant or public input)");
+        }
         (aux ? p.aasserts : p.masserts).push_back(s);
     }
     for (uint32_t i = 0; i < nb; i++) {
-        Builder b{rd.u32(), rd.u32(), rd.u32()};
+        Builder b;
+        b.init = rd.u32(); b.num = rd.u32(); b.den = rd.u32();
+        if (version >= 2) { b.add_num = rd.u32(); b.add_den = rd.u32(); }      // version 2: affine recurrence (running sums, mixed forms)
         check_ref(b.init, nn, "an aux builder"); check_ref(b.num, nn, "an aux builder");
         if (b.den != REF_NONE) check_ref(b.den, nn, "an aux builder");
+        if (b.add_num != REF_NONE) check_ref(b.add_num, nn, "an aux builder");
+        if (b.add_den != REF_NONE) { if (b.add_num == REF_NONE) fail("air program: an aux builder's additive denominator needs a numerator"); check_ref(b.add_den, nn, "an aux builder"); }
         if (ref_row_dep(p, b.init)) fail("air program: an aux builder's initial value must not depend on the trace");
-        if (ref_uses_aux(p, b.num) || (b.den != REF_NONE && ref_uses_aux(p, b.den))) fail("air program: an aux builder's factors may only read the main segment");
+        for (uint32_t r : {b.num, b.den, b.add_num, b.add_den})
+            if (r != REF_NONE && ref_uses_aux(p, r)) fail("air program: an aux builder's terms may only read the main segment");
         p.builders.push_back(b);
     }
     if (rd.off != len) fail("air program: trailing bytes");
@@ -507,7 +530,7 @@ inline Program load(const uint8_t* bytes, size_t len) {
         auto count_use = [&](uint32_t ref) { if (ref != REF_NONE && ref_kind(ref) == K_NODE) node_uses[ref_index(ref)]++; };
         for (auto& nd : p.nodes) { count_use(nd.a); count_use(nd.b); }
         for (auto& t : p.trans) count_use(t.root);
-        for (auto& b : p.builders) { count_use(b.init); count_use(b.num); count_use(b.den); }
+        for (auto& b : p.builders) { count_use(b.init); count_use(b.num); count_use(b.den); count_use(b.add_num); count_use(b.add_den); }
         for (auto* v : {&p.masserts, &p.aasserts}) for (auto& as : *v) count_use(as.value);
         for (uint32_t g = 0; g < p.dgroups.size(); g++) {
             for (uint32_t k = 0; k < p.trans.size(); k++) {
@@ -550,8 +573,8 @@ inline Program load(const uint8_t* bytes, size_t len) {
 // ---- instance: what depends on the trace length -------------------------------------------------------------------------------
 // An assertion as the instance sees it: member id = position in the program (main assertions, then aux); `coef` = its place in
 // the sorted order that hands out the composition coefficients; `group` = its divisor group (numerator column 1 + group).
-struct BoundaryMember { uint32_t col, aux, coef, group, val_ext, val_idx; };   // value = scalB[val_idx] or scalE[val_idx]
-struct BoundaryGroup { uint32_t stride; uint64_t first, a, b, adj; };
+struct BoundaryMember { uint32_t col, aux, coef, group, val_ext, val_idx; int32_t seq = -1; };   // value = scalB[val_idx] or scalE[val_idx]; seq >= 0: sequences[seq]
+struct BoundaryGroup { uint32_t stride; uint64_t first, a, b, adj; bool has_seq = false; };
 struct Instance {
     int log_n = 0;
     uint64_t n = 0, ce_n = 0;
@@ -604,6 +627,15 @@ inline Instance instantiate(const Program& p, int log_n) {
                 bg.b = gl::pow(g, bg.first * bg.a);
                 bg.adj = (in.ce_n - 1 + bg.a) - (n - 1);
                 in.bgroups.push_back(bg);
+            }
+            if (ref_kind(s.value) == K_SEQ) {
+                // values at first + i * stride for i < n / stride: the interpolant of the values at x * w_n^-first (winter-air 0.4, boundary constraint "poly_offset")
+                if ((uint64_t)p.sequences[ref_index(s.value)].size() * s.stride != n) fail("air program: a sequence assertion needs stride * number of values = trace length");
+                BoundaryMember bm{s.col, (uint32_t)seg, coef++, (uint32_t)j, 0u, 0u};
+                bm.seq = (int32_t)ref_index(s.value);
+                in.members[it.id] = bm;
+                in.bgroups[j].has_seq = true;
+                continue;
             }
             const DOperand val = device_operand(p, s.value);     // row-independent: a scalar
             in.members[it.id] = BoundaryMember{s.col, (uint32_t)seg, coef++, (uint32_t)j, val.kind == D_SCAL_E ? 1u : 0u, val.idx};
@@ -676,13 +708,39 @@ inline std::vector<uint64_t> periodic_table(const std::vector<uint64_t>& cycle, 
     return t;
 }
 
+// Coefficients (natural order) of the value polynomial of sequence `k` in the variable x: P(x w_n^-first) with P the interpolant of the
+// values over the subgroup of their own size - i.e. coefficient j of P times w_n^(-first j).
+inline std::vector<uint64_t> sequence_poly(const Program& p, uint32_t k, int log_n, uint64_t first) {
+    std::vector<uint64_t> co = p.sequences[k];
+    host_ntt(co, true);
+    if (first) {
+        const uint64_t gi = gl::inv(gl::pow(gl::root_of_unity(log_n), first));
+        uint64_t sc = 1;
+        for (auto& c : co) { c = gl::mul(c, sc); sc = gl::mul(sc, gi); }
+    }
+    return co;
+}
+// value of every sequence assertion at the point x (0 for the other members): what host_evaluate takes as seq_at_x
+template <class F> std::vector<typename F::T> sequence_values_at(const Program& p, const Instance& in, typename F::T x) {
+    std::vector<typename F::T> out(in.members.size(), F::zero());
+    for (size_t m = 0; m < in.members.size(); m++) {
+        const BoundaryMember& bm = in.members[m];
+        if (bm.seq < 0) continue;
+        const std::vector<uint64_t> co = sequence_poly(p, (uint32_t)bm.seq, in.log_n, in.bgroups[bm.group].first);
+        typename F::T acc = F::zero();
+        for (size_t i = co.size(); i-- > 0;) acc = F::add(F::mul(acc, x), F::from(co[i]));
+        out[m] = acc;
+    }
+    return out;
+}
+
 // ---- host execution of the compiled constraint program over E (the verifier's out-of-domain check) ------------------------------
 // Frame, periodic values and x are E-valued; `xpow(e)` returns x^e. Returns the numerator of every column.
 template <class F>
 std::vector<typename F::T> host_evaluate(const Program& p, const Instance& in, const Scalars<F>& sc, const typename F::T* cur, const typename F::T* nxt,
                                          const std::vector<typename F::T>& per, const std::vector<typename F::T>& ta, const std::vector<typename F::T>& tb,
                                          const std::vector<typename F::T>& ba, const std::vector<typename F::T>& bb,
-                                         const std::function<typename F::T(uint64_t)>& xpow) {
+                                         const std::function<typename F::T(uint64_t)>& xpow, const std::vector<typename F::T>& seq_at_x = {}) {
     typedef typename F::T T;
     std::vector<T> slotB(p.cons_slotsB, F::zero()), slotE(p.cons_slotsE, F::zero());
     auto fetch = [&](uint32_t kind, uint32_t idx) -> T {
@@ -754,8 +812,11 @@ std::vector<typename F::T> host_evaluate(const Program& p, const Instance& in, c
     }
     out[0] = F::add(total, acc_a);
     // the assertions' values: sum (alpha + beta x^adj)(v - value) = [sa - sum alpha value] + x^adj [sb - sum beta value]
-    for (const BoundaryMember& bm : in.members) {
-        const T val = bm.val_ext ? sc.e[bm.val_idx] : F::from(sc.b[bm.val_idx]);
+    for (size_t m = 0; m < in.members.size(); m++) {
+        const BoundaryMember& bm = in.members[m];
+        // sequence assertions: the value polynomial at the point (seq_at_x[member], see sequence_value_at)
+        if (bm.seq >= 0 && seq_at_x.size() != in.members.size()) fail("air program: sequence values missing", ST_INTERNAL);
+        const T val = bm.seq >= 0 ? seq_at_x[m] : bm.val_ext ? sc.e[bm.val_idx] : F::from(sc.b[bm.val_idx]);
         gsa[bm.group] = F::sub(gsa[bm.group], F::mul(ba[bm.coef], val));
         gsb[bm.group] = F::sub(gsb[bm.group], F::mul(bb[bm.coef], val));
     }

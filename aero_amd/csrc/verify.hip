@@ -186,7 +186,7 @@ template <class F> void verify_impl(const Parsed& pr, const std::vector<uint64_t
         }
         const air::Scalars<F> sc = air::fold_scalars<F>(*prog, pub.data(), rands.data());
         const std::vector<T> num = air::host_evaluate<F>(*prog, pinst, sc, ood_cur.data(), ood_next.data(), per, ta, tb, ba, bb,
-                                                         [&](uint64_t e) { return gl::fpow<F>(z, e); });
+                                                         [&](uint64_t e) { return gl::fpow<F>(z, e); }, air::sequence_values_at<F>(*prog, pinst, z));
         T tdiv = F::inv(F::sub(gl::fpow<F>(z, n), F::one()));
         for (uint32_t i = 1; i <= prog->exemptions; i++) tdiv = F::mul(tdiv, F::sub(z, F::from(gl::pow(g, n - i))));
         T lhs = F::mul(num[0], tdiv);

@@ -14,7 +14,11 @@
 //   * assertions sorted by (stride, first_step, column) take the boundary coefficients in that order, main then aux; one divisor per
 //     (stride, first_step): x - w^step or x^(n/stride) - w^(step n/stride); adj = (ce_n - 1 + deg(divisor)) - (n - 1); aux
 //     assertions join the main group with the same divisor, otherwise form a new column behind the main ones;
-//   * periodic columns are the interpolants of one cycle evaluated at x^(n/cycle).
+//   * periodic columns are the interpolants of one cycle evaluated at x^(n/cycle);
+//   * `Assertion::sequence(column, first_step, stride, values)` (AEROAIR version 2): winter-air 0.4 `BoundaryConstraint::new` interpolates
+//     the values over the subgroup of their own size and evaluates the polynomial at x * g^-first_step ("poly_offset"): the
+//     constraint's numerator is column(x) - P(x g^-first), its divisor the periodic one for (stride, first_step);
+//   * auxiliary builders of version 2 are affine recurrences column(i+1) = column(i) * num / den + add_num / add_den.
 // This interpreter is deliberately naive (every node evaluated in E per row, exponentiations by square-and-multiply): it shares no
 // code and no evaluation strategy with aero_amd/csrc/air_program.hpp / air_kernels.hip.
 #pragma once
@@ -25,12 +29,13 @@ namespace orc {
 
 struct ProgramAir {
     enum { KNOWN = 1 };
-    enum { K_NODE = 0, K_MAIN_CUR, K_MAIN_NXT, K_AUX_CUR, K_AUX_NXT, K_PERIODIC, K_CONST, K_PUB, K_RAND };
+    enum { K_NODE = 0, K_MAIN_CUR, K_MAIN_NXT, K_AUX_CUR, K_AUX_NXT, K_PERIODIC, K_CONST, K_PUB, K_RAND, K_SEQ };
     static const uint32_t NONE = 0xFFFFFFFFu;
     // ---- the program as written
     uint32_t W = 0, A = 0, R = 0, num_pub = 0, exemptions = 1;
     Col consts;
     std::vector<Col> periodic;
+    std::vector<Col> sequences;        // version 2: value lists of `Assertion::sequence`
     struct Node { uint32_t op, a, b; };
     std::vector<Node> nodes;
     std::vector<uint8_t> node_deps;    // bit 0: depends on the auxiliary frame, bit 1: on the random elements
@@ -39,7 +44,7 @@ struct ProgramAir {
     size_t n_main_trans = 0;
     struct Assertion { uint32_t col; int64_t first; uint32_t stride, value; };
     std::vector<Assertion> masserts, aasserts;
-    struct Builder { uint32_t init, num, den; };
+    struct Builder { uint32_t init, num, den, add_num, add_den; };
     std::vector<Builder> builders;
     // ---- the instance (bind)
     int log_n = 0;
@@ -50,6 +55,7 @@ struct ProgramAir {
     struct Group { uint32_t stride; uint64_t first; uint64_t a, b, adj; std::vector<Member> members; };
     std::vector<Group> groups;         // one per distinct boundary divisor, in column order
     std::vector<Col> ppoly;            // periodic columns: interpolant coefficients
+    std::vector<Col> spoly;            // sequences: interpolant of the values over the subgroup of their size
 
     size_t n() const { return (size_t)1 << log_n; }
     size_t num_transition() const { return trans.size(); }
@@ -67,7 +73,8 @@ struct ProgramAir {
         auto u32 = [&]() { need(4); uint32_t v; memcpy(&v, p + off, 4); off += 4; return v; };
         auto u64 = [&]() { need(8); uint64_t v; memcpy(&v, p + off, 8); off += 8; if (v >= P) throw Err("air program: non-canonical element"); return v; };
         need(8);
-        if (memcmp(p, "AEROAIR\x01", 8) != 0) throw Err("air program: bad magic");
+        if (memcmp(p, "AEROAIR", 7) != 0 || (p[7] != 1 && p[7] != 2)) throw Err("air program: bad magic");
+        const int version = p[7];
         off = 8;
         uint32_t h[16];
         for (auto& v : h) v = u32();
@@ -76,6 +83,8 @@ struct ProgramAir {
         const uint32_t nc = h[5], np = h[6], nn = h[7], nmt = h[8], nat = h[9], nma = h[10], naa = h[11], nb = h[12];
         if (a.W < 1 || a.W > 255 || a.A > 255 - a.W || (a.A == 0) != (a.R == 0) || a.R > 255 || a.exemptions < 1) throw Err("air program: bad header");
         if (nb != 0 && nb != a.A) throw Err("air program: one builder per aux column or none");
+        const uint32_t nseq = version >= 2 ? h[13] : 0;
+        if ((version < 2 && h[13]) || h[14] || h[15]) throw Err("air program: reserved header words");
         if ((size_t)nc * 8 + (size_t)nn * 12 > len) throw Err("air program: truncated");
         for (uint32_t i = 0; i < nc; i++) a.consts.push_back(u64());
         for (uint32_t i = 0; i < np; i++) {
@@ -84,6 +93,13 @@ struct ProgramAir {
             Col v(cl);
             for (auto& x : v) x = u64();
             a.periodic.push_back(v);
+        }
+        for (uint32_t i = 0; i < nseq; i++) {
+            uint32_t cnt = u32();
+            if (cnt < 2 || (cnt & (cnt - 1)) || (size_t)cnt * 8 > len) throw Err("air program: bad sequence");
+            Col v(cnt);
+            for (auto& x : v) x = u64();
+            a.sequences.push_back(v);
         }
         auto check_ref = [&](uint32_t ref, uint32_t node_limit) {
             const uint32_t k = kind(ref), i = index(ref);
@@ -115,14 +131,18 @@ struct ProgramAir {
         }
         for (uint32_t i = 0; i < nma + naa; i++) {
             Assertion s; s.col = u32(); s.first = (int32_t)u32(); s.stride = u32(); s.value = u32();
-            check_ref(s.value, nn);
+            if (kind(s.value) == K_SEQ) { if (index(s.value) >= nseq || !s.stride) throw Err("air program: bad sequence assertion"); }
+            else check_ref(s.value, nn);
             if (s.col >= (i < nma ? a.W : a.A)) throw Err("air program: assertion column out of range");
             (i < nma ? a.masserts : a.aasserts).push_back(s);
         }
         for (uint32_t i = 0; i < nb; i++) {
-            Builder b{u32(), u32(), u32()};
+            Builder b{u32(), u32(), u32(), NONE, NONE};
+            if (version >= 2) { b.add_num = u32(); b.add_den = u32(); }
             check_ref(b.init, nn); check_ref(b.num, nn);
             if (b.den != NONE) check_ref(b.den, nn);
+            if (b.add_num != NONE) check_ref(b.add_num, nn);
+            if (b.add_den != NONE) { if (b.add_num == NONE) throw Err("air program: builder denominator without a numerator"); check_ref(b.add_den, nn); }
             a.builders.push_back(b);
         }
         if (off != len) throw Err("air program: trailing bytes");
@@ -149,6 +169,8 @@ struct ProgramAir {
         for (auto& v : periodic) if (v.size() > n_) throw Err("air program: periodic cycle longer than the trace");
         ppoly.clear();
         for (auto& v : periodic) { Col c = v; intt(c.data(), c.size()); ppoly.push_back(c); }
+        spoly.clear();
+        for (auto& v : sequences) { Col c = v; intt(c.data(), c.size()); spoly.push_back(c); }
         // assertions: resolve steps, sort, hand out coefficients, group by divisor
         const uint64_t g = gl_root_of_unity(log_n);
         groups.clear();
@@ -159,6 +181,7 @@ struct ProgramAir {
                 if (s.first < 0) s.first += (int64_t)n_;
                 if (s.first < 0 || (uint64_t)s.first >= n_) throw Err("air program: assertion step out of range");
                 if (s.stride && (s.stride < 2 || (s.stride & (s.stride - 1)) || s.stride >= n_ || (uint64_t)s.first >= s.stride)) throw Err("air program: bad assertion stride");
+                if (kind(s.value) == K_SEQ && (uint64_t)sequences[index(s.value)].size() * s.stride != n_) throw Err("air program: a sequence assertion needs stride * values = trace length");
             }
             std::stable_sort(v.begin(), v.end(), [](const Assertion& x, const Assertion& y) {
                 if (x.stride != y.stride) return x.stride < y.stride;
@@ -241,7 +264,15 @@ struct ProgramAir {
             T s = F::zero();
             for (auto& m : groups[j].members) {
                 const T v = m.aux ? acur[m.col] : mcur[m.col];
-                s = F::add(s, F::mul(F::add(cc.ba[m.coef], F::mul(cc.bb[m.coef], xp)), F::sub(v, operand<F>(m.value, f, vals))));
+                T want;
+                if (kind(m.value) == K_SEQ) {
+                    // P(x g^-first): P interpolates the values over the subgroup of their own size (w_n^stride generates it)
+                    const Col& pc = spoly[index(m.value)];
+                    const T y = F::mulb(x, gl_inv(gl_pow(gl_root_of_unity(log_n), groups[j].first)));
+                    want = F::zero();
+                    for (size_t i = pc.size(); i-- > 0;) want = F::add(F::mul(want, y), F::from(pc[i]));
+                } else want = operand<F>(m.value, f, vals);
+                s = F::add(s, F::mul(F::add(cc.ba[m.coef], F::mul(cc.bb[m.coef], xp)), F::sub(v, want)));
             }
             out[1 + j] = s;
         }
@@ -304,7 +335,8 @@ struct ProgramAir {
         typedef typename F::T T;
         if (builders.size() != A) throw Err("air program: no aux builders, the auxiliary columns cannot be constructed");
         const size_t n_ = n();
-        std::vector<std::vector<T>> mult(A, std::vector<T>(n_));
+        std::vector<std::vector<T>> mult(A, std::vector<T>(n_)), addv(A);
+        for (uint32_t c = 0; c < A; c++) if (builders[c].add_num != NONE) addv[c].assign(n_, F::zero());
         std::vector<T> init(A);
 #pragma omp parallel
         {
@@ -320,6 +352,11 @@ struct ProgramAir {
                     T m = operand<F>(builders[c].num, f, vals);
                     if (builders[c].den != NONE) m = F::mul(m, F::inv(operand<F>(builders[c].den, f, vals)));
                     mult[c][i] = m;
+                    if (builders[c].add_num != NONE) {
+                        T t = operand<F>(builders[c].add_num, f, vals);
+                        if (builders[c].add_den != NONE) t = F::mul(t, F::inv(operand<F>(builders[c].add_den, f, vals)));
+                        addv[c][i] = t;
+                    }
                     if (i == 0) init[c] = operand<F>(builders[c].init, f, vals);
                 }
             }
@@ -330,6 +367,7 @@ struct ProgramAir {
             for (size_t i = 0; i < n_; i++) {
                 for (int k = 0; k < F::DEG; k++) acols[c * F::DEG + k][i] = F::comp(p, k);
                 p = F::mul(p, mult[c][i]);
+                if (!addv[c].empty()) p = F::add(p, addv[c][i]);
             }
         }
     }
