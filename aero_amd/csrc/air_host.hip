@@ -259,14 +259,14 @@ void air_build_aux(Context* ctx, const Program& p, const uint64_t* trace_dev, in
     }
     const Pool<F> pool = build_pool<F>(p, p.aux_code, p.aux_desc, sc, pt, {}, {}, {}, {}, {});
     ParamPack pp(ctx);
-    const size_t i_code = pp.add(pool.code), i_pool = pp.add(pool.words), i_pt = pp.add(pt.tab), i_hd = pp.add(p.has_den), i_in = pp.add(init);
+    const size_t i_code = pp.add(pool.code), i_pool = pp.add(pool.words), i_pt = pp.add(pt.tab), i_hd = pp.add(p.has_den), i_in = pp.add(init), i_ha = pp.add(p.has_add);
     pp.commit();
     AirAuxArgs<F> a{};
     a.trace = trace_dev; a.n = n; a.W = p.W; a.A = p.A;
     a.code = pp.ptr<Insn>(i_code); a.pool = pp.ptr<uint64_t>(i_pool); a.slotsB = p.aux_slotsB; a.slotsE = p.aux_slotsE;
     a.ptab = pp.ptr<uint64_t>(i_pt);
-    a.has_den = pp.ptr<uint8_t>(i_hd); a.init = pp.ptr<T>(i_in); a.out = out;
-    launch_air_aux<F>(ctx, a, p.has_den);
+    a.has_den = pp.ptr<uint8_t>(i_hd); a.has_add = pp.ptr<uint8_t>(i_ha); a.init = pp.ptr<T>(i_in); a.out = out;
+    launch_air_aux<F>(ctx, a, p.has_den, p.has_add);
 }
 template void air_build_aux<FB>(Context*, const Program&, const uint64_t*, int, const uint64_t*, const uint64_t*, uint64_t*);
 template void air_build_aux<FQ>(Context*, const Program&, const uint64_t*, int, const uint64_t*, const gl::E2*, uint64_t*);

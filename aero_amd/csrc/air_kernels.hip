@@ -500,11 +500,11 @@ template <class F> __device__ __forceinline__ typename F::T air_fac_at(const uin
     return F::make(fac[o], F::DEG > 1 ? fac[o + n] : 0);
 }
 // grid (blocks, 2A): product of each block's rows of factor column j
-template <class F> __global__ __launch_bounds__(256) void air_fac_totals_kernel(const uint64_t* fac, size_t n, const uint8_t* has_den, typename F::T* totals) {
+template <class F> __global__ __launch_bounds__(256) void air_fac_totals_kernel(const uint64_t* fac, size_t n, const uint8_t* has_den, const uint8_t* has_add, typename F::T* totals) {
     typedef typename F::T T;
     __shared__ T sh[256];
     const uint32_t j = blockIdx.y;
-    if ((j & 1) && !has_den[j >> 1]) return;
+    if (((j & 1) && !has_den[j >> 1]) || has_add[j >> 1]) return;        // affine columns take their own path (air_aff_*)
     const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_K;
     T p = F::one();
 #pragma unroll
@@ -513,11 +513,11 @@ template <class F> __global__ __launch_bounds__(256) void air_fac_totals_kernel(
     if (threadIdx.x == 255) totals[(size_t)j * gridDim.x + blockIdx.x] = inc;
 }
 // in place: totals[j][b] <- product of totals[j][0..b) (one workgroup per factor column)
-template <class F> __global__ __launch_bounds__(256) void air_scan_totals_kernel(typename F::T* totals, uint32_t nblk, const uint8_t* has_den) {
+template <class F> __global__ __launch_bounds__(256) void air_scan_totals_kernel(typename F::T* totals, uint32_t nblk, const uint8_t* has_den, const uint8_t* has_add) {
     typedef typename F::T T;
     __shared__ T sh[256];
     const uint32_t j = blockIdx.x;
-    if ((j & 1) && !has_den[j >> 1]) return;
+    if (((j & 1) && !has_den[j >> 1]) || has_add[j >> 1]) return;
     T* row = totals + (size_t)j * nblk;
     const uint32_t per = (nblk + 255) / 256, lo = threadIdx.x * per;
     T p = F::one();
@@ -527,11 +527,12 @@ template <class F> __global__ __launch_bounds__(256) void air_scan_totals_kernel
     for (uint32_t i = lo; i < lo + per && i < nblk; i++) { const T v = row[i]; row[i] = run; run = F::mul(run, v); }
 }
 // grid (blocks, A): column c = init * prefix(num) / prefix(den)
-template <class F> __global__ __launch_bounds__(256) void air_fac_apply_kernel(const uint64_t* fac, size_t n, const uint8_t* has_den, const typename F::T* init,
-                                                                            const typename F::T* totals, uint64_t* out) {
+template <class F> __global__ __launch_bounds__(256) void air_fac_apply_kernel(const uint64_t* fac, size_t n, const uint8_t* has_den, const uint8_t* has_add,
+                                                                            const typename F::T* init, const typename F::T* totals, uint64_t* out) {
     typedef typename F::T T;
     __shared__ T sh[256];
     const uint32_t c = blockIdx.y;
+    if (has_add[c]) return;
     const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_K;
     T fn[SCAN_K];
     T p = F::one();
@@ -562,11 +563,120 @@ template <class F> __global__ __launch_bounds__(256) void air_fac_apply_kernel(c
         if (first + k < n)
             for (int d = 0; d < F::DEG; d++) out[((size_t)c * F::DEG + d) * n + first + k] = F::comp(val[k], d);
 }
-template <class F> void launch_air_aux(Context* ctx, const AirAuxArgs<F>& a, const std::vector<uint8_t>& has_den_host) {
+// ---- affine builders (AEROAIR version 2): column(i + 1) = column(i) * m_i + t_i with m_i = num_i / den_i, t_i = add_i / add_den_i.
+// Row maps x -> m x + t compose associatively, (m2, t2) o (m1, t1) = (m1 m2, t1 m2 + t2), so the column is a prefix scan over pairs -
+// the running product above is the special case t = 0. Step 0 turns the factor columns of an affine column into m and t (in
+// place: one inversion per lane for the up to 2 SCAN_K denominators of its rows); then block totals, scan of the totals, apply.
+template <class F> struct AffPair { typename F::T m, t; };
+template <class F> __device__ __forceinline__ AffPair<F> aff_then(const AffPair<F>& first, const AffPair<F>& second) {      // second o first
+    return AffPair<F>{F::mul(first.m, second.m), F::add(F::mul(first.t, second.m), second.t)};
+}
+template <class F> __device__ __forceinline__ AffPair<F> air_wg_scan_aff(AffPair<F> v, typename F::T* shm, typename F::T* sht) {   // inclusive, 256 lanes
+    const int t = threadIdx.x;
+    shm[t] = v.m; sht[t] = v.t;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        AffPair<F> u{shm[t], sht[t]};
+        if (t >= off) u = aff_then<F>(AffPair<F>{shm[t - off], sht[t - off]}, u);
+        __syncthreads();
+        shm[t] = u.m; sht[t] = u.t;
+        __syncthreads();
+    }
+    return AffPair<F>{shm[t], sht[t]};
+}
+template <class F> __device__ __forceinline__ void air_fac_put(uint64_t* fac, size_t n, uint32_t j, size_t i, typename F::T v) {
+    const size_t o = (size_t)(j * F::DEG) * n + i;
+    for (int d = 0; d < F::DEG; d++) fac[o + (size_t)d * n] = F::comp(v, d);
+}
+// grid (blocks, A): factor columns of an affine column -> m (in column 2c) and t (in column 2A + 2c)
+template <class F> __global__ __launch_bounds__(256) void air_aff_ratio_kernel(uint64_t* fac, size_t n, uint32_t A, const uint8_t* has_den, const uint8_t* has_add) {
+    typedef typename F::T T;
+    const uint32_t c = blockIdx.y;
+    if (!has_add[c]) return;
+    const bool hd = has_den[c], ad = has_add[c] & 2;
+    if (!hd && !ad) return;
+    const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_K;
+    T den[2 * SCAN_K], pre[2 * SCAN_K];
+    T run = F::one();
+#pragma unroll
+    for (int k = 0; k < SCAN_K; k++) {
+        den[k] = hd ? air_fac_at<F>(fac, n, 2 * c + 1, first + k) : F::one();
+        den[SCAN_K + k] = ad ? air_fac_at<F>(fac, n, 2 * A + 2 * c + 1, first + k) : F::one();
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * SCAN_K; k++) { pre[k] = run; run = F::mul(run, den[k]); }
+    T inv = F::inv(run);
+#pragma unroll
+    for (int k = 2 * SCAN_K - 1; k >= 0; k--) { const T di = F::mul(inv, pre[k]); inv = F::mul(inv, den[k]); den[k] = di; }     // den[k] <- 1 / den[k]
+#pragma unroll
+    for (int k = 0; k < SCAN_K; k++) {
+        if (first + k >= n) continue;
+        if (hd) air_fac_put<F>(fac, n, 2 * c, first + k, F::mul(air_fac_at<F>(fac, n, 2 * c, first + k), den[k]));
+        if (ad) air_fac_put<F>(fac, n, 2 * A + 2 * c, first + k, F::mul(air_fac_at<F>(fac, n, 2 * A + 2 * c, first + k), den[SCAN_K + k]));
+    }
+}
+template <class F> __device__ __forceinline__ AffPair<F> air_aff_at(const uint64_t* fac, size_t n, uint32_t A, uint32_t c, size_t i) {
+    if (i >= n) return AffPair<F>{F::one(), F::zero()};
+    const size_t om = (size_t)(2 * c * F::DEG) * n + i, ot = (size_t)((2 * A + 2 * c) * F::DEG) * n + i;
+    return AffPair<F>{F::make(fac[om], F::DEG > 1 ? fac[om + n] : 0), F::make(fac[ot], F::DEG > 1 ? fac[ot + n] : 0)};
+}
+// grid (blocks, A): composition of each block's rows; totals[c][b] = (m, t)
+template <class F> __global__ __launch_bounds__(256) void air_aff_totals_kernel(const uint64_t* fac, size_t n, uint32_t A, const uint8_t* has_add, AffPair<F>* totals) {
+    typedef typename F::T T;
+    __shared__ T shm[256], sht[256];
+    const uint32_t c = blockIdx.y;
+    if (!has_add[c]) return;
+    const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_K;
+    AffPair<F> p{F::one(), F::zero()};
+#pragma unroll
+    for (int k = 0; k < SCAN_K; k++) p = aff_then<F>(p, air_aff_at<F>(fac, n, A, c, first + k));
+    const AffPair<F> inc = air_wg_scan_aff<F>(p, shm, sht);
+    if (threadIdx.x == 255) totals[(size_t)c * gridDim.x + blockIdx.x] = inc;
+}
+// in place: totals[c][b] <- composition of totals[c][0..b) (one workgroup per column)
+template <class F> __global__ __launch_bounds__(256) void air_aff_scan_totals_kernel(AffPair<F>* totals, uint32_t nblk, const uint8_t* has_add) {
+    typedef typename F::T T;
+    __shared__ T shm[256], sht[256];
+    const uint32_t c = blockIdx.x;
+    if (!has_add[c]) return;
+    AffPair<F>* row = totals + (size_t)c * nblk;
+    const uint32_t per = (nblk + 255) / 256, lo = threadIdx.x * per;
+    AffPair<F> p{F::one(), F::zero()};
+    for (uint32_t i = lo; i < lo + per && i < nblk; i++) p = aff_then<F>(p, row[i]);
+    air_wg_scan_aff<F>(p, shm, sht);
+    AffPair<F> run = threadIdx.x == 0 ? AffPair<F>{F::one(), F::zero()} : AffPair<F>{shm[threadIdx.x - 1], sht[threadIdx.x - 1]};
+    for (uint32_t i = lo; i < lo + per && i < nblk; i++) { const AffPair<F> v = row[i]; row[i] = run; run = aff_then<F>(run, v); }
+}
+// grid (blocks, A): column c(i) = (prefix map up to row i)(init)
+template <class F> __global__ __launch_bounds__(256) void air_aff_apply_kernel(const uint64_t* fac, size_t n, uint32_t A, const uint8_t* has_add, const typename F::T* init,
+                                                                            const AffPair<F>* totals, uint64_t* out) {
+    typedef typename F::T T;
+    __shared__ T shm[256], sht[256];
+    const uint32_t c = blockIdx.y;
+    if (!has_add[c]) return;
+    const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_K;
+    AffPair<F> f[SCAN_K];
+    AffPair<F> p{F::one(), F::zero()};
+#pragma unroll
+    for (int k = 0; k < SCAN_K; k++) { f[k] = air_aff_at<F>(fac, n, A, c, first + k); p = aff_then<F>(p, f[k]); }
+    air_wg_scan_aff<F>(p, shm, sht);
+    AffPair<F> before = totals[(size_t)c * gridDim.x + blockIdx.x];
+    if (threadIdx.x) before = aff_then<F>(before, AffPair<F>{shm[threadIdx.x - 1], sht[threadIdx.x - 1]});
+    T x = F::add(F::mul(init[c], before.m), before.t);
+#pragma unroll
+    for (int k = 0; k < SCAN_K; k++) {
+        if (first + k < n)
+            for (int d = 0; d < F::DEG; d++) out[((size_t)c * F::DEG + d) * n + first + k] = F::comp(x, d);
+        x = F::add(F::mul(x, f[k].m), f[k].t);
+    }
+}
+template <class F> void launch_air_aux(Context* ctx, const AirAuxArgs<F>& a, const std::vector<uint8_t>& has_den_host, const std::vector<uint8_t>& has_add_host) {
     typedef typename F::T T;
     const size_t n = a.n;
     const uint32_t A = a.A;
-    uint64_t* fac = (uint64_t*)ctx->scratch_alloc((size_t)2 * A * F::DEG * n * 8);
+    bool any_affine = false, any_product = false;
+    for (uint32_t c = 0; c < A; c++) { if (c < has_add_host.size() && has_add_host[c]) any_affine = true; else any_product = true; }
+    uint64_t* fac = (uint64_t*)ctx->scratch_alloc((size_t)(any_affine ? 4 : 2) * A * F::DEG * n * 8);
     const size_t slots = (size_t)a.slotsB + (size_t)a.slotsE * F::DEG;
     const size_t lds = (slots ? slots : 1) * AIR_WG * 8;
     air_set_lds((const void*)air_aux_factors_kernel<F>, lds);
@@ -574,12 +684,21 @@ template <class F> void launch_air_aux(Context* ctx, const AirAuxArgs<F>& a, con
     const uint32_t nblk = (uint32_t)((n + (size_t)SCAN_K * 256 - 1) / ((size_t)SCAN_K * 256));
     T* totals = (T*)ctx->scratch_alloc(sizeof(T) * (size_t)2 * A * nblk);
     (void)has_den_host;
-    AERO_LAUNCH(ctx, "air_aux_kernel", (size_t)A * n * 8 * F::DEG, (air_fac_totals_kernel<F>), dim3(nblk, 2 * A), dim3(256), 0, fac, n, a.has_den, totals);
-    AERO_LAUNCH(ctx, "air_aux_kernel", 0, (air_scan_totals_kernel<F>), dim3(2 * A), dim3(256), 0, totals, nblk, a.has_den);
-    AERO_LAUNCH(ctx, "air_aux_kernel", (size_t)A * n * 8 * 2 * F::DEG, (air_fac_apply_kernel<F>), dim3(nblk, A), dim3(256), 0, fac, n, a.has_den, a.init, totals, a.out);
+    if (any_product) {
+        AERO_LAUNCH(ctx, "air_aux_kernel", (size_t)A * n * 8 * F::DEG, (air_fac_totals_kernel<F>), dim3(nblk, 2 * A), dim3(256), 0, fac, n, a.has_den, a.has_add, totals);
+        AERO_LAUNCH(ctx, "air_aux_kernel", 0, (air_scan_totals_kernel<F>), dim3(2 * A), dim3(256), 0, totals, nblk, a.has_den, a.has_add);
+        AERO_LAUNCH(ctx, "air_aux_kernel", (size_t)A * n * 8 * 2 * F::DEG, (air_fac_apply_kernel<F>), dim3(nblk, A), dim3(256), 0, fac, n, a.has_den, a.has_add, a.init, totals, a.out);
+    }
+    if (any_affine) {
+        AffPair<F>* atot = (AffPair<F>*)ctx->scratch_alloc(sizeof(AffPair<F>) * (size_t)A * nblk);
+        AERO_LAUNCH(ctx, "air_aux_kernel", (size_t)A * n * 8 * 4 * F::DEG, (air_aff_ratio_kernel<F>), dim3(nblk, A), dim3(256), 0, fac, n, A, a.has_den, a.has_add);
+        AERO_LAUNCH(ctx, "air_aux_kernel", (size_t)A * n * 8 * 2 * F::DEG, (air_aff_totals_kernel<F>), dim3(nblk, A), dim3(256), 0, (const uint64_t*)fac, n, A, a.has_add, atot);
+        AERO_LAUNCH(ctx, "air_aux_kernel", 0, (air_aff_scan_totals_kernel<F>), dim3(A), dim3(256), 0, atot, nblk, a.has_add);
+        AERO_LAUNCH(ctx, "air_aux_kernel", (size_t)A * n * 8 * 3 * F::DEG, (air_aff_apply_kernel<F>), dim3(nblk, A), dim3(256), 0, (const uint64_t*)fac, n, A, a.has_add, a.init, (const AffPair<F>*)atot, a.out);
+    }
     ctx->check_launch("air_aux");
 }
-template void launch_air_aux<FB>(Context*, const AirAuxArgs<FB>&, const std::vector<uint8_t>&);
-template void launch_air_aux<FQ>(Context*, const AirAuxArgs<FQ>&, const std::vector<uint8_t>&);
+template void launch_air_aux<FB>(Context*, const AirAuxArgs<FB>&, const std::vector<uint8_t>&, const std::vector<uint8_t>&);
+template void launch_air_aux<FQ>(Context*, const AirAuxArgs<FQ>&, const std::vector<uint8_t>&, const std::vector<uint8_t>&);
 
 }  // namespace aero

@@ -87,7 +87,7 @@ template <class F> void launch_air_divide(Context* ctx, const AirDivideArgs<F>& 
 // dst[pos[i]] = val[i]
 void launch_air_scatter(Context* ctx, uint64_t* dst, const uint64_t* pos, const uint64_t* val, size_t count);
 
-// Auxiliary segment from the program's builders: column c(0) = init_c, c(i+1) = c(i) * num_c(i) / den_c(i).
+// Auxiliary segment from the program's builders: column c(0) = init_c, c(i+1) = c(i) * num_c(i) / den_c(i) [+ add_c(i) / add_den_c(i)].
 template <class F> struct AirAuxArgs {
     typedef typename F::T T;
     const uint64_t* trace;       // W x n main segment
@@ -98,9 +98,10 @@ template <class F> struct AirAuxArgs {
     uint32_t slotsB, slotsE;
     const uint64_t* ptab;
     const uint8_t* has_den;      // per aux column (device)
+    const uint8_t* has_add;      // per aux column (device): 0 product only, 1 additive term, 3 additive term with denominator (affine builders)
     const T* init;               // per aux column (device)
     uint64_t* out;               // (A * DEG) x n component columns
 };
-template <class F> void launch_air_aux(Context* ctx, const AirAuxArgs<F>& a, const std::vector<uint8_t>& has_den_host);
+template <class F> void launch_air_aux(Context* ctx, const AirAuxArgs<F>& a, const std::vector<uint8_t>& has_den_host, const std::vector<uint8_t>& has_add_host);
 
 }  // namespace aero

@@ -110,6 +110,7 @@ struct Program {
     std::vector<uint32_t> cons_desc, aux_desc;       // LOAD descriptors
     uint32_t cons_slotsB = 0, cons_slotsE = 0, aux_slotsB = 0, aux_slotsE = 0;
     std::vector<uint8_t> has_den;             // per aux column
+    std::vector<uint8_t> has_add;             // per aux column: 0 = pure running product, 1 = additive term, 3 = additive term with a denominator
     mutable std::shared_ptr<void> jit_cache;  // code objects of the run-time compiled evaluation kernels (air_jit.hip), shared by copies
 
     size_t num_transition() const { return trans.size(); }
@@ -548,11 +549,23 @@ inline Program load(const uint8_t* bytes, size_t len) {
         cg.marker(OP_END, 0);
         cg.allocate(p.cons_code, p.cons_desc, &p.cons_slotsB, &p.cons_slotsE);
     }
-    // ---- aux builder code: output column 2c = numerator factor, 2c + 1 = denominator factor of aux column c
+    // ---- aux builder code: output column 2c = numerator factor, 2c + 1 = denominator factor of aux column c; affine builders
+    //      (version 2) additionally 2A + 2c = numerator and 2A + 2c + 1 = denominator of the additive term
     if (p.has_builders()) {
         CodeGen cg(p);
         p.has_den.assign(p.A, 0);
+        p.has_add.assign(p.A, 0);
         for (uint32_t c = 0; c < p.A; c++) {
+            if (p.builders[c].add_num != REF_NONE) {
+                p.has_add[c] = 1;
+                cg.gen(p.builders[c].add_num);
+                cg.emit(ref_is_ext(p, p.builders[c].add_num) ? OP_OUT_E : OP_OUT_B, 2 * p.A + 2 * c, p.builders[c].add_num);
+                if (p.builders[c].add_den != REF_NONE) {
+                    p.has_add[c] = 3;
+                    cg.gen(p.builders[c].add_den);
+                    cg.emit(ref_is_ext(p, p.builders[c].add_den) ? OP_OUT_E : OP_OUT_B, 2 * p.A + 2 * c + 1, p.builders[c].add_den);
+                }
+            }
             cg.gen(p.builders[c].num);
             cg.emit(ref_is_ext(p, p.builders[c].num) ? OP_OUT_E : OP_OUT_B, 2 * c, p.builders[c].num);
             if (p.builders[c].den != REF_NONE) {

@@ -16,16 +16,18 @@
  * (mirrored for the verifier in src/stark_verifier/air/transitions/evaluator.cairo:79-86,131-150,216-218), allocates registers,
  * and a device interpreter runs the result once per row of the constraint-evaluation domain.
  *
- * ---- AEROAIR version 1 (all integers little-endian; field elements canonical u64 < p) -----------------------------------------
- *   bytes 0..7   "AEROAIR" followed by the version byte 1
+ * ---- AEROAIR versions 1 and 2 (all integers little-endian; field elements canonical u64 < p) ---------------------------------
+ *   bytes 0..7   "AEROAIR" followed by the version byte: 1, or 2 for programs that use what is marked [v2] below (a version-1
+ *                program is also a valid version-2 program except for the size of its builder records)
  *   u32 x 16     main_width W (1..255), aux_width A (0..255-W), aux_rands R (0 iff A = 0, <= 255), num_pub (<= 4096),
  *                num_exemptions e (>= 1: the transition divisor is (x^n - 1) / prod_{i=1..e} (x - w^(n-i)); Winterfell's default 1),
  *                num_consts, num_periodic, num_nodes,
  *                num_main_transition, num_aux_transition, num_main_assertions, num_aux_assertions,
- *                num_aux_builders (0, or A), reserved x 3 (0)
+ *                num_aux_builders (0, or A), num_sequences [v2; 0 in version 1], reserved x 2 (0)
  *   consts       num_consts x u64
  *   periodic     per column: u32 cycle_len (a power of two >= 2; must not exceed the trace length at proving time), cycle_len x u64.
  *                The column's value at trace step i is values[i mod cycle_len] (`Air::get_periodic_column_values`).
+ *   sequences    [v2] per sequence: u32 count (a power of two >= 2), count x u64: the values of one `Assertion::sequence`
  *   nodes        num_nodes x { u32 op; u32 a; u32 b }   op: 1 = a + b, 2 = a - b, 3 = a * b. a, b = operand references; a node may
  *                reference only nodes before it.
  *   transition constraints, main then aux: { u32 root; u32 degree_base; u32 n_cycles; u32 cycle_len x n_cycles }
@@ -38,15 +40,28 @@
  *                stride > 0 (a power of two < n, first_step < stride) = `Assertion::periodic(column, first_step, stride, value)`:
  *                the column equals `value` at first_step, first_step + stride, ... . value = operand reference: CONST or PUB for
  *                main assertions; for aux assertions also RAND or a node built from CONST / PUB / RAND only.
- *                (`Assertion::sequence` is not representable in version 1.)
+ *                [v2] value = 9 << 24 | sequence index with stride > 0 = `Assertion::sequence(column, first_step, stride, values)`: the
+ *                column equals values[i] at step first_step + i * stride; at proving time stride * count must equal the trace length.
+ *                winter-air 0.4 turns the values into the interpolant P over the subgroup of their own size and checks
+ *                column(x) - P(x * w_n^-first_step) against the periodic divisor of (stride, first_step) ("poly_offset"); one
+ *                (alpha, beta) pair per assertion, as for the other kinds. Values are program constants (base field), on main and
+ *                auxiliary columns alike.
  *   aux builders (how the prover constructs the auxiliary columns, the `build_aux_segment` of this AIR), one per aux column:
- *                { u32 init; u32 num; u32 den }   column(0) = init, column(i + 1) = column(i) * num(i) / den(i), where num / den are
- *                operand references evaluated on the frame (row i, row i + 1 mod n) of the MAIN segment (MAIN_*, PERIODIC, CONST,
- *                PUB, RAND and nodes of those); den = 0xFFFFFFFF means 1. init: CONST, PUB, RAND or a row-independent node.
- *                This is the running-product shape of every multiset / permutation argument. A program without builders can be
- *                verified and its constraints evaluated, but proving needs the columns.
+ *                version 1: { u32 init; u32 num; u32 den }   column(0) = init, column(i + 1) = column(i) * num(i) / den(i), where
+ *                num / den are operand references evaluated on the frame (row i, row i + 1 mod n) of the MAIN segment (MAIN_*,
+ *                PERIODIC, CONST, PUB, RAND and nodes of those); den = 0xFFFFFFFF means 1. init: CONST, PUB, RAND or a
+ *                row-independent node. This is the running-product shape of every multiset / permutation argument.
+ *                [v2] { u32 init; u32 num; u32 den; u32 add_num; u32 add_den }: the affine recurrence
+ *                column(i + 1) = column(i) * num(i) / den(i) + add_num(i) / add_den(i) (add_num = 0xFFFFFFFF: no additive term;
+ *                add_den = 0xFFFFFFFF: 1) - running sums (log-derivative arguments: num = 1), and mixed forms; row maps
+ *                x -> m x + t compose associatively, so the device builds the column with a prefix scan like the products.
+ *                A recurrence that is not affine in the column's own previous value (column(i)^2 ...) cannot be scanned and is
+ *                not representable; nor is more than ONE auxiliary segment - winter-air 0.4's TraceLayout has NUM_AUX_SEGMENTS = 1
+ *                and its proof bytes hold exactly one (width, random elements) pair (proof_format.hpp; pinned on proofs/fib.bin).
+ *                A program without builders can be verified and its constraints evaluated, but proving needs the columns.
  *   operand reference = kind << 24 | index:
- *                0 NODE, 1 MAIN_CUR (column of the current row), 2 MAIN_NXT, 3 AUX_CUR, 4 AUX_NXT, 5 PERIODIC, 6 CONST, 7 PUB, 8 RAND
+ *                0 NODE, 1 MAIN_CUR (column of the current row), 2 MAIN_NXT, 3 AUX_CUR, 4 AUX_NXT, 5 PERIODIC, 6 CONST, 7 PUB, 8 RAND,
+ *                9 SEQ [v2; only as the value of an assertion]
  *
  * Derived quantities (Winterfell 0.4, restated; `n` = trace length, known at proving time):
  *   constraint-evaluation blowup C = number of composition columns = max over constraints of max(next_pow2(degree_base + n_cycles), 2);
@@ -79,6 +94,7 @@ extern "C" {
 #define AERO_AIR_CONST 6u
 #define AERO_AIR_PUB 7u
 #define AERO_AIR_RAND 8u
+#define AERO_AIR_SEQ 9u
 #define AERO_AIR_NONE 0xFFFFFFFFu
 
 /* AIR id of a trace file (aero_trace_file_*) whose constraint set travels as an AEROAIR program next to it. */

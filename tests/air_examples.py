@@ -134,3 +134,44 @@ def tiny_no_assertion_groups(log_n):
     b.assert_single(0, 0, b.pub(0))
     col = [pow(2, i, P) * 5 % P for i in range(n)]
     return b, np.array([col], dtype=np.uint64), [5]
+
+
+def v2_air(log_n, seq_stride=4):
+    """An AIR that needs AEROAIR version 2: `Assertion::sequence` on main and auxiliary columns and affine auxiliary builders.
+    Main: 0,1 Fibonacci pair | 2 counter 5 + 3 i | 3 multiplicity (i mod 3). Auxiliary (4 random elements):
+      0  running product with denominator   p' = p (r0 + m0) / (r0 + m2)
+      1  running SUM (log-derivative shape) s' = s + m3 / (r1 + m2)
+      2  mixed affine                       u' = u (r2 + m1) + m0 m3
+      3  constant 7                         c' = c
+    Assertions: singles, a sequence on the counter (every seq_stride-th step from step 1), a two-value sequence on column 0,
+    a sequence on the constant auxiliary column. Returns (builder, trace, pub)."""
+    n = 1 << log_n
+    b = A.AirBuilder(4, 4, 4, num_pub=1)
+    m, mn, a, an, r = b.main, b.main_next, b.aux, b.aux_next, b.rand
+    b.transition(mn(0) - (m(0) + m(1)), 1)
+    b.transition(mn(1) - (m(1) + mn(0)), 1)
+    b.transition(mn(2) - m(2) - 3, 1)
+    b.transition(m(3) * (m(3) - 1) * (m(3) - 2), 3)
+    b.aux_transition(an(0) * (r(0) + m(2)) - a(0) * (r(0) + m(0)), 2)
+    b.aux_transition((an(1) - a(1)) * (r(1) + m(2)) - m(3), 2)
+    b.aux_transition(an(2) - a(2) * (r(2) + m(1)) - m(0) * m(3), 2)
+    b.aux_transition(an(3) - a(3), 1)
+    t = np.zeros((4, n), np.uint64)
+    x, y = 1, 2
+    for i in range(n):
+        t[0][i], t[1][i], t[2][i], t[3][i] = x, y, (5 + 3 * i) % P, i % 3
+        x, y = (x + y) % P, (y + x + y) % P
+    b.assert_single(0, 0, 1)
+    b.assert_single(1, 0, 2)
+    b.assert_single(1, -1, b.pub(0))
+    b.assert_sequence(2, 1, seq_stride, [int(t[2][1 + seq_stride * i]) for i in range(n // seq_stride)])
+    b.assert_sequence(0, 0, n // 2, [int(t[0][0]), int(t[0][n // 2])])
+    b.aux_assert_single(0, 0, 1)
+    b.aux_assert_single(1, 0, 0)
+    b.aux_assert_single(2, 0, b.rand(3))
+    b.aux_assert_sequence(3, 1, 2, [7] * (n // 2))
+    b.aux_builder(0, 1, r(0) + m(0), r(0) + m(2))
+    b.aux_builder(1, 0, 1, None, m(3), r(1) + m(2))
+    b.aux_builder(2, b.rand(3), r(2) + m(1), None, m(0) * m(3))
+    b.aux_builder(3, 7, 1)
+    return b, t, [int(t[1][-1])]

@@ -159,3 +159,55 @@ def test_message_and_proof_parsers_survive_mutations_under_sanitizers(tmp_path, 
         paths.append(str(p))
     r = subprocess.run([exe, *paths, "6000", "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "no memory error" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+# ---- AEROAIR version 2 (no GPU: the oracle proves, the library's verifier and loader are host code) ---------------------------------
+def test_version2_oracle_proof_is_accepted_by_the_library_verifier(oracle):
+    from tests import air_examples as ex
+    for log_n, opt in ((4, [27, 8, 8, 4, 1, 8, 4]), (6, [16, 8, 4, 4, 2, 4, 5]), (7, [20, 16, 4, 4, 1, 2, 5])):
+        b, trace, pub = ex.v2_air(log_n)
+        program = b.to_bytes()
+        assert program[:8] == b"AEROAIR\x02"
+        proof, _ = oracle.prove_air(program, trace, pub, opt)
+        oracle.verify_air(proof, program, pub, log_n)
+        air = aero_amd.Air(program)
+        aero_amd.verify_air(proof, pub, air, min_query_security_bits=0, expected_log_n=log_n)
+        for which in (0, 2):                     # a main sequence, the auxiliary one
+            b2, _, _ = ex.v2_air(log_n)
+            b2.sequences[which][-1] = (b2.sequences[which][-1] + 1) % ex.P
+            with pytest.raises(aero_amd.AeroError):
+                aero_amd.verify_air(proof, pub, aero_amd.Air(b2.to_bytes()), min_query_security_bits=0)
+            with pytest.raises(RuntimeError):
+                oracle.verify_air(proof, b2.to_bytes(), pub, log_n)
+
+
+def test_version2_loader_rules():
+    from aero_amd import air as A
+    b = A.AirBuilder(1)
+    b.transition(b.main_next(0) - b.main(0) - 1, 1)
+    b.assert_sequence(0, 0, 4, [0, 4, 8, 12])
+    program = b.to_bytes()
+    air = aero_amd.Air(program)                              # loads: the length rule is checked against a trace length
+    assert air.num_divisors(4) == 2                          # 16 rows = 4 values x stride 4
+    with pytest.raises(aero_amd.AeroError):
+        air.num_divisors(5)                                  # 32 rows: stride * values != trace length
+    v1 = bytearray(program)
+    v1[7] = 1                                                # the same bytes under the version-1 magic: a reserved header word is set
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.Air(bytes(v1))
+    bad = A.AirBuilder(1)
+    bad.transition(bad.main_next(0) - bad.main(0) - 1, 1)
+    bad.main_asserts.append((0, 0, 0, (A.SEQ << 24) | 0))    # a sequence value on a single-step assertion
+    bad.sequences.append([1, 2])
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.Air(bad.to_bytes())
+    # affine builders: an additive denominator needs an additive numerator
+    c = A.AirBuilder(1, 1, 1)
+    c.transition(c.main_next(0) - c.main(0), 1)
+    c.aux_transition(c.aux_next(0) - c.aux(0) - c.main(0), 1)
+    c.builders[0] = (c.const(0).ref, c.const(1).ref, A.NONE, A.NONE, c.rand(0).ref)
+    raw = bytearray(c.to_bytes())
+    assert raw[7] == 1                                       # no additive numerator: written as version 1 (3-word builders) ...
+    raw[7] = 2
+    with pytest.raises(aero_amd.AeroError):                  # ... and as version 2 the record is too short
+        aero_amd.Air(bytes(raw))

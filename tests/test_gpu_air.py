@@ -313,3 +313,80 @@ def test_one_program_handle_validates_traces_of_different_lengths(ctx):
         assert ctx.validate_trace(air, ctx.trace_upload(trace), pub) is None, log_n
         row, kind, _ = ctx.validate_trace(air, ctx.trace_upload(trace), [pub[0] ^ 1, pub[1]])
         assert (row, kind) == ((1 << log_n) - 1, "assertion"), log_n
+
+
+# ---- AEROAIR version 2: Assertion::sequence and affine auxiliary builders ------------------------------------------------------
+@pytest.mark.parametrize("log_n,stride,opt", [
+    (5, 4, [6, 4, 0, 4, 1, 2, 3]),
+    (8, 4, [27, 8, 8, 4, 1, 8, 6]),
+    (10, 2, [20, 8, 8, 4, 2, 4, 6]),              # quadratic extension; a sequence of n / 2 values
+    (12, 16, [27, 16, 8, 4, 1, 4, 7]),            # blowup 16 > constraint blowup 4
+    (14, 8, [27, 8, 16, 4, 1, 8, 8]),
+])
+def test_version2_program_compiled_interpreted_and_oracle_agree(ctx, ctx_interp, oracle, log_n, stride, opt):
+    b, trace, pub = ex.v2_air(log_n, stride)
+    program = b.to_bytes()
+    assert program[7] == 2
+    air = aero_amd.Air(program)
+    want, _ = oracle.prove_air(program, trace, pub, opt)
+    got, names = _kernels_of(ctx, lambda: ctx.prove_air(air, ctx.trace_upload(trace), pub, options(opt)))
+    assert "air_jit_kernel" in names and "air_scatter_kernel" in names, names          # the sequence tables were built on the device
+    assert got == want
+    ref, names_i = _kernels_of(ctx_interp, lambda: ctx_interp.prove_air(air, trace, pub, options(opt)))      # host hand-over + interpreter
+    assert "air_constraints_kernel" in names_i and ref == want
+    oracle.verify_air(got, program, pub, log_n)
+    aero_amd.verify_air(got, pub, air, min_query_security_bits=0, expected_log_n=log_n)
+    # another sequence: the same proof must not verify
+    b2, _, _ = ex.v2_air(log_n, stride)
+    b2.sequences[0][1] ^= 1
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.verify_air(got, pub, aero_amd.Air(b2.to_bytes()), min_query_security_bits=0)
+
+
+@pytest.mark.parametrize("ext,nfrag", [(1, 1), (2, 4)])
+def test_version2_stage_entry_points(ctx, oracle, ext, nfrag):
+    # the affine builders against the oracle's auxiliary columns, the numerator fragments (with the sequence tables) against its table
+    log_n, opt = 9, [27, 8, 8, 4, ext, 8, 6]
+    deg = 2 if ext == 2 else 1
+    b, trace, pub = ex.v2_air(log_n)
+    program = b.to_bytes()
+    air = aero_amd.Air(program)
+    info = air.info()
+    n, C, ncols = 1 << log_n, info["ce_blowup"], air.num_divisors(log_n)
+    oracle.prove_air(program, trace, pub, opt, keep_artifacts=True)
+    nt, na = info["main_transition"] + info["aux_transition"], info["main_assertions"] + info["aux_assertions"]
+    coeffs = oracle.artifact("cons_coeffs", 2 * deg * (nt + na))
+    rands = oracle.artifact("aux_rands", deg * 4)
+    dev = ctx.trace_upload(trace)
+    auxm = ctx.aux_columns_program(air, dev, pub, rands, ext)
+    assert (auxm.download() == oracle.artifact("aux_cols", 4 * deg * n).reshape(4 * deg, n)).all()
+    lde = ctx.evaluate_columns_over(ctx.interpolate_columns(dev), 3)
+    alde = ctx.evaluate_columns_over(ctx.interpolate_columns(auxm), 3)
+    want = oracle.artifact("ce_cols", ncols * deg * C * n).reshape(ncols * deg, C * n)
+    got = np.zeros_like(want)
+    for k in range(nfrag):
+        fi, cols = ctx.eval_constraints_program(air, lde, alde, 3, pub, rands, coeffs, ext, k, nfrag)
+        got[:, fi:fi + cols.shape[1]] = cols
+    assert (got == want).all()
+    # Trace::validate on the device knows the sequences too
+    assert ctx.validate_trace(air, dev, pub, aux=auxm, rands=rands, field_extension=ext) is None
+    bad = trace.copy()
+    bad[2][1 + 4 * 5] ^= 1                                 # the 6th asserted step of the counter's sequence (and two transitions around it)
+    got_bad = ctx.validate_trace(air, ctx.trace_upload(bad), pub)
+    assert got_bad is not None and got_bad[0] in (20, 21)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_version2_program_sharded_over_thread_ranks(world, oracle):
+    from aero_amd.shard import LocalGroup
+    log_n, opt = 10, [27, 8, 8, 4, 1, 4, 6]
+    b, trace, pub = ex.v2_air(log_n)
+    program = b.to_bytes()
+    air = aero_amd.Air(program)
+    want, _ = oracle.prove_air(program, trace, pub, opt)
+    g = LocalGroup(world, min_peer_digests=64)
+    try:
+        proofs = g.run(lambda r, c, comm: c.prove_air(air, c.trace_upload(trace), pub, options(opt), comm=comm))
+    finally:
+        g.close()
+    assert all(p == want for p in proofs)

@@ -69,7 +69,7 @@ class Gen:
         c = self.r.randrange(self.W)
         return self.b.main_next(c) - self.b.main(c), 1, []
 
-    def build(self, log_n, max_deg):
+    def build(self, log_n, max_deg, v2=False):
         r, b, n = self.r, self.b, 1 << log_n
         for _ in range(r.randint(1, 4)):
             e, d, cyc = self.constraint(False, max_deg)
@@ -95,10 +95,29 @@ class Gen:
                 if key not in used:
                     used.add(key)
                     b.assert_single(col, step, b.pub(r.randrange(self.npub)) if r.random() < 0.4 else b.const(r.randrange(P)))
+        if v2:
+            # Assertion::sequence on main (and auxiliary) columns: values at first + i * stride, as many as the trace length asks for
+            for _ in range(r.randint(1, 3)):
+                aux_col = self.Aw and r.random() < 0.3
+                col = r.randrange(self.Aw if aux_col else self.W)
+                stride = r.choice([2, 4, 8, n // 2])
+                key = ("a" if aux_col else "m", col, stride, r.randrange(stride))
+                if key in used or (not aux_col and (col, stride, key[3]) in used):
+                    continue
+                used.add(key)
+                used.add((col, stride, key[3]))
+                vals = [r.randrange(P) for _ in range(n // stride)]
+                (b.aux_assert_sequence if aux_col else b.assert_sequence)(col, key[3], stride, vals)
         for c in range(self.Aw):
             init = b.const(1) if r.random() < 0.5 else b.rand(0) * b.rand(self.R - 1) + 1
             num = b.rand(r.randrange(self.R)) + b.main(r.randrange(self.W)) * (b.main_next(r.randrange(self.W)) if r.random() < 0.5 else 1)
             den = (b.rand(r.randrange(self.R)) + b.main(r.randrange(self.W))) if r.random() < 0.5 else None
+            if v2 and r.random() < 0.7:              # affine builder: additive term, with or without its own denominator
+                add = b.main(r.randrange(self.W)) * (b.rand(r.randrange(self.R)) if r.random() < 0.5 else 3)
+                add_den = (b.rand(r.randrange(self.R)) + b.main_next(r.randrange(self.W))) if r.random() < 0.5 else None
+                b.aux_builder(c, init, num if r.random() < 0.7 else 1, den, add, add_den)
+                b.aux_assert_single(c, 0, init)
+                continue
             b.aux_builder(c, init, num, den)
             b.aux_assert_single(c, 0, init)
             if r.random() < 0.3:
@@ -151,3 +170,34 @@ def test_random_programs_three_evaluators_one_proof(ctxs, oracle, seed):
     assert got == want, f"compiled kernel vs oracle: seed {seed} {info}"
     ref = interp.prove_air(air, interp.trace_upload(trace), pub, aero_amd.ProofOptions(*opt))          # resident trace on this one
     assert ref == want, f"interpreter vs oracle: seed {seed} {info}"
+
+
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_random_version2_programs_three_evaluators_one_proof(ctxs, oracle, seed):
+    """The same differential over AEROAIR version 2: sequence assertions (main and auxiliary, strides 2 .. n / 2) and affine auxiliary builders."""
+    jit, interp = ctxs
+    rng = random.Random(5000 + seed)
+    log_n = rng.randint(4, 10)
+    blowup = rng.choice([8, 8, 16])
+    ext = rng.choice([1, 1, 2])
+    opt = [rng.randint(3, 8), blowup, rng.randint(0, 4), 4, ext, rng.choice([2, 4, 8]), rng.randint(3, 6)]
+    while True:
+        dom = blowup << log_n
+        while dom > (1 << opt[6]):
+            dom //= opt[5]
+        if dom >= opt[5]:
+            break
+        opt[6] += 1
+    g = Gen(seed)
+    if seed % 2 == 0 and not g.Aw:                 # half of the cases carry an auxiliary segment for sure
+        g = Gen(seed + 1000)
+    program = g.build(log_n, max_deg=blowup if blowup <= 8 else 8, v2=True)
+    air = aero_amd.Air(program)
+    nrng = np.random.default_rng(seed)
+    trace = (nrng.integers(0, P, size=(g.W, 1 << log_n), dtype=np.uint64, endpoint=False))
+    pub = [int(x) for x in nrng.integers(0, P, size=g.npub, dtype=np.uint64)]
+    want, _ = oracle.prove_air(program, trace, pub, opt)
+    got = jit.prove_air(air, trace, pub, aero_amd.ProofOptions(*opt))
+    assert got == want, f"compiled kernel vs oracle: seed {seed} {air.info()}"
+    ref = interp.prove_air(air, interp.trace_upload(trace), pub, aero_amd.ProofOptions(*opt))
+    assert ref == want, f"interpreter vs oracle: seed {seed} {air.info()}"
