@@ -147,6 +147,14 @@ public:
     void stage_reset() { stage_off = 0; }
     unsigned int* pinned_word();         // one pinned 32-bit word that outlives stage_reset() (deferred input-check verdict)
     size_t bytes_in_use = 0, bytes_peak = 0;
+    // AERO_POOL_GUARD=1 (diagnosis): every block is mapped by itself at the END of its own virtual-address reservation with an unmapped
+    // granule behind it (hipMemAddressReserve / hipMemMap), nothing is reused - a kernel that reads or writes one byte past a buffer
+    // takes a GPU memory fault at that access instead of silently touching a neighbour. Slow; for the test-suite, not for proving.
+    bool guard_mode = false;
+    struct GuardBlock { void* va; size_t va_bytes, map_bytes; hipMemGenericAllocationHandle_t handle; size_t user_bytes; };
+    std::map<void*, GuardBlock> guard_blocks;
+    void* guard_alloc(size_t bytes);
+    void guard_free(void* p);
 
     void check_launch(const char* what);
     void sync();

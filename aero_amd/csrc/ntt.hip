@@ -496,7 +496,21 @@ __global__ void fill_block_factors(uint64_t* tab, int bits, uint64_t abase, uint
 // wavefront is one contiguous 512-byte segment. The pass-boundary twiddle depends on (block, row) only: it comes from a small
 // per-pass table (2^(log_n - log_s) entries, row b * R + k = w^(S * rev(b) * k)) that every lane of a workgroup reads at the
 // same address.
-template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_fwd_strided_reg(PassArgs a) {
+typedef uint32_t nttv2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint64_t buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const nttv2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return gl::mk64(v.x, v.y);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint64_t x) {
+    nttv2u v; v.x = (uint32_t)x; v.y = (uint32_t)(x >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+// descriptor over the 2^LOGR rows of block b of a strided pass (2^(log_s + LOGR + 3) bytes: the launcher checks that it fits 32 bits)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pass_rsrc(const uint64_t* col, uint32_t b, int logr, int log_s) {
+    const size_t blk = ((size_t)b << logr) << log_s;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(col + blk), 0, (uint32_t)((((size_t)1 << logr) << log_s) * 8), 0x00020000);
+}
+template <int LOGR, bool BUF = false> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_fwd_strided_reg(PassArgs a) {
     constexpr int R = 1 << LOGR;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;            // over 2^(log_n - LOGR) threads per column
     const size_t lo = t & (((size_t)1 << a.log_s) - 1);
@@ -505,8 +519,15 @@ template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void nt
     const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
     uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
     uint64_t y[R];
+    const uint32_t row_bytes = 8u << a.log_s, vo = (uint32_t)lo * 8;
+    if constexpr (BUF) {
+        const __amdgpu_buffer_rsrc_t rin = pass_rsrc(in, b, LOGR, a.log_s);
 #pragma unroll
-    for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
+        for (int k = 0; k < R; k++) y[k] = buf_ld(rin, vo, (uint32_t)k * row_bytes);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
+    }
     if (LOGR == 6) __builtin_amdgcn_sched_barrier(0);   // all 64 loads in flight before the first butterfly (the scheduler otherwise sinks half of them)
     dft_dit_reg<LOGR>(y);
     if (!a.first && b) {
@@ -514,8 +535,14 @@ template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void nt
 #pragma unroll
         for (int k = 1; k < R; k++) y[k] = mul(y[k], tw[k]);
     }
+    if constexpr (BUF) {
+        const __amdgpu_buffer_rsrc_t rout = pass_rsrc(out, b, LOGR, a.log_s);
 #pragma unroll
-    for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
+        for (int k = 0; k < R; k++) buf_st(rout, vo, (uint32_t)k * row_bytes, y[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
+    }
     if (a.compact && (lo & (((size_t)1 << a.compact_log) - 1)) == 0) {
         // every 2^compact_log-th row once more, densely: what the per-row kernels that walk the LDE with that stride read
         // (constraint evaluation, DEEP) - a strided walk over the full matrix drags in a whole 64-byte sector per 8 useful bytes
@@ -578,6 +605,69 @@ __global__ __launch_bounds__(256) void ntt_fwd_strided_reg6x2(PassArgs a) {
         }
     }
 }
+// Variants for measurement (AERO_NTT_R6=<digit>): BUF addresses the 64 row accesses of a lane through a buffer descriptor whose base
+// (column + block) lives in SGPRs - the row part of every address is a scalar offset (k << log_s, SALU) and the lane part one VGPR
+// computed once, instead of a 64-bit vector shift-add per access; MINB asks the compiler for MINB workgroups per CU (4 = 128 VGPRs).
+template <bool BUF, int MINB> __global__ __launch_bounds__(256, MINB) void ntt_fwd_strided_reg6x2_v(PassArgs a) {
+    const uint32_t lane = threadIdx.x & 63, half = lane >> 5;
+    const size_t p = (((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) << 5) + (lane & 31);    // over 2^(log_n - 6) positions per column
+    const size_t lo = p & (((size_t)1 << a.log_s) - 1);
+    const uint32_t b = (uint32_t)(((size_t)blockIdx.x * 128) >> a.log_s);                  // S >= 128: uniform over the workgroup
+    const size_t base = lo + (((size_t)b << 6) << a.log_s);
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    uint64_t y[32];
+    // descriptors over this block's 64 rows (2^(log_s + 9) bytes <= 2^31: the launcher checks)
+    const size_t blk = ((size_t)b << 6) << a.log_s;
+    const uint32_t span = (uint32_t)(((size_t)64 << a.log_s) * 8);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(in + blk), 0, span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + blk, 0, span, 0x00020000);
+    const uint32_t row_bytes = 8u << a.log_s;
+    if constexpr (BUF) {
+        const uint32_t vo = (uint32_t)lo * 8 + half * 32 * row_bytes;
+#pragma unroll
+        for (int i = 0; i < 32; i++) y[i] = buf_ld(rin, vo, (uint32_t)i * row_bytes);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; i++) y[i] = in[base + ((size_t)(32 * half + i) << a.log_s)];
+    }
+    dft_dit_reg<5>(y);
+#pragma unroll
+    for (int i = 0; i < 16; i++) swap_halves(y[i], y[16 + i]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { const uint64_t t = mul_w4(y[16 + i]); y[16 + i] = half ? t : y[16 + i]; }
+    last_stage_pairs<0>(y);
+    const uint32_t r0 = 16 * half;
+    if (!a.first && b) {
+        const uint64_t* tw = a.tw_pass + ((size_t)b << 6) + r0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { y[i] = mul(y[i], tw[i]); y[16 + i] = mul(y[16 + i], tw[32 + i]); }
+    }
+    if constexpr (BUF) {
+        const uint32_t vo = (uint32_t)lo * 8 + half * 16 * row_bytes;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            buf_st(rout, vo, (uint32_t)i * row_bytes, y[i]);
+            buf_st(rout, vo, (uint32_t)(32 + i) * row_bytes, y[16 + i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            out[base + ((size_t)(r0 + i) << a.log_s)] = y[i];
+            out[base + ((size_t)(r0 + 32 + i) << a.log_s)] = y[16 + i];
+        }
+    }
+    if (a.compact && (lo & (((size_t)1 << a.compact_log) - 1)) == 0) {
+        uint64_t* co = a.compact + (size_t)blockIdx.y * a.compact_col_stride;
+        const size_t part_len = (((size_t)1 << a.log_n) >> a.compact_log) >> a.compact_split, pmask = ((size_t)1 << a.compact_split) - 1;
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const uint32_t row = r0 + (i & 15) + 2 * (i & 16);
+            const size_t j = (base + ((size_t)row << a.log_s)) >> a.compact_log;
+            co[(j & pmask) * part_len + (j >> a.compact_split)] = y[i];
+        }
+    }
+}
 // Radix-128 pass, each 128-point transform shared by two lanes (l and l + 32), 64 values per lane: lane half h holds rows 64 h + i, the
 // first six stages are the 64-point register transform of each half (shift twiddles), the last stage pairs row j with row j + 64
 // across the halves (V_PERMLANE32_SWAP: rows (i, 64 + i) end up in the lower half, (32 + i, 96 + i) in the upper) with the
@@ -626,7 +716,7 @@ __global__ __launch_bounds__(256, 3) void ntt_fwd_strided_reg7x2(PassArgs a) {
         }
     }
 }
-template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_inv_strided_reg(PassArgs a) {
+template <int LOGR, bool BUF = false> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_inv_strided_reg(PassArgs a) {
     constexpr int R = 1 << LOGR;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t lo = t & (((size_t)1 << a.log_s) - 1);
@@ -635,8 +725,15 @@ template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void nt
     const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
     uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
     uint64_t y[R];
+    const uint32_t row_bytes = 8u << a.log_s, vo = (uint32_t)lo * 8;
+    if constexpr (BUF) {
+        const __amdgpu_buffer_rsrc_t rin = pass_rsrc(in, b, LOGR, a.log_s);
 #pragma unroll
-    for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
+        for (int k = 0; k < R; k++) y[k] = buf_ld(rin, vo, (uint32_t)k * row_bytes);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
+    }
     if (LOGR == 6) __builtin_amdgcn_sched_barrier(0);
     if (a.bad) {
         bool any = false;
@@ -650,8 +747,14 @@ template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void nt
         for (int k = 1; k < R; k++) y[k] = mul(y[k], tw[k]);
     }
     dft_dif_inv_reg<LOGR>(y);
+    if constexpr (BUF) {
+        const __amdgpu_buffer_rsrc_t rout = pass_rsrc(out, b, LOGR, a.log_s);
 #pragma unroll
-    for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
+        for (int k = 0; k < R; k++) buf_st(rout, vo, (uint32_t)k * row_bytes, y[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
+    }
 }
 // tab[(b << log_r) + k] = root^((S * rev(b) * k) mod n), rev over bbits = log_n - log_s - log_r bits
 __global__ void fill_pass_twiddles(uint64_t* tab, int log_n, int log_s, int log_r, uint64_t root) {
@@ -678,6 +781,9 @@ __global__ void fill_pow_linear(uint64_t* tab, uint32_t count, uint64_t root, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// AERO_NTT_BUF=1: the strided register passes address their rows through buffer descriptors (measurement switch)
+static const bool ntt_buf = getenv("AERO_NTT_BUF") && getenv("AERO_NTT_BUF")[0] == '1';
+
 NttTables* Context::ntt_tables(int log_n) {
     auto it = ntt_tabs.find(log_n);
     if (it != ntt_tabs.end()) return &it->second;
@@ -792,12 +898,25 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
                     AERO_LAUNCH(this, pass_names ? "ntt_fwd_reg7" : nm, abytes, ntt_fwd_strided_reg7x2, dim3((unsigned)((((size_t)1 << log_out) >> 6) / 256), ncols), dim3(256), 0, a);
                     break;
                 case 6:
-                    if (a.log_s >= 7)    // two lanes per transform: 32 values per lane (the block index stays uniform over a workgroup)
-                        AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg6x2, dim3((unsigned)((((size_t)1 << log_out) >> 5) / 256), ncols), dim3(256), 0, a);
+                    if (a.log_s >= 7) {  // two lanes per transform: 32 values per lane (the block index stays uniform over a workgroup)
+                        static const int r6 = getenv("AERO_NTT_R6") ? atoi(getenv("AERO_NTT_R6")) : 0;
+                        const dim3 g6((unsigned)((((size_t)1 << log_out) >> 5) / 256), ncols);
+                        const bool buf_ok = a.log_s + 9 <= 31;
+                        if (r6 == 1 && buf_ok) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<true, 3>), g6, dim3(256), 0, a);
+                        else if (r6 == 2) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<false, 4>), g6, dim3(256), 0, a);
+                        else if (r6 == 3 && buf_ok) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<true, 4>), g6, dim3(256), 0, a);
+                        else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg6x2, g6, dim3(256), 0, a);
+                    }
                     else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<6>, rgrid, dim3(256), 0, a);
                     break;
-                case 5: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<5>, rgrid, dim3(256), 0, a); break;
-                case 4: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<4>, rgrid, dim3(256), 0, a); break;
+                case 5:
+                    if (ntt_buf && a.log_s + 8 <= 31) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg<5, true>), rgrid, dim3(256), 0, a);
+                    else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<5>, rgrid, dim3(256), 0, a);
+                    break;
+                case 4:
+                    if (ntt_buf && a.log_s + 7 <= 31) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg<4, true>), rgrid, dim3(256), 0, a);
+                    else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<4>, rgrid, dim3(256), 0, a);
+                    break;
                 case 3: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<3>, rgrid, dim3(256), 0, a); break;
                 case 2: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<2>, rgrid, dim3(256), 0, a); break;
                 default: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<1>, rgrid, dim3(256), 0, a); break;
@@ -832,7 +951,8 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
     static const bool inv2p_env = !(getenv("AERO_INV_2PHASE") && getenv("AERO_INV_2PHASE")[0] == '0');
     // (measured: -20 % on 72 columns x 2^20 and on 2 x 2^24, -7 % on 2 x 2^21; on 2 x 2^20 - one wave per SIMD, pure latency - it
     // equals the LDS rounds, which keep the smaller launches)
-    const bool inv2p = inv2p_env && reg_passes && log_n >= 13 && ((size_t)ncols << log_n) >= ((size_t)1 << 22);
+    static const int inv2p_min = getenv("AERO_INV_2PHASE_MIN") ? atoi(getenv("AERO_INV_2PHASE_MIN")) : 22;      // log2 of the smallest launch (elements) that takes it
+    const bool inv2p = inv2p_env && reg_passes && log_n >= 13 && ((size_t)ncols << log_n) >= ((size_t)1 << inv2p_min);
     std::vector<NttPass> plan = plan_passes(log_n, reg_passes, inv2p ? 11 : 12, false);
     const int r1 = plan[0].log_r;
     // per-k table for the final (contiguous) pass
@@ -875,9 +995,18 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
             dim3 rgrid((unsigned)((((size_t)1 << log_n) >> a.log_r) / 256), ncols);
             const size_t abytes = (size_t)ncols * 16 * ((size_t)1 << log_n);
             switch (a.log_r) {
-                case 6: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<6>, rgrid, dim3(256), 0, a); break;
-                case 5: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<5>, rgrid, dim3(256), 0, a); break;
-                case 4: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<4>, rgrid, dim3(256), 0, a); break;
+                case 6:
+                    if (ntt_buf && a.log_s + 9 <= 31) AERO_LAUNCH(this, "ntt_inv_pass", abytes, (ntt_inv_strided_reg<6, true>), rgrid, dim3(256), 0, a);
+                    else AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<6>, rgrid, dim3(256), 0, a);
+                    break;
+                case 5:
+                    if (ntt_buf && a.log_s + 8 <= 31) AERO_LAUNCH(this, "ntt_inv_pass", abytes, (ntt_inv_strided_reg<5, true>), rgrid, dim3(256), 0, a);
+                    else AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<5>, rgrid, dim3(256), 0, a);
+                    break;
+                case 4:
+                    if (ntt_buf && a.log_s + 7 <= 31) AERO_LAUNCH(this, "ntt_inv_pass", abytes, (ntt_inv_strided_reg<4, true>), rgrid, dim3(256), 0, a);
+                    else AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<4>, rgrid, dim3(256), 0, a);
+                    break;
                 case 3: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<3>, rgrid, dim3(256), 0, a); break;
                 case 2: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<2>, rgrid, dim3(256), 0, a); break;
                 default: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<1>, rgrid, dim3(256), 0, a); break;

@@ -30,10 +30,15 @@ Context::Context(int dev) : device(dev) {
     if (const char* e = getenv("AERO_QUAD_TOPS")) quad_tops = e[0] != '0';
     if (const char* e = getenv("AERO_AIR_JIT")) air_jit = e[0] != '0';
     if (const char* e = getenv("AERO_NTT_R128")) radix128 = e[0] != '0';
+    if (const char* e = getenv("AERO_POOL_GUARD")) guard_mode = e[0] == '1';
 }
 Context::~Context() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    if (guard_mode) {
+        while (!guard_blocks.empty()) guard_free(guard_blocks.begin()->first);
+        free_blocks.clear(); live_blocks.clear(); persistent.clear();
+    }
     for (auto& kv : free_blocks) (void)hipFree(kv.second);
     for (auto& kv : live_blocks) (void)hipFree(kv.first);
     for (void* p : persistent) (void)hipFree(p);
@@ -62,7 +67,50 @@ hipEvent_t Context::sync_event(size_t i) {
     }
     return sync_events[i];
 }
+void* Context::guard_alloc(size_t bytes) {
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    AERO_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+    if (gran < 4096) gran = 4096;
+    const size_t user = (bytes + 255) & ~(size_t)255;                  // what pool_alloc hands out: an access past THIS is outside the block in normal operation too
+    GuardBlock g{};
+    g.user_bytes = user;
+    g.map_bytes = (user + gran - 1) / gran * gran;
+    g.va_bytes = g.map_bytes + gran;                                   // the last granule stays unmapped
+    AERO_HIP(hipMemAddressReserve(&g.va, g.va_bytes, gran, nullptr, 0));
+    hipError_t e = hipMemCreate(&g.handle, g.map_bytes, &prop, 0);
+    if (e != hipSuccess) { (void)hipMemAddressFree(g.va, g.va_bytes); (void)hipGetLastError(); throw Error(ST_OOM, std::string("guard allocation failed: ") + hipGetErrorString(e)); }
+    AERO_HIP(hipMemMap(g.va, g.map_bytes, 0, g.handle, 0));
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    AERO_HIP(hipMemSetAccess(g.va, g.map_bytes, &acc, 1));
+    void* p = (char*)g.va + (g.map_bytes - user);                      // the block ends where the mapping ends
+    guard_blocks[p] = g;
+    return p;
+}
+void Context::guard_free(void* p) {
+    auto it = guard_blocks.find(p);
+    if (it == guard_blocks.end()) return;
+    (void)hipStreamSynchronize(stream);
+    if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+    const GuardBlock g = it->second;
+    guard_blocks.erase(it);
+    (void)hipMemUnmap(g.va, g.map_bytes);
+    (void)hipMemRelease(g.handle);
+    (void)hipMemAddressFree(g.va, g.va_bytes);
+}
 void* Context::pool_alloc(size_t bytes) {
+    if (guard_mode) {
+        void* p = guard_alloc(bytes ? bytes : 16);
+        live_blocks[p] = bytes;
+        bytes_in_use += bytes;
+        if (bytes_in_use > bytes_peak) bytes_peak = bytes_in_use;
+        return p;
+    }
     if (bytes == 0) bytes = 256;
     bytes = (bytes + 255) & ~(size_t)255;
     void* p = nullptr;
@@ -93,10 +141,12 @@ void Context::pool_free(void* p) {
     auto it = live_blocks.find(p);
     if (it == live_blocks.end()) return;
     bytes_in_use -= it->second;
+    if (guard_mode) { live_blocks.erase(it); guard_free(p); return; }
     free_blocks.insert({it->second, p});   // single stream: reuse is stream-ordered
     live_blocks.erase(it);
 }
 void* Context::dev_alloc(size_t bytes) {
+    if (guard_mode) return guard_alloc(bytes ? bytes : 16);          // released with the context
     void* p = nullptr;
     AERO_HIP(hipMalloc(&p, bytes ? bytes : 256));
     persistent.push_back(p);
