@@ -899,12 +899,18 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
                     break;
                 case 6:
                     if (a.log_s >= 7) {  // two lanes per transform: 32 values per lane (the block index stays uniform over a workgroup)
-                        static const int r6 = getenv("AERO_NTT_R6") ? atoi(getenv("AERO_NTT_R6")) : 0;
+                        // Default: rows addressed through a buffer descriptor (96 VGPRs instead of 135: the 32 row addresses no longer live in
+                        // VGPR pairs; measured on MI355X, profiles/r4_ntt_ab.txt: middle pass 65.5 -> 61.0 us on 2 columns 2^23, 1837 -> 1741 us
+                        // on 72; the LAST pass gains on narrow launches (49.2 -> 46.0 us) and loses on wide ones (1824 -> 1938 us, five waves
+                        // per SIMD streaming 64 rows each plus the compact copy), so it keeps the pointer form from 16 columns on.
+                        // AERO_NTT_R6=0 pointer form everywhere, 1 buffer form everywhere, 2 / 3 the four-workgroup variants (measured slower).
+                        static const int r6 = getenv("AERO_NTT_R6") ? atoi(getenv("AERO_NTT_R6")) : -1;
                         const dim3 g6((unsigned)((((size_t)1 << log_out) >> 5) / 256), ncols);
                         const bool buf_ok = a.log_s + 9 <= 31;
-                        if (r6 == 1 && buf_ok) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<true, 3>), g6, dim3(256), 0, a);
-                        else if (r6 == 2) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<false, 4>), g6, dim3(256), 0, a);
+                        const bool want_buf = r6 == 1 || (r6 < 0 && (!a.first || ncols < 16));
+                        if (r6 == 2) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<false, 4>), g6, dim3(256), 0, a);
                         else if (r6 == 3 && buf_ok) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<true, 4>), g6, dim3(256), 0, a);
+                        else if (want_buf && buf_ok) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<true, 3>), g6, dim3(256), 0, a);
                         else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg6x2, g6, dim3(256), 0, a);
                     }
                     else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<6>, rgrid, dim3(256), 0, a);
@@ -949,9 +955,10 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
     NttTables* t = ntt_tables(log_n);
     // two-phase contiguous pass (11 bits) where the transform is large enough to keep its strided passes' count
     static const bool inv2p_env = !(getenv("AERO_INV_2PHASE") && getenv("AERO_INV_2PHASE")[0] == '0');
-    // (measured: -20 % on 72 columns x 2^20 and on 2 x 2^24, -7 % on 2 x 2^21; on 2 x 2^20 - one wave per SIMD, pure latency - it
-    // equals the LDS rounds, which keep the smaller launches)
-    static const int inv2p_min = getenv("AERO_INV_2PHASE_MIN") ? atoi(getenv("AERO_INV_2PHASE_MIN")) : 22;      // log2 of the smallest launch (elements) that takes it
+    // (measured: -20 % on 72 columns x 2^20 and on 2 x 2^24, -7 % on 2 x 2^21, -8 % on 2 x 2^20 (75.9 -> 69.9 us, round 4: fewer
+    // VALU instructions matter with several proofs in flight even where one proof alone is latency-bound); below 2^21 elements the LDS
+    // rounds keep the launch)
+    static const int inv2p_min = getenv("AERO_INV_2PHASE_MIN") ? atoi(getenv("AERO_INV_2PHASE_MIN")) : 21;      // log2 of the smallest launch (elements) that takes it
     const bool inv2p = inv2p_env && reg_passes && log_n >= 13 && ((size_t)ncols << log_n) >= ((size_t)1 << inv2p_min);
     std::vector<NttPass> plan = plan_passes(log_n, reg_passes, inv2p ? 11 : 12, false);
     const int r1 = plan[0].log_r;
