@@ -64,6 +64,7 @@ struct PassArgs {
     // inverse, first executed pass only (optional): OR 1 into *bad when an input element is not canonical (>= p) - the validation
     // of a trace handed over by the host rides on the pass that reads it anyway
     unsigned int* bad;
+    int chains;       // ntt_fwd_first_pass_8: number of interleaved pass-boundary progressions (1, 2 or 4; AERO_NTT_F8_CHAINS)
 };
 
 // LDS index skew: one extra slot per 32 elements breaks the power-of-two strides of the radix-8 gathers
@@ -330,10 +331,33 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArg
     if (!a.first && rbk) {
         uint64_t cur = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)lane) & nmask), a.tw_h);
         const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
+        if (a.chains == 2) {
+            // two interleaved progressions (even and odd rows): the serial chain cur <- cur * step is half as deep
+            uint64_t cur1 = mul(cur, step);
+            const uint64_t step2 = mul(step, step);
+#pragma unroll
+            for (int i = 0; i < 32; i += 2) {
+                out[base + lane + 64 * i] = mul(y[i], cur);
+                out[base + lane + 64 * (i + 1)] = mul(y[i + 1], cur1);
+                cur = mul(cur, step2); cur1 = mul(cur1, step2);
+            }
+        } else if (a.chains == 4) {
+            const uint64_t step2 = mul(step, step), step4 = mul(step2, step2);
+            uint64_t c0 = cur, c1 = mul(cur, step), c2 = mul(cur, step2), c3 = mul(c1, step2);
+#pragma unroll
+            for (int i = 0; i < 32; i += 4) {
+                out[base + lane + 64 * i] = mul(y[i], c0);
+                out[base + lane + 64 * (i + 1)] = mul(y[i + 1], c1);
+                out[base + lane + 64 * (i + 2)] = mul(y[i + 2], c2);
+                out[base + lane + 64 * (i + 3)] = mul(y[i + 3], c3);
+                c0 = mul(c0, step4); c1 = mul(c1, step4); c2 = mul(c2, step4); c3 = mul(c3, step4);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 32; i++) {
             out[base + lane + 64 * i] = mul(y[i], cur);
             cur = mul(cur, step);
+        }
         }
     } else {
 #pragma unroll
@@ -674,7 +698,7 @@ template <bool BUF, int MINB> __global__ __launch_bounds__(256, MINB) void ntt_f
 // twiddle w_128^j = w_128^(j mod 32) * (w_4 = 2^48 in the upper half): w_128 is not a power of two (2 has order 192), so this one
 // stage multiplies by 31 table constants (w_4096^(32 i), uniform over the wavefront) - half a multiplication per element. Used where
 // it saves a whole pass: a 2^25-point LDE (2^22-row traces, BASELINE configs[4]) is 11 + 7 + 7 bits instead of 11 + 5 + 5 + 4.
-__global__ __launch_bounds__(256, 3) void ntt_fwd_strided_reg7x2(PassArgs a) {
+template <bool BUF> __global__ __launch_bounds__(256, 3) void ntt_fwd_strided_reg7x2(PassArgs a) {
     const uint32_t lane = threadIdx.x & 63, half = lane >> 5;
     const size_t p = (((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) << 5) + (lane & 31);    // over 2^(log_n - 7) positions per column
     const size_t lo = p & (((size_t)1 << a.log_s) - 1);
@@ -683,8 +707,16 @@ __global__ __launch_bounds__(256, 3) void ntt_fwd_strided_reg7x2(PassArgs a) {
     const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
     uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
     uint64_t y[64];
+    const uint32_t row_bytes = 8u << a.log_s;
+    const __amdgpu_buffer_rsrc_t rin = pass_rsrc(in, b, 7, a.log_s), rout = pass_rsrc(out, b, 7, a.log_s);
+    if constexpr (BUF) {
+        const uint32_t vo = (uint32_t)lo * 8 + half * 64 * row_bytes;
 #pragma unroll
-    for (int i = 0; i < 64; i++) y[i] = in[base + ((size_t)(64 * half + i) << a.log_s)];
+        for (int i = 0; i < 64; i++) y[i] = buf_ld(rin, vo, (uint32_t)i * row_bytes);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; i++) y[i] = in[base + ((size_t)(64 * half + i) << a.log_s)];
+    }
     __builtin_amdgcn_sched_barrier(0);
     dft_dit_reg<6>(y);
 #pragma unroll
@@ -707,8 +739,14 @@ __global__ __launch_bounds__(256, 3) void ntt_fwd_strided_reg7x2(PassArgs a) {
         uint64_t lo_row = add(u, v), hi_row = sub(u, v);
         if (twiddle) { lo_row = mul(lo_row, tw[i]); hi_row = mul(hi_row, tw[64 + i]); }
         const size_t p0 = base + ((size_t)(r0 + i) << a.log_s), p1 = base + ((size_t)(r0 + 64 + i) << a.log_s);
-        out[p0] = lo_row;
-        out[p1] = hi_row;
+        if constexpr (BUF) {
+            const uint32_t vo = (uint32_t)lo * 8 + r0 * row_bytes;
+            buf_st(rout, vo, (uint32_t)i * row_bytes, lo_row);
+            buf_st(rout, vo, (uint32_t)(64 + i) * row_bytes, hi_row);
+        } else {
+            out[p0] = lo_row;
+            out[p1] = hi_row;
+        }
         if (compact) {
             const size_t j0 = p0 >> a.compact_log, j1 = p1 >> a.compact_log;
             co[(j0 & pmask) * part_len + (j0 >> a.compact_split)] = lo_row;
@@ -895,7 +933,10 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
             const char* nm = pass_names ? (a.log_r == 6 ? (a.first ? "ntt_fwd_reg6_last" : "ntt_fwd_reg6_mid") : a.log_r == 5 ? "ntt_fwd_reg5" : a.log_r == 4 ? "ntt_fwd_reg4" : "ntt_fwd_reg123") : "ntt_fwd_pass";
             switch (a.log_r) {
                 case 7:
-                    AERO_LAUNCH(this, pass_names ? "ntt_fwd_reg7" : nm, abytes, ntt_fwd_strided_reg7x2, dim3((unsigned)((((size_t)1 << log_out) >> 6) / 256), ncols), dim3(256), 0, a);
+                    if (ntt_buf && a.log_s + 10 <= 31)
+                        AERO_LAUNCH(this, pass_names ? "ntt_fwd_reg7" : nm, abytes, ntt_fwd_strided_reg7x2<true>, dim3((unsigned)((((size_t)1 << log_out) >> 6) / 256), ncols), dim3(256), 0, a);
+                    else
+                        AERO_LAUNCH(this, pass_names ? "ntt_fwd_reg7" : nm, abytes, ntt_fwd_strided_reg7x2<false>, dim3((unsigned)((((size_t)1 << log_out) >> 6) / 256), ncols), dim3(256), 0, a);
                     break;
                 case 6:
                     if (a.log_s >= 7) {  // two lanes per transform: 32 values per lane (the block index stays uniform over a workgroup)
@@ -933,6 +974,8 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         dim3 grid((unsigned)(((size_t)1 << log_out) / E), ncols);
         if (q == 0 && a.log_r == 11 && a.log_pad == 3 && fwd_two_phase(log_out, log_pad)) {
             a.tw_mt = twmt_fwd;
+            static const int f8_chains = getenv("AERO_NTT_F8_CHAINS") ? atoi(getenv("AERO_NTT_F8_CHAINS")) : 1;
+            a.chains = f8_chains;
             const size_t tiles = ((size_t)1 << log_out) >> 11;
             const char* nm = pass_names ? "ntt_fwd_first8" : "ntt_fwd_pass";
             AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8, dim3((unsigned)(tiles / F8_WAVES), ncols), dim3(64 * F8_WAVES), 0, a);

@@ -76,3 +76,43 @@ def test_null_arguments_return_status_codes(lib):
     assert lib.aero_fib_trace(C.c_uint32(2), C.c_uint32(4), None) == -1
     opts = aero_amd.ProofOptions.with_96_bit_security()
     assert opts.to_list() == [27, 8, 16, 4, 1, 8, 8] and C.sizeof(opts) == 7
+
+
+def test_crash_reporter_names_the_aborting_thread_even_when_stderr_was_redirected(tmp_path):
+    """Round 3's driver run died with SIGABRT on a runtime thread and left no message (fd capture). The reporter installed by
+    AERO_CRASH_TRACE=1 (aero_amd/csrc/diag.hip) must write the signal, the thread and a native backtrace to the stderr that existed
+    when the library was loaded AND to AERO_CRASH_LOG - from a thread Python does not know, with fd 2 pointing elsewhere by then."""
+    import subprocess
+    import sys
+    log = tmp_path / "crash.log"
+    code = r'''
+import ctypes, os, sys, threading
+sys.path.insert(0, %r)
+import aero_amd
+aero_amd.lib()                                    # loads libaero_stark: the reporter installs itself (AERO_CRASH_TRACE=1)
+devnull = os.open(os.devnull, os.O_WRONLY)
+os.dup2(devnull, 2)                               # a harness redirects fd 2 afterwards
+libc = ctypes.CDLL(None)
+libpthread = ctypes.CDLL("libpthread.so.0")
+ABORT = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p)(lambda _: libc.abort())
+tid = ctypes.c_ulong()
+libpthread.pthread_create(ctypes.byref(tid), None, ABORT, None)      # a native thread, like the HIP runtime's event thread
+import time; time.sleep(5)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AERO_CRASH_TRACE="1", AERO_CRASH_LOG=str(log))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == -6, (r.returncode, r.stderr[-500:])
+    for text in (r.stderr, log.read_text()):       # the original stderr (saved descriptor) and the log file
+        assert "[libaero_stark] fatal signal SIGABRT" in text and "tid=" in text
+        assert "libaero_stark.so" in text and "abort" in text          # the native backtrace
+    assert lib_symbol_exists("aero_install_crash_diagnostics")
+
+
+def lib_symbol_exists(name):
+    import ctypes
+    import aero_amd
+    try:
+        getattr(aero_amd.lib(), name)
+        return True
+    except AttributeError:
+        return False
