@@ -173,6 +173,10 @@ int32_t aero_local_group_create(uint32_t world, aero_local_group** out) {
 int32_t aero_local_group_comm(aero_local_group* g, aero_ctx* ctx, int32_t rank, uint32_t min_peer_digests, aero_comm* out) {
     if (!g || !ctx || !ctx->c || !out || rank < 0 || (uint32_t)rank >= g->world) return AERO_E_BAD_ARG;
     aero_local_group::Slot& s = g->slots[rank];
+    // ranks bind from their own threads, possibly at the same moment, and each looks at the slots bound so far (peer access): under the
+    // group's mutex - two ranks that bound simultaneously could otherwise each see the other as unbound and neither enable peer access
+    // (found by ThreadSanitizer over the stand-in runtime, tools/hipstub)
+    std::lock_guard<std::mutex> bind_lock(g->mu);
     if (!s.bound) {
         if (hipSetDevice(ctx->c->device) != hipSuccess) return AERO_E_HIP;
         s.device = ctx->c->device; s.stream = ctx->c->stream;

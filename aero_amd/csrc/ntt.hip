@@ -974,8 +974,10 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         dim3 grid((unsigned)(((size_t)1 << log_out) / E), ncols);
         if (q == 0 && a.log_r == 11 && a.log_pad == 3 && fwd_two_phase(log_out, log_pad)) {
             a.tw_mt = twmt_fwd;
-            static const int f8_chains = getenv("AERO_NTT_F8_CHAINS") ? atoi(getenv("AERO_NTT_F8_CHAINS")) : 1;
-            a.chains = f8_chains;
+            // pass-boundary progression as two interleaved chains on narrow launches (2 columns 2^20 -> 2^23: 94.3 -> 91.4 us; 72 columns: 2950 ->
+            // 2977 us, so wide launches keep the single chain; four chains gain nothing: profiles/r4_ntt_ab.txt). AERO_NTT_F8_CHAINS overrides.
+            static const int f8_chains = getenv("AERO_NTT_F8_CHAINS") ? atoi(getenv("AERO_NTT_F8_CHAINS")) : 0;
+            a.chains = f8_chains ? f8_chains : (ncols < 16 ? 2 : 1);
             const size_t tiles = ((size_t)1 << log_out) >> 11;
             const char* nm = pass_names ? "ntt_fwd_first8" : "ntt_fwd_pass";
             AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8, dim3((unsigned)(tiles / F8_WAVES), ncols), dim3(64 * F8_WAVES), 0, a);
