@@ -108,29 +108,37 @@ const uint64_t* seq_tables(Context* ctx, const Program& p, const Instance& in, u
     for (size_t j = 0; j < in.bgroups.size(); j++) {
         if (!in.bgroups[j].has_seq) continue;
         const BoundaryGroup& bg = in.bgroups[j];
-        std::map<uint64_t, T> bucket;                  // coefficient index mod rows -> sum of c_k offset^k
+        // (coefficient index mod rows, c_k offset^k) pairs of every member, then sorted and merged: at most 2 n / stride entries per member
+        std::vector<std::pair<uint64_t, T>> terms;
+        const uint64_t hadj = gl::pow(h, bg.adj);
         for (size_t m = 0; m < in.members.size(); m++) {
             const BoundaryMember& bm = in.members[m];
             if (bm.seq < 0 || bm.group != j) continue;
-            const std::vector<uint64_t> co = sequence_poly(p, (uint32_t)bm.seq, in.log_n, bg.first);
+            const std::shared_ptr<const std::vector<uint64_t>> co_keep = sequence_poly_cached(p, (uint32_t)bm.seq, in.log_n, bg.first);
+            const std::vector<uint64_t>& co = *co_keep;
+            terms.reserve(terms.size() + 2 * co.size());
             uint64_t hk = 1;                                           // offset^k
-            const uint64_t hadj = gl::pow(h, bg.adj);
             for (size_t k = 0; k < co.size(); k++) {
                 if (co[k]) {
                     const uint64_t c = gl::mul(co[k], hk);
-                    auto add_to = [&](uint64_t idx, T v) { auto it = bucket.find(idx); if (it == bucket.end()) bucket[idx] = v; else it->second = F::add(it->second, v); };
-                    add_to(k & (rows - 1), F::mulb(ba[bm.coef], c));
-                    add_to((k + bg.adj) & (rows - 1), F::mulb(bb[bm.coef], gl::mul(c, hadj)));
+                    terms.push_back({k & (rows - 1), F::mulb(ba[bm.coef], c)});
+                    terms.push_back({(k + bg.adj) & (rows - 1), F::mulb(bb[bm.coef], gl::mul(c, hadj))});
                 }
                 hk = gl::mul(hk, h);
             }
         }
+        std::sort(terms.begin(), terms.end(), [](const std::pair<uint64_t, T>& x, const std::pair<uint64_t, T>& y) { return x.first < y.first; });
         const uint64_t col0 = (uint64_t)(groups[j].seq - 1) * F::DEG;
-        for (auto& kv : bucket)
+        for (size_t i = 0; i < terms.size();) {
+            T acc = terms[i].second;
+            size_t e = i + 1;
+            while (e < terms.size() && terms[e].first == terms[i].first) acc = F::add(acc, terms[e++].second);
             for (int d = 0; d < F::DEG; d++) {
-                pos.push_back((col0 + d) * rows + gl::bitrev((uint32_t)kv.first, lg));
-                val.push_back(F::comp(kv.second, d));
+                pos.push_back((col0 + d) * rows + gl::bitrev((uint32_t)terms[i].first, lg));
+                val.push_back(F::comp(acc, d));
             }
+            i = e;
+        }
     }
     const size_t ncols = (size_t)ntab * F::DEG;
     uint64_t* tab = (uint64_t*)ctx->scratch_alloc(ncols * rows * 8);

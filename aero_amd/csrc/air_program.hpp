@@ -30,6 +30,8 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
+#include <tuple>
 #include <queue>
 #include <string>
 #include <vector>
@@ -112,6 +114,7 @@ struct Program {
     std::vector<uint8_t> has_den;             // per aux column
     std::vector<uint8_t> has_add;             // per aux column: 0 = pure running product, 1 = additive term, 3 = additive term with a denominator
     mutable std::shared_ptr<void> jit_cache;  // code objects of the run-time compiled evaluation kernels (air_jit.hip), shared by copies
+    mutable std::shared_ptr<void> seq_cache;  // interpolants of the sequence assertions per (sequence, trace length, first step)
 
     size_t num_transition() const { return trans.size(); }
     size_t num_assertions() const { return masserts.size() + aasserts.size(); }
@@ -732,6 +735,28 @@ inline std::vector<uint64_t> sequence_poly(const Program& p, uint32_t k, int log
         for (auto& c : co) { c = gl::mul(c, sc); sc = gl::mul(sc, gi); }
     }
     return co;
+}
+// the same, kept per (sequence, trace length, first step) in the program handle: a prover asks for the same polynomials proof after proof
+struct SeqPolyCache {
+    std::mutex mu;
+    std::map<std::tuple<uint32_t, int, uint64_t>, std::shared_ptr<const std::vector<uint64_t>>> polys;
+};
+inline std::shared_ptr<const std::vector<uint64_t>> sequence_poly_cached(const Program& p, uint32_t k, int log_n, uint64_t first) {
+    static std::mutex create_mu;
+    std::shared_ptr<SeqPolyCache> cache;
+    {
+        std::lock_guard<std::mutex> lk(create_mu);
+        if (!p.seq_cache) p.seq_cache = std::make_shared<SeqPolyCache>();
+        cache = std::static_pointer_cast<SeqPolyCache>(p.seq_cache);
+    }
+    std::lock_guard<std::mutex> lk(cache->mu);
+    auto key = std::make_tuple(k, log_n, first);
+    auto it = cache->polys.find(key);
+    if (it == cache->polys.end()) {
+        if (cache->polys.size() >= 64) cache->polys.clear();          // bounded: a prover works with a handful of trace lengths
+        it = cache->polys.emplace(key, std::make_shared<const std::vector<uint64_t>>(sequence_poly(p, k, log_n, first))).first;
+    }
+    return it->second;            // shared: the map may be cleared by another thread of a pool while this polynomial is in use
 }
 // value of every sequence assertion at the point x (0 for the other members): what host_evaluate takes as seq_at_x
 template <class F> std::vector<typename F::T> sequence_values_at(const Program& p, const Instance& in, typename F::T x) {

@@ -168,6 +168,10 @@ namespace aero { Context* ctx_of(aero_ctx* c); }
 
 extern "C" {
 
+// Is a usable RCCL present in this process? Binds the library, creates nothing (a rank other than rank 0 must not ask RCCL for a
+// unique id just to find out: that starts a bootstrap listener it will never use).
+int32_t aero_rccl_available(void) { return rccl_api() ? AERO_OK : AERO_E_COMM; }
+
 int32_t aero_rccl_unique_id(uint8_t id_out[AERO_RCCL_ID_BYTES]) {
     if (!id_out) return AERO_E_BAD_ARG;
     RcclApi* api = rccl_api();

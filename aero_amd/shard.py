@@ -103,10 +103,10 @@ class RcclComm:
             share_id = _share_over_torch_dist if world > 1 else (lambda b: b)
             if agree is None and world > 1:
                 agree = _agree_over_torch_dist
-        # pre-flight on every rank (binds librccl, asks it for an id that only rank 0's copy of is used): a rank without a usable RCCL
-        # is known BEFORE anybody enters ncclCommInitRank
+        # pre-flight on every rank: a rank without a usable RCCL is known BEFORE anybody enters ncclCommInitRank. Rank 0 asks for the id
+        # (which binds librccl on the way); the others only bind it (aero_rccl_available creates nothing)
         buf = (C.c_uint8 * 128)()
-        rc0 = self.lib.aero_rccl_unique_id(buf)
+        rc0 = self.lib.aero_rccl_unique_id(buf) if rank == 0 else self.lib.aero_rccl_available()
         text0 = self.lib.aero_rccl_last_error(None).decode() if rc0 != 0 else ""
         if agree is not None:
             worst = agree(rc0)

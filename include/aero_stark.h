@@ -281,6 +281,10 @@ typedef struct aero_comm {
  * (The reference has no multi-device prover; its gather step is the worker-pool fan-in of proving_worker.rs:302-310,428-437.) */
 #define AERO_RCCL_ID_BYTES 128
 typedef struct aero_rccl aero_rccl;
+/* AERO_OK when librccl can be bound in this process (nothing is created), AERO_E_COMM + aero_rccl_last_error(NULL) otherwise: the
+ * pre-flight every rank runs before anybody enters the collective `ncclCommInitRank` (a rank without RCCL must make all ranks give
+ * up instead of leaving its peers in the bootstrap). */
+int32_t aero_rccl_available(void);
 int32_t aero_rccl_unique_id(uint8_t id_out[AERO_RCCL_ID_BYTES]);
 int32_t aero_rccl_create(aero_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[AERO_RCCL_ID_BYTES], aero_rccl** out);
 int32_t aero_rccl_comm(aero_rccl* r, uint32_t min_peer_digests, aero_comm* out);

@@ -137,6 +137,9 @@ class _FakeRcclLib:
     def aero_rccl_unique_id(self, buf):
         return self.preflight_rc
 
+    def aero_rccl_available(self):
+        return self.preflight_rc
+
     def aero_rccl_create(self, *a):
         self.created += 1
         return self.create_rc
