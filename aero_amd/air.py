@@ -21,6 +21,7 @@ MAGIC = b"AEROAIR\x01"
 OP_ADD, OP_SUB, OP_MUL = 1, 2, 3
 NODE, MAIN_CUR, MAIN_NXT, AUX_CUR, AUX_NXT, PERIODIC, CONST, PUB, RAND, SEQ = range(10)
 NONE = 0xFFFFFFFF
+GENERAL = 0xFFFFFFFE
 
 
 class Expr:
@@ -146,10 +147,16 @@ class AirBuilder:
         self.builders[column] = (self._e(init).ref, self._e(num).ref, NONE if den is None else self._e(den).ref,
                                  NONE if add is None else self._e(add).ref, NONE if add_den is None else self._e(add_den).ref)
 
+    def aux_builder_general(self, column, init, nxt):
+        """aux column(0) = init, column(i+1) = nxt evaluated on (main row i, main row i+1, CURRENT row of the auxiliary columns up to
+        `column` itself): any recurrence - e.g. one that squares its own previous value. It cannot be scanned: the library builds such a
+        column row after row on the host (a fallback for exotic AIRs; products, sums and affine forms stay on the device)."""
+        self.builders[column] = (self._e(init).ref, self._e(nxt).ref, GENERAL, NONE, NONE)
+
     def to_bytes(self):
         nb = len(self.builders)
         assert nb in (0, self.A) and sorted(self.builders) == list(range(nb)), "one aux builder per aux column, or none"
-        v2 = bool(self.sequences) or any(b[3] != NONE for b in self.builders.values())
+        v2 = bool(self.sequences) or any(b[3] != NONE or b[2] == GENERAL for b in self.builders.values())
         out = bytearray(b"AEROAIR\x02" if v2 else MAGIC)
         out += struct.pack("<16I", self.W, self.A, self.R, self.num_pub, self.exemptions, len(self.consts), len(self.periodics),
                            len(self.nodes), len(self.main_trans), len(self.aux_trans), len(self.main_asserts), len(self.aux_asserts),

@@ -275,6 +275,53 @@ void air_build_aux(Context* ctx, const Program& p, const uint64_t* trace_dev, in
     a.ptab = pp.ptr<uint64_t>(i_pt);
     a.has_den = pp.ptr<uint8_t>(i_hd); a.has_add = pp.ptr<uint8_t>(i_ha); a.init = pp.ptr<T>(i_in); a.out = out;
     launch_air_aux<F>(ctx, a, p.has_den, p.has_add);
+    // General recurrences (den = REF_GENERAL): column(i + 1) = expr(main row i, main row i + 1, aux row i of the columns up to its own).
+    // Nothing about such a recurrence can be scanned, so it is evaluated row after row on the HOST, after the columns the device built:
+    // the main columns it reads and the auxiliary columns so far come down, the finished columns go back up. A fallback for exotic
+    // AIRs (about 0.1 us per row and node), not a fast path: running products / sums / mixed affine forms never take it.
+    bool any_general = false;
+    for (uint32_t c = 0; c < p.A; c++) any_general |= p.has_add[c] == 4;
+    if (!any_general) return;
+    ctx->sync();
+    std::vector<std::vector<uint64_t>> mcols(p.W);
+    for (uint32_t c : p.general_main_cols) {
+        mcols[c].resize(n);
+        AERO_HIP(hipMemcpyAsync(mcols[c].data(), trace_dev + (size_t)c * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    std::vector<uint64_t> aux((size_t)p.A * F::DEG * n);
+    AERO_HIP(hipMemcpyAsync(aux.data(), out, aux.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    std::vector<T> vals(p.nodes.size(), F::zero());
+    for (uint32_t c = 0; c < p.A; c++) {
+        if (p.has_add[c] != 4) continue;
+        auto aux_at = [&](uint32_t col, uint64_t i) { return F::make(aux[((size_t)col * F::DEG) * n + i], F::DEG > 1 ? aux[((size_t)col * F::DEG + 1) * n + i] : 0); };
+        auto put = [&](uint64_t i, T v) { for (int d = 0; d < F::DEG; d++) aux[((size_t)c * F::DEG + d) * n + i] = F::comp(v, d); };
+        put(0, init[c]);
+        for (uint64_t i = 0; i + 1 < n; i++) {
+            auto operand = [&](uint32_t ref) -> T {
+                const uint32_t k = ref_kind(ref), j = ref_index(ref);
+                switch (k) {
+                    case K_NODE: return p.scalar_of[j] >= 0 ? (p.is_ext[j] ? sc.e[p.scalar_of[j]] : F::from(sc.b[p.scalar_of[j]])) : vals[j];
+                    case K_MAIN_CUR: return F::from(mcols[j][i]);
+                    case K_MAIN_NXT: return F::from(mcols[j][i + 1]);
+                    case K_AUX_CUR: return aux_at(j, i);
+                    case K_PERIODIC: return F::from(p.periodic[j][i % p.periodic[j].size()]);
+                    case K_CONST: return F::from(p.consts[j]);
+                    case K_PUB: return F::from(sc.b[p.consts.size() + j]);
+                    case K_RAND: return sc.e[j];
+                    default: fail("air program: operand not available to a general aux recurrence", ST_INTERNAL); return F::zero();
+                }
+            };
+            for (uint32_t j : p.general_nodes[c]) {
+                const Node& nd = p.nodes[j];
+                const T x = operand(nd.a), y = operand(nd.b);
+                vals[j] = nd.op == 1 ? F::add(x, y) : nd.op == 2 ? F::sub(x, y) : F::mul(x, y);
+            }
+            put(i + 1, operand(p.builders[c].num));
+        }
+        AERO_HIP(hipMemcpyAsync(out + (size_t)c * F::DEG * n, aux.data() + (size_t)c * F::DEG * n, (size_t)F::DEG * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->sync();          // `aux` is pageable host memory that dies with this frame
 }
 template void air_build_aux<FB>(Context*, const Program&, const uint64_t*, int, const uint64_t*, const uint64_t*, uint64_t*);
 template void air_build_aux<FQ>(Context*, const Program&, const uint64_t*, int, const uint64_t*, const gl::E2*, uint64_t*);

@@ -592,7 +592,7 @@ template <class F> __device__ __forceinline__ void air_fac_put(uint64_t* fac, si
 template <class F> __global__ __launch_bounds__(256) void air_aff_ratio_kernel(uint64_t* fac, size_t n, uint32_t A, const uint8_t* has_den, const uint8_t* has_add) {
     typedef typename F::T T;
     const uint32_t c = blockIdx.y;
-    if (!has_add[c]) return;
+    if (!has_add[c] || has_add[c] == 4) return;
     const bool hd = has_den[c], ad = has_add[c] & 2;
     if (!hd && !ad) return;
     const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_K;
@@ -625,7 +625,7 @@ template <class F> __global__ __launch_bounds__(256) void air_aff_totals_kernel(
     typedef typename F::T T;
     __shared__ T shm[256], sht[256];
     const uint32_t c = blockIdx.y;
-    if (!has_add[c]) return;
+    if (!has_add[c] || has_add[c] == 4) return;      // 4: general recurrence, built on the host
     const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_K;
     AffPair<F> p{F::one(), F::zero()};
 #pragma unroll
@@ -638,7 +638,7 @@ template <class F> __global__ __launch_bounds__(256) void air_aff_scan_totals_ke
     typedef typename F::T T;
     __shared__ T shm[256], sht[256];
     const uint32_t c = blockIdx.x;
-    if (!has_add[c]) return;
+    if (!has_add[c] || has_add[c] == 4) return;
     AffPair<F>* row = totals + (size_t)c * nblk;
     const uint32_t per = (nblk + 255) / 256, lo = threadIdx.x * per;
     AffPair<F> p{F::one(), F::zero()};
@@ -653,7 +653,7 @@ template <class F> __global__ __launch_bounds__(256) void air_aff_apply_kernel(c
     typedef typename F::T T;
     __shared__ T shm[256], sht[256];
     const uint32_t c = blockIdx.y;
-    if (!has_add[c]) return;
+    if (!has_add[c] || has_add[c] == 4) return;      // 4: general recurrence, built on the host
     const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_K;
     AffPair<F> f[SCAN_K];
     AffPair<F> p{F::one(), F::zero()};
@@ -675,7 +675,7 @@ template <class F> void launch_air_aux(Context* ctx, const AirAuxArgs<F>& a, con
     const size_t n = a.n;
     const uint32_t A = a.A;
     bool any_affine = false, any_product = false;
-    for (uint32_t c = 0; c < A; c++) { if (c < has_add_host.size() && has_add_host[c]) any_affine = true; else any_product = true; }
+    for (uint32_t c = 0; c < A; c++) { const uint8_t k = c < has_add_host.size() ? has_add_host[c] : 0; if (k == 4) continue; if (k) any_affine = true; else any_product = true; }
     uint64_t* fac = (uint64_t*)ctx->scratch_alloc((size_t)(any_affine ? 4 : 2) * A * F::DEG * n * 8);
     const size_t slots = (size_t)a.slotsB + (size_t)a.slotsE * F::DEG;
     const size_t lds = (slots ? slots : 1) * AIR_WG * 8;

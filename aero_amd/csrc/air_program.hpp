@@ -45,6 +45,7 @@ namespace air {
 
 enum Kind : uint32_t { K_NODE = 0, K_MAIN_CUR, K_MAIN_NXT, K_AUX_CUR, K_AUX_NXT, K_PERIODIC, K_CONST, K_PUB, K_RAND, K_COUNT, K_SEQ = K_COUNT };   // K_SEQ: value of a sequence assertion only
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
+constexpr uint32_t REF_GENERAL = 0xFFFFFFFEu;    // aux builder, `den` field: column(i+1) = num evaluated on (main row i, main row i+1, aux row i): any recurrence, built on the host
 inline uint32_t ref_kind(uint32_t r) { return r >> 24; }
 inline uint32_t ref_index(uint32_t r) { return r & 0xFFFFFFu; }
 inline uint32_t mk_ref(uint32_t k, uint32_t i) { return (k << 24) | i; }
@@ -112,7 +113,9 @@ struct Program {
     std::vector<uint32_t> cons_desc, aux_desc;       // LOAD descriptors
     uint32_t cons_slotsB = 0, cons_slotsE = 0, aux_slotsB = 0, aux_slotsE = 0;
     std::vector<uint8_t> has_den;             // per aux column
-    std::vector<uint8_t> has_add;             // per aux column: 0 = pure running product, 1 = additive term, 3 = additive term with a denominator
+    std::vector<uint8_t> has_add;             // per aux column: 0 = pure running product, 1 = additive term, 3 = additive term with a denominator, 4 = general recurrence (host)
+    std::vector<std::vector<uint32_t>> general_nodes;   // per aux column with a general recurrence: the nodes its expression needs, ascending
+    std::vector<uint32_t> general_main_cols;  // main columns the general recurrences read (the host evaluation downloads these)
     mutable std::shared_ptr<void> jit_cache;  // code objects of the run-time compiled evaluation kernels (air_jit.hip), shared by copies
     mutable std::shared_ptr<void> seq_cache;  // interpolants of the sequence assertions per (sequence, trace length, first step)
 
@@ -517,10 +520,15 @@ inline Program load(const uint8_t* bytes, size_t len) {
         b.init = rd.u32(); b.num = rd.u32(); b.den = rd.u32();
         if (version >= 2) { b.add_num = rd.u32(); b.add_den = rd.u32(); }      // version 2: affine recurrence (running sums, mixed forms)
         check_ref(b.init, nn, "an aux builder"); check_ref(b.num, nn, "an aux builder");
-        if (b.den != REF_NONE) check_ref(b.den, nn, "an aux builder");
+        if (b.den != REF_NONE && b.den != REF_GENERAL) check_ref(b.den, nn, "an aux builder");
         if (b.add_num != REF_NONE) check_ref(b.add_num, nn, "an aux builder");
         if (b.add_den != REF_NONE) { if (b.add_num == REF_NONE) fail("air program: an aux builder's additive denominator needs a numerator"); check_ref(b.add_den, nn, "an aux builder"); }
         if (ref_row_dep(p, b.init)) fail("air program: an aux builder's initial value must not depend on the trace");
+        if (b.den == REF_GENERAL) {
+            // general recurrence: `num` is the whole next value; it may read the current row of auxiliary columns up to and including its own
+            if (version < 2) fail("air program: general aux recurrences need version 2");
+            if (b.add_num != REF_NONE || b.add_den != REF_NONE) fail("air program: a general aux recurrence has no additive term");
+        } else
         for (uint32_t r : {b.num, b.den, b.add_num, b.add_den})
             if (r != REF_NONE && ref_uses_aux(p, r)) fail("air program: an aux builder's terms may only read the main segment");
         p.builders.push_back(b);
@@ -534,7 +542,7 @@ inline Program load(const uint8_t* bytes, size_t len) {
         auto count_use = [&](uint32_t ref) { if (ref != REF_NONE && ref_kind(ref) == K_NODE) node_uses[ref_index(ref)]++; };
         for (auto& nd : p.nodes) { count_use(nd.a); count_use(nd.b); }
         for (auto& t : p.trans) count_use(t.root);
-        for (auto& b : p.builders) { count_use(b.init); count_use(b.num); count_use(b.den); count_use(b.add_num); count_use(b.add_den); }
+        for (auto& b : p.builders) { count_use(b.init); count_use(b.num); if (b.den != REF_GENERAL) count_use(b.den); count_use(b.add_num); count_use(b.add_den); }
         for (auto* v : {&p.masserts, &p.aasserts}) for (auto& as : *v) count_use(as.value);
         for (uint32_t g = 0; g < p.dgroups.size(); g++) {
             for (uint32_t k = 0; k < p.trans.size(); k++) {
@@ -558,7 +566,31 @@ inline Program load(const uint8_t* bytes, size_t len) {
         CodeGen cg(p);
         p.has_den.assign(p.A, 0);
         p.has_add.assign(p.A, 0);
+        p.general_nodes.assign(p.A, {});
+        std::vector<uint8_t> gmain(p.W, 0);
         for (uint32_t c = 0; c < p.A; c++) {
+            if (p.builders[c].den == REF_GENERAL) {
+                // evaluated row after row on the host (air_host.hip: host_general_column): the nodes the expression reaches, in index order
+                p.has_add[c] = 4;
+                std::vector<uint8_t> seen(p.nodes.size(), 0);
+                std::vector<uint32_t> stack;
+                auto visit_ref = [&](uint32_t r) {
+                    const uint32_t k = ref_kind(r), i = ref_index(r);
+                    if (k == K_NODE) { if (!seen[i] && p.scalar_of[i] < 0) { seen[i] = 1; stack.push_back(i); } }
+                    else if (k == K_MAIN_CUR || k == K_MAIN_NXT) gmain[i] = 1;
+                    else if (k == K_AUX_NXT) fail("air program: a general aux recurrence reads the CURRENT row of the auxiliary segment only");
+                    else if (k == K_AUX_CUR && i > c) fail("air program: a general aux recurrence may read auxiliary columns up to its own index only");
+                };
+                visit_ref(p.builders[c].num);
+                while (!stack.empty()) {
+                    const uint32_t i = stack.back();
+                    stack.pop_back();
+                    p.general_nodes[c].push_back(i);
+                    visit_ref(p.nodes[i].a); visit_ref(p.nodes[i].b);
+                }
+                std::sort(p.general_nodes[c].begin(), p.general_nodes[c].end());
+                continue;
+            }
             if (p.builders[c].add_num != REF_NONE) {
                 p.has_add[c] = 1;
                 cg.gen(p.builders[c].add_num);
@@ -577,6 +609,7 @@ inline Program load(const uint8_t* bytes, size_t len) {
                 cg.emit(ref_is_ext(p, p.builders[c].den) ? OP_OUT_E : OP_OUT_B, 2 * c + 1, p.builders[c].den);
             }
         }
+        for (uint32_t c = 0; c < p.W; c++) if (gmain[c]) p.general_main_cols.push_back(c);
         cg.lower({});
         cg.marker(OP_END, 0);
         cg.allocate(p.aux_code, p.aux_desc, &p.aux_slotsB, &p.aux_slotsE);

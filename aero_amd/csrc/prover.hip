@@ -989,7 +989,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
                 // the main columns the auxiliary builders read: few of them (9 of 72 for the stand-in) come straight from the host,
                 // otherwise the evaluations are all-gathered over the GPU links
                 std::vector<uint8_t> need(W, 0);
-                if (prog) { for (uint32_t d : prog->aux_desc) if (!(d & 0x40000000u)) need[d & 0xffff] = 1; }
+                if (prog) { for (uint32_t d : prog->aux_desc) if (!(d & 0x40000000u)) need[d & 0xffff] = 1; for (uint32_t c : prog->general_main_cols) need[c] = 1; }
                 else for (uint32_t c = 0; c < A; c++) need[c % W] = 1;
                 // The choice must be the SAME on every rank (the all-gather is a collective): it is made from the largest number of
                 // foreign needed columns any rank would have to fetch, computed here for all ranks alike - not from this rank's own count

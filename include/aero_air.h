@@ -55,8 +55,12 @@
  *                column(i + 1) = column(i) * num(i) / den(i) + add_num(i) / add_den(i) (add_num = 0xFFFFFFFF: no additive term;
  *                add_den = 0xFFFFFFFF: 1) - running sums (log-derivative arguments: num = 1), and mixed forms; row maps
  *                x -> m x + t compose associatively, so the device builds the column with a prefix scan like the products.
- *                A recurrence that is not affine in the column's own previous value (column(i)^2 ...) cannot be scanned and is
- *                not representable; nor is more than ONE auxiliary segment - winter-air 0.4's TraceLayout has NUM_AUX_SEGMENTS = 1
+ *                [v2] den = 0xFFFFFFFE marks a GENERAL recurrence: column(i + 1) = num, where num may read MAIN_*, PERIODIC, CONST, PUB,
+ *                RAND and the CURRENT row of the auxiliary columns up to and including its own (AUX_CUR | j, j <= column): any
+ *                per-row recurrence over the frame, e.g. one that squares its own previous value. Such a column cannot be scanned:
+ *                the library builds it row after row on the HOST after the device-built columns (about 0.1 us per row and node - a
+ *                completeness fallback, not a fast path; products, sums and affine forms never take it).
+ *                Not representable: more than ONE auxiliary segment - winter-air 0.4's TraceLayout has NUM_AUX_SEGMENTS = 1
  *                and its proof bytes hold exactly one (width, random elements) pair (proof_format.hpp; pinned on proofs/fib.bin).
  *                A program without builders can be verified and its constraints evaluated, but proving needs the columns.
  *   operand reference = kind << 24 | index:
@@ -96,6 +100,7 @@ extern "C" {
 #define AERO_AIR_RAND 8u
 #define AERO_AIR_SEQ 9u
 #define AERO_AIR_NONE 0xFFFFFFFFu
+#define AERO_AIR_GENERAL 0xFFFFFFFEu /* aux builder `den`: general recurrence (see the format description) */
 
 /* AIR id of a trace file (aero_trace_file_*) whose constraint set travels as an AEROAIR program next to it. */
 #define AERO_AIR_PROGRAM 2u

@@ -23,6 +23,7 @@
 // code and no evaluation strategy with aero_amd/csrc/air_program.hpp / air_kernels.hip.
 #pragma once
 #include <cstring>
+#include <functional>
 #include "stark.hpp"
 
 namespace orc {
@@ -31,6 +32,7 @@ struct ProgramAir {
     enum { KNOWN = 1 };
     enum { K_NODE = 0, K_MAIN_CUR, K_MAIN_NXT, K_AUX_CUR, K_AUX_NXT, K_PERIODIC, K_CONST, K_PUB, K_RAND, K_SEQ };
     static const uint32_t NONE = 0xFFFFFFFFu;
+    static const uint32_t GENERAL = 0xFFFFFFFEu;     // builder.den: column(i+1) = num on (main row i, i+1; aux row i of columns <= its own)
     // ---- the program as written
     uint32_t W = 0, A = 0, R = 0, num_pub = 0, exemptions = 1;
     Col consts;
@@ -140,7 +142,8 @@ struct ProgramAir {
             Builder b{u32(), u32(), u32(), NONE, NONE};
             if (version >= 2) { b.add_num = u32(); b.add_den = u32(); }
             check_ref(b.init, nn); check_ref(b.num, nn);
-            if (b.den != NONE) check_ref(b.den, nn);
+            if (b.den != NONE && b.den != GENERAL) check_ref(b.den, nn);
+            if (b.den == GENERAL && (version < 2 || b.add_num != NONE || b.add_den != NONE)) throw Err("air program: bad general builder");
             if (b.add_num != NONE) check_ref(b.add_num, nn);
             if (b.add_den != NONE) { if (b.add_num == NONE) throw Err("air program: builder denominator without a numerator"); check_ref(b.add_den, nn); }
             a.builders.push_back(b);
@@ -349,6 +352,7 @@ struct ProgramAir {
                 Frame<F> f{mc.data(), mn.data(), nullptr, nullptr, rands.data(), per.data()};
                 run_nodes<F>(f, vals);
                 for (uint32_t c = 0; c < A; c++) {
+                    if (builders[c].den == GENERAL) { if (i == 0) init[c] = operand<F>(builders[c].init, f, vals); continue; }
                     T m = operand<F>(builders[c].num, f, vals);
                     if (builders[c].den != NONE) m = F::mul(m, F::inv(operand<F>(builders[c].den, f, vals)));
                     mult[c][i] = m;
@@ -363,11 +367,41 @@ struct ProgramAir {
         }
 #pragma omp parallel for schedule(dynamic, 1)
         for (uint32_t c = 0; c < A; c++) {
+            if (builders[c].den == GENERAL) continue;
             T p = init[c];
             for (size_t i = 0; i < n_; i++) {
                 for (int k = 0; k < F::DEG; k++) acols[c * F::DEG + k][i] = F::comp(p, k);
                 p = F::mul(p, mult[c][i]);
                 if (!addv[c].empty()) p = F::add(p, addv[c][i]);
+            }
+        }
+        // general recurrences, in column order, row after row: the expression sees the main frame and the current row of the
+        // auxiliary columns up to its own (every node is evaluated recursively - no sharing, no ordering tricks)
+        for (uint32_t c = 0; c < A; c++) {
+            if (builders[c].den != GENERAL) continue;
+            T p = init[c];
+            for (size_t i = 0; i < n_; i++) {
+                for (int k = 0; k < F::DEG; k++) acols[c * F::DEG + k][i] = F::comp(p, k);
+                if (i + 1 == n_) break;
+                std::function<T(uint32_t)> ev = [&](uint32_t ref) -> T {
+                    const uint32_t j = index(ref);
+                    switch (kind(ref)) {
+                        case K_NODE: { const T a = ev(nodes[j].a), b = ev(nodes[j].b); return nodes[j].op == 1 ? F::add(a, b) : nodes[j].op == 2 ? F::sub(a, b) : F::mul(a, b); }
+                        case K_MAIN_CUR: return F::from(trace[j][i]);
+                        case K_MAIN_NXT: return F::from(trace[j][i + 1]);
+                        case K_AUX_CUR: {
+                            if (j > c) throw Err("air program: a general builder reads a later auxiliary column");
+                            const uint64_t comp[2] = {acols[j * F::DEG][i], F::DEG > 1 ? acols[j * F::DEG + F::DEG - 1][i] : 0};
+                            return F::make(comp);
+                        }
+                        case K_PERIODIC: return F::from(periodic[j][i % periodic[j].size()]);
+                        case K_CONST: return F::from(consts[j]);
+                        case K_PUB: return F::from(pub[j]);
+                        case K_RAND: return rands[j];
+                        default: throw Err("air program: operand not available to a general builder");
+                    }
+                };
+                p = ev(builders[c].num);
             }
         }
     }

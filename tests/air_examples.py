@@ -143,10 +143,11 @@ def v2_air(log_n, seq_stride=4):
       1  running SUM (log-derivative shape) s' = s + m3 / (r1 + m2)
       2  mixed affine                       u' = u (r2 + m1) + m0 m3
       3  constant 7                         c' = c
+      4  general (cannot be scanned)        g' = g g + m0 + r0 a1      (reads its own and an earlier auxiliary column)
     Assertions: singles, a sequence on the counter (every seq_stride-th step from step 1), a two-value sequence on column 0,
     a sequence on the constant auxiliary column. Returns (builder, trace, pub)."""
     n = 1 << log_n
-    b = A.AirBuilder(4, 4, 4, num_pub=1)
+    b = A.AirBuilder(4, 5, 4, num_pub=1)
     m, mn, a, an, r = b.main, b.main_next, b.aux, b.aux_next, b.rand
     b.transition(mn(0) - (m(0) + m(1)), 1)
     b.transition(mn(1) - (m(1) + mn(0)), 1)
@@ -156,6 +157,7 @@ def v2_air(log_n, seq_stride=4):
     b.aux_transition((an(1) - a(1)) * (r(1) + m(2)) - m(3), 2)
     b.aux_transition(an(2) - a(2) * (r(2) + m(1)) - m(0) * m(3), 2)
     b.aux_transition(an(3) - a(3), 1)
+    b.aux_transition(an(4) - (a(4) * a(4) + m(0) + r(0) * a(1)), 2)
     t = np.zeros((4, n), np.uint64)
     x, y = 1, 2
     for i in range(n):
@@ -174,4 +176,6 @@ def v2_air(log_n, seq_stride=4):
     b.aux_builder(1, 0, 1, None, m(3), r(1) + m(2))
     b.aux_builder(2, b.rand(3), r(2) + m(1), None, m(0) * m(3))
     b.aux_builder(3, 7, 1)
+    b.aux_assert_single(4, 0, 3)
+    b.aux_builder_general(4, 3, a(4) * a(4) + m(0) + r(0) * a(1))
     return b, t, [int(t[1][-1])]

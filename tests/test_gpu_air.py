@@ -359,7 +359,8 @@ def test_version2_stage_entry_points(ctx, oracle, ext, nfrag):
     rands = oracle.artifact("aux_rands", deg * 4)
     dev = ctx.trace_upload(trace)
     auxm = ctx.aux_columns_program(air, dev, pub, rands, ext)
-    assert (auxm.download() == oracle.artifact("aux_cols", 4 * deg * n).reshape(4 * deg, n)).all()
+    A_ = info["aux_width"]                                 # 5: product with denominator, running sum, mixed affine, constant, general (host-built)
+    assert (auxm.download() == oracle.artifact("aux_cols", A_ * deg * n).reshape(A_ * deg, n)).all()
     lde = ctx.evaluate_columns_over(ctx.interpolate_columns(dev), 3)
     alde = ctx.evaluate_columns_over(ctx.interpolate_columns(auxm), 3)
     want = oracle.artifact("ce_cols", ncols * deg * C * n).reshape(ncols * deg, C * n)
