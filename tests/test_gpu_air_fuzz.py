@@ -112,7 +112,7 @@ class Gen:
             init = b.const(1) if r.random() < 0.5 else b.rand(0) * b.rand(self.R - 1) + 1
             num = b.rand(r.randrange(self.R)) + b.main(r.randrange(self.W)) * (b.main_next(r.randrange(self.W)) if r.random() < 0.5 else 1)
             den = (b.rand(r.randrange(self.R)) + b.main(r.randrange(self.W))) if r.random() < 0.5 else None
-            if v2 and r.random() < 0.25:             # general recurrence (host-built): non-affine in its own previous value, may read earlier aux columns
+            if v2 and r.random() < 0.45:             # general recurrence (host-built): non-affine in its own previous value, may read earlier aux columns
                 other = b.aux(r.randrange(c + 1))
                 b.aux_builder_general(c, init, b.aux(c) * other + b.main(r.randrange(self.W)) * b.rand(r.randrange(self.R)) + 1)
                 b.aux_assert_single(c, 0, init)
