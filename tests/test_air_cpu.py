@@ -211,3 +211,37 @@ def test_version2_loader_rules():
     raw[7] = 2
     with pytest.raises(aero_amd.AeroError):                  # ... and as version 2 the record is too short
         aero_amd.Air(bytes(raw))
+
+
+def test_general_recurrence_loader_rules():
+    from aero_amd import air as A
+
+    def base():
+        b = A.AirBuilder(1, 2, 1)
+        b.transition(b.main_next(0) - b.main(0), 1)
+        b.aux_transition(b.aux_next(0) - b.aux(0), 1)
+        b.aux_transition(b.aux_next(1) - b.aux(1) * b.aux(1), 2)
+        b.aux_builder(0, 1, 1)
+        return b
+    ok = base()
+    ok.aux_builder_general(1, 2, ok.aux(1) * ok.aux(1) + ok.aux(0) * ok.rand(0) + ok.main_next(0))    # own and earlier columns, current row
+    prog = ok.to_bytes()
+    assert prog[7] == 2
+    assert aero_amd.Air(prog).info()["has_aux_builders"] == 1
+    later = base()
+    later.builders[0] = (later.const(1).ref, (later.aux(1) + 1).ref, A.GENERAL, A.NONE, A.NONE)          # column 0 reading column 1
+    later.aux_builder_general(1, 2, later.aux(1))
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.Air(later.to_bytes())
+    nxt = base()
+    nxt.aux_builder_general(1, 2, nxt.aux_next(0) + 1)                                                  # the NEXT row of the auxiliary segment does not exist yet
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.Air(nxt.to_bytes())
+    v1 = bytearray(prog)
+    v1[7] = 1
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.Air(bytes(v1))
+    affine_reads_aux = base()
+    affine_reads_aux.aux_builder(1, 2, affine_reads_aux.aux(0) + 1)                                     # only a general recurrence may read the auxiliary segment
+    with pytest.raises(aero_amd.AeroError):
+        aero_amd.Air(affine_reads_aux.to_bytes())
