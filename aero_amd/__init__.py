@@ -96,36 +96,31 @@ def fib_trace(width, log_n):
 
 
 class PinnedTrace:
-    """A host trace in pinned memory (aero_host_register) for asynchronous DMA; `.array` is the (width, n) uint64 matrix.
+    """A host trace in pinned memory for asynchronous DMA; `.array` is the (width, n) uint64 matrix.
     The reference's traces live in host memory when `Prover::prove` is called (proving_worker.rs:140,465-467).
 
-    The object OWNS its memory: the caller's array is copied once into a private, page-aligned buffer of whole pages and THAT is
-    registered. (Round 3 registered the caller's own array when it was contiguous: pinned and pageable hand-overs of "the same"
-    trace then aliased one buffer, its lifetime and page alignment were the caller's, and a registration could outlive pages the
-    allocator had already recycled. A Rust host does the equivalent by registering the Vec it owns.)"""
-    _PAGE = 4096
+    The object OWNS its memory: the caller's array is copied once into a buffer the library's runtime allocated pinned
+    (aero_host_alloc = hipHostMalloc). (Round 3 registered the caller's own numpy array: pinned and pageable hand-overs of "the same"
+    trace aliased one buffer and a user-pointer registration lived on pages whose lifetime was the allocator's. A Rust host does the
+    equivalent by filling a buffer from aero_host_alloc, or registers the Vec it owns with aero_host_register.)"""
 
     def __init__(self, trace: np.ndarray):
         src = np.ascontiguousarray(trace, np.uint64)
         self.width, n = src.shape
         self.log_n = int(n).bit_length() - 1
-        nbytes = src.nbytes
-        span = (nbytes + self._PAGE - 1) // self._PAGE * self._PAGE
-        self._raw = np.empty(span + self._PAGE, np.uint8)
-        off = (-self._raw.ctypes.data) % self._PAGE
-        self._base = self._raw.ctypes.data + off
-        self._span = span
-        self.array = self._raw[off:off + nbytes].view(np.uint64).reshape(src.shape)
-        self.array[...] = src
-        rc = lib().aero_host_register(C.c_void_p(self._base), C.c_size_t(span))
+        self._ptr = C.c_void_p()
+        rc = lib().aero_host_alloc(C.c_size_t(src.nbytes), C.byref(self._ptr))
         if rc != 0:
             raise AeroError(rc, lib().aero_last_error(None).decode())
-        self._registered = True
+        flat = np.ctypeslib.as_array((C.c_uint64 * src.size).from_address(self._ptr.value))
+        self.array = flat.reshape(src.shape)
+        self.array[...] = src
 
     def release(self):
-        if getattr(self, "_registered", False):
-            lib().aero_host_unregister(C.c_void_p(self._base))
-            self._registered = False
+        if getattr(self, "_ptr", None) is not None and self._ptr.value:
+            self.array = None
+            lib().aero_host_free(self._ptr)
+            self._ptr = C.c_void_p()
 
     def __del__(self):
         try:

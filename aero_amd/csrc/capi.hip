@@ -631,6 +631,21 @@ int32_t aero_host_unregister(void* p) {
     if (e != hipSuccess) { (void)hipGetLastError(); g_create_err = std::string("hipHostUnregister: ") + hipGetErrorString(e); return AERO_E_HIP; }
     return AERO_OK;
 }
+// Pinned host memory owned by the library's runtime (hipHostMalloc): DMA-able from the start, nothing of the caller's address space is
+// registered after the fact (no user-pointer mapping that has to follow the kernel's page migrations).
+int32_t aero_host_alloc(size_t bytes, void** out) {
+    if (!out || !bytes) return AERO_E_BAD_ARG;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; g_create_err = std::string("hipHostMalloc: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? AERO_E_OOM : AERO_E_HIP; }
+    return AERO_OK;
+}
+int32_t aero_host_free(void* p) {
+    if (!p) return AERO_OK;
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); g_create_err = std::string("hipHostFree: ") + hipGetErrorString(e); return AERO_E_HIP; }
+    return AERO_OK;
+}
 int32_t aero_proof_container(const uint8_t* inputs, size_t inputs_len, const uint8_t* proof, size_t proof_len, uint8_t** out, size_t* out_len) {
     if (!out || !out_len || (!inputs && inputs_len) || (!proof && proof_len)) return AERO_E_BAD_ARG;
     size_t total = 16 + inputs_len + proof_len;

@@ -241,6 +241,11 @@ int32_t aero_prove_fib_host(aero_ctx* ctx, const uint64_t* trace_col_major, uint
  * trace hand-overs from it are asynchronous DMA transfers. On failure the text is available from aero_last_error(NULL). */
 int32_t aero_host_register(void* p, size_t bytes);
 int32_t aero_host_unregister(void* p);
+/* Pinned host memory allocated by the library's HIP runtime (`hipHostMalloc`) - the alternative to registering memory the host
+ * already owns: a host that can choose where its trace lives (the Vec<Felt> behind `Matrix<Felt>`, utils.rs:235-236) fills such a
+ * buffer and hands it to the *_host entry points. aero_host_free(NULL) is a no-op. Text on failure: aero_last_error(NULL). */
+int32_t aero_host_alloc(size_t bytes, void** out);
+int32_t aero_host_free(void* p);
 /* ---- one proof sharded over the GPUs of a node ------------------------------------------------------------------------------ */
 /* The exchange steps of a sharded proof, supplied by the host (one process per GPU; torch.distributed over RCCL in this
  * repo's harness, `ncclSend/Recv`-style bindings from Rust). The reference has no multi-device prover; its parallel
