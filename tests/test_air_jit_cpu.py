@@ -87,3 +87,24 @@ def test_a_cache_directory_others_can_write_to_is_ignored(tmp_path, monkeypatch)
     monkeypatch.setenv("AERO_AIR_JIT_CACHE", str(d))
     aero_amd.Air(aero_amd.fib_program(4)).jit_compile(8, 1, True)                # still compiles ...
     assert not list(d.iterdir())                                                 # ... but neither reads nor writes there
+
+
+def test_prepare_builds_the_kernel_a_proof_will_ask_for():
+    # aero_air_prepare: exactly the (field, rows per thread) form a proof of that length uses, ahead of the proof; no GPU involved
+    import time
+    from tests import air_examples as ex
+    b, _, _ = ex.v2_air(10)
+    air = aero_amd.Air(b.to_bytes())
+    opt = aero_amd.ProofOptions(27, 8, 8, 4, 2, 4, 6)
+    t0 = time.perf_counter()
+    air.prepare(10, opt)
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    air.prepare(10, opt)                                   # cached in the handle
+    air.prepare(10, opt, world=1)
+    assert time.perf_counter() - t0 < max(0.05, first / 5)
+    air.prepare(10, opt, world=4)                          # a rank's share of the domain: possibly another rows-per-thread form
+    with pytest.raises(aero_amd.AeroError):
+        air.prepare(10, opt, world=3)                      # ranks are a power of two
+    with pytest.raises(aero_amd.AeroError):
+        air.prepare(2, opt)                                # trace lengths start at 2^3
