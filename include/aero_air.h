@@ -153,7 +153,8 @@ int32_t aero_air_jit_compile(const aero_air* air, uint32_t log_n, uint32_t field
 /* Build, ahead of the first proof, exactly the evaluation kernel a proof of 2^log_n rows under `options` will ask for (`world` =
  * ranks the proof is sharded over, 1 = one GPU). The pool entry points above and aero_prove_air_sharded_host call it themselves
  * before their workers / ranks start; a host that wants the cold start off its first proof calls it when it loads the program
- * (the reference pays the equivalent once, when rustc monomorphises `ProcessorAir`). AERO_OK also when the interpreter is
+ * (the reference pays the equivalent once, when rustc monomorphises `ConstraintEvaluator<ProcessorAir, _>`:
+ * constraints_worker.rs:32-43). AERO_OK also when the interpreter is
  * selected (AERO_AIR_JIT=0); AERO_E_UNSUPPORTED + aero_last_error(NULL) when hiprtc refuses the kernel (the proof still works, interpreted). */
 int32_t aero_air_prepare(const aero_air* air, uint32_t log_n, const aero_proof_options* options, uint32_t world);
 int32_t aero_air_jit_source(const aero_air* air, uint32_t log_n, uint32_t field_extension, int32_t fused, uint8_t** source, size_t* len);

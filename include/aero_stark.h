@@ -288,7 +288,8 @@ typedef struct aero_comm {
 typedef struct aero_rccl aero_rccl;
 /* AERO_OK when librccl can be bound in this process (nothing is created), AERO_E_COMM + aero_rccl_last_error(NULL) otherwise: the
  * pre-flight every rank runs before anybody enters the collective `ncclCommInitRank` (a rank without RCCL must make all ranks give
- * up instead of leaving its peers in the bootstrap). */
+ * up instead of leaving its peers in the bootstrap). (No counterpart in the reference: its prover is single-device, the fan-in of
+ * its worker pool is proving_worker.rs:302-310,428-437.) */
 int32_t aero_rccl_available(void);
 int32_t aero_rccl_unique_id(uint8_t id_out[AERO_RCCL_ID_BYTES]);
 int32_t aero_rccl_create(aero_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[AERO_RCCL_ID_BYTES], aero_rccl** out);
