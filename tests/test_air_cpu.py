@@ -2,6 +2,8 @@
 library's host side (parser / validator / compiler, and the verifier that runs the COMPILED program over E for the
 out-of-domain check) against proofs the oracle produced. Format: include/aero_air.h; reference seam:
 aero-sdk/miden-wasm/src/constraints_worker.rs:32-59."""
+import os
+
 import numpy as np
 import pytest
 
@@ -245,3 +247,29 @@ def test_general_recurrence_loader_rules():
     affine_reads_aux.aux_builder(1, 2, affine_reads_aux.aux(0) + 1)                                     # only a general recurrence may read the auxiliary segment
     with pytest.raises(aero_amd.AeroError):
         aero_amd.Air(affine_reads_aux.to_bytes())
+
+
+def test_cpp_recorder_writes_the_same_programs_as_the_python_builder(tmp_path):
+    """include/aero_air_builder.hpp: an AIR written as C++ expressions -> AEROAIR bytes (what a Rust host does with a symbolic field
+    element over `Air::evaluate_transition`, constraints_worker.rs:32-43). Same construction order = same bytes as aero_amd/air.py."""
+    import shutil
+    import subprocess
+    from aero_amd import air as A
+    from tests import air_examples as ex
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "air_builder_demo")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", os.path.join(root, "tests", "c_abi", "air_builder_demo.cpp"), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cases = [(["fib", "2", "0", "0", "2"], A.fib_air(2).to_bytes()),
+             (["fib", "4", "2", "3", "3"], A.fib_air(4, (2, 3, 3)).to_bytes()),
+             (["fib", "72", "9", "16", "8"], A.fib_air(72, (9, 16, 8)).to_bytes()),
+             (["v2", "6", "4"], ex.v2_air(6, 4)[0].to_bytes()),                      # version 2: sequences, affine and general builders
+             (["v2", "10", "2"], ex.v2_air(10, 2)[0].to_bytes())]
+    for args, want in cases:
+        got = bytes.fromhex(subprocess.check_output([exe] + args, text=True).strip())
+        assert got == want, args
+        aero_amd.Air(got)                                                            # and the library loads it
+    assert cases[0][1] == aero_amd.fib_program(2)                                    # ... which is also what the library's own emitter writes
