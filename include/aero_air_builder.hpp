@@ -4,7 +4,7 @@
 // calling it ONCE with an element whose arithmetic appends nodes instead of computing records the constraint system the reference
 // instantiates at aero-sdk/miden-wasm/src/constraints_worker.rs:32-43 (`ProcessorAir::new` -> `ConstraintEvaluator::new`).
 //
-//     aero_air::Builder b(/*main*/ 2, /*aux*/ 0, /*rands*/ 0, /*public inputs*/ 1);
+//     aero_air_builder::Builder b(/*main*/ 2, /*aux*/ 0, /*rands*/ 0, /*public inputs*/ 1);
 //     auto a = b.main(0), bb = b.main(1), na = b.main_next(0), nb = b.main_next(1);
 //     b.transition(na - (a + bb), 1);
 //     b.transition(nb - (bb + na), 1);
@@ -22,7 +22,7 @@
 #include <tuple>
 #include <vector>
 
-namespace aero_air {
+namespace aero_air_builder {
 
 constexpr uint64_t P = 0xFFFFFFFF00000001ull;
 constexpr uint32_t NONE = 0xFFFFFFFFu, GENERAL = 0xFFFFFFFEu;
@@ -48,7 +48,7 @@ class Builder {
 public:
     Builder(uint32_t main_width, uint32_t aux_width = 0, uint32_t aux_rands = 0, uint32_t num_pub = 0, uint32_t exemptions = 1)
         : W(main_width), A(aux_width), R(aux_rands), num_pub_(num_pub), exemptions_(exemptions) {
-        if (W < 1 || W > 255 || A > 255 - W || (A == 0) != (R == 0) || R > 255) throw std::invalid_argument("aero_air::Builder: bad shape");
+        if (W < 1 || W > 255 || A > 255 - W || (A == 0) != (R == 0) || R > 255) throw std::invalid_argument("aero_air_builder::Builder: bad shape");
         builders_.assign(A, BuilderRec{});
     }
     // ---- operands
@@ -102,7 +102,7 @@ public:
     std::vector<uint8_t> to_bytes() const {
         uint32_t nb = 0;
         for (auto& r : builders_) nb += r.set;
-        if (nb != 0 && nb != A) throw std::logic_error("aero_air::Builder: one aux builder per auxiliary column, or none");
+        if (nb != 0 && nb != A) throw std::logic_error("aero_air_builder::Builder: one aux builder per auxiliary column, or none");
         bool v2 = !sequences_.empty();
         for (auto& r : builders_) v2 |= r.set && (r.add_num != NONE || r.den == GENERAL);
         std::vector<uint8_t> out;
@@ -144,7 +144,7 @@ private:
     std::vector<BuilderRec> builders_;
 
     Expr ref(uint32_t kind, uint32_t idx) { return Expr(this, (kind << 24) | idx); }
-    static void check(bool ok) { if (!ok) throw std::out_of_range("aero_air::Builder: operand or argument out of range"); }
+    static void check(bool ok) { if (!ok) throw std::out_of_range("aero_air_builder::Builder: operand or argument out of range"); }
     static void check_stride(int32_t first, uint32_t stride) { check(stride >= 2 && (stride & (stride - 1)) == 0 && first >= 0 && (uint32_t)first < stride); }
     static std::vector<uint64_t> reduced(const std::vector<uint64_t>& v) { std::vector<uint64_t> r(v); for (auto& x : r) x %= P; return r; }
     uint32_t sequence(int32_t first, uint32_t stride, const std::vector<uint64_t>& values) {
@@ -168,7 +168,7 @@ inline Expr operator+(uint64_t a, Expr b) { return lift(b, a) + b; }
 inline Expr operator-(uint64_t a, Expr b) { return lift(b, a) - b; }
 inline Expr operator*(uint64_t a, Expr b) { return lift(b, a) * b; }
 inline Expr Expr::pow(unsigned e) const {          // square-and-multiply, as the Python builder's `**`
-    if (e < 1) throw std::invalid_argument("aero_air::Expr::pow: exponent >= 1");
+    if (e < 1) throw std::invalid_argument("aero_air_builder::Expr::pow: exponent >= 1");
     Expr r, base = *this;
     bool have = false;
     while (e) {
@@ -179,4 +179,4 @@ inline Expr Expr::pow(unsigned e) const {          // square-and-multiply, as th
     return r;
 }
 
-}  // namespace aero_air
+}  // namespace aero_air_builder

@@ -8,9 +8,9 @@
 
 #include "../../include/aero_air_builder.hpp"
 
-using aero_air::Builder;
-using aero_air::Expr;
-static const uint64_t P = aero_air::P;
+using aero_air_builder::Builder;
+using aero_air_builder::Expr;
+static const uint64_t P = aero_air_builder::P;
 
 static std::vector<uint8_t> fib(uint32_t width, uint32_t A, uint32_t R, uint32_t D) {
     Builder b(width, A, A ? R : 0, width / 2);

@@ -113,3 +113,59 @@ def test_c_host_proves_a_constraint_program(tmp_path, oracle):
     trace, pub = aero_amd.synth_vm_trace(10, 3)
     want, _ = oracle.prove_air(program, trace, pub, [27, 8, 16, 4, 1, 4, 8])
     assert out.read_bytes() == want
+
+
+# ---- an AIR recorded in C++ (include/aero_air_builder.hpp), proven and verified from a C++ host ------------------------------------
+def build_recorder_prover(tmp_path):
+    exe = str(tmp_path / "air_recorder_prover")
+    lib_dir = os.path.join(ROOT, "aero_amd")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "air_recorder_prover.cpp"),
+           "-L", lib_dir, "-laero_stark", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_cpp_recorder_host_compiles_and_refuses_without_a_gpu(tmp_path):
+    exe = build_recorder_prover(tmp_path)
+    r = subprocess.run([exe, "8", str(tmp_path / "p.proof")], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 2), (r.returncode, r.stdout, r.stderr)
+    if r.returncode == 2:
+        assert "no device" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [6, 11])
+def test_cpp_recorded_air_is_proven_and_matches_the_oracle(tmp_path, oracle, log_n):
+    """The whole C++ flow: record the AIR (version 2: sequence assertion, running sum, a general recurrence), aero_air_load,
+    aero_air_prepare, aero_prove_air_host, aero_verify_air - and the bytes are the oracle's for the same system written in Python."""
+    import json
+    import numpy as np
+    from aero_amd import air as A
+    exe = build_recorder_prover(tmp_path)
+    out = tmp_path / "p.proof"
+    r = subprocess.run([exe, str(log_n), str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["version"] == 2 and res["verified"] and res["wrong_statement_rejected"]
+    # the same AIR with the Python builder (the proof depends on the order of constraints and assertions, not on node numbers)
+    n, P = 1 << log_n, A.P
+    t = np.zeros((3, n), np.uint64)
+    x, y = 1, 2
+    for i in range(n):
+        t[0][i], t[1][i], t[2][i] = x, y, (5 + 3 * i) % P
+        x, y = (x + y) % P, (y + x + y) % P
+    b = A.AirBuilder(3, 2, 2, num_pub=1)
+    m, mn, a, an, rd = b.main, b.main_next, b.aux, b.aux_next, b.rand
+    b.transition(mn(0) - (m(0) + m(1)), 1)
+    b.transition(mn(1) - (m(1) + mn(0)), 1)
+    b.transition(mn(2) - m(2) - 3, 1)
+    b.aux_transition((an(0) - a(0)) * (rd(0) + m(2)) - m(0), 2)
+    b.aux_transition(an(1) - (a(1) * a(1) + rd(1) * a(0) + m(1)), 2)
+    b.assert_single(0, 0, 1); b.assert_single(1, 0, 2); b.assert_single(1, -1, b.pub(0))
+    b.assert_sequence(2, 3, 8, [int(t[2][3 + 8 * i]) for i in range(n // 8)])
+    b.aux_assert_single(0, 0, 0); b.aux_assert_single(1, 0, 5)
+    b.aux_builder(0, 0, 1, None, m(0), rd(0) + m(2))
+    b.aux_builder_general(1, 5, a(1) * a(1) + rd(1) * a(0) + m(1))
+    want, _ = oracle.prove_air(b.to_bytes(), t, [int(t[1][-1])], [27, 8, 8, 4, 1, 4, 6])
+    assert out.read_bytes() == want
