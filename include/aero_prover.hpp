@@ -17,6 +17,7 @@
 #include <utility>
 #include <vector>
 
+#include "aero_air.h"
 #include "aero_stark.h"
 
 namespace aero_host {
@@ -219,6 +220,66 @@ inline void verify(const StarkProof& proof, const FibPublicInputs& pub_inputs, c
     char err[512] = {0};
     const std::vector<uint8_t>& b = proof.to_bytes();
     const int32_t rc = aero_verify_fib(b.data(), b.size(), pub_inputs.results.data(), (uint32_t)pub_inputs.results.size(), &air, &policy, err, sizeof err);
+    if (rc != AERO_OK) throw VerifierError(rc, err);
+}
+
+// ---- any AIR, handed over as a constraint program (include/aero_air.h; recorded e.g. with include/aero_air_builder.hpp) ------------
+// `Air` = what `ProcessorAir::new(trace_info, pub_inputs, options)` gives the reference (constraints_worker.rs:32-36): loaded once,
+// immutable, shareable between contexts and threads.
+class Air {
+public:
+    explicit Air(const std::vector<uint8_t>& program) {
+        char err[512] = {0};
+        const int32_t rc = aero_air_load(program.data(), program.size(), &h_, err, sizeof err);
+        if (rc != AERO_OK) throw ProverError(rc, std::string("Air: ") + err);
+    }
+    ~Air() { if (h_) aero_air_free(h_); }
+    Air(const Air&) = delete;
+    Air& operator=(const Air&) = delete;
+    Air(Air&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    const aero_air* raw() const { return h_; }
+    uint32_t main_width() const { uint32_t v[16]; aero_air_info(h_, v); return v[0]; }
+    uint32_t num_pub_inputs() const { uint32_t v[16]; aero_air_info(h_, v); return v[3]; }
+    // build the evaluation kernel a proof of 2^log_length rows will use, ahead of the first proof (aero_air_prepare)
+    void prepare(uint32_t log_length, const ProofOptions& options) const { (void)aero_air_prepare(h_, log_length, &options.raw(), 1); }
+
+private:
+    aero_air* h_ = nullptr;
+};
+// The Prover trait for a program AIR: the public inputs are the statement's elements in the order the program's PUB operands number
+// them; `prove` is `Prover::prove(trace)` + `to_bytes()` on the GPU (proving_worker.rs:465-467 with the generic `Air`).
+class AirProver : public Prover<std::vector<uint64_t>> {
+public:
+    AirProver(Context& ctx, const Air& air, ProofOptions options, std::vector<uint64_t> pub_inputs)
+        : ctx_(ctx), air_(air), options_(options), pub_(std::move(pub_inputs)) {}
+    std::vector<uint64_t> get_pub_inputs(const TraceTable&) const override { return pub_; }
+    const ProofOptions& options() const override { return options_; }
+    StarkProof prove(const TraceTable& trace) const override {
+        if (trace.width() != air_.main_width()) throw ProverError(AERO_E_BAD_ARG, "AirProver: the trace width is not the program's main width");
+        uint8_t* out = nullptr;
+        size_t n = 0;
+        const int32_t rc = aero_prove_air_host(ctx_.raw(), air_.raw(), trace.data(), trace.log_length(), pub_.data(), (uint32_t)pub_.size(), &options_.raw(), &out, &n);
+        if (rc != AERO_OK) throw ProverError(rc, aero_last_error(ctx_.raw()));
+        std::vector<uint8_t> bytes(out, out + n);
+        aero_free(out);
+        return StarkProof::from_bytes(std::move(bytes));
+    }
+
+private:
+    Context& ctx_;
+    const Air& air_;
+    ProofOptions options_;
+    std::vector<uint64_t> pub_;
+};
+// winter_verifier::verify::<AIR>(proof, pub_inputs, &acceptable_options) for a program AIR (with the out-of-domain constraint check)
+inline void verify(const StarkProof& proof, const std::vector<uint64_t>& pub_inputs, const Air& air, const AcceptableOptions& acceptable = AcceptableOptions()) {
+    aero_verify_policy policy{};
+    policy.min_query_security_bits = acceptable.min_query_security;
+    policy.min_conjectured_security_bits = acceptable.min_conjectured_security;
+    policy.expected_log_n = acceptable.expected_log_trace_length;
+    char err[512] = {0};
+    const std::vector<uint8_t>& b = proof.to_bytes();
+    const int32_t rc = aero_verify_air(b.data(), b.size(), pub_inputs.data(), (uint32_t)pub_inputs.size(), air.raw(), &policy, err, sizeof err);
     if (rc != AERO_OK) throw VerifierError(rc, err);
 }
 

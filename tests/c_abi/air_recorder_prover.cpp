@@ -1,17 +1,19 @@
 // An AIR written in C++ (include/aero_air_builder.hpp), handed to the library as bytes, proven on the GPU and verified - no Python, no
 // torch in this process. The AIR is version 2: a Fibonacci pair, a counter with a SEQUENCE assertion, an auxiliary running SUM (affine
 // builder) and a general (squaring) auxiliary column. What a Rust `impl Prover` does after recording its `Air` once
-// (constraints_worker.rs:32-43 -> aero_air_load; proving_worker.rs:465-467 -> aero_prove_air_host).
+// (constraints_worker.rs:32-43 -> Air / aero_air_load; proving_worker.rs:465-467 -> AirProver::prove / aero_prove_air_host), written
+// against the C++ host surface of include/aero_prover.hpp (Winterfell's names).
 //   air_recorder_prover <log_n> <out.proof>     prints one JSON line; exit 2 = no device (the library has no CPU fallback)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
-#include "../../include/aero_air.h"
 #include "../../include/aero_air_builder.hpp"
+#include "../../include/aero_prover.hpp"
 
 using aero_air_builder::Builder;
 using aero_air_builder::Expr;
+using namespace aero_host;
 static const uint64_t P = aero_air_builder::P;
 static uint64_t addp(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + b) % P); }
 
@@ -50,27 +52,32 @@ int main(int argc, char** argv) {
     b.aux_builder_general(1, b.constant(5), sq + b.rand(1) * b.aux(0) + b.main(1));
     const std::vector<uint8_t> program = b.to_bytes();
 
-    char err[512] = {0};
-    aero_air* air = nullptr;
-    if (aero_air_load(program.data(), program.size(), &air, err, sizeof err) != AERO_OK) { fprintf(stderr, "aero_air_load: %s\n", err); return 1; }
-    aero_ctx* ctx = nullptr;
-    if (aero_ctx_create(0, &ctx) != AERO_OK) { printf("no device: %s\n", aero_last_error(nullptr)); aero_air_free(air); return 2; }
-    const aero_proof_options opt = {27, 8, 8, 4, 1, 4, 6};
-    (void)aero_air_prepare(air, (uint32_t)log_n, &opt, 1);
-    uint8_t* proof = nullptr;
-    size_t len = 0;
-    int32_t rc = aero_prove_air_host(ctx, air, trace.data(), (uint32_t)log_n, pub, 1, &opt, &proof, &len);
-    if (rc != AERO_OK) { fprintf(stderr, "aero_prove_air_host: %s\n", aero_last_error(ctx)); return 1; }
-    aero_verify_policy policy{};
-    policy.expected_log_n = (uint32_t)log_n;
-    rc = aero_verify_air(proof, len, pub, 1, air, &policy, err, sizeof err);
-    const uint64_t wrong[1] = {pub[0] ^ 1};
-    const int32_t rc_wrong = aero_verify_air(proof, len, wrong, 1, air, &policy, err, sizeof err);
-    if (FILE* f = fopen(argv[2], "wb")) { fwrite(proof, 1, len, f); fclose(f); }
-    printf("{\"program_bytes\": %zu, \"version\": %d, \"proof_bytes\": %zu, \"verified\": %s, \"wrong_statement_rejected\": %s}\n", program.size(), (int)program[7], len,
-           rc == AERO_OK ? "true" : "false", rc_wrong != AERO_OK ? "true" : "false");
-    aero_free(proof);
-    aero_ctx_destroy(ctx);
-    aero_air_free(air);
-    return rc == AERO_OK && rc_wrong != AERO_OK ? 0 : 1;
+    try {
+        Air air(program);                                                   // aero_air_load: `ProcessorAir::new`
+        Context ctx(0);
+        const ProofOptions options(27, 8, 8, HashFunction::Blake2s_256, FieldExtension::None, 4, 64);
+        air.prepare((uint32_t)log_n, options);
+        TraceTable table(3, n);
+        for (size_t c = 0; c < 3; c++) for (size_t i = 0; i < n; i++) table.set(c, i, trace[c * n + i]);
+        AirProver prover(ctx, air, options, {pub[0]});
+        const StarkProof proof = prover.prove(table);                       // `Prover::prove(trace)`
+        AcceptableOptions acceptable;
+        acceptable.min_query_security = 80;
+        acceptable.expected_log_trace_length = (uint32_t)log_n;
+        verify(proof, prover.get_pub_inputs(table), air, acceptable);       // `winter_verifier::verify::<AIR>`
+        bool rejected = false;
+        try { verify(proof, std::vector<uint64_t>{pub[0] ^ 1}, air, acceptable); } catch (const VerifierError&) { rejected = true; }
+        const std::vector<uint8_t>& bytes = proof.to_bytes();
+        if (FILE* f = fopen(argv[2], "wb")) { fwrite(bytes.data(), 1, bytes.size(), f); fclose(f); }
+        printf("{\"program_bytes\": %zu, \"version\": %d, \"proof_bytes\": %zu, \"verified\": true, \"wrong_statement_rejected\": %s}\n", program.size(), (int)program[7],
+               bytes.size(), rejected ? "true" : "false");
+        return rejected ? 0 : 1;
+    } catch (const ProverError& e) {
+        if (e.status == AERO_E_HIP) { printf("no device: %s\n", e.what()); return 2; }
+        fprintf(stderr, "ProverError(%d): %s\n", e.status, e.what());
+        return 1;
+    } catch (const VerifierError& e) {
+        fprintf(stderr, "VerifierError(%d): %s\n", e.status, e.what());
+        return 1;
+    }
 }
