@@ -41,6 +41,44 @@ static void lifetimes(int tid) {
     }
 }
 
+// the stage entry points: parameter blocks through the pinned staging ring (which wraps), table caches, handle creation on every
+// path - the kernels are skipped, so only the host side (sizes, copies, lifetimes) is what runs; results are not inspected
+static void stages(int tid) {
+    aero_ctx* ctx = nullptr;
+    CHECK(aero_ctx_create(0, &ctx) == AERO_OK);
+    for (int it = 0; it < 120; it++) {
+        const uint32_t w = 2 * (1 + it % 3), log_n = 4 + (it % 7);
+        const size_t n = (size_t)1 << log_n;
+        std::vector<uint64_t> host(w * n);
+        fill(host, tid * 31 + it);
+        aero_matrix *m = nullptr, *polys = nullptr, *lde = nullptr;
+        CHECK(aero_trace_upload(ctx, host.data(), w, log_n, &m) == AERO_OK);
+        CHECK(aero_interpolate_columns(ctx, m, &polys) == AERO_OK);
+        CHECK(aero_evaluate_columns_over(ctx, polys, 3, &lde) == AERO_OK);
+        std::vector<uint64_t> ev(w);
+        CHECK(aero_poly_eval(ctx, polys, 12345, ev.data()) == AERO_OK);
+        std::vector<uint8_t> digests(8 * n * 32), root(32);
+        CHECK(aero_hash_matrix_rows(ctx, lde, digests.data()) == AERO_OK);
+        aero_tree* tree = nullptr;
+        CHECK(aero_merkle_commit_rows(ctx, lde, &tree, root.data()) == AERO_OK);
+        const uint64_t pos[3] = {1, 5, (8 * n) - 1};
+        std::vector<uint8_t> open(1 + 3 * (1 + 32 * 40));
+        size_t open_len = 0;
+        CHECK(aero_merkle_open_batch(ctx, tree, pos, 3, open.data(), open.size(), &open_len) == AERO_OK);
+        CHECK(open_len <= open.size());
+        aero_tree_free(ctx, tree);
+        std::vector<uint64_t> rows(n * 3), hd(n * 32 / 8);
+        CHECK(aero_hash_rows(ctx, rows.data(), 3, n, reinterpret_cast<uint8_t*>(hd.data())) == AERO_OK);
+        std::vector<uint64_t> folded(8 * n / 4);
+        std::vector<uint64_t> vals(8 * n);
+        CHECK(aero_fri_fold(ctx, vals.data(), 8 * n, 4, 7, folded.data()) == AERO_OK);
+        aero_matrix_free(ctx, lde); aero_matrix_free(ctx, polys); aero_matrix_free(ctx, m);
+        CHECK(aero_merkle_from_leaves(ctx, digests.data(), 3, &tree, nullptr) != AERO_OK);      // not a power of two
+        CHECK(aero_evaluate_columns_over(ctx, nullptr, 3, &lde) != AERO_OK);
+    }
+    aero_ctx_destroy(ctx);
+}
+
 static void pools() {
     for (int it = 0; it < 6; it++) {
         aero_pool* pool = nullptr;
@@ -129,6 +167,7 @@ int main() {
     {
         std::vector<std::thread> th;
         for (int t = 0; t < 4; t++) th.emplace_back(lifetimes, t);
+        for (int t = 0; t < 3; t++) th.emplace_back(stages, t);
         th.emplace_back(pools);
         for (auto& t : th) t.join();
     }
