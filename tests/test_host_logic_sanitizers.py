@@ -1,7 +1,9 @@
 """The library's HOST logic under ThreadSanitizer and AddressSanitizer against a stand-in HIP runtime (tools/hipstub: streams are
 ordered queues on worker threads, copies move bytes, events order streams, kernels do not run) - no GPU involved: context and
 matrix lifetimes from several threads, the pool's worker threads, the thread-rank group's rendezvous + event protocol with every
-exchanged byte checked, the abort path, error codes. (TSan found the unsynchronised slot binding of
+exchanged byte checked, the abort path, error codes, the stage entry points (staging ring, table caches), and whole proofs of the
+built-in AIR and of a constraint program run as far as the prover's own consistency check lets them without kernels (the host
+pipeline, the module path of the run-time compiled kernel, the error path that drains the streams). (TSan found the unsynchronised slot binding of
 aero_local_group_comm this way.) The reference's counterpart is the worker pool of aero-sdk/miden-wasm/src/proving_worker.rs:276-321."""
 import os
 import shutil

@@ -8,6 +8,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/aero_air.h"
 #include "../../include/aero_stark.h"
 
 #define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "FAILED %s (line %d)\n", #cond, __LINE__); exit(1); } } while (0)
@@ -75,6 +76,42 @@ static void stages(int tid) {
         aero_matrix_free(ctx, lde); aero_matrix_free(ctx, polys); aero_matrix_free(ctx, m);
         CHECK(aero_merkle_from_leaves(ctx, digests.data(), 3, &tree, nullptr) != AERO_OK);      // not a power of two
         CHECK(aero_evaluate_columns_over(ctx, nullptr, 3, &lde) != AERO_OK);
+    }
+    aero_ctx_destroy(ctx);
+}
+
+// whole proofs: with kernels that do nothing the device transcript cannot agree with the host's, so a proof ends in the prover's
+// consistency check - after the whole host pipeline up to the FRI layers has run (staging, parameter packs, handle and scratch
+// lifetimes, the run-time compiled kernel's module path) and through the error path that drains the streams and resets the scratch list
+static void proofs(int tid) {
+    aero_ctx* ctx = nullptr;
+    CHECK(aero_ctx_create(0, &ctx) == AERO_OK);
+    for (int it = 0; it < 6; it++) {
+        const uint32_t w = 2 + 2 * (it % 2), log_n = 4 + 2 * (it % 3);
+        std::vector<uint64_t> t((size_t)w << log_n), pub(w);
+        CHECK(aero_fib_trace(w, log_n, t.data()) == AERO_OK);
+        const aero_proof_options opt = {8, 8, 0, 4, (uint8_t)(1 + it % 2), 4, 4};       // no grinding: its search would never end without a kernel
+        uint8_t* proof = nullptr;
+        size_t len = 0;
+        const aero_fib_air aux = {2, 3, 2};
+        const int32_t rc = (it & 1) ? aero_prove_fib_air_host(ctx, t.data(), w, log_n, &aux, &opt, &proof, &len, pub.data())
+                                    : aero_prove_fib_host(ctx, t.data(), w, log_n, &opt, &proof, &len, pub.data());
+        CHECK(rc == AERO_OK || aero_last_error(ctx)[0] != 0);
+        aero_free(proof);
+        // the same through a constraint program (the AIR-as-data path: pool of scalars, code generation + module load against the stand-in)
+        uint8_t* program = nullptr;
+        size_t plen = 0;
+        CHECK(aero_air_fib_program(w, (it & 1) ? &aux : nullptr, &program, &plen) == AERO_OK);
+        aero_air* air = nullptr;
+        char err[256];
+        CHECK(aero_air_load(program, plen, &air, err, sizeof err) == AERO_OK);
+        aero_free(program);
+        proof = nullptr;
+        const int32_t rc2 = aero_prove_air_host(ctx, air, t.data(), log_n, pub.data(), w / 2, &opt, &proof, &len);
+        CHECK(rc2 == AERO_OK || aero_last_error(ctx)[0] != 0);
+        aero_free(proof);
+        aero_air_free(air);
+        (void)tid;
     }
     aero_ctx_destroy(ctx);
 }
@@ -168,6 +205,7 @@ int main() {
         std::vector<std::thread> th;
         for (int t = 0; t < 4; t++) th.emplace_back(lifetimes, t);
         for (int t = 0; t < 3; t++) th.emplace_back(stages, t);
+        for (int t = 0; t < 2; t++) th.emplace_back(proofs, t);
         th.emplace_back(pools);
         for (auto& t : th) t.join();
     }
