@@ -88,6 +88,9 @@ int32_t exchange(aero_local_group::Slot* s, const void* send, void* recv, uint64
         if (peer.bytes != bytes) { s->err = "peers disagree on the exchange size"; g->rendezvous(); return 1; }
         if ((int)p != s->rank) LOCAL_HIP(hipStreamWaitEvent(s->stream, peer.ready, 0));
         const uint8_t* src = static_cast<const uint8_t*>(peer.send) + (kind == 0 ? (size_t)s->rank * bytes : 0);
+        // an in-place all-gather names the rank's own piece as source AND destination: copying it onto itself would be a write to bytes
+        // the peers are reading at that very moment (the same values, but a race all the same: ThreadSanitizer over tools/hipstub)
+        if (src == d + (size_t)p * bytes) continue;
         LOCAL_HIP(hipMemcpyAsync(d + (size_t)p * bytes, src, bytes, hipMemcpyDeviceToDevice, s->stream));
     }
     LOCAL_HIP(hipEventRecord(s->done, s->stream));

@@ -197,6 +197,27 @@ static void local_group(uint32_t world, int rounds, bool abort_midway) {
     for (auto& d : rd) aero_ctx_destroy(d.ctx);
 }
 
+// one proof over thread ranks inside the library (aero_prove_fib_sharded_local): contexts, rank threads, host hand-over, every exchange
+// of the sharded pipeline up to the point where the kernel-less transcript is found out - all ranks must come back, none may hang
+static void sharded_proofs() {
+    for (uint32_t world : {2u, 4u}) {
+        const uint32_t w = 4, log_n = 7;
+        std::vector<uint64_t> t((size_t)w << log_n), pub(w);
+        CHECK(aero_fib_trace(w, log_n, t.data()) == AERO_OK);
+        const aero_proof_options opt = {8, 8, 0, 4, 1, 4, 4};
+        std::vector<int32_t> devs(world, 0);
+        std::vector<uint8_t*> proofs(world, nullptr);
+        std::vector<size_t> lens(world, 0);
+        std::vector<double> ms(world, 0);
+        std::vector<uint64_t> sent(world, 0);
+        char err[1024] = {0};
+        const int32_t rc = aero_prove_fib_sharded_local(devs.data(), world, t.data(), w, log_n, nullptr, &opt, 0, proofs.data(), lens.data(), pub.data(), ms.data(),
+                                                        sent.data(), err, sizeof err);
+        CHECK(rc == AERO_OK || err[0] != 0);
+        for (uint8_t* p : proofs) aero_free(p);
+    }
+}
+
 extern "C" uint64_t hipstub_launches();
 extern "C" uint64_t hipstub_copies();
 
@@ -211,6 +232,7 @@ int main() {
     }
     for (uint32_t world : {2u, 4u, 8u}) local_group(world, 24, false);
     local_group(4, 12, true);                 // one rank leaves: its peers must come back with an error, not hang
+    sharded_proofs();
     printf("host logic ok: %llu copies moved, %llu kernel launches skipped\n", (unsigned long long)hipstub_copies(), (unsigned long long)hipstub_launches());
     return 0;
 }
