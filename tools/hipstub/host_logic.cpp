@@ -218,6 +218,27 @@ static void sharded_proofs() {
     }
 }
 
+// a batch through the pool: every slot's worker thread runs the host pipeline of a proof from host memory (copy gate between the slots),
+// the batch comes back with the workers' statuses
+static void pool_batches() {
+    aero_pool* pool = nullptr;
+    CHECK(aero_pool_create(0, 3, &pool) == AERO_OK);
+    const uint32_t w = 2, log_n = 6;
+    std::vector<uint64_t> t((size_t)w << log_n);
+    CHECK(aero_fib_trace(w, log_n, t.data()) == AERO_OK);
+    const aero_proof_options opt = {8, 8, 0, 4, 1, 4, 4};
+    for (int it = 0; it < 4; it++) {
+        const uint64_t* hosts[3] = {t.data(), t.data(), t.data()};
+        uint8_t* proofs[3] = {nullptr, nullptr, nullptr};
+        size_t lens[3] = {0, 0, 0};
+        std::vector<uint64_t> pubs(3 * w);
+        const int32_t rc = aero_pool_prove_fib_host(pool, hosts, w, log_n, 3, nullptr, &opt, 2, proofs, lens, pubs.data());
+        CHECK(rc == AERO_OK || aero_last_error(aero_pool_ctx(pool, 0))[0] != 0);
+        for (uint8_t* p : proofs) aero_free(p);
+    }
+    aero_pool_destroy(pool);
+}
+
 extern "C" uint64_t hipstub_launches();
 extern "C" uint64_t hipstub_copies();
 
@@ -233,6 +254,7 @@ int main() {
     for (uint32_t world : {2u, 4u, 8u}) local_group(world, 24, false);
     local_group(4, 12, true);                 // one rank leaves: its peers must come back with an error, not hang
     sharded_proofs();
+    pool_batches();
     printf("host logic ok: %llu copies moved, %llu kernel launches skipped\n", (unsigned long long)hipstub_copies(), (unsigned long long)hipstub_launches());
     return 0;
 }
