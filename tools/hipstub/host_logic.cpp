@@ -218,6 +218,47 @@ static void sharded_proofs() {
     }
 }
 
+// a constraint program proven over thread ranks from host memory (aero_prove_air_sharded_host): the program's kernel is prepared once,
+// every rank copies its share of the columns, the auxiliary-segment exchanges and the constraint-domain gather run as far as the
+// kernel-less transcript allows; a rank that fails releases its peers (aero_local_group_abort)
+static void sharded_program_proofs() {
+    for (uint32_t world : {2u, 4u}) {
+        const uint32_t w = 8, log_n = 6;
+        std::vector<uint64_t> t((size_t)w << log_n);
+        CHECK(aero_fib_trace(w, log_n, t.data()) == AERO_OK);
+        const aero_fib_air aux = {3, 4, 2};
+        uint8_t* program = nullptr;
+        size_t plen = 0;
+        CHECK(aero_air_fib_program(w, &aux, &program, &plen) == AERO_OK);
+        aero_air* air = nullptr;
+        char err[256];
+        CHECK(aero_air_load(program, plen, &air, err, sizeof err) == AERO_OK);
+        aero_free(program);
+        std::vector<uint64_t> pub(w / 2);
+        for (uint32_t k = 0; k < w / 2; k++) pub[k] = t[(size_t)(2 * k + 1) * ((size_t)1 << log_n) + ((size_t)1 << log_n) - 1];
+        const aero_proof_options opt = {8, 8, 0, 4, 1, 4, 4};
+        aero_local_group* g = nullptr;
+        CHECK(aero_local_group_create(world, &g) == AERO_OK);
+        std::vector<aero_ctx*> ctxs(world, nullptr);
+        std::vector<std::thread> th;
+        for (uint32_t r = 0; r < world; r++)
+            th.emplace_back([&, r] {
+                CHECK(aero_ctx_create(0, &ctxs[r]) == AERO_OK);
+                aero_comm comm{};
+                CHECK(aero_local_group_comm(g, ctxs[r], (int32_t)r, 0, &comm) == AERO_OK);
+                uint8_t* proof = nullptr;
+                size_t len = 0;
+                const int32_t rc = aero_prove_air_sharded_host(ctxs[r], &comm, air, t.data(), log_n, pub.data(), w / 2, &opt, &proof, &len);
+                if (rc != AERO_OK) aero_local_group_abort(g);
+                aero_free(proof);
+            });
+        for (auto& x : th) x.join();
+        aero_local_group_destroy(g);
+        for (aero_ctx* c : ctxs) aero_ctx_destroy(c);
+        aero_air_free(air);
+    }
+}
+
 // a batch through the pool: every slot's worker thread runs the host pipeline of a proof from host memory (copy gate between the slots),
 // the batch comes back with the workers' statuses
 static void pool_batches() {
@@ -254,6 +295,7 @@ int main() {
     for (uint32_t world : {2u, 4u, 8u}) local_group(world, 24, false);
     local_group(4, 12, true);                 // one rank leaves: its peers must come back with an error, not hang
     sharded_proofs();
+    sharded_program_proofs();
     pool_batches();
     printf("host logic ok: %llu copies moved, %llu kernel launches skipped\n", (unsigned long long)hipstub_copies(), (unsigned long long)hipstub_launches());
     return 0;
