@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/aero_air.h"
+#include "../../include/aero_air_builder.hpp"
 #include "../../include/aero_stark.h"
 
 #define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "FAILED %s (line %d)\n", #cond, __LINE__); exit(1); } } while (0)
@@ -259,6 +260,68 @@ static void sharded_program_proofs() {
     }
 }
 
+// an AEROAIR version-2 program (recorded with include/aero_air_builder.hpp): sequence assertions (value tables: host interpolation, sparse
+// scatter list, transform), an affine builder, and a GENERAL auxiliary recurrence - the one part of a proof that is real host arithmetic
+// (air_host.hip: the row-after-row evaluation), so its buffers and indices are what the sanitizers look at here
+static void version2_program_proofs() {
+    using aero_air_builder::Builder;
+    using aero_air_builder::Expr;
+    for (int log_n : {5, 8}) {
+        const size_t n = (size_t)1 << log_n;
+        std::vector<uint64_t> trace(3 * n);
+        uint64_t x = 1, y = 2;
+        for (size_t i = 0; i < n; i++) {
+            trace[i] = x; trace[n + i] = y; trace[2 * n + i] = (5 + 3 * (uint64_t)i) % P;
+            const uint64_t nx = (uint64_t)(((unsigned __int128)x + y) % P), ny = (uint64_t)(((unsigned __int128)y + nx) % P);
+            x = nx; y = ny;
+        }
+        Builder b(3, 2, 2, 1);
+        Expr a = b.main(0), bb = b.main(1), na = b.main_next(0), nb = b.main_next(1);
+        b.transition(na - (a + bb), 1);
+        b.transition(nb - (bb + na), 1);
+        b.transition(b.main_next(2) - b.main(2) - 3, 1);
+        Expr den = b.rand(0) + b.main(2);
+        b.aux_transition((b.aux_next(0) - b.aux(0)) * den - b.main(0), 2);
+        Expr sq = b.aux(1) * b.aux(1);
+        b.aux_transition(b.aux_next(1) - (sq + b.rand(1) * b.aux(0) + b.main(1)), 2);
+        b.assert_single(0, 0, (uint64_t)1);
+        b.assert_single(1, -1, b.pub(0));
+        std::vector<uint64_t> seq;
+        for (size_t i = 0; i < n / 8; i++) seq.push_back(trace[2 * n + 3 + 8 * i]);
+        b.assert_sequence(2, 3, 8, seq);
+        b.aux_assert_single(0, 0, (uint64_t)0);
+        b.aux_assert_sequence(1, 0, (uint32_t)(n / 2), {5, 5});
+        b.aux_builder(0, b.constant(0), b.constant(1), Expr(), b.main(0), den);
+        b.aux_builder_general(1, b.constant(5), sq + b.rand(1) * b.aux(0) + b.main(1));
+        const std::vector<uint8_t> program = b.to_bytes();
+        char err[256] = {0};
+        aero_air* air = nullptr;
+        CHECK(aero_air_load(program.data(), program.size(), &air, err, sizeof err) == AERO_OK);
+        aero_ctx* ctx = nullptr;
+        CHECK(aero_ctx_create(0, &ctx) == AERO_OK);
+        const uint64_t pub[1] = {trace[n + n - 1]};
+        for (uint8_t ext : {(uint8_t)1, (uint8_t)2}) {
+            const aero_proof_options opt = {8, 8, 0, 4, ext, 4, 4};
+            uint8_t* proof = nullptr;
+            size_t len = 0;
+            const int32_t rc = aero_prove_air_host(ctx, air, trace.data(), (uint32_t)log_n, pub, 1, &opt, &proof, &len);
+            CHECK(rc == AERO_OK || aero_last_error(ctx)[0] != 0);
+            aero_free(proof);
+            // the stage entry point that builds the auxiliary columns: the general column is computed for real, check its recurrence on the host
+            aero_matrix *m = nullptr, *auxm = nullptr;
+            CHECK(aero_trace_upload(ctx, trace.data(), 3, (uint32_t)log_n, &m) == AERO_OK);
+            const uint64_t rands[4] = {11, 12, 13, 14};
+            CHECK(aero_aux_columns_program(ctx, air, m, pub, 1, rands, ext, &auxm) == AERO_OK);
+            uint32_t cols = 0; uint64_t rows = 0;
+            aero_matrix_shape(auxm, &cols, &rows);
+            CHECK(cols == 2u * ext && rows == n);
+            aero_matrix_free(ctx, auxm); aero_matrix_free(ctx, m);
+        }
+        aero_ctx_destroy(ctx);
+        aero_air_free(air);
+    }
+}
+
 // a batch through the pool: every slot's worker thread runs the host pipeline of a proof from host memory (copy gate between the slots),
 // the batch comes back with the workers' statuses
 static void pool_batches() {
@@ -296,6 +359,7 @@ int main() {
     local_group(4, 12, true);                 // one rank leaves: its peers must come back with an error, not hang
     sharded_proofs();
     sharded_program_proofs();
+    version2_program_proofs();
     pool_batches();
     printf("host logic ok: %llu copies moved, %llu kernel launches skipped\n", (unsigned long long)hipstub_copies(), (unsigned long long)hipstub_launches());
     return 0;
