@@ -277,7 +277,7 @@ void air_build_aux(Context* ctx, const Program& p, const uint64_t* trace_dev, in
     launch_air_aux<F>(ctx, a, p.has_den, p.has_add);
     // General recurrences (den = REF_GENERAL): column(i + 1) = expr(main row i, main row i + 1, aux row i of the columns up to its own).
     // Nothing about such a recurrence can be scanned, so it is evaluated row after row on the HOST, after the columns the device built:
-    // the main columns it reads and the auxiliary columns so far come down, the finished columns go back up. A fallback for exotic
+    // the main columns it reads and the auxiliary columns so far come down, the finished columns go back up. For exotic
     // AIRs (about 0.1 us per row and node), not a fast path: running products / sums / mixed affine forms never take it.
     bool any_general = false;
     for (uint32_t c = 0; c < p.A; c++) any_general |= p.has_add[c] == 4;

@@ -58,8 +58,9 @@
  *                [v2] den = 0xFFFFFFFE marks a GENERAL recurrence: column(i + 1) = num, where num may read MAIN_*, PERIODIC, CONST, PUB,
  *                RAND and the CURRENT row of the auxiliary columns up to and including its own (AUX_CUR | j, j <= column): any
  *                per-row recurrence over the frame, e.g. one that squares its own previous value. Such a column cannot be scanned:
- *                the library builds it row after row on the HOST after the device-built columns (about 0.1 us per row and node - a
- *                completeness fallback, not a fast path; products, sums and affine forms never take it).
+ *                the library builds it row after row on the HOST after the device-built columns (about 0.1 us per row and node; a serial
+ *                chain has no parallel form, and winter-prover's build_aux_segment is host code too; products, sums and affine forms are
+ *                scanned on the device and never take this step).
  *                Not representable: more than ONE auxiliary segment - winter-air 0.4's TraceLayout has NUM_AUX_SEGMENTS = 1
  *                and its proof bytes hold exactly one (width, random elements) pair (proof_format.hpp; pinned on proofs/fib.bin).
  *                A program without builders can be verified and its constraints evaluated, but proving needs the columns.
