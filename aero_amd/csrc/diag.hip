@@ -5,8 +5,8 @@
 // duplicate of the stderr that existed at install time AND to the current fd 2.
 //   * std::terminate: what() of the escaping exception + native backtrace, then the previous terminate handler;
 //   * SIGABRT / SIGSEGV / SIGBUS: signal name, thread id and name, native backtrace (backtrace_symbols_fd is async-signal-safe
-//     enough for a process that is about to die), the tail of /proc/self/maps lines that name this library, then the previous
-//     disposition (so Python's faulthandler and core dumps still happen).
+//     enough for a process that is about to die; its lines are `object(+0xoffset)`, which llvm-addr2line resolves against the
+//     line tables the library is built with), then the previous disposition (so Python's faulthandler and core dumps still happen).
 #include <cxxabi.h>
 #include <execinfo.h>
 #include <fcntl.h>

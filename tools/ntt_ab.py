@@ -13,7 +13,7 @@ ctx = aero_amd.Context(0)
 out = {"env": {k: v for k, v in os.environ.items() if k.startswith("AERO_") and k not in ("AERO_CRASH_TRACE",)}}
 for sh in shapes:
     log_n, cols = (int(v) for v in sh.split("x"))
-    dev = ctx.trace_upload(aero_amd.fib_trace(cols, log_n))
+    dev = ctx.trace_upload(aero_amd.fib_trace(cols + (cols & 1), log_n)[:cols])      # odd widths: one column less of the next even width
     for _ in range(3):
         p = ctx.interpolate_columns(dev); l = ctx.evaluate_columns_over(p, 3); l.free(); p.free()
     reps = 10
