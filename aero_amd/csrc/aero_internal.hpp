@@ -188,7 +188,10 @@ public:
     bool ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride, int ncols, int log_out, int log_pad,
                      const CompactOut* compact = nullptr);
     // bad (optional, device): 1 is ORed in when an input element is >= p (checked by the pass that reads the input)
-    void ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift, unsigned int* bad = nullptr);
+    // `src` (optional): where the values are read from - the pass that reads them writes into `data`, the rest runs in place there (saves the
+    // copy a caller would make to keep its evaluations)
+    void ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift, unsigned int* bad = nullptr,
+                     const uint64_t* src = nullptr, size_t src_stride = 0);
 
     // ---- hashing (hash.hip) ----
     // leaf j = hash_elements(row j) of a column-major matrix (ncols columns, `rows` rows, column stride in elements)

@@ -75,13 +75,13 @@ constexpr int LDS_ELEMS = 4096 + 128;
 // One register round over bits [s, s+RB) of the pass-local index k (tile element e = (k << log_tl) | tl, data in LDS).
 // Cooley-Tukey step: the 2^RB sub-transform values of a group (bit-reversed order) are multiplied by T^rev(i),
 // T = w_(2^(s+RB))^(k mod 2^s), then combined by the plain 2^RB-point DFT above. tw = w_4096^e (forward) or w_4096^-e.
-template <int RB, bool INV>
+template <int RB, bool INV, int NT = 256>
 __device__ __forceinline__ void ntt_round(uint64_t* lds, int log_e, int log_tl, int s, const uint64_t* __restrict__ tw) {
     constexpr int G = 1 << RB;
     const int shift = s + log_tl;
     const int ngroups = 1 << (log_e - RB);
     const int tsh = 12 - s - RB;
-    for (int g = threadIdx.x; g < ngroups; g += 256) {
+    for (int g = threadIdx.x; g < ngroups; g += NT) {
         const int base = (g & ((1 << shift) - 1)) | ((g >> shift) << (shift + RB));
         const int klow = (base >> log_tl) & ((1 << s) - 1);
         uint64_t y[G];
@@ -125,7 +125,9 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t nblocks) {
 }
 
 // Forward: decimation in time, bit-reversed input -> natural output (within the pass' index bits).
-__global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
+// NT = threads per 4096-element tile: 256 (16 elements per thread) or 512 (8 per thread: small launches, where a tile per CU leaves one
+// wave per SIMD and the pass takes as long as ONE wave needs for its share - half the share, half the time).
+template <int NT> __global__ __launch_bounds__(NT) void ntt_fwd_pass(PassArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
     const int TL = 1 << a.log_tl, log_e = a.log_r + a.log_tl, E = 1 << log_e;
     const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
     const size_t base = (size_t)lo0 + (((size_t)b << a.log_r) << a.log_s);
 
     if (a.log_pad == 0) {
-        for (int e = threadIdx.x; e < E; e += 256) {
+        for (int e = threadIdx.x; e < E; e += NT) {
             int tl = e & (TL - 1), k = e >> a.log_tl;
             lds[skew(e)] = in[base + tl + ((size_t)k << a.log_s)];
         }
@@ -145,19 +147,19 @@ __global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
         // contiguous pass of a zero-padded transform: position k of the block holds coefficient (b*R + k) >> log_pad
         // when k = 0 mod 2^log_pad, zero otherwise; the first log_pad butterfly stages therefore broadcast it.
         const size_t cbase = ((size_t)b << a.log_r) >> a.log_pad;
-        for (int e = threadIdx.x; e < E; e += 256) lds[skew(e)] = in[cbase + (e >> a.log_pad)];
+        for (int e = threadIdx.x; e < E; e += NT) lds[skew(e)] = in[cbase + (e >> a.log_pad)];
     }
     __syncthreads();
     for (int s = a.log_pad; s < a.log_r;) {
         const int rb = a.log_r - s >= 3 ? 3 : a.log_r - s;
-        if (rb == 3) ntt_round<3, false>(lds, log_e, a.log_tl, s, a.tw_r);
-        else if (rb == 2) ntt_round<2, false>(lds, log_e, a.log_tl, s, a.tw_r);
-        else ntt_round<1, false>(lds, log_e, a.log_tl, s, a.tw_r);
+        if (rb == 3) ntt_round<3, false, NT>(lds, log_e, a.log_tl, s, a.tw_r);
+        else if (rb == 2) ntt_round<2, false, NT>(lds, log_e, a.log_tl, s, a.tw_r);
+        else ntt_round<1, false, NT>(lds, log_e, a.log_tl, s, a.tw_r);
         s += rb;
     }
     const int bbits = a.log_n - a.log_s - a.log_r;
     const uint32_t rb = gl::bitrev(b, bbits);
-    for (int e = threadIdx.x; e < E; e += 256) {
+    for (int e = threadIdx.x; e < E; e += NT) {
         int tl = e & (TL - 1), k = e >> a.log_tl;
         uint64_t v = lds[skew(e)];
         if (!a.first && rb && k) {
@@ -173,13 +175,13 @@ __global__ __launch_bounds__(256) void ntt_fwd_pass(PassArgs a) {
 // operands straight from global memory (zero-padded transforms: the broadcast coefficient), the last round applies the
 // pass-boundary twiddle and stores straight to global memory, so a tile crosses LDS once per round boundary only
 // (2 exchanges and 2 barriers for 9 butterfly stages instead of 4 and 5).
-template <int RB, bool FIRST, bool LAST>
+template <int RB, bool FIRST, bool LAST, int NT>
 __device__ __forceinline__ void first_pass_round(const PassArgs& a, uint64_t* lds, const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                  size_t base, size_t cbase, int s, uint32_t rbk) {
     constexpr int G = 1 << RB;
     const int ngroups = 1 << (a.log_r - RB);
     const int tsh = 12 - s - RB;
-    for (int g = threadIdx.x; g < ngroups; g += 256) {
+    for (int g = threadIdx.x; g < ngroups; g += NT) {
         const int b0 = (g & ((1 << s) - 1)) | ((g >> s) << (s + RB));
         const int klow = b0 & ((1 << s) - 1);
         uint64_t y[G];
@@ -209,14 +211,14 @@ __device__ __forceinline__ void first_pass_round(const PassArgs& a, uint64_t* ld
         }
     }
 }
-template <bool FIRST, bool LAST>
+template <bool FIRST, bool LAST, int NT>
 __device__ __forceinline__ void first_pass_round_any(int rb, const PassArgs& a, uint64_t* lds, const uint64_t* in, uint64_t* out, size_t base,
                                                      size_t cbase, int s, uint32_t rbk) {
-    if (rb == 3) first_pass_round<3, FIRST, LAST>(a, lds, in, out, base, cbase, s, rbk);
-    else if (rb == 2) first_pass_round<2, FIRST, LAST>(a, lds, in, out, base, cbase, s, rbk);
-    else first_pass_round<1, FIRST, LAST>(a, lds, in, out, base, cbase, s, rbk);
+    if (rb == 3) first_pass_round<3, FIRST, LAST, NT>(a, lds, in, out, base, cbase, s, rbk);
+    else if (rb == 2) first_pass_round<2, FIRST, LAST, NT>(a, lds, in, out, base, cbase, s, rbk);
+    else first_pass_round<1, FIRST, LAST, NT>(a, lds, in, out, base, cbase, s, rbk);
 }
-__global__ __launch_bounds__(256) void ntt_fwd_first_pass(PassArgs a) {
+template <int NT> __global__ __launch_bounds__(NT) void ntt_fwd_first_pass(PassArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
     const uint32_t b = xcd_tile(blockIdx.x, gridDim.x);
     const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
@@ -228,10 +230,10 @@ __global__ __launch_bounds__(256) void ntt_fwd_first_pass(PassArgs a) {
     for (int rd = 0; rd < nrounds; rd++) {
         const int rb = a.log_r - s >= 3 ? 3 : a.log_r - s;
         const bool first = rd == 0, last = rd + 1 == nrounds;
-        if (first && last) first_pass_round_any<true, true>(rb, a, lds, in, out, base, cbase, s, rbk);
-        else if (first) first_pass_round_any<true, false>(rb, a, lds, in, out, base, cbase, s, rbk);
-        else if (last) first_pass_round_any<false, true>(rb, a, lds, in, out, base, cbase, s, rbk);
-        else first_pass_round_any<false, false>(rb, a, lds, in, out, base, cbase, s, rbk);
+        if (first && last) first_pass_round_any<true, true, NT>(rb, a, lds, in, out, base, cbase, s, rbk);
+        else if (first) first_pass_round_any<true, false, NT>(rb, a, lds, in, out, base, cbase, s, rbk);
+        else if (last) first_pass_round_any<false, true, NT>(rb, a, lds, in, out, base, cbase, s, rbk);
+        else first_pass_round_any<false, false, NT>(rb, a, lds, in, out, base, cbase, s, rbk);
         if (!last) __syncthreads();
         s += rb;
     }
@@ -372,7 +374,7 @@ __global__ void fill_mul_table64(uint64_t* tab, uint32_t rows, uint64_t root) {
 }
 
 // Inverse: exact mirror (decimation in frequency with inverse roots), natural input -> bit-reversed output.
-__global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
+template <int NT> __global__ __launch_bounds__(NT) void ntt_inv_pass(PassArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
     const int TL = 1 << a.log_tl, log_e = a.log_r + a.log_tl, E = 1 << log_e;
     const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
     const int bbits = a.log_n - a.log_s - a.log_r;
     const uint32_t rb = gl::bitrev(b, bbits);
 
-    for (int e = threadIdx.x; e < E; e += 256) {
+    for (int e = threadIdx.x; e < E; e += NT) {
         int tl = e & (TL - 1), k = e >> a.log_tl;
         uint64_t v = in[base + tl + ((size_t)k << a.log_s)];
         if (a.bad && v >= gl::P) atomicOr(a.bad, 1u);
@@ -398,16 +400,16 @@ __global__ __launch_bounds__(256) void ntt_inv_pass(PassArgs a) {
     __syncthreads();
     // mirror of the forward rounds: same bit groups, highest first
     const int nfull = a.log_r / 3, rem = a.log_r % 3;     // forward rounds: nfull x 3 bits from bit 0, then `rem` bits
-    if (rem == 2) ntt_round<2, true>(lds, log_e, a.log_tl, 3 * nfull, a.tw_r);
-    else if (rem == 1) ntt_round<1, true>(lds, log_e, a.log_tl, 3 * nfull, a.tw_r);
-    for (int q = nfull - 1; q >= 0; q--) ntt_round<3, true>(lds, log_e, a.log_tl, 3 * q, a.tw_r);
+    if (rem == 2) ntt_round<2, true, NT>(lds, log_e, a.log_tl, 3 * nfull, a.tw_r);
+    else if (rem == 1) ntt_round<1, true, NT>(lds, log_e, a.log_tl, 3 * nfull, a.tw_r);
+    for (int q = nfull - 1; q >= 0; q--) ntt_round<3, true, NT>(lds, log_e, a.log_tl, 3 * q, a.tw_r);
 
     uint64_t bf = 1;
     if (a.ktab) {
         // every thread derives the (uniform) block factor itself: <= 2*bbits multiplies, cheaper than a broadcast
         bf = mul(gl::pow(a.sc_a, rb), gl::pow(a.sc_b, rb >> a.sc_shift));
     }
-    for (int e = threadIdx.x; e < E; e += 256) {
+    for (int e = threadIdx.x; e < E; e += NT) {
         int tl = e & (TL - 1), k = e >> a.log_tl;
         uint64_t v = lds[skew(e)];
         if (a.ktab) v = mul(v, mul(a.ktab[k], bf));
@@ -436,14 +438,15 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_inv_last_pass_11(PassArg
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t* lds = f8_lds + wave * (F8_TILE_LDS / 2);
     const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * F8_WAVES + wave;
-    uint64_t* data = a.out + (size_t)blockIdx.y * a.out_col_stride + ((size_t)b << 11);       // in place
+    uint64_t* data = a.out + (size_t)blockIdx.y * a.out_col_stride + ((size_t)b << 11);
+    const uint64_t* src = a.in + (size_t)blockIdx.y * a.in_col_stride + ((size_t)b << 11);    // = data unless the caller transforms out of place
     const int h = lane & 31;
     const uint32_t half = (uint32_t)lane >> 5;
     const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
     const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
     uint64_t y[32];
 #pragma unroll
-    for (int i = 0; i < 32; i++) y[i] = data[lane + 64 * i];
+    for (int i = 0; i < 32; i++) y[i] = src[lane + 64 * i];
     if (a.bad) {
         bool any = false;
 #pragma unroll
@@ -873,6 +876,16 @@ void Context::ensure_small_twiddles() {
     check_launch("small twiddles");
 }
 
+// LDS-round passes (ntt_fwd_pass, ntt_fwd_first_pass, ntt_inv_pass) with 512 threads per 4096-element tile instead of 256 on launches of up
+// to 2^21 elements (columns x points; AERO_NTT_LDS512_MAX=<log2>, 0 = never). A small launch is one tile per CU or less - one wave per
+// SIMD, and the pass lasts as long as that wave needs for its 16 elements per lane; with 8 per lane and two waves per SIMD the same work
+// takes less: measured (profiles/r4_lds512_ab.txt) inverse of 1 column 2^20 (the DEEP stage's) 61.1 -> 51.0 us, of 2 columns 2^19
+// 59.7 -> 49.5 us, interpolation + LDE of 2 columns 2^16 95.2 -> 79.0 us. Larger launches fill the SIMDs either way and keep 256.
+static bool lds_wide(int ncols, int log_n) {
+    static const int lim = getenv("AERO_NTT_LDS512_MAX") ? atoi(getenv("AERO_NTT_LDS512_MAX")) : 21;
+    return lim > 0 && ((size_t)ncols << log_n) <= ((size_t)1 << lim);
+}
+
 // Pass plan for a transform of 2^L points: first the contiguous pass (<= 12 bits), then strided passes. With register
 // passes every strided pass has radix <= 64 (one more pass over HBM beats a radix-128/256 pass through LDS: measured 2^25
 // points, 4 columns: 1162 us for the LDS radix-128 pass against 550 us for a register radix-64 pass); without them the
@@ -984,18 +997,22 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
             continue;
         }
         if (q == 0 && reg_passes && a.log_r > a.log_pad) {
-            AERO_LAUNCH(this, pass_names ? "ntt_fwd_first" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass, grid, dim3(256), 0, a);
+            if (lds_wide(ncols, log_out)) AERO_LAUNCH(this, pass_names ? "ntt_fwd_first" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass<512>, grid, dim3(512), 0, a);
+            else AERO_LAUNCH(this, pass_names ? "ntt_fwd_first" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass<256>, grid, dim3(256), 0, a);
             continue;
         }
-        AERO_LAUNCH(this, pass_names ? (a.log_r == 7 ? "ntt_fwd_lds7" : a.log_r == 8 ? "ntt_fwd_lds8" : "ntt_fwd_ldsX") : "ntt_fwd_pass", abytes, ntt_fwd_pass, grid, dim3(256), 0, a);
+        if (lds_wide(ncols, log_out)) AERO_LAUNCH(this, pass_names ? (a.log_r == 7 ? "ntt_fwd_lds7" : a.log_r == 8 ? "ntt_fwd_lds8" : "ntt_fwd_ldsX") : "ntt_fwd_pass", abytes, ntt_fwd_pass<512>, grid, dim3(512), 0, a);
+        else AERO_LAUNCH(this, pass_names ? (a.log_r == 7 ? "ntt_fwd_lds7" : a.log_r == 8 ? "ntt_fwd_lds8" : "ntt_fwd_ldsX") : "ntt_fwd_pass", abytes, ntt_fwd_pass<256>, grid, dim3(256), 0, a);
     }
     check_launch("ntt_forward");
     return compact_written;
 }
 
 // evaluations in natural order over <w_n> (n = 2^log_n) -> coefficients in bit-reversed order, where coefficient
-// with natural index I is multiplied by c0 * sa^I * sb^(I >> shift). In place.
-void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift, unsigned int* bad) {
+// with natural index I is multiplied by c0 * sa^I * sb^(I >> shift). In place, or from `src` into `data` (every pass reads a.in and writes
+// a.out: the first executed one takes its values from `src`, the others find them in `data`).
+void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, uint64_t c0, uint64_t sa, uint64_t sb, int shift, unsigned int* bad,
+                          const uint64_t* src, size_t src_stride) {
     ensure_small_twiddles();
     NttTables* t = ntt_tables(log_n);
     // two-phase contiguous pass (11 bits) where the transform is large enough to keep its strided passes' count
@@ -1039,6 +1056,7 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
         a.in = data; a.out = data; a.in_col_stride = stride; a.out_col_stride = stride;
         a.log_n = log_n; a.log_s = plan[qi].log_s; a.log_r = plan[qi].log_r; a.log_tl = plan[qi].log_tl;
         a.first = (qi + 1 == plan.size());
+        if (a.first && src) { a.in = src; a.in_col_stride = src_stride ? src_stride : stride; }
         a.bad = a.first ? bad : nullptr;      // the pass that reads the caller's values
         a.tw_r = tw4096_inv; a.tw_lo = t->lo_inv; a.tw_hi = t->hi_inv; a.tw_h = t->h;
         if (qi == 0) { a.ktab = ktab; a.sc_a = sa; a.sc_b = sb; a.sc_shift = shift; }
@@ -1086,7 +1104,8 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
         }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
         dim3 grid((unsigned)(((size_t)1 << log_n) / E), ncols);
-        AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass, grid, dim3(256), 0, a);
+        if (lds_wide(ncols, log_n)) AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass<512>, grid, dim3(512), 0, a);
+        else AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass<256>, grid, dim3(256), 0, a);
     }
     check_launch("ntt_inverse");
 }

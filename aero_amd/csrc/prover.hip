@@ -470,9 +470,8 @@ Bytes open_batch(Context* ctx, const MerkleTree& tree, const std::vector<uint64_
 Matrix Prover::interpolate_columns(const uint64_t* trace_dev, uint32_t width, int log_n) {
     size_t n = (size_t)1 << log_n;
     Matrix polys(ctx_, (int)width, n);
-    AERO_HIP(hipMemcpyAsync(polys.data.get(), trace_dev, (size_t)width * n * 8, hipMemcpyDeviceToDevice, ctx_->stream));
-    // coefficient i scaled by 7^i so the LDE needs no coset-shift pass (see ntt.hip)
-    ctx_->ntt_inverse(polys.data.get(), n, (int)width, log_n, 1, gl::GEN, 1, 0);
+    // coefficient i scaled by 7^i so the LDE needs no coset-shift pass (see ntt.hip); the first pass reads the caller's matrix, nothing is copied
+    ctx_->ntt_inverse(polys.data.get(), n, (int)width, log_n, 1, gl::GEN, 1, 0, nullptr, trace_dev, n);
     return polys;
 }
 Matrix Prover::evaluate_columns_over(const Matrix& polys, int log_blowup) {
@@ -1077,8 +1076,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         AERO_HIP(hipMemcpyAsync(host_verdict_, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
         trace_src = A ? trace_keep.get() : nullptr;
     } else {
-        AERO_HIP(hipMemcpyAsync(polys.data.get(), trace_dev, (size_t)W * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0);
+        ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0, nullptr, trace_dev, n);      // read from the caller's matrix: no copy
         ms.interpolate = clk.lap();
         have_tc = extend_columns(0, W);
     }
