@@ -1021,6 +1021,15 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
     // VALU instructions matter with several proofs in flight even where one proof alone is latency-bound); below 2^21 elements the LDS
     // rounds keep the launch)
     static const int inv2p_min = getenv("AERO_INV_2PHASE_MIN") ? atoi(getenv("AERO_INV_2PHASE_MIN")) : 21;      // log2 of the smallest launch (elements) that takes it
+    // Small launches (lds_wide) of 2^18 .. 2^20 points: the 6 - 8 bits behind the 12-bit contiguous pass as ONE strided pass through LDS tiles
+    // (512 threads) instead of one or two register passes - two launches instead of three where every launch is latency. Measured
+    // (profiles/r4_inv_lds_plan_ab.txt): 2 columns 2^20 76.0 -> 63.4 us, 1 column 2^20 52.4 -> 46.7, 2 columns 2^18 49.6 -> 43.7, 2^19 50.9 -> 48.5;
+    // 2 columns 2^16 (4 bits behind the first pass: one radix-16 register pass) 30.5 -> 33.5, so shorter transforms keep the register pass.
+    // One proof alone: 2.30 - 2.35 -> 2.28 - 2.31 ms; eight in flight: unchanged (1.251 / 1.265 against 1.263 / 1.260 G cells/s).
+    // AERO_INV_LDS_PLAN=0 switches it off.
+    static const bool lds_plan_env = !(getenv("AERO_INV_LDS_PLAN") && getenv("AERO_INV_LDS_PLAN")[0] == '0');
+    const bool lds_plan = lds_plan_env && log_n >= 18 && log_n <= 20 && lds_wide(ncols, log_n);
+    const bool reg_passes = this->reg_passes && !lds_plan;          // shadows the member for the rest of this transform
     const bool inv2p = inv2p_env && reg_passes && log_n >= 13 && ((size_t)ncols << log_n) >= ((size_t)1 << inv2p_min);
     std::vector<NttPass> plan = plan_passes(log_n, reg_passes, inv2p ? 11 : 12, false);
     const int r1 = plan[0].log_r;
