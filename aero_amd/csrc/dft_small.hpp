@@ -103,9 +103,9 @@ template <int K> __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
         const uint32_t y1 = r ? ((x0 >> ((32 - r) & 31)) | (x1 << r)) : x1;
         const uint32_t y2 = r ? (x1 >> ((32 - r) & 31)) : 0u;
         if constexpr (q == 0) {
-            uint64_t lo = gl::mk64(y0, y1);
-            lo = lo >= gl::P ? lo - gl::P : lo;
-            return add(lo, ((uint64_t)y2 << 32) - y2);
+            // (y1:y0) may exceed p, but (y1:y0) + y2 EPS < 2^64 + 2^63 < 2p: gl::add's single conditional "+ EPS" (taken when the sum wraps past
+            // 2^64 or lands in [p, 2^64)) already returns the canonical residue - no canonicalisation of the first operand (4 instructions)
+            return add(gl::mk64(y0, y1), ((uint64_t)y2 << 32) - y2);
         } else if constexpr (q == 1) {
             return sub(add(gl::mk64(0u, y0), ((uint64_t)y1 << 32) - y1), (uint64_t)y2);
         } else {

@@ -366,6 +366,101 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArg
         for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = y[i];
     }
 }
+// ------------------------------------------------------------------------------------------------
+// The same pass with TWO wavefronts per 2048-point tile and 16 values per lane (round 5): ntt_fwd_first_pass_8 holds 32 values per lane,
+// 158 VGPRs, three waves per SIMD, and its waves spend 29 % of their residency waiting on their own carry chains
+// (profiles/r4_ntt_gap.md). Here a lane holds half as much in both phases:
+//   A  lane (h, q) of the 128: row h, the two positions klow = 2q, 2q + 1 (mod 8) of it - 16 of the row's 64 values. q = 2 wave + (lane >> 5):
+//      the factor w_64^(4 rev(j)) of the second wave is a wave-uniform branch, the factor w_64^(2 rev(j)) of the upper half-wave a select.
+//   -- the same XOR-swizzled 32 x 64 exchange, 16 KiB per tile, ONE workgroup barrier: ten tiles per CU = five waves per SIMD --
+//   B  the 32-point transform of column k is shared by lanes (k, 0) and (k, 1) of one wave (the two-lane split of
+//      ntt_fwd_strided_reg6x2): half h holds rows 16 h + j, four shift-twiddle stages on its 16 values, then ONE V_PERMLANE32_SWAP
+//      round pairs row j with row j + 16 across the halves (w_32^8 = 2^48 on the upper half as a select). Wave w owns columns
+//      [32 w, 32 w + 32); the pass-boundary progression runs as two chains of 8 per lane (rows r0 + j and r0 + 16 + j, r0 = 8 half).
+//      A wavefront's store is two contiguous 256-byte segments.
+template <int KLOW> __device__ __forceinline__ void first8_pairs(const uint64_t (&c)[8], uint64_t (&v)[8]) {
+    v[0] = c[0]; v[1] = mul_w64<KLOW * 4>(c[1]); v[2] = mul_w64<KLOW * 2>(c[2]); v[3] = mul_w64<KLOW * 6>(c[3]);
+    v[4] = mul_w64<KLOW * 1>(c[4]); v[5] = mul_w64<KLOW * 5>(c[5]); v[6] = mul_w64<KLOW * 3>(c[6]); v[7] = mul_w64<KLOW * 7>(c[7]);
+    dft_dit<3>(v);
+}
+template <int I> __device__ __forceinline__ void last_stage_pairs32(uint64_t (&y)[16]) {
+    bfly_w64<2 * I>(y[I], y[8 + I]);
+    if constexpr (I + 1 < 8) last_stage_pairs32<I + 1>(y);
+}
+__global__ __launch_bounds__(128, 5) void ntt_fwd_first_pass_8x2(PassArgs a) {
+    __shared__ __attribute__((aligned(16))) uint64_t lds[F8_TILE_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x);
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride + ((size_t)b << 11);
+    const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
+    const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
+    {
+        const int h = lane & 31;
+        const bool upper = lane >= 32;
+        uint64_t c[8];
+        const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(in + ((size_t)b << 8) + 8 * h);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const ulonglong2 t = cp[q]; c[2 * q] = t.x; c[2 * q + 1] = t.y; }
+        if (wave) {      // klow += 4: c[j] * w_64^(4 rev3(j))
+            c[1] = mul_w64<16>(c[1]); c[2] = mul_w64<8>(c[2]); c[3] = mul_w64<24>(c[3]); c[4] = mul_w64<4>(c[4]);
+            c[5] = mul_w64<20>(c[5]); c[6] = mul_w64<12>(c[6]); c[7] = mul_w64<28>(c[7]);
+        }
+        { uint64_t t;    // klow += 2 in the upper half-wave: c[j] * w_64^(2 rev3(j))
+          t = mul_w64<8>(c[1]);  c[1] = upper ? t : c[1];   t = mul_w64<4>(c[2]);  c[2] = upper ? t : c[2];
+          t = mul_w64<12>(c[3]); c[3] = upper ? t : c[3];   t = mul_w64<2>(c[4]);  c[4] = upper ? t : c[4];
+          t = mul_w64<10>(c[5]); c[5] = upper ? t : c[5];   t = mul_w64<6>(c[6]);  c[6] = upper ? t : c[6];
+          t = mul_w64<14>(c[7]); c[7] = upper ? t : c[7]; }
+        uint64_t v0[8], v1[8];
+        first8_pairs<0>(c, v0);
+        first8_pairs<1>(c, v1);
+        // row h, columns col0 + 8 i (v0) and col0 + 1 + 8 i (v1): one 16-byte store per pair (col0 and the swizzle are even)
+        ulonglong2* row = reinterpret_cast<ulonglong2*>(lds + h * 64);
+        const int sw = (2 * h) & 63, col0 = 4 * wave + (upper ? 2 : 0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { ulonglong2 t; t.x = v0[i]; t.y = v1[i]; row[((col0 + 8 * i) ^ sw) >> 1] = t; }
+    }
+    __syncthreads();
+    const int half = lane >> 5, k = 32 * wave + (lane & 31);
+    uint64_t y[16];
+    {
+        // rows 16 half + j of column k: (2 row) & 63 = 32 half + 2 j
+        const uint64_t* colp = lds + (16 * half) * 64;
+        const int kx = k ^ (32 * half);
+#pragma unroll
+        for (int j = 0; j < 16; j++) y[j] = colp[j * 64 + (kx ^ (2 * j))];
+    }
+    {
+        // row r = 16 half + j of the table w_2048^(k rev5(r)): rev5(r) = 2 rev4(j) + half
+        const uint64_t* mt = a.tw_mt + half * 64 + k;
+#pragma unroll
+        for (int j = 0; j < 16; j++) y[j] = mul(y[j], mt[(int)gl::bitrev((uint32_t)j, 4) * 128]);
+    }
+    dft_dit_reg<4>(y);
+#pragma unroll
+    for (int i = 0; i < 8; i++) swap_halves(y[i], y[8 + i]);              // lower: rows (i, 16 + i), upper: rows (8 + i, 24 + i)
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const uint64_t t = mul_w4(y[8 + i]); y[8 + i] = half ? t : y[8 + i]; }
+    last_stage_pairs32<0>(y);
+    // y[i] = row r0 + i, y[8 + i] = row r0 + 16 + i of column k
+    const uint32_t r0 = 8 * half;
+    uint64_t* dst = out + k + 64 * r0;
+    if (!a.first && rbk) {
+        uint64_t c0 = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)(k + 64 * r0)) & nmask), a.tw_h);
+        const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
+        uint64_t c1 = mul(c0, tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 1024u) & nmask), a.tw_h));
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            dst[64 * i] = mul(y[i], c0);
+            dst[64 * (16 + i)] = mul(y[8 + i], c1);
+            if (i < 7) { c0 = mul(c0, step); c1 = mul(c1, step); }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { dst[64 * i] = y[i]; dst[64 * (16 + i)] = y[8 + i]; }
+    }
+}
 // tab[r * 64 + k] = root^(r * k), r < rows
 __global__ void fill_mul_table64(uint64_t* tab, uint32_t rows, uint64_t root) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -993,6 +1088,10 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
             a.chains = f8_chains ? f8_chains : (ncols < 16 ? 2 : 1);
             const size_t tiles = ((size_t)1 << log_out) >> 11;
             const char* nm = pass_names ? "ntt_fwd_first8" : "ntt_fwd_pass";
+            // AERO_NTT_F8X2=0: one wavefront per tile, 32 values per lane (the round-3 kernel); default: two wavefronts per tile, 16 per lane
+            static const bool f8x2 = !(getenv("AERO_NTT_F8X2") && getenv("AERO_NTT_F8X2")[0] == '0');
+            if (f8x2) AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8x2, dim3((unsigned)tiles, ncols), dim3(128), 0, a);
+            else
             AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8, dim3((unsigned)(tiles / F8_WAVES), ncols), dim3(64 * F8_WAVES), 0, a);
             continue;
         }

@@ -654,6 +654,16 @@ __global__ __launch_bounds__(256) void field_selftest_kernel(const uint64_t* __r
     for (int k = 0; k < 40; k++) { gl::wmac(w, u, v); u = gl::sub(gl::P - 1, mul_2_24(u)); v = gl::add(v, x); }
     o[16] = gl::wreduce(w);
 }
+// every shift multiplication of the register transforms: out[i * 96 + K] = x_i * 2^K, K < 96
+template <int K> __device__ __forceinline__ void pow2_all(uint64_t x, uint64_t* o) {
+    o[K] = mul_pow2<K>(x);
+    if constexpr (K + 1 < 96) pow2_all<K + 1>(x, o);
+}
+__global__ __launch_bounds__(256) void pow2_selftest_kernel(const uint64_t* __restrict__ a, size_t n, uint64_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    pow2_all<0>(a[i], out + i * 96);
+}
 static uint64_t ref_mulmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % gl::P); }
 static uint64_t ref_addmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + b) % gl::P); }
 static uint64_t ref_submod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + gl::P - b) % gl::P); }
@@ -680,6 +690,35 @@ void field_selftest(Context* ctx, size_t n, uint64_t seed) {
     static const char* names[17] = {"add", "sub", "mul", "sqr", "neg", "mul(sub, add)", "sub(mul, mul)", "mul_2_24", "mul_w4 (2^48)", "mul_2_72",
                                     "add(pow2<39>, pow2<78>)", "sub(pow2<60>, pow2<7>)", "pow2<95>", "E2 mul (component 0)", "E2 mul (component 1)", "inv",
                                     "160-bit sum of 40 products (Wide)"};
+    {
+        // all 96 shift multiplications on the values whose shifted limbs straddle p: x = 2^(64 - r) - 1 - d puts (x << r) mod 2^64 at or just
+        // below 2^64 - 2^r (>= p for r < 32), plus the generic edge values and the first random samples
+        std::vector<uint64_t> xs;
+        for (int r = 1; r < 32; r++) for (uint64_t d = 0; d < 3; d++) xs.push_back((((uint64_t)1 << (64 - r)) - 1 - d) % gl::P);
+        for (uint64_t e : edge) xs.push_back(e % gl::P);
+        xs.push_back(0); xs.push_back(gl::P - 2);
+        for (size_t i = 0; i < n && i < 1024; i++) xs.push_back(a[i]);
+        const size_t m = xs.size();
+        DevBuf<uint64_t> dx(ctx, m), dp(ctx, m * 96);
+        AERO_HIP(hipMemcpyAsync(dx.get(), xs.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
+        AERO_LAUNCH(ctx, "pow2_selftest_kernel", 0, pow2_selftest_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, dx.get(), m, dp.get());
+        ctx->check_launch("pow2_selftest");
+        std::vector<uint64_t> po(m * 96);
+        AERO_HIP(hipMemcpyAsync(po.data(), dp.get(), m * 96 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        for (size_t i = 0; i < m; i++) {
+            uint64_t want = xs[i];
+            for (int k = 0; k < 96; k++) {
+                if (po[i * 96 + k] != want) {
+                    char msg[256];
+                    snprintf(msg, sizeof msg, "field self-test: device mul_pow2<%d> is wrong for x = %llu: got %llu, expected %llu", k, (unsigned long long)xs[i],
+                             (unsigned long long)po[i * 96 + k], (unsigned long long)want);
+                    fail(msg, ST_INTERNAL);
+                }
+                want = ref_addmod(want, want);
+            }
+        }
+    }
     for (size_t i = 0; i < n; i++) {
         const uint64_t x = a[i], y = b[i];
         uint64_t want[17];

@@ -56,7 +56,9 @@ int main() {
     const int blocks = 256 * 12, iters = 64;
     u64* out; CK(hipMalloc(&out, blocks * 256 * 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-#ifdef GL_LAZY_ADD_UNSAFE
+#ifdef GL_ASM
+    printf("variant: hand-written VOP2 carry chains (GL_ASM)\n");
+#elif defined(GL_LAZY_ADD_UNSAFE)
     printf("variant: gl::add WITHOUT canonicalisation (upper bound on the gain, results are not field elements)\n");
 #else
     printf("variant: the product's canonical gl::add / gl::sub\n");
@@ -65,7 +67,10 @@ int main() {
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters); CK(hipDeviceSynchronize());
         float best = 1e9;
         for (int r = 0; r < 3; r++) { CK(hipEventRecord(e0)); hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms; }
-        printf("%-44s %8.3f ms  %9.1f Gelem/s\n", name, best, iters * elems_per_thread_iter * blocks * 256.0 / (best * 1e-3) / 1e9);
+        static u64 host[256 * 12 * 256];
+        CK(hipMemcpy(host, out, sizeof(host), hipMemcpyDeviceToHost));
+        u64 sum = 0; for (size_t i = 0; i < sizeof(host) / 8; i++) sum = sum * 0x9E3779B97F4A7C15ull + host[i];
+        printf("%-44s %8.3f ms  %9.1f Gelem/s  checksum %016llx\n", name, best, iters * elems_per_thread_iter * blocks * 256.0 / (best * 1e-3) / 1e9, (unsigned long long)sum);
     };
     timeit("phase B (mul + dft32 + 2 mul) per element", phase_b32, 32.0);
     timeit("dft32 shift-twiddle stages only", dft32_only, 32.0);
