@@ -130,6 +130,13 @@ public:
     };
     std::shared_ptr<CopyGate> copy_gate;   // shared with the pool: a context kept alive by one of its matrices may outlive aero_pool_destroy
     hipEvent_t gate_event = nullptr;       // this context's last gated copy
+    // Pool prefetch (capi.hip: aero_pool::worker): while a slot proves trace r, the copy of trace r + 1 runs on its copy stream into the other of
+    // two landing buffers. The next host-trace proof on this context then finds its trace at `dev` once `ready` has fired - the resident path
+    // plus an event wait and the canonical-form check of the host path (Prover::set_landed_trace). Cleared by the worker after the call.
+    struct LandedTrace {
+        const uint64_t* dev = nullptr;
+        hipEvent_t ready = nullptr;
+    } landed;
     // second stream + events for the host-to-device copy of a wide trace: column group g + 1 travels while group g is transformed
     hipStream_t copy_stream = nullptr;
     hipStream_t get_copy_stream();

@@ -376,14 +376,12 @@ template <class F, int MODE> static bool air_launch_mode(Context* ctx, const Air
     // Rows per lane. Measured on fib_2^20 x 72 (MI355X, tools/air_bench.py): 2 rows per lane 1.48 ms, 4 rows 1.71 ms (170 VGPRs and
     // 16 KiB of LDS per wave leave 2.5 waves per SIMD), 1 row with LDS accumulators 1.94 ms.
     constexpr int RW = 2;
-    static const int r_env = getenv("AERO_AIR_ROWS") ? atoi(getenv("AERO_AIR_ROWS")) : 0;      // experiments: 1 = one row per lane, 4 = four
     const bool wide = a.count % 4 == 0 && a.count >= (size_t)4 * AIR_WG * 64;       // enough rows to fill the chip several at a time
-    if (wide && r_env == 4 && F::DEG == 1 && a.n_bgroups <= 2 && air_launch_variant<F, MODE, 4, 2>(ctx, a, abytes)) return true;
-    if (wide && r_env != 1 && a.n_bgroups <= 2 && air_launch_variant<F, MODE, RW, 2>(ctx, a, abytes)) return true;
-    if (wide && r_env != 1 && a.n_bgroups <= 4 && air_launch_variant<F, MODE, RW, 4>(ctx, a, abytes)) return true;
+    if (wide && a.n_bgroups <= 2 && air_launch_variant<F, MODE, RW, 2>(ctx, a, abytes)) return true;
+    if (wide && a.n_bgroups <= 4 && air_launch_variant<F, MODE, RW, 4>(ctx, a, abytes)) return true;
     // a VM's assertions (first / last / interior steps, a few periodic strides) make 5 - 8 divisor groups: their accumulators still fit
     // the registers (2 rows x 8 groups x 2 sums), which keeps the read-modify-write of every BOUND out of the LDS
-    if (wide && r_env != 1 && a.n_bgroups <= 8 && air_launch_variant<F, MODE, RW, 8>(ctx, a, abytes)) return true;
+    if (wide && a.n_bgroups <= 8 && air_launch_variant<F, MODE, RW, 8>(ctx, a, abytes)) return true;
     return air_launch_variant<F, MODE, 1, 0>(ctx, a, abytes);
 }
 template <class F> bool launch_air_constraints(Context* ctx, const AirConsArgs<F>& a, int mode) {

@@ -525,7 +525,10 @@ static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, i
     ProofOptions po{o->num_queries, o->blowup_factor, o->grinding_factor, o->hash_fn, o->field_extension, o->fri_folding_factor, o->fri_log_max_remainder};
     Prover p(ctx->c, po);
     p.set_aux_segment(aux_width, aux_rands, aux_degree);
-    if (trace_host) p.set_host_trace(trace_host, verdict);
+    if (trace_host) {
+        if (ctx->c->landed.dev && !(comm && comm->world > 1)) { trace_dev = ctx->c->landed.dev; p.set_landed_trace(trace_host, ctx->c->landed.ready, verdict); }
+        else p.set_host_trace(trace_host, verdict);
+    }
     if (comm) {
         REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "prove_fib_sharded: bad rank / world");
         REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "prove_fib_sharded: missing exchange callback");
@@ -537,7 +540,7 @@ static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, i
         p.set_comm(sc);
     }
     p.collect_stage_times = ctx->stage_timing;
-    if (ctx->concurrent_peers) p.h2d_pipeline = false;
+    if (ctx->concurrent_peers) p.h2d_pipeline = false;      // column groups on a second stream: no gain under other proofs (profiles/r5_h2d.md)
     std::vector<uint64_t> pub;
     Bytes b = p.prove(trace_dev, width, log_n, &pub);
     ctx->last_ms = p.last_stage_ms;
@@ -830,8 +833,43 @@ struct aero_pool {
             // (the entry points below catch their own) becomes the slot's status
             try {
             pub.resize((size_t)(s->host_trace ? host_width : (uint32_t)s->trace->m.cols) / 2);
+            // Prefetch (round 5): a slot whose stream sits behind a 10 ms copy is a slot that does not compute - eight slots of 2^20 x 72
+            // proofs behaved like four or five (3.5 against 4.2 G cells/s resident with the link at half its rate, profiles/r5_h2d.md).
+            // With several rounds ahead the copy of trace r + 1 runs on the copy stream, into the other of two landing buffers, WHILE
+            // trace r is proven; every trace still crosses the link inside the call. Narrow traces (< 32 MiB) keep the in-stream copy:
+            // their copy is short and hides behind the other proofs as it is. AERO_POOL_PREFETCH_MIN_MB overrides the size, 0 = never.
+            static const long prefetch_mb = getenv("AERO_POOL_PREFETCH_MIN_MB") ? atol(getenv("AERO_POOL_PREFETCH_MIN_MB")) : 32;
+            uint32_t trace_w = host_width;
+            if (program) { uint32_t info[16] = {0}; if (aero_air_info(program, info) == AERO_OK) trace_w = info[0]; }      // main_width
+            const size_t trace_bytes = s->host_trace ? ((size_t)trace_w << host_log_n) * 8 : 0;
+            const bool prefetch = s->host_trace && rounds > 1 && prefetch_mb > 0 && trace_bytes >= ((size_t)prefetch_mb << 20);
+            Context* const c = s->ctx->c;
+            DevBuf<uint64_t> land[2];
+            hipStream_t cs = nullptr;
+            auto send = [&](uint32_t r) {       // the copy of round r's trace, behind whatever the copy stream still carries
+                // one copy at a time per pool, in the order the slots ask (Context::CopyGate): the first fills then start the slots one copy
+                // apart and they stay out of phase - proofs that run in lockstep queue their latency-bound stages behind each other
+                std::lock_guard<std::mutex> lk(gate->mu);
+                if (gate->last) AERO_HIP(hipStreamWaitEvent(cs, gate->last, 0));
+                AERO_HIP(hipMemcpyAsync(land[r & 1].get(), s->host_trace, trace_bytes, hipMemcpyHostToDevice, cs));
+                AERO_HIP(hipEventRecord(c->sync_event(32 + (r & 1)), cs));
+                gate->last = c->sync_event(32 + (r & 1));
+            };
+            if (prefetch) {
+                rc = guard(s->ctx, [&] {
+                    land[0] = DevBuf<uint64_t>(c, trace_bytes / 8); land[1] = DevBuf<uint64_t>(c, trace_bytes / 8);
+                    cs = c->get_copy_stream();
+                    send(0);
+                });
+            }
             for (uint32_t r = 0; r < rounds && rc == AERO_OK; r++) {
                 if (out) { free(out); out = nullptr; }
+                if (prefetch) {
+                    // round r - 1 has returned (the calls below are synchronous): its landing buffer is free for round r + 1
+                    if (r + 1 < rounds) rc = guard(s->ctx, [&] { send(r + 1); });
+                    if (rc != AERO_OK) break;
+                    c->landed.dev = land[r & 1].get(); c->landed.ready = c->sync_event(32 + (r & 1));
+                }
                 if (program) {
                     const uint32_t np = (uint32_t)program_pub.size();
                     if (s->host_trace) rc = aero_prove_air_host(s->ctx, program, s->host_trace, host_log_n, program_pub.data(), np, &opt, &out, &len);
@@ -839,6 +877,13 @@ struct aero_pool {
                 }
                 else if (s->host_trace) rc = aero_prove_fib_air_host(s->ctx, s->host_trace, host_width, host_log_n, &air, &opt, &out, &len, pub.data());
                 else rc = aero_prove_fib_air(s->ctx, nullptr, s->trace, &air, &opt, &out, &len, pub.data());
+                c->landed = Context::LandedTrace{};
+            }
+            if (prefetch) {     // nothing of this job is left on the copy stream when the landing buffers go back to the context's allocator
+                c->landed = Context::LandedTrace{};
+                if (cs) (void)hipStreamSynchronize(cs);
+                std::lock_guard<std::mutex> lk(gate->mu);      // a fired event is a no-op to wait on, but it is this context's: leave none behind
+                if (gate->last == c->sync_event(32) || gate->last == c->sync_event(33)) gate->last = nullptr;
             }
             } catch (const std::bad_alloc&) { rc = AERO_E_OOM; s->ctx->err = "pool worker: host allocation failed"; }
             catch (...) { rc = AERO_E_INTERNAL; s->ctx->err = "pool worker: unexpected exception"; }

@@ -143,7 +143,10 @@ static void prove_program(aero_ctx* ctx, const aero_comm* comm, const aero_air* 
     if (p.A && !p.has_builders()) fail("prove_air: the program does not say how its auxiliary columns are built (no aux builders)", ST_UNSUPPORTED);
     Prover pr(ctx->c, to_options(o));
     pr.set_program(&p, pubv);
-    if (trace_host) pr.set_host_trace(trace_host, verdict);
+    if (trace_host) {
+        if (ctx->c->landed.dev && !(comm && comm->world > 1)) { trace_dev = ctx->c->landed.dev; pr.set_landed_trace(trace_host, ctx->c->landed.ready, verdict); }
+        else pr.set_host_trace(trace_host, verdict);
+    }
     if (comm) {
         REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "prove_air: bad rank / world");
         REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "prove_air: missing exchange callback");
@@ -155,7 +158,7 @@ static void prove_program(aero_ctx* ctx, const aero_comm* comm, const aero_air* 
         pr.set_comm(sc);
     }
     pr.collect_stage_times = ctx->stage_timing;
-    if (ctx->concurrent_peers) pr.h2d_pipeline = false;
+    if (ctx->concurrent_peers) pr.h2d_pipeline = false;      // column groups on a second stream: no gain under other proofs (profiles/r5_h2d.md)
     const Bytes b = pr.prove(trace_dev, width, log_n, nullptr);
     ctx->last_ms = pr.last_stage_ms;
     *proof = to_malloc(b, proof_len);

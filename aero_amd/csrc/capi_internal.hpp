@@ -79,3 +79,4 @@ template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
 
 static inline int ilog2u(uint64_t x) { int r = 0; while ((1ull << r) < x) r++; return r; }
 
+

@@ -34,27 +34,7 @@ constexpr int TWO_ADICITY = 32;
 // (tools/ubench_field.hip) add 6.7 T/s vs 4.8, sub 7.7 vs 6.2, mul 1.65 vs 1.34 T/s for the plain u64 formulation.
 GL_HD uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 GL_HD uint64_t add(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_ASM)
-    // Hand-written VOP2 carry chain on VCC (4-byte encodings; the compiler interleaves two chains and pays 8-byte VOP3 encodings for the one
-    // whose carries live in an SGPR pair - tools/kernel_regs.py / isa_histogram.py). gfx950 wants two wait states between a VALU write of
-    // VCC and a VALU read of it; inline assembly is not seen by the hazard recogniser, so they are spelled out.
-    uint32_t s0, s1, t0, t1;
-    uint64_t sv;
-    asm("v_add_co_u32 %[s0], vcc, %[a0], %[b0]\n\t"
-        "s_nop 1\n\t"
-        "v_addc_co_u32 %[s1], vcc, %[a1], %[b1], vcc\n\t"
-        "s_mov_b64 %[sv], vcc\n\t"
-        "v_add_co_u32 %[t0], vcc, -1, %[s0]\n\t"
-        "s_nop 1\n\t"
-        "v_addc_co_u32 %[t1], vcc, 0, %[s1], vcc\n\t"
-        "s_or_b64 vcc, vcc, %[sv]\n\t"
-        "v_cndmask_b32 %[s0], %[s0], %[t0], vcc\n\t"
-        "v_cndmask_b32 %[s1], %[s1], %[t1], vcc"
-        : [s0] "=&v"(s0), [s1] "=&v"(s1), [t0] "=&v"(t0), [t1] "=&v"(t1), [sv] "=&s"(sv)
-        : [a0] "v"((uint32_t)a), [a1] "v"((uint32_t)(a >> 32)), [b0] "v"((uint32_t)b), [b1] "v"((uint32_t)(b >> 32))
-        : "vcc", "scc");      // s_or_b64 writes SCC
-    return mk64(s0, s1);
-#elif defined(__HIP_DEVICE_COMPILE__) && defined(GL_LAZY_ADD_UNSAFE)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_LAZY_ADD_UNSAFE)
     // MEASUREMENT ONLY (tools/ubench_dft.hip): one wrap correction, no canonicalisation, a second wrap goes unnoticed - not a field add.
     uint32_t c, c1;
     uint32_t s0 = __builtin_addc((uint32_t)a, (uint32_t)b, 0u, &c), s1 = __builtin_addc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &c1);
@@ -79,22 +59,7 @@ GL_HD uint64_t add(uint64_t a, uint64_t b) {
 // function of the operands (profiles/r3_carry_sub_miscompile.md has the instruction-level account). GL_CARRY_SUB selects it with an
 // optimisation barrier on the high limb that keeps the combiner from looking through the subtraction.
 GL_HD uint64_t sub(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_ASM)
-    // a - b, then - EPS (= + p mod 2^64) under the borrow: five VOP2 instructions, no select
-    uint32_t d0, d1, m;
-    asm("v_sub_co_u32 %[d0], vcc, %[a0], %[b0]\n\t"
-        "s_nop 1\n\t"
-        "v_subb_co_u32 %[d1], vcc, %[a1], %[b1], vcc\n\t"
-        "s_nop 1\n\t"
-        "v_subbrev_co_u32 %[m], vcc, 0, %[z], vcc\n\t"
-        "v_sub_co_u32 %[d0], vcc, %[d0], %[m]\n\t"
-        "s_nop 1\n\t"
-        "v_subbrev_co_u32 %[d1], vcc, 0, %[d1], vcc"
-        : [d0] "=&v"(d0), [d1] "=&v"(d1), [m] "=&v"(m)
-        : [a0] "v"((uint32_t)a), [a1] "v"((uint32_t)(a >> 32)), [b0] "v"((uint32_t)b), [b1] "v"((uint32_t)(b >> 32)), [z] "v"(0u)
-        : "vcc");
-    return mk64(d0, d1);
-#elif defined(__HIP_DEVICE_COMPILE__) && defined(GL_CARRY_SUB)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_CARRY_SUB)
     uint32_t c, c1;
     uint32_t d0 = __builtin_subc((uint32_t)a, (uint32_t)b, 0u, &c), d1 = __builtin_subc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, &c1);
     uint32_t t0 = __builtin_subc(d0, 0xFFFFFFFFu, 0u, &c), t1 = __builtin_subc(d1, 0u, c, &c);   // d + p = d - EPS (mod 2^64)
@@ -130,44 +95,7 @@ GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
     return r >= P ? r - P : r;
 }
 GL_HD uint64_t mul(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_ASM)
-    // product by the compiler (4 x v_mad_u64_u32), x0 + x1 2^32 + x2 (2^32 - 1) - x3 and the canonical form on VOP2 carry chains
-    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-    const uint64_t t = (uint64_t)a0 * b0;
-    const uint64_t u = (uint64_t)a0 * b1 + (t >> 32);
-    const uint64_t v = (uint64_t)a1 * b0 + (uint32_t)u;
-    const uint64_t w = (uint64_t)a1 * b1 + ((u >> 32) + (v >> 32));
-    uint32_t r0, r1, l0, l1, m, e0, e1, t0, t1;
-    uint64_t sc;
-    asm("v_sub_co_u32 %[l0], vcc, %[x0], %[x3]\n\t"
-        "v_sub_co_u32 %[e0], %[sc], 0, %[x2]\n\t"
-        "s_nop 0\n\t"
-        "v_subbrev_co_u32 %[l1], vcc, 0, %[x1], vcc\n\t"
-        "s_nop 1\n\t"
-        "v_subbrev_co_u32 %[m], vcc, 0, %[z], vcc\n\t"
-        "v_sub_co_u32 %[l0], vcc, %[l0], %[m]\n\t"
-        "v_subbrev_co_u32 %[e1], %[sc], 0, %[x2], %[sc]\n\t"
-        "s_nop 0\n\t"
-        "v_subbrev_co_u32 %[l1], vcc, 0, %[l1], vcc\n\t"
-        "v_add_co_u32 %[r0], vcc, %[l0], %[e0]\n\t"
-        "s_nop 1\n\t"
-        "v_addc_co_u32 %[r1], vcc, %[l1], %[e1], vcc\n\t"
-        "s_nop 1\n\t"
-        "v_subbrev_co_u32 %[m], vcc, 0, %[z], vcc\n\t"
-        "v_add_co_u32 %[r0], vcc, %[r0], %[m]\n\t"
-        "s_nop 1\n\t"
-        "v_addc_co_u32 %[r1], vcc, 0, %[r1], vcc\n\t"
-        "v_add_co_u32 %[t0], vcc, -1, %[r0]\n\t"
-        "s_nop 1\n\t"
-        "v_addc_co_u32 %[t1], vcc, 0, %[r1], vcc\n\t"
-        "s_nop 1\n\t"
-        "v_cndmask_b32 %[r0], %[r0], %[t0], vcc\n\t"
-        "v_cndmask_b32 %[r1], %[r1], %[t1], vcc"
-        : [r0] "=&v"(r0), [r1] "=&v"(r1), [l0] "=&v"(l0), [l1] "=&v"(l1), [m] "=&v"(m), [e0] "=&v"(e0), [e1] "=&v"(e1), [t0] "=&v"(t0), [t1] "=&v"(t1), [sc] "=&s"(sc)
-        : [x0] "v"((uint32_t)t), [x1] "v"((uint32_t)v), [x2] "v"((uint32_t)w), [x3] "v"((uint32_t)(w >> 32)), [z] "v"(0u)
-        : "vcc");
-    return mk64(r0, r1);
-#elif defined(__HIP_DEVICE_COMPILE__) && !defined(GL_PLAIN_MUL)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_PLAIN_MUL)
     // 4 x v_mad_u64_u32 schoolbook product (x0..x3), then x0 + x1 2^32 + x2 (2^32 - 1) - x3 on carry chains
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     const uint64_t t = (uint64_t)a0 * b0;

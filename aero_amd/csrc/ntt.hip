@@ -64,7 +64,7 @@ struct PassArgs {
     // inverse, first executed pass only (optional): OR 1 into *bad when an input element is not canonical (>= p) - the validation
     // of a trace handed over by the host rides on the pass that reads it anyway
     unsigned int* bad;
-    int chains;       // ntt_fwd_first_pass_8: number of interleaved pass-boundary progressions (1, 2 or 4; AERO_NTT_F8_CHAINS)
+    int chains;       // ntt_fwd_first_pass_8: number of interleaved pass-boundary progressions (1 or 2)
 };
 
 // LDS index skew: one extra slot per 32 elements breaks the power-of-two strides of the radix-8 gathers
@@ -343,17 +343,6 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArg
                 out[base + lane + 64 * (i + 1)] = mul(y[i + 1], cur1);
                 cur = mul(cur, step2); cur1 = mul(cur1, step2);
             }
-        } else if (a.chains == 4) {
-            const uint64_t step2 = mul(step, step), step4 = mul(step2, step2);
-            uint64_t c0 = cur, c1 = mul(cur, step), c2 = mul(cur, step2), c3 = mul(c1, step2);
-#pragma unroll
-            for (int i = 0; i < 32; i += 4) {
-                out[base + lane + 64 * i] = mul(y[i], c0);
-                out[base + lane + 64 * (i + 1)] = mul(y[i + 1], c1);
-                out[base + lane + 64 * (i + 2)] = mul(y[i + 2], c2);
-                out[base + lane + 64 * (i + 3)] = mul(y[i + 3], c3);
-                c0 = mul(c0, step4); c1 = mul(c1, step4); c2 = mul(c2, step4); c3 = mul(c3, step4);
-            }
         } else {
 #pragma unroll
         for (int i = 0; i < 32; i++) {
@@ -366,101 +355,10 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArg
         for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = y[i];
     }
 }
-// ------------------------------------------------------------------------------------------------
-// The same pass with TWO wavefronts per 2048-point tile and 16 values per lane (round 5): ntt_fwd_first_pass_8 holds 32 values per lane,
-// 158 VGPRs, three waves per SIMD, and its waves spend 29 % of their residency waiting on their own carry chains
-// (profiles/r4_ntt_gap.md). Here a lane holds half as much in both phases:
-//   A  lane (h, q) of the 128: row h, the two positions klow = 2q, 2q + 1 (mod 8) of it - 16 of the row's 64 values. q = 2 wave + (lane >> 5):
-//      the factor w_64^(4 rev(j)) of the second wave is a wave-uniform branch, the factor w_64^(2 rev(j)) of the upper half-wave a select.
-//   -- the same XOR-swizzled 32 x 64 exchange, 16 KiB per tile, ONE workgroup barrier: ten tiles per CU = five waves per SIMD --
-//   B  the 32-point transform of column k is shared by lanes (k, 0) and (k, 1) of one wave (the two-lane split of
-//      ntt_fwd_strided_reg6x2): half h holds rows 16 h + j, four shift-twiddle stages on its 16 values, then ONE V_PERMLANE32_SWAP
-//      round pairs row j with row j + 16 across the halves (w_32^8 = 2^48 on the upper half as a select). Wave w owns columns
-//      [32 w, 32 w + 32); the pass-boundary progression runs as two chains of 8 per lane (rows r0 + j and r0 + 16 + j, r0 = 8 half).
-//      A wavefront's store is two contiguous 256-byte segments.
-template <int KLOW> __device__ __forceinline__ void first8_pairs(const uint64_t (&c)[8], uint64_t (&v)[8]) {
-    v[0] = c[0]; v[1] = mul_w64<KLOW * 4>(c[1]); v[2] = mul_w64<KLOW * 2>(c[2]); v[3] = mul_w64<KLOW * 6>(c[3]);
-    v[4] = mul_w64<KLOW * 1>(c[4]); v[5] = mul_w64<KLOW * 5>(c[5]); v[6] = mul_w64<KLOW * 3>(c[6]); v[7] = mul_w64<KLOW * 7>(c[7]);
-    dft_dit<3>(v);
-}
-template <int I> __device__ __forceinline__ void last_stage_pairs32(uint64_t (&y)[16]) {
-    bfly_w64<2 * I>(y[I], y[8 + I]);
-    if constexpr (I + 1 < 8) last_stage_pairs32<I + 1>(y);
-}
-__global__ __launch_bounds__(128, 5) void ntt_fwd_first_pass_8x2(PassArgs a) {
-    __shared__ __attribute__((aligned(16))) uint64_t lds[F8_TILE_LDS];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x);
-    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
-    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride + ((size_t)b << 11);
-    const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
-    const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
-    {
-        const int h = lane & 31;
-        const bool upper = lane >= 32;
-        uint64_t c[8];
-        const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(in + ((size_t)b << 8) + 8 * h);
-#pragma unroll
-        for (int q = 0; q < 4; q++) { const ulonglong2 t = cp[q]; c[2 * q] = t.x; c[2 * q + 1] = t.y; }
-        if (wave) {      // klow += 4: c[j] * w_64^(4 rev3(j))
-            c[1] = mul_w64<16>(c[1]); c[2] = mul_w64<8>(c[2]); c[3] = mul_w64<24>(c[3]); c[4] = mul_w64<4>(c[4]);
-            c[5] = mul_w64<20>(c[5]); c[6] = mul_w64<12>(c[6]); c[7] = mul_w64<28>(c[7]);
-        }
-        { uint64_t t;    // klow += 2 in the upper half-wave: c[j] * w_64^(2 rev3(j))
-          t = mul_w64<8>(c[1]);  c[1] = upper ? t : c[1];   t = mul_w64<4>(c[2]);  c[2] = upper ? t : c[2];
-          t = mul_w64<12>(c[3]); c[3] = upper ? t : c[3];   t = mul_w64<2>(c[4]);  c[4] = upper ? t : c[4];
-          t = mul_w64<10>(c[5]); c[5] = upper ? t : c[5];   t = mul_w64<6>(c[6]);  c[6] = upper ? t : c[6];
-          t = mul_w64<14>(c[7]); c[7] = upper ? t : c[7]; }
-        uint64_t v0[8], v1[8];
-        first8_pairs<0>(c, v0);
-        first8_pairs<1>(c, v1);
-        // row h, columns col0 + 8 i (v0) and col0 + 1 + 8 i (v1): one 16-byte store per pair (col0 and the swizzle are even)
-        ulonglong2* row = reinterpret_cast<ulonglong2*>(lds + h * 64);
-        const int sw = (2 * h) & 63, col0 = 4 * wave + (upper ? 2 : 0);
-#pragma unroll
-        for (int i = 0; i < 8; i++) { ulonglong2 t; t.x = v0[i]; t.y = v1[i]; row[((col0 + 8 * i) ^ sw) >> 1] = t; }
-    }
-    __syncthreads();
-    const int half = lane >> 5, k = 32 * wave + (lane & 31);
-    uint64_t y[16];
-    {
-        // rows 16 half + j of column k: (2 row) & 63 = 32 half + 2 j
-        const uint64_t* colp = lds + (16 * half) * 64;
-        const int kx = k ^ (32 * half);
-#pragma unroll
-        for (int j = 0; j < 16; j++) y[j] = colp[j * 64 + (kx ^ (2 * j))];
-    }
-    {
-        // row r = 16 half + j of the table w_2048^(k rev5(r)): rev5(r) = 2 rev4(j) + half
-        const uint64_t* mt = a.tw_mt + half * 64 + k;
-#pragma unroll
-        for (int j = 0; j < 16; j++) y[j] = mul(y[j], mt[(int)gl::bitrev((uint32_t)j, 4) * 128]);
-    }
-    dft_dit_reg<4>(y);
-#pragma unroll
-    for (int i = 0; i < 8; i++) swap_halves(y[i], y[8 + i]);              // lower: rows (i, 16 + i), upper: rows (8 + i, 24 + i)
-#pragma unroll
-    for (int i = 0; i < 8; i++) { const uint64_t t = mul_w4(y[8 + i]); y[8 + i] = half ? t : y[8 + i]; }
-    last_stage_pairs32<0>(y);
-    // y[i] = row r0 + i, y[8 + i] = row r0 + 16 + i of column k
-    const uint32_t r0 = 8 * half;
-    uint64_t* dst = out + k + 64 * r0;
-    if (!a.first && rbk) {
-        uint64_t c0 = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)(k + 64 * r0)) & nmask), a.tw_h);
-        const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
-        uint64_t c1 = mul(c0, tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 1024u) & nmask), a.tw_h));
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            dst[64 * i] = mul(y[i], c0);
-            dst[64 * (16 + i)] = mul(y[8 + i], c1);
-            if (i < 7) { c0 = mul(c0, step); c1 = mul(c1, step); }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; i++) { dst[64 * i] = y[i]; dst[64 * (16 + i)] = y[8 + i]; }
-    }
-}
+// Round 5 measured this pass with TWO wavefronts per tile and 16 values per lane (74 VGPRs, five waves per SIMD instead of three, commit
+// d4aaeb6): 7.6 % more VALU instructions per tile (the phase-A pre-multiplications are shared by half as many values) and 8.5 % more time
+// on 2 and on 72 columns - both kernels retire one VALU instruction per 3.5 cycles and SIMD whatever their occupancy: the pass is bound by
+// VALU issue (40 % of its instructions are 8-byte VOP3 encodings), not by latency (profiles/r5_ntt_first_pass.md).
 // tab[r * 64 + k] = root^(r * k), r < rows
 __global__ void fill_mul_table64(uint64_t* tab, uint32_t rows, uint64_t root) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -632,7 +530,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pass_rsrc(const uint64_t* col,
     const size_t blk = ((size_t)b << logr) << log_s;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(col + blk), 0, (uint32_t)((((size_t)1 << logr) << log_s) * 8), 0x00020000);
 }
-template <int LOGR, bool BUF = false> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_fwd_strided_reg(PassArgs a) {
+template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_fwd_strided_reg(PassArgs a) {
     constexpr int R = 1 << LOGR;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;            // over 2^(log_n - LOGR) threads per column
     const size_t lo = t & (((size_t)1 << a.log_s) - 1);
@@ -641,15 +539,8 @@ template <int LOGR, bool BUF = false> __global__ __launch_bounds__(256, LOGR == 
     const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
     uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
     uint64_t y[R];
-    const uint32_t row_bytes = 8u << a.log_s, vo = (uint32_t)lo * 8;
-    if constexpr (BUF) {
-        const __amdgpu_buffer_rsrc_t rin = pass_rsrc(in, b, LOGR, a.log_s);
 #pragma unroll
-        for (int k = 0; k < R; k++) y[k] = buf_ld(rin, vo, (uint32_t)k * row_bytes);
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
-    }
+    for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
     if (LOGR == 6) __builtin_amdgcn_sched_barrier(0);   // all 64 loads in flight before the first butterfly (the scheduler otherwise sinks half of them)
     dft_dit_reg<LOGR>(y);
     if (!a.first && b) {
@@ -657,14 +548,8 @@ template <int LOGR, bool BUF = false> __global__ __launch_bounds__(256, LOGR == 
 #pragma unroll
         for (int k = 1; k < R; k++) y[k] = mul(y[k], tw[k]);
     }
-    if constexpr (BUF) {
-        const __amdgpu_buffer_rsrc_t rout = pass_rsrc(out, b, LOGR, a.log_s);
 #pragma unroll
-        for (int k = 0; k < R; k++) buf_st(rout, vo, (uint32_t)k * row_bytes, y[k]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
-    }
+    for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
     if (a.compact && (lo & (((size_t)1 << a.compact_log) - 1)) == 0) {
         // every 2^compact_log-th row once more, densely: what the per-row kernels that walk the LDE with that stride read
         // (constraint evaluation, DEEP) - a strided walk over the full matrix drags in a whole 64-byte sector per 8 useful bytes
@@ -727,10 +612,11 @@ __global__ __launch_bounds__(256) void ntt_fwd_strided_reg6x2(PassArgs a) {
         }
     }
 }
-// Variants for measurement (AERO_NTT_R6=<digit>): BUF addresses the 64 row accesses of a lane through a buffer descriptor whose base
-// (column + block) lives in SGPRs - the row part of every address is a scalar offset (k << log_s, SALU) and the lane part one VGPR
-// computed once, instead of a 64-bit vector shift-add per access; MINB asks the compiler for MINB workgroups per CU (4 = 128 VGPRs).
-template <bool BUF, int MINB> __global__ __launch_bounds__(256, MINB) void ntt_fwd_strided_reg6x2_v(PassArgs a) {
+// The same pass with the 64 row accesses of a lane addressed through a buffer descriptor whose base (column + block) lives in SGPRs - the row
+// part of every address is a scalar offset (k << log_s, SALU) and the lane part one VGPR computed once, instead of a 64-bit vector shift-add
+// per access: 96 VGPRs instead of 135, five waves per SIMD (profiles/r4_ntt_gap.md). Asking for four workgroups per CU by launch bounds alone
+// (128 VGPRs, spills) measured slower in both forms and is gone.
+__global__ __launch_bounds__(256, 3) void ntt_fwd_strided_reg6x2_buf(PassArgs a) {
     const uint32_t lane = threadIdx.x & 63, half = lane >> 5;
     const size_t p = (((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) << 5) + (lane & 31);    // over 2^(log_n - 6) positions per column
     const size_t lo = p & (((size_t)1 << a.log_s) - 1);
@@ -745,14 +631,9 @@ template <bool BUF, int MINB> __global__ __launch_bounds__(256, MINB) void ntt_f
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(in + blk), 0, span, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + blk, 0, span, 0x00020000);
     const uint32_t row_bytes = 8u << a.log_s;
-    if constexpr (BUF) {
-        const uint32_t vo = (uint32_t)lo * 8 + half * 32 * row_bytes;
+    const uint32_t vi = (uint32_t)lo * 8 + half * 32 * row_bytes;
 #pragma unroll
-        for (int i = 0; i < 32; i++) y[i] = buf_ld(rin, vo, (uint32_t)i * row_bytes);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 32; i++) y[i] = in[base + ((size_t)(32 * half + i) << a.log_s)];
-    }
+    for (int i = 0; i < 32; i++) y[i] = buf_ld(rin, vi, (uint32_t)i * row_bytes);
     dft_dit_reg<5>(y);
 #pragma unroll
     for (int i = 0; i < 16; i++) swap_halves(y[i], y[16 + i]);
@@ -765,19 +646,11 @@ template <bool BUF, int MINB> __global__ __launch_bounds__(256, MINB) void ntt_f
 #pragma unroll
         for (int i = 0; i < 16; i++) { y[i] = mul(y[i], tw[i]); y[16 + i] = mul(y[16 + i], tw[32 + i]); }
     }
-    if constexpr (BUF) {
-        const uint32_t vo = (uint32_t)lo * 8 + half * 16 * row_bytes;
+    const uint32_t vo = (uint32_t)lo * 8 + half * 16 * row_bytes;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            buf_st(rout, vo, (uint32_t)i * row_bytes, y[i]);
-            buf_st(rout, vo, (uint32_t)(32 + i) * row_bytes, y[16 + i]);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            out[base + ((size_t)(r0 + i) << a.log_s)] = y[i];
-            out[base + ((size_t)(r0 + 32 + i) << a.log_s)] = y[16 + i];
-        }
+    for (int i = 0; i < 16; i++) {
+        buf_st(rout, vo, (uint32_t)i * row_bytes, y[i]);
+        buf_st(rout, vo, (uint32_t)(32 + i) * row_bytes, y[16 + i]);
     }
     if (a.compact && (lo & (((size_t)1 << a.compact_log) - 1)) == 0) {
         uint64_t* co = a.compact + (size_t)blockIdx.y * a.compact_col_stride;
@@ -796,7 +669,7 @@ template <bool BUF, int MINB> __global__ __launch_bounds__(256, MINB) void ntt_f
 // twiddle w_128^j = w_128^(j mod 32) * (w_4 = 2^48 in the upper half): w_128 is not a power of two (2 has order 192), so this one
 // stage multiplies by 31 table constants (w_4096^(32 i), uniform over the wavefront) - half a multiplication per element. Used where
 // it saves a whole pass: a 2^25-point LDE (2^22-row traces, BASELINE configs[4]) is 11 + 7 + 7 bits instead of 11 + 5 + 5 + 4.
-template <bool BUF> __global__ __launch_bounds__(256, 3) void ntt_fwd_strided_reg7x2(PassArgs a) {
+__global__ __launch_bounds__(256, 3) void ntt_fwd_strided_reg7x2(PassArgs a) {
     const uint32_t lane = threadIdx.x & 63, half = lane >> 5;
     const size_t p = (((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) << 5) + (lane & 31);    // over 2^(log_n - 7) positions per column
     const size_t lo = p & (((size_t)1 << a.log_s) - 1);
@@ -805,16 +678,8 @@ template <bool BUF> __global__ __launch_bounds__(256, 3) void ntt_fwd_strided_re
     const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
     uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
     uint64_t y[64];
-    const uint32_t row_bytes = 8u << a.log_s;
-    const __amdgpu_buffer_rsrc_t rin = pass_rsrc(in, b, 7, a.log_s), rout = pass_rsrc(out, b, 7, a.log_s);
-    if constexpr (BUF) {
-        const uint32_t vo = (uint32_t)lo * 8 + half * 64 * row_bytes;
 #pragma unroll
-        for (int i = 0; i < 64; i++) y[i] = buf_ld(rin, vo, (uint32_t)i * row_bytes);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 64; i++) y[i] = in[base + ((size_t)(64 * half + i) << a.log_s)];
-    }
+    for (int i = 0; i < 64; i++) y[i] = in[base + ((size_t)(64 * half + i) << a.log_s)];
     __builtin_amdgcn_sched_barrier(0);
     dft_dit_reg<6>(y);
 #pragma unroll
@@ -837,14 +702,9 @@ template <bool BUF> __global__ __launch_bounds__(256, 3) void ntt_fwd_strided_re
         uint64_t lo_row = add(u, v), hi_row = sub(u, v);
         if (twiddle) { lo_row = mul(lo_row, tw[i]); hi_row = mul(hi_row, tw[64 + i]); }
         const size_t p0 = base + ((size_t)(r0 + i) << a.log_s), p1 = base + ((size_t)(r0 + 64 + i) << a.log_s);
-        if constexpr (BUF) {
-            const uint32_t vo = (uint32_t)lo * 8 + r0 * row_bytes;
-            buf_st(rout, vo, (uint32_t)i * row_bytes, lo_row);
-            buf_st(rout, vo, (uint32_t)(64 + i) * row_bytes, hi_row);
-        } else {
-            out[p0] = lo_row;
-            out[p1] = hi_row;
-        }
+        out[p0] = lo_row;
+        out[p1] = hi_row;
+    
         if (compact) {
             const size_t j0 = p0 >> a.compact_log, j1 = p1 >> a.compact_log;
             co[(j0 & pmask) * part_len + (j0 >> a.compact_split)] = lo_row;
@@ -852,7 +712,7 @@ template <bool BUF> __global__ __launch_bounds__(256, 3) void ntt_fwd_strided_re
         }
     }
 }
-template <int LOGR, bool BUF = false> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_inv_strided_reg(PassArgs a) {
+template <int LOGR> __global__ __launch_bounds__(256, LOGR == 6 ? 3 : 1) void ntt_inv_strided_reg(PassArgs a) {
     constexpr int R = 1 << LOGR;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t lo = t & (((size_t)1 << a.log_s) - 1);
@@ -861,15 +721,8 @@ template <int LOGR, bool BUF = false> __global__ __launch_bounds__(256, LOGR == 
     const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
     uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
     uint64_t y[R];
-    const uint32_t row_bytes = 8u << a.log_s, vo = (uint32_t)lo * 8;
-    if constexpr (BUF) {
-        const __amdgpu_buffer_rsrc_t rin = pass_rsrc(in, b, LOGR, a.log_s);
 #pragma unroll
-        for (int k = 0; k < R; k++) y[k] = buf_ld(rin, vo, (uint32_t)k * row_bytes);
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
-    }
+    for (int k = 0; k < R; k++) y[k] = in[base + ((size_t)k << a.log_s)];
     if (LOGR == 6) __builtin_amdgcn_sched_barrier(0);
     if (a.bad) {
         bool any = false;
@@ -883,14 +736,8 @@ template <int LOGR, bool BUF = false> __global__ __launch_bounds__(256, LOGR == 
         for (int k = 1; k < R; k++) y[k] = mul(y[k], tw[k]);
     }
     dft_dif_inv_reg<LOGR>(y);
-    if constexpr (BUF) {
-        const __amdgpu_buffer_rsrc_t rout = pass_rsrc(out, b, LOGR, a.log_s);
 #pragma unroll
-        for (int k = 0; k < R; k++) buf_st(rout, vo, (uint32_t)k * row_bytes, y[k]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
-    }
+    for (int k = 0; k < R; k++) out[base + ((size_t)k << a.log_s)] = y[k];
 }
 // tab[(b << log_r) + k] = root^((S * rev(b) * k) mod n), rev over bbits = log_n - log_s - log_r bits
 __global__ void fill_pass_twiddles(uint64_t* tab, int log_n, int log_s, int log_r, uint64_t root) {
@@ -917,8 +764,8 @@ __global__ void fill_pow_linear(uint64_t* tab, uint32_t count, uint64_t root, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// AERO_NTT_BUF=1: the strided register passes address their rows through buffer descriptors (measurement switch)
-static const bool ntt_buf = getenv("AERO_NTT_BUF") && getenv("AERO_NTT_BUF")[0] == '1';
+// (The buffer-descriptor form was also built for the radix-16 / 32 / 128 register passes and the inverse ones, round 4: their VGPR count
+// does not move - 51 to 96, 168 for radix 128 - and nothing measurable changed; only the two-lane radix-64 pass keeps it.)
 
 NttTables* Context::ntt_tables(int log_n) {
     auto it = ntt_tabs.find(log_n);
@@ -972,14 +819,11 @@ void Context::ensure_small_twiddles() {
 }
 
 // LDS-round passes (ntt_fwd_pass, ntt_fwd_first_pass, ntt_inv_pass) with 512 threads per 4096-element tile instead of 256 on launches of up
-// to 2^21 elements (columns x points; AERO_NTT_LDS512_MAX=<log2>, 0 = never). A small launch is one tile per CU or less - one wave per
-// SIMD, and the pass lasts as long as that wave needs for its 16 elements per lane; with 8 per lane and two waves per SIMD the same work
-// takes less: measured (profiles/r4_lds512_ab.txt) inverse of 1 column 2^20 (the DEEP stage's) 61.1 -> 51.0 us, of 2 columns 2^19
-// 59.7 -> 49.5 us, interpolation + LDE of 2 columns 2^16 95.2 -> 79.0 us. Larger launches fill the SIMDs either way and keep 256.
-static bool lds_wide(int ncols, int log_n) {
-    static const int lim = getenv("AERO_NTT_LDS512_MAX") ? atoi(getenv("AERO_NTT_LDS512_MAX")) : 21;
-    return lim > 0 && ((size_t)ncols << log_n) <= ((size_t)1 << lim);
-}
+// to 2^21 elements (columns x points). A small launch is one tile per CU or less - one wave per SIMD, and the pass lasts as long as that wave
+// needs for its 16 elements per lane; with 8 per lane and two waves per SIMD the same work takes less: measured (profiles/r4_lds512_ab.txt)
+// inverse of 1 column 2^20 (the DEEP stage's) 61.1 -> 51.0 us, of 2 columns 2^19 59.7 -> 49.5 us, interpolation + LDE of 2 columns 2^16
+// 95.2 -> 79.0 us. Larger launches fill the SIMDs either way and keep 256.
+static bool lds_wide(int ncols, int log_n) { return ((size_t)ncols << log_n) <= ((size_t)1 << 21); }
 
 // Pass plan for a transform of 2^L points: first the contiguous pass (<= 12 bits), then strided passes. With register
 // passes every strided pass has radix <= 64 (one more pass over HBM beats a radix-128/256 pass through LDS: measured 2^25
@@ -1041,37 +885,24 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
             const char* nm = pass_names ? (a.log_r == 6 ? (a.first ? "ntt_fwd_reg6_last" : "ntt_fwd_reg6_mid") : a.log_r == 5 ? "ntt_fwd_reg5" : a.log_r == 4 ? "ntt_fwd_reg4" : "ntt_fwd_reg123") : "ntt_fwd_pass";
             switch (a.log_r) {
                 case 7:
-                    if (ntt_buf && a.log_s + 10 <= 31)
-                        AERO_LAUNCH(this, pass_names ? "ntt_fwd_reg7" : nm, abytes, ntt_fwd_strided_reg7x2<true>, dim3((unsigned)((((size_t)1 << log_out) >> 6) / 256), ncols), dim3(256), 0, a);
-                    else
-                        AERO_LAUNCH(this, pass_names ? "ntt_fwd_reg7" : nm, abytes, ntt_fwd_strided_reg7x2<false>, dim3((unsigned)((((size_t)1 << log_out) >> 6) / 256), ncols), dim3(256), 0, a);
+                    AERO_LAUNCH(this, pass_names ? "ntt_fwd_reg7" : nm, abytes, ntt_fwd_strided_reg7x2, dim3((unsigned)((((size_t)1 << log_out) >> 6) / 256), ncols), dim3(256), 0, a);
                     break;
                 case 6:
                     if (a.log_s >= 7) {  // two lanes per transform: 32 values per lane (the block index stays uniform over a workgroup)
-                        // Default: rows addressed through a buffer descriptor (96 VGPRs instead of 135: the 32 row addresses no longer live in
-                        // VGPR pairs; measured on MI355X, profiles/r4_ntt_ab.txt: middle pass 65.5 -> 61.0 us on 2 columns 2^23, 1837 -> 1741 us
-                        // on 72; the LAST pass gains on narrow launches (49.2 -> 46.0 us) and loses on wide ones (1824 -> 1938 us, five waves
-                        // per SIMD streaming 64 rows each plus the compact copy), so it keeps the pointer form from 16 columns on.
-                        // AERO_NTT_R6=0 pointer form everywhere, 1 buffer form everywhere, 2 / 3 the four-workgroup variants (measured slower).
-                        static const int r6 = getenv("AERO_NTT_R6") ? atoi(getenv("AERO_NTT_R6")) : -1;
+                        // Rows addressed through a buffer descriptor (96 VGPRs instead of 135: the 32 row addresses no longer live in VGPR pairs;
+                        // measured on MI355X, profiles/r4_ntt_ab.txt: middle pass 65.5 -> 61.0 us on 2 columns 2^23, 1837 -> 1741 us on 72); the
+                        // LAST pass gains on narrow launches (49.2 -> 46.0 us) and loses on wide ones (1824 -> 1938 us, five waves per SIMD
+                        // streaming 64 rows each plus the compact copy), so it keeps the pointer form from 16 columns on.
                         const dim3 g6((unsigned)((((size_t)1 << log_out) >> 5) / 256), ncols);
                         const bool buf_ok = a.log_s + 9 <= 31;
-                        const bool want_buf = r6 == 1 || (r6 < 0 && (!a.first || ncols < 16));
-                        if (r6 == 2) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<false, 4>), g6, dim3(256), 0, a);
-                        else if (r6 == 3 && buf_ok) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<true, 4>), g6, dim3(256), 0, a);
-                        else if (want_buf && buf_ok) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg6x2_v<true, 3>), g6, dim3(256), 0, a);
+                        const bool want_buf = !a.first || ncols < 16;
+                        if (want_buf && buf_ok) AERO_LAUNCH(this, pass_names ? (a.first ? "ntt_fwd_reg6_last_buf" : "ntt_fwd_reg6_mid_buf") : nm, abytes, ntt_fwd_strided_reg6x2_buf, g6, dim3(256), 0, a);
                         else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg6x2, g6, dim3(256), 0, a);
                     }
-                    else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<6>, rgrid, dim3(256), 0, a);
+                    else AERO_LAUNCH(this, pass_names ? "ntt_fwd_reg6_1lane" : nm, abytes, ntt_fwd_strided_reg<6>, rgrid, dim3(256), 0, a);
                     break;
-                case 5:
-                    if (ntt_buf && a.log_s + 8 <= 31) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg<5, true>), rgrid, dim3(256), 0, a);
-                    else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<5>, rgrid, dim3(256), 0, a);
-                    break;
-                case 4:
-                    if (ntt_buf && a.log_s + 7 <= 31) AERO_LAUNCH(this, nm, abytes, (ntt_fwd_strided_reg<4, true>), rgrid, dim3(256), 0, a);
-                    else AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<4>, rgrid, dim3(256), 0, a);
-                    break;
+                case 5: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<5>, rgrid, dim3(256), 0, a); break;
+                case 4: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<4>, rgrid, dim3(256), 0, a); break;
                 case 3: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<3>, rgrid, dim3(256), 0, a); break;
                 case 2: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<2>, rgrid, dim3(256), 0, a); break;
                 default: AERO_LAUNCH(this, nm, abytes, ntt_fwd_strided_reg<1>, rgrid, dim3(256), 0, a); break;
@@ -1083,25 +914,20 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
         if (q == 0 && a.log_r == 11 && a.log_pad == 3 && fwd_two_phase(log_out, log_pad)) {
             a.tw_mt = twmt_fwd;
             // pass-boundary progression as two interleaved chains on narrow launches (2 columns 2^20 -> 2^23: 94.3 -> 91.4 us; 72 columns: 2950 ->
-            // 2977 us, so wide launches keep the single chain; four chains gain nothing: profiles/r4_ntt_ab.txt). AERO_NTT_F8_CHAINS overrides.
-            static const int f8_chains = getenv("AERO_NTT_F8_CHAINS") ? atoi(getenv("AERO_NTT_F8_CHAINS")) : 0;
-            a.chains = f8_chains ? f8_chains : (ncols < 16 ? 2 : 1);
+            // 2977 us, so wide launches keep the single chain; four chains gained nothing: profiles/r4_ntt_ab.txt)
+            a.chains = ncols < 16 ? 2 : 1;
             const size_t tiles = ((size_t)1 << log_out) >> 11;
             const char* nm = pass_names ? "ntt_fwd_first8" : "ntt_fwd_pass";
-            // AERO_NTT_F8X2=0: one wavefront per tile, 32 values per lane (the round-3 kernel); default: two wavefronts per tile, 16 per lane
-            static const bool f8x2 = !(getenv("AERO_NTT_F8X2") && getenv("AERO_NTT_F8X2")[0] == '0');
-            if (f8x2) AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8x2, dim3((unsigned)tiles, ncols), dim3(128), 0, a);
-            else
             AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8, dim3((unsigned)(tiles / F8_WAVES), ncols), dim3(64 * F8_WAVES), 0, a);
             continue;
         }
         if (q == 0 && reg_passes && a.log_r > a.log_pad) {
-            if (lds_wide(ncols, log_out)) AERO_LAUNCH(this, pass_names ? "ntt_fwd_first" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass<512>, grid, dim3(512), 0, a);
-            else AERO_LAUNCH(this, pass_names ? "ntt_fwd_first" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass<256>, grid, dim3(256), 0, a);
+            if (lds_wide(ncols, log_out)) AERO_LAUNCH(this, pass_names ? "ntt_fwd_first_512" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass<512>, grid, dim3(512), 0, a);
+            else AERO_LAUNCH(this, pass_names ? "ntt_fwd_first_256" : "ntt_fwd_pass", abytes, ntt_fwd_first_pass<256>, grid, dim3(256), 0, a);
             continue;
         }
-        if (lds_wide(ncols, log_out)) AERO_LAUNCH(this, pass_names ? (a.log_r == 7 ? "ntt_fwd_lds7" : a.log_r == 8 ? "ntt_fwd_lds8" : "ntt_fwd_ldsX") : "ntt_fwd_pass", abytes, ntt_fwd_pass<512>, grid, dim3(512), 0, a);
-        else AERO_LAUNCH(this, pass_names ? (a.log_r == 7 ? "ntt_fwd_lds7" : a.log_r == 8 ? "ntt_fwd_lds8" : "ntt_fwd_ldsX") : "ntt_fwd_pass", abytes, ntt_fwd_pass<256>, grid, dim3(256), 0, a);
+        if (lds_wide(ncols, log_out)) AERO_LAUNCH(this, pass_names ? "ntt_fwd_lds_512" : "ntt_fwd_pass", abytes, ntt_fwd_pass<512>, grid, dim3(512), 0, a);
+        else AERO_LAUNCH(this, pass_names ? "ntt_fwd_lds_256" : "ntt_fwd_pass", abytes, ntt_fwd_pass<256>, grid, dim3(256), 0, a);
     }
     check_launch("ntt_forward");
     return compact_written;
@@ -1114,22 +940,17 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
                           const uint64_t* src, size_t src_stride) {
     ensure_small_twiddles();
     NttTables* t = ntt_tables(log_n);
-    // two-phase contiguous pass (11 bits) where the transform is large enough to keep its strided passes' count
-    static const bool inv2p_env = !(getenv("AERO_INV_2PHASE") && getenv("AERO_INV_2PHASE")[0] == '0');
-    // (measured: -20 % on 72 columns x 2^20 and on 2 x 2^24, -7 % on 2 x 2^21, -8 % on 2 x 2^20 (75.9 -> 69.9 us, round 4: fewer
-    // VALU instructions matter with several proofs in flight even where one proof alone is latency-bound); below 2^21 elements the LDS
-    // rounds keep the launch)
-    static const int inv2p_min = getenv("AERO_INV_2PHASE_MIN") ? atoi(getenv("AERO_INV_2PHASE_MIN")) : 21;      // log2 of the smallest launch (elements) that takes it
+    // Two-phase contiguous pass (11 bits) on launches of at least 2^21 elements (measured: -20 % on 72 columns x 2^20 and on 2 x 2^24, -7 % on
+    // 2 x 2^21, -8 % on 2 x 2^20 (75.9 -> 69.9 us, round 4: fewer VALU instructions matter with several proofs in flight even where one proof
+    // alone is latency-bound); below that the LDS rounds keep the launch (profiles/r4_inv_threshold_ab.txt).
     // Small launches (lds_wide) of 2^18 .. 2^20 points: the 6 - 8 bits behind the 12-bit contiguous pass as ONE strided pass through LDS tiles
     // (512 threads) instead of one or two register passes - two launches instead of three where every launch is latency. Measured
     // (profiles/r4_inv_lds_plan_ab.txt): 2 columns 2^20 76.0 -> 63.4 us, 1 column 2^20 52.4 -> 46.7, 2 columns 2^18 49.6 -> 43.7, 2^19 50.9 -> 48.5;
     // 2 columns 2^16 (4 bits behind the first pass: one radix-16 register pass) 30.5 -> 33.5, so shorter transforms keep the register pass.
     // One proof alone: 2.30 - 2.35 -> 2.28 - 2.31 ms; eight in flight: unchanged (1.251 / 1.265 against 1.263 / 1.260 G cells/s).
-    // AERO_INV_LDS_PLAN=0 switches it off.
-    static const bool lds_plan_env = !(getenv("AERO_INV_LDS_PLAN") && getenv("AERO_INV_LDS_PLAN")[0] == '0');
-    const bool lds_plan = lds_plan_env && log_n >= 18 && log_n <= 20 && lds_wide(ncols, log_n);
+    const bool lds_plan = this->reg_passes && log_n >= 18 && log_n <= 20 && lds_wide(ncols, log_n);
     const bool reg_passes = this->reg_passes && !lds_plan;          // shadows the member for the rest of this transform
-    const bool inv2p = inv2p_env && reg_passes && log_n >= 13 && ((size_t)ncols << log_n) >= ((size_t)1 << inv2p_min);
+    const bool inv2p = reg_passes && log_n >= 13 && ((size_t)ncols << log_n) >= ((size_t)1 << 21);
     std::vector<NttPass> plan = plan_passes(log_n, reg_passes, inv2p ? 11 : 12, false);
     const int r1 = plan[0].log_r;
     // per-k table for the final (contiguous) pass
@@ -1172,22 +993,14 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
             if (!a.first) a.tw_pass = pass_twiddles(log_n, a.log_s, a.log_r, true);
             dim3 rgrid((unsigned)((((size_t)1 << log_n) >> a.log_r) / 256), ncols);
             const size_t abytes = (size_t)ncols * 16 * ((size_t)1 << log_n);
+            const char* nm = pass_names ? (a.log_r == 6 ? "ntt_inv_reg6" : a.log_r == 5 ? "ntt_inv_reg5" : a.log_r == 4 ? "ntt_inv_reg4" : "ntt_inv_reg123") : "ntt_inv_pass";
             switch (a.log_r) {
-                case 6:
-                    if (ntt_buf && a.log_s + 9 <= 31) AERO_LAUNCH(this, "ntt_inv_pass", abytes, (ntt_inv_strided_reg<6, true>), rgrid, dim3(256), 0, a);
-                    else AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<6>, rgrid, dim3(256), 0, a);
-                    break;
-                case 5:
-                    if (ntt_buf && a.log_s + 8 <= 31) AERO_LAUNCH(this, "ntt_inv_pass", abytes, (ntt_inv_strided_reg<5, true>), rgrid, dim3(256), 0, a);
-                    else AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<5>, rgrid, dim3(256), 0, a);
-                    break;
-                case 4:
-                    if (ntt_buf && a.log_s + 7 <= 31) AERO_LAUNCH(this, "ntt_inv_pass", abytes, (ntt_inv_strided_reg<4, true>), rgrid, dim3(256), 0, a);
-                    else AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<4>, rgrid, dim3(256), 0, a);
-                    break;
-                case 3: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<3>, rgrid, dim3(256), 0, a); break;
-                case 2: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<2>, rgrid, dim3(256), 0, a); break;
-                default: AERO_LAUNCH(this, "ntt_inv_pass", abytes, ntt_inv_strided_reg<1>, rgrid, dim3(256), 0, a); break;
+                case 6: AERO_LAUNCH(this, nm, abytes, ntt_inv_strided_reg<6>, rgrid, dim3(256), 0, a); break;
+                case 5: AERO_LAUNCH(this, nm, abytes, ntt_inv_strided_reg<5>, rgrid, dim3(256), 0, a); break;
+                case 4: AERO_LAUNCH(this, nm, abytes, ntt_inv_strided_reg<4>, rgrid, dim3(256), 0, a); break;
+                case 3: AERO_LAUNCH(this, nm, abytes, ntt_inv_strided_reg<3>, rgrid, dim3(256), 0, a); break;
+                case 2: AERO_LAUNCH(this, nm, abytes, ntt_inv_strided_reg<2>, rgrid, dim3(256), 0, a); break;
+                default: AERO_LAUNCH(this, nm, abytes, ntt_inv_strided_reg<1>, rgrid, dim3(256), 0, a); break;
             }
             continue;
         }
@@ -1206,14 +1019,15 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
             }
             a.tw_mt = twmt_inv;
             const size_t tiles = ((size_t)1 << log_n) >> 11;
-            AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_last_pass_11, dim3((unsigned)(tiles / F8_WAVES), ncols),
+            AERO_LAUNCH(this, pass_names ? "ntt_inv_last11" : "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_last_pass_11, dim3((unsigned)(tiles / F8_WAVES), ncols),
                         dim3(64 * F8_WAVES), 0, a, (const uint64_t*)bftab);
             continue;
         }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);
         dim3 grid((unsigned)(((size_t)1 << log_n) / E), ncols);
-        if (lds_wide(ncols, log_n)) AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass<512>, grid, dim3(512), 0, a);
-        else AERO_LAUNCH(this, "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass<256>, grid, dim3(256), 0, a);
+        const char* lnm = pass_names ? (a.log_s ? (lds_wide(ncols, log_n) ? "ntt_inv_lds_strided_512" : "ntt_inv_lds_strided_256") : (lds_wide(ncols, log_n) ? "ntt_inv_lds_512" : "ntt_inv_lds_256")) : "ntt_inv_pass";
+        if (lds_wide(ncols, log_n)) AERO_LAUNCH(this, lnm, (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass<512>, grid, dim3(512), 0, a);
+        else AERO_LAUNCH(this, lnm, (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_pass<256>, grid, dim3(256), 0, a);
     }
     check_launch("ntt_inverse");
 }

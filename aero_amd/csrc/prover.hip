@@ -899,10 +899,15 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     //    nothing before the first commitment depends on the coin: their read-back is only enqueued here and consumed after the
     //    stream synchronisation the trace commitment performs anyway (one host round trip less per proof).
     air.results.resize(W / 2);
-    const uint64_t* const host_trace = host_trace_;     // trace still in HOST memory (pipelined hand-over below), or nullptr
+    const bool landed = landed_;                        // host trace already on its way into `trace_dev` (pool prefetch): resident path + event + check
+    if (landed) {
+        if (G != 1 || !trace_dev || !host_trace_) fail("prove: a landed trace needs one GPU, the landing buffer and the host trace", ST_INTERNAL);
+        AERO_HIP(hipStreamWaitEvent(ctx->stream, landed_ready_, 0));
+    }
+    const uint64_t* const host_trace = landed ? nullptr : host_trace_;     // trace still in HOST memory (pipelined hand-over below), or nullptr
     uint64_t* h_last_row = (uint64_t*)ctx->stage_alloc((size_t)W * 8);
-    if (host_trace) {
-        for (uint32_t c = 0; c < W; c++) h_last_row[c] = host_trace[(size_t)c * n + (n - 1)];
+    if (host_trace_) {
+        for (uint32_t c = 0; c < W; c++) h_last_row[c] = host_trace_[(size_t)c * n + (n - 1)];
     } else {
         uint64_t* h_pos = (uint64_t*)ctx->stage_alloc(8);
         *h_pos = n - 1;
@@ -1076,7 +1081,13 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         AERO_HIP(hipMemcpyAsync(host_verdict_, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
         trace_src = A ? trace_keep.get() : nullptr;
     } else {
-        ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0, nullptr, trace_dev, n);      // read from the caller's matrix: no copy
+        unsigned int* d_bad = nullptr;
+        if (landed) {       // nobody has looked at these values yet: the pass that reads them checks the canonical form
+            d_bad = (unsigned int*)ctx->scratch_alloc(8);
+            AERO_HIP(hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+        }
+        ctx->ntt_inverse(polys.data.get(), n, (int)W, log_n, 1, h, 1, 0, d_bad, trace_dev, n);      // read from the caller's matrix: no copy
+        if (landed) AERO_HIP(hipMemcpyAsync(host_verdict_, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
         ms.interpolate = clk.lap();
         have_tc = extend_columns(0, W);
     }

@@ -175,6 +175,10 @@ public:
     // straight into the interpolation buffer (a device copy is kept only while an auxiliary segment still has to be built from it).
     // *verdict (pinned) receives 0 when every element was canonical.
     void set_host_trace(const uint64_t* trace_host, unsigned int* verdict) { host_trace_ = trace_host; host_verdict_ = verdict; }
+    // The host trace has already been sent on its way: a copy into the buffer prove() is given as `trace_dev` is in flight on another stream and
+    // `ready` fires when it has landed. prove() waits for the event on its stream, reads the public inputs' row from `trace_host`, and lets the
+    // first inverse pass check the canonical form (as set_host_trace does); the landing buffer is not modified. One GPU only.
+    void set_landed_trace(const uint64_t* trace_host, hipEvent_t ready, unsigned int* verdict) { host_trace_ = trace_host; host_verdict_ = verdict; landed_ready_ = ready; landed_ = true; }
     // Prove against a program AIR (air_program.hpp; include/aero_air.h) instead of the built-in FibAir: the constraint set, the
     // assertions, the auxiliary segment's shape and construction all come from the program; `pub` = its public inputs (they seed
     // the coin). The program must outlive the proof.
@@ -237,6 +241,8 @@ private:
     uint32_t aux_width_ = 0, aux_rands_ = 0, aux_degree_ = 2;
     const uint64_t* host_trace_ = nullptr;
     unsigned int* host_verdict_ = nullptr;
+    hipEvent_t landed_ready_ = nullptr;
+    bool landed_ = false;
     const air::Program* program_ = nullptr;
     std::vector<uint64_t> program_pub_;
 };

@@ -163,11 +163,8 @@ template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F
         else AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + 3 * F::DEG), (fib_constraints_kernel<F, 0, 1, false>), g1, dim3(256), 0, a);
     } else if (cnt % 4 == 0) {   // 4 rows per thread share one batched inversion (measured best of 4 / 2 / 1 in both fields)
         // with the 160-bit sums 2 rows per thread: 6 sums x 5 limbs per row are live, 4 rows cost the occupancy (2^20 x 72: 0.81 ms with 4
-        // rows, 0.56 with 2, 0.54 with 1; 2^20 x 8: 0.195 / 0.176 / 0.232) - AERO_FIB_WIDE_ROWS for the comparison
-        static const int wk = getenv("AERO_FIB_WIDE_ROWS") ? atoi(getenv("AERO_FIB_WIDE_ROWS")) : 2;
-        if (wide && wk == 2) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 2, true>), dim3((unsigned)((cnt / 2 + 255) / 256)), dim3(256), 0, a);
-        else if (wide && wk == 1) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 1, true>), g1, dim3(256), 0, a);
-        else if (wide) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 4, true>), g4, dim3(256), 0, a);
+        // rows, 0.56 with 2, 0.54 with 1; 2^20 x 8: 0.195 / 0.176 / 0.232)
+        if (wide) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 2, true>), dim3((unsigned)((cnt / 2 + 255) / 256)), dim3(256), 0, a);
         else AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 4, false>), g4, dim3(256), 0, a);
     } else {
         if (wide) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 1, true>), g1, dim3(256), 0, a);

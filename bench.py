@@ -551,6 +551,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world} (launch with torch.distributed.run --nproc-per-node {args.gpus}, "
                          "or run `python bench.py --gpus N` without RANK/WORLD_SIZE in the environment and it starts its own ranks)")
 
+    import numpy as np
     import torch
     import aero_amd
 
@@ -664,7 +665,23 @@ def main():
             ts.append((time.perf_counter() - t1) * 1e3)
         return median(ts)
 
+    # the link the hand-over crosses: this box's pinned host-to-device rate on THIS trace buffer (a roofline of every H2D-inclusive figure:
+    # cells/s <= rate / 8 B; tools/ubench_h2d.hip measures the same thing stand-alone -> profiles/ceilings.json)
+    def h2d_rate_GBps(reps=5):
+        flat = torch.from_numpy(hosts[0].array.reshape(-1).view(np.int64))
+        d = torch.empty(flat.shape, dtype=torch.int64, device=torch.device("cuda", local_rank))
+        best = 0.0
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            d.copy_(flat)
+            torch.cuda.synchronize()
+            best = max(best, flat.numel() * 8 / (time.perf_counter() - t1) / 1e9)
+        del d
+        return best
+
     barrier()
+    link_GBps = h2d_rate_GBps()
     single_ms = one_proof_ms(hosts[0])
     single_resident_ms = one_proof_ms(dev)
 
@@ -726,6 +743,12 @@ def main():
         "single_proof_value": (1 << log_n) * cols / ((single_ms if h2d else single_resident_ms) * 1e-3),
     }
 
+    # host link: bytes of trace handed over per second against the measured pinned rate of the same buffer
+    h2d_value = value if h2d else other_value
+    link_used = h2d_value * 8 / 1e9 / world
+    out["pcie"] = {"h2d_pinned_GBps_measured": link_GBps, "achieved_GBps": link_used, "frac": link_used / link_GBps if link_GBps else None,
+                   "what": "8 B per trace cell of the H2D-inclusive figure / this box's pinned host-to-device rate on the same buffer (one copy at a time, best of 5)",
+                   "binds": bool(link_GBps and link_used / link_GBps >= 0.9)}
     if rank == 0:
         calls, ms, abytes = dom_rep
         achieved = (abytes / (ms * 1e-3)) / 1e9 if ms > 0 else 0.0

@@ -1,0 +1,212 @@
+"""Every switch of the library that selects a kernel or a plan, and every plan the library selects by SHAPE, against the oracle.
+
+Two kinds of selection exist inside a prover whose contract is bit-exactness:
+ * by shape - which NTT pass kernels a transform of a given size and width runs through (two-phase contiguous passes, one- and
+   two-lane register passes, buffer-descriptor or pointer addressing, 256- or 512-thread LDS tiles, the two-launch inverse plan):
+   `test_every_ntt_plan_is_reached` runs shapes chosen to reach each of them, checks by NAME (AERO_NTT_NAMES=1 labels the launches
+   per plan) that each was reached, and compares the values with the oracle;
+ * by environment variable - the fallbacks and alternatives listed in tools/README.md ("switches"): one test id per switch here
+   or in tests/test_gpu_fallback_paths.py / test_gpu_host_handover.py / test_gpu_sharded_local.py / test_gpu_air.py.
+Each case runs in its own process: the switches are read once, when the library meets them."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HEAD = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import aero_amd
+from tests import oracle_lib
+from tests import air_examples as ex
+P = 0xFFFFFFFF00000001
+orc = oracle_lib.load()
+orc.set_threads(16)
+ctx = aero_amd.Context(0)
+'''
+
+
+def run(tmp_path, body, env, timeout=900):
+    script = tmp_path / "worker.py"
+    script.write_text(HEAD % {"root": ROOT} + body)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **env), cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-800:], r.stderr[-2000:])
+    return r.stdout
+
+
+# ---- plans selected by shape ------------------------------------------------------------------------------------------------------
+PLANS = r'''
+SHAPES = json.loads(os.environ.get("AERO_TEST_SHAPES", "null"))
+# (log_n, columns, log_blowup): interpolate + LDE; columns beyond the first two repeat them, so that the oracle transforms two columns
+# whatever the width and every other column is checked against its twin on the device
+shapes = SHAPES or [(3, 2, 3), (8, 2, 1), (10, 4, 3), (12, 2, 3), (13, 2, 3), (16, 2, 3), (18, 1, 3), (20, 2, 3), (20, 72, 3), (21, 1, 3), (22, 1, 3), (22, 2, 1)]
+seen = {}
+for log_n, cols, lb in shapes:
+    rng = np.random.default_rng(77 + log_n + cols)
+    base = (rng.integers(0, 1 << 63, (min(cols, 2), 1 << log_n), dtype=np.uint64) % np.uint64(P)).astype(np.uint64)
+    trace = np.concatenate([base[c % len(base)][None, :] for c in range(cols)])
+    dev = ctx.trace_upload(trace)
+    ctx.set_kernel_timing(True)
+    polys = ctx.interpolate_columns(dev)
+    lde = ctx.evaluate_columns_over(polys, lb)
+    names = sorted(ctx.kernel_timing_report())
+    ctx.set_kernel_timing(False)
+    seen["%dx%d/%d" % (log_n, cols, lb)] = names
+    got = lde.download()
+    for c in range(len(base)):
+        want = orc.lde(orc.intt(base[c]), 1 << lb)
+        assert (got[c] == want).all(), ("LDE differs from the oracle", log_n, cols, lb, c)
+    for c in range(len(base), cols):
+        assert (got[c] == got[c % len(base)]).all(), ("column differs from its twin", log_n, cols, lb, c)
+    lde.free(); polys.free(); dev.free()
+print(json.dumps(seen))
+print("ok")
+'''
+
+# every per-plan launch label of ntt.hip that the default configuration can produce (the LDS-only forward passes run under
+# AERO_NTT_REG=0 and the 12-bit forward first pass of a blowup-8 LDE under AERO_NTT_2PHASE=0: tests/test_gpu_fallback_paths.py)
+EXPECTED = {
+    "ntt_fwd_first8",            # two-phase contiguous first pass of a blowup-8 LDE
+    "ntt_fwd_first_512", "ntt_fwd_first_256",      # LDS-round first pass (small transforms, other blowups), 512 / 256 threads per tile
+    "ntt_fwd_reg6_mid_buf", "ntt_fwd_reg6_last_buf", "ntt_fwd_reg6_last",      # two-lane radix 64: buffer form / pointer form from 16 columns on
+    "ntt_fwd_reg7",              # two-lane radix 128 (2^24- and 2^25-point transforms)
+    "ntt_fwd_reg5", "ntt_fwd_reg4", "ntt_fwd_reg123",
+    "ntt_inv_last11",            # two-phase contiguous last pass (launches of >= 2^21 elements)
+    "ntt_inv_lds_512", "ntt_inv_lds_strided_512",          # LDS rounds (small launches); the two-launch plan of 2^18..2^20-point small launches
+    "ntt_inv_reg6", "ntt_inv_reg5", "ntt_inv_reg4", "ntt_inv_reg123",
+}
+
+
+def test_every_ntt_plan_is_reached(tmp_path):
+    out = run(tmp_path, PLANS, {"AERO_NTT_NAMES": "1"}, timeout=1500)
+    seen = json.loads(out.strip().split("\n")[-2])
+    reached = set(n for names in seen.values() for n in names if n.startswith("ntt_"))
+    assert EXPECTED <= reached, ("plans never reached by the shapes above", sorted(EXPECTED - reached), seen)
+    assert reached <= EXPECTED, ("launch labels this test does not know", sorted(reached - EXPECTED), seen)
+
+
+# the LDS-only plans (AERO_NTT_REG=0: no register passes, no two-phase passes) on launches large enough for their 256-thread tiles,
+# which no default plan reaches any more: 2^22 and 2^23 elements, 72 columns
+def test_ntt_lds_only_plans_on_large_launches(tmp_path):
+    out = run(tmp_path, PLANS, {"AERO_NTT_NAMES": "1", "AERO_NTT_REG": "0", "AERO_TEST_SHAPES": "[[20, 4, 3], [14, 72, 3], [21, 1, 3], [16, 2, 3]]"}, timeout=1500)
+    seen = json.loads(out.strip().split("\n")[-2])
+    reached = set(n for names in seen.values() for n in names if n.startswith("ntt_"))
+    assert reached == {"ntt_fwd_lds_256", "ntt_fwd_lds_512", "ntt_inv_lds_256", "ntt_inv_lds_512", "ntt_inv_lds_strided_256", "ntt_inv_lds_strided_512"}, seen
+
+
+def test_ntt_without_two_phase_passes_on_large_launches(tmp_path):
+    """AERO_NTT_2PHASE=0: the 12-bit LDS-round first pass in front of the register passes (the forward direction's fallback)."""
+    out = run(tmp_path, PLANS, {"AERO_NTT_NAMES": "1", "AERO_NTT_2PHASE": "0", "AERO_TEST_SHAPES": "[[20, 4, 3], [14, 72, 3], [16, 2, 3]]"}, timeout=1500)
+    seen = json.loads(out.strip().split("\n")[-2])
+    reached = set(n for names in seen.values() for n in names if n.startswith("ntt_fwd"))
+    assert "ntt_fwd_first8" not in reached and {"ntt_fwd_first_256", "ntt_fwd_first_512"} <= reached, seen
+
+
+# ---- switches -----------------------------------------------------------------------------------------------------------------
+R128 = r'''
+for log_n in (21, 22):
+    rng = np.random.default_rng(log_n)
+    a = (rng.integers(0, 1 << 63, (1, 1 << log_n), dtype=np.uint64) % np.uint64(P)).astype(np.uint64)
+    ctx.set_kernel_timing(True)
+    lde = ctx.evaluate_columns_over(ctx.interpolate_columns(ctx.trace_upload(a)), 3)
+    names = set(ctx.kernel_timing_report())
+    ctx.set_kernel_timing(False)
+    assert ("ntt_fwd_reg7" in names) == (os.environ.get("AERO_NTT_R128") != "0"), names
+    assert (lde.download()[0] == orc.lde(orc.intt(a[0]), 8)).all()
+    lde.free()
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("flag", ["1", "0"])
+def test_ntt_r128(tmp_path, flag):
+    """AERO_NTT_R128=0: 2^24 / 2^25-point transforms take radix <= 64 passes (one pass more) instead of the two-lane radix-128 pass."""
+    run(tmp_path, R128, {"AERO_NTT_R128": flag, "AERO_NTT_NAMES": "1"})
+
+
+POOL = r'''
+opt = [27, 8, 8, 4, 1, 8, 6]
+o = aero_amd.ProofOptions(*opt)
+pool = aero_amd.Pool(0, 3)
+for width, log_n, aux in ((8, 14, (0, 0, 2)), (8, 12, (3, 4, 4)), (72, 13, (0, 0, 2))):
+    trace = aero_amd.fib_trace(width, log_n)
+    want = orc.prove_fib_aux(width, log_n, aux[0], aux[1], opt, D=aux[2])[0] if aux[0] else orc.prove_fib(width, log_n, opt)[0]
+    hosts = [aero_amd.PinnedTrace(trace.copy()) for _ in range(3)]
+    for rounds in (1, 2, 5):
+        for p, _ in pool.prove_fib_host(hosts, o, aux, rounds=rounds):
+            assert p == want, ("pool proof differs from the oracle", width, log_n, aux, rounds)
+    # a non-canonical element in ONE slot's trace: that batch fails, the pool stays usable
+    hosts[1].array[width - 1][123] = P + 5
+    try:
+        pool.prove_fib_host(hosts, o, aux, rounds=3)
+        raise SystemExit("non-canonical element went unnoticed")
+    except aero_amd.AeroError as e:
+        assert "non-canonical" in str(e), str(e)
+    hosts[1].array[...] = trace
+    for p, _ in pool.prove_fib_host(hosts, o, aux, rounds=3):
+        assert p == want
+    for h in hosts: h.release()
+# a program AIR with auxiliary builders through the pool (the builders read main columns of the landing buffer again)
+b, trace, pub = ex.synth_vm(10, 6, 5)
+air = aero_amd.Air(b.to_bytes())
+vopt = [27, 8, 8, 4, 1, 4, 6]
+want, _ = orc.prove_air(b.to_bytes(), trace, pub, vopt)
+hosts = [aero_amd.PinnedTrace(trace.copy()) for _ in range(3)]
+for rounds in (1, 4):
+    for p in pool.prove_air(air, hosts, pub, aero_amd.ProofOptions(*vopt), rounds=rounds):
+        assert p == want, "pool program proof differs from the oracle"
+for h in hosts: h.release()
+pool.close()
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("min_mb", ["0", "32", "1"])
+def test_pool_prefetch(tmp_path, min_mb):
+    """AERO_POOL_PREFETCH_MIN_MB: traces of at least that many MiB are copied one round ahead into a second landing buffer while the
+    slot proves the current one (the default, 32, leaves these small traces on the in-stream copy; 1 sends them through the prefetch,
+    0 switches it off). Bytes against the oracle, with and without an auxiliary segment, for a constraint program, and the
+    canonical-form check of a landed trace."""
+    run(tmp_path, POOL, {"AERO_POOL_PREFETCH_MIN_MB": min_mb})
+
+
+TUNE = r'''
+b, trace, pub = ex.synth_vm(10, 6, 5)
+air = aero_amd.Air(b.to_bytes())
+for vopt in ([27, 8, 8, 4, 1, 4, 6], [20, 8, 4, 4, 2, 8, 5]):
+    want, _ = orc.prove_air(b.to_bytes(), trace, pub, vopt)
+    ctx.set_kernel_timing(True)
+    got = ctx.prove_air(air, trace, pub, aero_amd.ProofOptions(*vopt))
+    assert "air_jit_kernel" in set(ctx.kernel_timing_report()), "the run-time compiled kernel did not run"
+    ctx.set_kernel_timing(False)
+    assert got == want
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("tune", ["", "wide=0", "early=0,rows=1", "barrier=1,rows=4,minblocks=1", "rows=2,wide=0,early=0"])
+def test_air_jit_tune(tmp_path, tune):
+    """AERO_AIR_JIT_TUNE: the code-generation variants of the run-time compiled constraint kernel (air_jit.hip: Tune)."""
+    env = {"AERO_AIR_JIT_TUNE": tune, "AERO_AIR_JIT_CACHE": str(tmp_path / "cache")} if tune else {"AERO_AIR_JIT_CACHE": str(tmp_path / "cache")}
+    run(tmp_path, TUNE, env)
+
+
+GUARD = r'''
+for width, log_n, aux, opt in ((2, 12, (0, 0, 2), [27, 8, 8, 4, 1, 8, 6]), (6, 10, (2, 3, 4), [20, 8, 4, 4, 2, 4, 5])):
+    want = orc.prove_fib_aux(width, log_n, aux[0], aux[1], opt, D=aux[2])[0] if aux[0] else orc.prove_fib(width, log_n, opt)[0]
+    for src in (aero_amd.fib_trace(width, log_n), ctx.trace_upload(aero_amd.fib_trace(width, log_n))):
+        got, _ = ctx.prove_fib_aux(src, aux[0], aux[1], aero_amd.ProofOptions(*opt), aux_degree=aux[2])
+        assert got == want
+print("ok")
+'''
+
+
+def test_pool_guard_allocator(tmp_path):
+    """AERO_POOL_GUARD=1: every device block of the context's allocator between unmapped guard pages (diagnosis mode of round 4)."""
+    run(tmp_path, GUARD, {"AERO_POOL_GUARD": "1"})
