@@ -149,8 +149,9 @@ class AirBuilder:
 
     def aux_builder_general(self, column, init, nxt):
         """aux column(0) = init, column(i+1) = nxt evaluated on (main row i, main row i+1, CURRENT row of the auxiliary columns up to
-        `column` itself): any recurrence - e.g. one that squares its own previous value. It cannot be scanned: the library builds such a
-        column row after row on the host (a serial chain has no parallel form; products, sums and affine forms are scanned on the device)."""
+        `column` itself): any recurrence - e.g. one that squares its own previous value. It cannot be scanned: the library walks such a
+        column row after row on the host (a serial chain has no parallel form; products, sums and affine forms are scanned on the device;
+        AERO_AIR_GENERAL_DEVICE=1 walks it with one wavefront per column on the device instead - correct, and about 80 times slower)."""
         self.builders[column] = (self._e(init).ref, self._e(nxt).ref, GENERAL, NONE, NONE)
 
     def to_bytes(self):

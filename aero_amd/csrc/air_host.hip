@@ -1,5 +1,6 @@
 // Per-proof device tables + launches of a program AIR (see air_host.hpp).
 #include "air_host.hpp"
+#include <map>
 
 namespace aero {
 
@@ -282,6 +283,91 @@ void air_build_aux(Context* ctx, const Program& p, const uint64_t* trace_dev, in
     bool any_general = false;
     for (uint32_t c = 0; c < p.A; c++) any_general |= p.has_add[c] == 4;
     if (!any_general) return;
+    // AERO_AIR_GENERAL_DEVICE=1 (round 5): one wavefront per general column on the proving stream, no copy of the columns to the host and back, no
+    // stream synchronisation (air_kernels.hpp: AirGeneralArgs). Measured on MI355X against the host evaluation below (v2 example, 4 nodes per row,
+    // profiles/r5_general_recurrence.md): 2^14 rows 20.2 ms against 0.37 ms, 2^18 rows 322 ms against 3.8 ms, 2^20 rows 1286 ms against 22 ms -
+    // a dependent chain of field multiplications costs a lone wavefront hundreds of cycles per link (about 1.2 us per row) and a host core a few
+    // nanoseconds; the two copies and the synchronisation the host step needs are noise next to that. A serial chain is the host's job: the host
+    // evaluation stays the default, the kernel stays as the tested alternative for a host that must not be interrupted.
+    static const bool general_host = !(getenv("AERO_AIR_GENERAL_DEVICE") && getenv("AERO_AIR_GENERAL_DEVICE")[0] == '1');
+    if (!general_host) {
+        struct Compiled { std::vector<GenLoad> loads; std::vector<GenInsn> par, ser; std::vector<T> consts; uint32_t res_kind = 0, res_idx = 0; };
+        std::vector<Compiled> progs(p.A);
+        bool fits = true;
+        for (uint32_t c = 0; c < p.A && fits; c++) {
+            if (p.has_add[c] != 4) continue;
+            Compiled& g = progs[c];
+            std::map<uint64_t, uint32_t> load_slot, const_idx;       // (kind, index) -> slot / pool index
+            std::vector<int> node_slot(p.nodes.size(), -1), node_ser(p.nodes.size(), -1);
+            uint32_t n_slots = 0, n_serial = 0;
+            struct Op { uint32_t kind, idx; bool serial; };
+            auto scalar = [&](T v) {
+                g.consts.push_back(v);
+                return (uint32_t)g.consts.size() - 1;
+            };
+            auto resolve = [&](uint32_t ref) -> Op {
+                const uint32_t k = ref_kind(ref), j = ref_index(ref);
+                auto load = [&](uint32_t kind, uint32_t col, uint32_t mask) {
+                    const uint64_t key = ((uint64_t)kind << 56) | ((uint64_t)mask << 28) | col;
+                    auto it = load_slot.find(key);
+                    if (it == load_slot.end()) { it = load_slot.emplace(key, n_slots++).first; g.loads.push_back(GenLoad{kind, col, it->second, mask}); }
+                    return Op{GOP_SLOT, it->second, false};
+                };
+                auto constant = [&](uint32_t space, uint32_t idx, T v) {
+                    const uint64_t key = ((uint64_t)space << 32) | idx;
+                    auto it = const_idx.find(key);
+                    if (it == const_idx.end()) it = const_idx.emplace(key, scalar(v)).first;
+                    return Op{GOP_CONST, it->second, false};
+                };
+                switch (k) {
+                    case K_NODE:
+                        if (p.scalar_of[j] >= 0) return constant(0, j, p.is_ext[j] ? sc.e[p.scalar_of[j]] : F::from(sc.b[p.scalar_of[j]]));
+                        if (node_ser[j] >= 0) return Op{GOP_SER, (uint32_t)node_ser[j], true};
+                        return Op{GOP_SLOT, (uint32_t)node_slot[j], false};
+                    case K_MAIN_CUR: return load(GLD_MAIN_CUR, j, 0);
+                    case K_MAIN_NXT: return load(GLD_MAIN_NXT, j, 0);
+                    case K_AUX_CUR: return j == c ? Op{GOP_X, 0, true} : load(GLD_AUX_CUR, j, 0);
+                    case K_PERIODIC: return load(GLD_PERIODIC, pt.off[j], pt.mask[j]);
+                    case K_CONST: return constant(1, j, F::from(p.consts[j]));
+                    case K_PUB: return constant(2, j, F::from(sc.b[p.consts.size() + j]));
+                    case K_RAND: return constant(3, j, sc.e[j]);
+                    default: fail("air program: operand not available to a general aux recurrence", ST_INTERNAL); return Op{0, 0, false};
+                }
+            };
+            for (uint32_t j : p.general_nodes[c]) {          // ascending = topological
+                const Node& nd = p.nodes[j];
+                const Op x = resolve(nd.a), y = resolve(nd.b);
+                if (x.serial || y.serial) { node_ser[j] = (int)n_serial++; g.ser.push_back(GenInsn{nd.op, (uint32_t)node_ser[j], x.kind, x.idx, y.kind, y.idx}); }
+                else { node_slot[j] = (int)n_slots++; g.par.push_back(GenInsn{nd.op, (uint32_t)node_slot[j], x.kind, x.idx, y.kind, y.idx}); }
+            }
+            const Op r = resolve(p.builders[c].num);
+            g.res_kind = r.kind; g.res_idx = r.idx;
+            if (n_slots > GEN_MAX_SLOTS - 1 || n_serial > GEN_MAX_SERIAL) fits = false;      // the last slot is the dummies' (below)
+            // ParamPack keeps POINTERS to its sources until commit(): no section may be empty, none may be a temporary
+            if (g.consts.empty()) g.consts.push_back(F::zero());
+            if (g.loads.empty()) g.loads.push_back(GenLoad{GLD_MAIN_CUR, 0, GEN_MAX_SLOTS - 1, 0});
+            if (g.par.empty()) g.par.push_back(GenInsn{1, GEN_MAX_SLOTS - 1, GOP_CONST, 0, GOP_CONST, 0});
+        }
+        const std::vector<uint64_t> ptab_or_dummy = pt.tab.empty() ? std::vector<uint64_t>(1, 0) : pt.tab;
+        if (fits) {
+            for (uint32_t c = 0; c < p.A; c++) {
+                if (p.has_add[c] != 4) continue;
+                const Compiled& g = progs[c];
+                ParamPack gp(ctx);
+                const size_t i_ld = gp.add(g.loads), i_par = gp.add(g.par), i_ser = gp.add(g.ser), i_c = gp.add(g.consts), i_pt2 = gp.add(ptab_or_dummy);
+                gp.commit();
+                AirGeneralArgs<F> ga{};
+                ga.trace = trace_dev; ga.aux = out; ga.n = n; ga.col = c;
+                ga.loads = gp.ptr<GenLoad>(i_ld); ga.n_loads = (uint32_t)g.loads.size();
+                ga.par = gp.ptr<GenInsn>(i_par); ga.n_par = (uint32_t)g.par.size();
+                ga.ser = gp.ptr<GenInsn>(i_ser); ga.n_ser = (uint32_t)g.ser.size();
+                ga.res_kind = g.res_kind; ga.res_idx = g.res_idx;
+                ga.consts = gp.ptr<T>(i_c); ga.ptab = gp.ptr<uint64_t>(i_pt2); ga.init = init[c];
+                launch_air_general_column<F>(ctx, ga);
+            }
+            return;
+        }
+    }
     ctx->sync();
     std::vector<std::vector<uint64_t>> mcols(p.W);
     for (uint32_t c : p.general_main_cols) {

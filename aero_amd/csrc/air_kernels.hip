@@ -699,4 +699,70 @@ template <class F> void launch_air_aux(Context* ctx, const AirAuxArgs<F>& a, con
 template void launch_air_aux<FB>(Context*, const AirAuxArgs<FB>&, const std::vector<uint8_t>&, const std::vector<uint8_t>&);
 template void launch_air_aux<FQ>(Context*, const AirAuxArgs<FQ>&, const std::vector<uint8_t>&, const std::vector<uint8_t>&);
 
+// ---- general auxiliary recurrence: one wavefront per column (air_kernels.hpp: AirGeneralArgs) ------------------------------------------
+__device__ __forceinline__ uint64_t gen_readlane(uint64_t v, uint32_t lane) {
+    return gl::mk64((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)lane), (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)lane));
+}
+__device__ __forceinline__ uint64_t gen_bcast(uint64_t v, uint32_t lane) { return gen_readlane(v, lane); }
+__device__ __forceinline__ gl::E2 gen_bcast(gl::E2 v, uint32_t lane) { return gl::E2{gen_readlane(v.a0, lane), gen_readlane(v.a1, lane)}; }
+template <class F> __global__ __launch_bounds__(64) void air_general_column_kernel(AirGeneralArgs<F> a) {
+    typedef typename F::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gen_lds_raw[];
+    T* slots = reinterpret_cast<T*>(gen_lds_raw);              // [slot][lane]
+    const uint32_t lane = threadIdx.x;
+    const size_t n = a.n;
+    uint64_t* out[2] = {a.aux + (size_t)a.col * F::DEG * n, a.aux + ((size_t)a.col * F::DEG + (F::DEG > 1 ? 1 : 0)) * n};
+    auto apply = [](uint32_t op, T x, T y) { return op == 1 ? F::add(x, y) : op == 2 ? F::sub(x, y) : F::mul(x, y); };
+    T x = a.init;
+    if (lane == 0) for (int d = 0; d < F::DEG; d++) out[d][0] = F::comp(x, d);
+    T sv = F::zero();                                           // value of serial node `lane`
+    for (size_t base = 0; base + 1 < n; base += 64) {
+        const size_t row = base + lane < n ? base + lane : n - 1;
+        for (uint32_t k = 0; k < a.n_loads; k++) {
+            const GenLoad L = a.loads[k];
+            T v;
+            if (L.kind == GLD_MAIN_CUR) v = F::from(a.trace[(size_t)L.col * n + row]);
+            else if (L.kind == GLD_MAIN_NXT) v = F::from(a.trace[(size_t)L.col * n + (row + 1 < n ? row + 1 : row)]);
+            else if (L.kind == GLD_AUX_CUR) v = F::make(a.aux[(size_t)L.col * F::DEG * n + row], F::DEG > 1 ? a.aux[((size_t)L.col * F::DEG + 1) * n + row] : 0);
+            else v = F::from(a.ptab[L.col + ((uint32_t)row & L.mask)]);
+            slots[L.slot * 64 + lane] = v;
+        }
+        for (uint32_t k = 0; k < a.n_par; k++) {
+            const GenInsn I = a.par[k];
+            const T u = I.ka == GOP_SLOT ? slots[I.ia * 64 + lane] : a.consts[I.ia];
+            const T w = I.kb == GOP_SLOT ? slots[I.ib * 64 + lane] : a.consts[I.ib];
+            slots[I.dst * 64 + lane] = apply(I.op, u, w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        T mine = F::zero();
+        const uint32_t rows_here = (uint32_t)(n - 1 - base < 64 ? n - 1 - base : 64);        // rows base + r, r < rows_here, have a successor
+        for (uint32_t r = 0; r < rows_here; r++) {
+            auto operand = [&](uint32_t kind, uint32_t idx) -> T {
+                if (kind == GOP_SLOT) return slots[idx * 64 + r];                                  // broadcast read
+                if (kind == GOP_SER) return gen_bcast(sv, idx);
+                if (kind == GOP_X) return x;
+                return a.consts[idx];
+            };
+            for (uint32_t k = 0; k < a.n_ser; k++) {
+                const GenInsn I = a.ser[k];
+                const T v = apply(I.op, operand(I.ka, I.ia), operand(I.kb, I.ib));
+                if (lane == I.dst) sv = v;
+            }
+            x = operand(a.res_kind, a.res_idx);
+            if (lane == r) mine = x;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rows_here) for (int d = 0; d < F::DEG; d++) out[d][base + lane + 1] = F::comp(mine, d);
+    }
+}
+template <class F> void launch_air_general_column(Context* ctx, const AirGeneralArgs<F>& a) {
+    const size_t lds = (size_t)GEN_MAX_SLOTS * 64 * sizeof(typename F::T);
+    AERO_LAUNCH(ctx, "air_general_column_kernel", (size_t)a.n * 8 * (a.n_loads + F::DEG), air_general_column_kernel<F>, dim3(1), dim3(64), lds, a);
+    ctx->check_launch("air_general_column");
+}
+template void launch_air_general_column<FB>(Context*, const AirGeneralArgs<FB>&);
+template void launch_air_general_column<FQ>(Context*, const AirGeneralArgs<FQ>&);
+
 }  // namespace aero

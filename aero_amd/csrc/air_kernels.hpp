@@ -104,4 +104,35 @@ template <class F> struct AirAuxArgs {
 };
 template <class F> void launch_air_aux(Context* ctx, const AirAuxArgs<F>& a, const std::vector<uint8_t>& has_den_host, const std::vector<uint8_t>& has_add_host);
 
+// General auxiliary recurrence of ONE column on the device (round 5; the reference builds its auxiliary columns inside
+// commit_to_trace_and_validate, aero-sdk/miden-wasm/src/proving_worker.rs:323-332): column(i + 1) = expr(main row i, main row i + 1,
+// auxiliary row i of the columns up to its own, periodic values, scalars). Nothing about it can be scanned; what CAN run in parallel is
+// every sub-expression that does not read the column itself. One wavefront walks the column in blocks of 64 rows:
+//   loads     lane l fetches the operands of row base + l (coalesced) into LDS slots,
+//   parallel  lane l evaluates the nodes that do not depend on the column, for its row, into LDS slots,
+//   serial    the wave as a whole (uniform control flow) walks the 64 rows: the dependent nodes read the row's slots as LDS broadcasts, the
+//             column's current value from a register and each other's results through lane registers (value of serial node s lives in lane s:
+//             v_readlane / a select, no LDS round trip on the chain); lane r keeps the value of row base + r + 1 and the block is stored coalesced.
+// Operand kinds of an instruction: slot (LDS, per row), serial (lane register), x (the column's current value), constant (pool).
+enum : uint32_t { GOP_SLOT = 0, GOP_SER = 1, GOP_X = 2, GOP_CONST = 3 };
+enum : uint32_t { GLD_MAIN_CUR = 0, GLD_MAIN_NXT = 1, GLD_AUX_CUR = 2, GLD_PERIODIC = 3 };
+struct GenInsn { uint32_t op, dst, ka, ia, kb, ib; };       // op: 1 add, 2 sub, 3 mul; dst: slot (parallel section) or serial lane (serial section)
+struct GenLoad { uint32_t kind, col, slot, mask; };          // periodic: col = offset into ptab, mask = cycle length - 1
+constexpr uint32_t GEN_MAX_SLOTS = 40, GEN_MAX_SERIAL = 64;
+template <class F> struct AirGeneralArgs {
+    typedef typename F::T T;
+    const uint64_t* trace;       // W x n main segment
+    uint64_t* aux;               // (A * DEG) x n component columns: earlier columns are read, column `col` is written
+    size_t n;
+    uint32_t col;
+    const GenLoad* loads; uint32_t n_loads;
+    const GenInsn* par; uint32_t n_par;
+    const GenInsn* ser; uint32_t n_ser;
+    uint32_t res_kind, res_idx;  // operand that holds the next value once the serial section has run
+    const T* consts;
+    const uint64_t* ptab;
+    T init;
+};
+template <class F> void launch_air_general_column(Context* ctx, const AirGeneralArgs<F>& a);
+
 }  // namespace aero

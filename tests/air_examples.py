@@ -179,3 +179,39 @@ def v2_air(log_n, seq_stride=4):
     b.aux_assert_single(4, 0, 3)
     b.aux_builder_general(4, 3, a(4) * a(4) + m(0) + r(0) * a(1))
     return b, t, [int(t[1][-1])]
+
+
+def general_chain_air(log_n):
+    """Three general auxiliary recurrences that read each other, every operand kind a general builder may use (own column, earlier general
+    columns, main current / next row, periodic column, public input, constant, random element), and no other auxiliary column:
+      0  g0' = g0 g0 + m0                       (init 3)
+      1  g1' = g1 g0 + k m1 + pub0 + 5          (k = periodic 1, 2, 3, 4; reads general column 0)
+      2  g2' = (g2 + r0) (g1 + m0')             (reads general column 1 and the NEXT main row)
+    Main: a Fibonacci pair. Returns (builder, trace, pub)."""
+    n = 1 << log_n
+    b = A.AirBuilder(2, 3, 2, num_pub=2)
+    m, mn, a, an, r = b.main, b.main_next, b.aux, b.aux_next, b.rand
+    k = b.periodic([1, 2, 3, 4])
+    b.transition(mn(0) - (m(0) + m(1)), 1)
+    b.transition(mn(1) - (m(1) + mn(0)), 1)
+    e0 = a(0) * a(0) + m(0)
+    e1 = a(1) * a(0) + k * m(1) + b.pub(0) + 5
+    e2 = (a(2) + r(0)) * (a(1) + mn(0))
+    b.aux_transition(an(0) - e0, 2)
+    b.aux_transition(an(1) - e1, 2, cycles=[4])
+    b.aux_transition(an(2) - e2, 2)
+    t = np.zeros((2, n), np.uint64)
+    x, y = 1, 2
+    for i in range(n):
+        t[0][i], t[1][i] = x, y
+        x, y = (x + y) % P, (y + x + y) % P
+    b.assert_single(0, 0, 1)
+    b.assert_single(1, 0, 2)
+    b.assert_single(1, -1, b.pub(1))
+    b.aux_assert_single(0, 0, 3)
+    b.aux_assert_single(1, 0, b.pub(0))
+    b.aux_assert_single(2, 0, b.rand(1))
+    b.aux_builder_general(0, 3, e0)
+    b.aux_builder_general(1, b.pub(0), e1)
+    b.aux_builder_general(2, b.rand(1), e2)
+    return b, t, [11, int(t[1][-1])]

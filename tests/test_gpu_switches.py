@@ -210,3 +210,38 @@ print("ok")
 def test_pool_guard_allocator(tmp_path):
     """AERO_POOL_GUARD=1: every device block of the context's allocator between unmapped guard pages (diagnosis mode of round 4)."""
     run(tmp_path, GUARD, {"AERO_POOL_GUARD": "1"})
+
+
+GENERAL = r'''
+log_n = int(os.environ["AERO_TEST_LOG_N"])
+for name, (b, trace, pub), nrand in (("v2", ex.v2_air(log_n), 4), ("chain", ex.general_chain_air(log_n), 2)):
+    program = b.to_bytes()
+    air = aero_amd.Air(program)
+    info = air.info()
+    n, A_ = 1 << log_n, info["aux_width"]
+    for ext in (1, 2):
+        opt = [27, 8, 8, 4, ext, 8, 6]
+        want, _ = orc.prove_air(program, trace, pub, opt, keep_artifacts=True)
+        rands = orc.artifact("aux_rands", ext * nrand)
+        dev = ctx.trace_upload(trace)
+        ctx.set_kernel_timing(True)
+        auxm = ctx.aux_columns_program(air, dev, pub, rands, ext)
+        names = set(ctx.kernel_timing_report())
+        ctx.set_kernel_timing(False)
+        assert ("air_general_column_kernel" in names) == (os.environ.get("AERO_AIR_GENERAL_DEVICE") == "1"), names
+        assert (auxm.download() == orc.artifact("aux_cols", A_ * ext * n).reshape(A_ * ext, n)).all(), (name, ext, "auxiliary columns differ from the oracle")
+        for src in (dev, trace):                      # resident, and from host memory (the builders read the kept copy)
+            assert ctx.prove_air(air, src, pub, aero_amd.ProofOptions(*opt)) == want, (name, ext)
+        auxm.free(); dev.free()
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("log_n,device", [(6, "1"), (10, "1"), (14, "1"), (10, "0"), (18, "0")])
+def test_general_aux_recurrences(tmp_path, log_n, device):
+    """General (non-scannable) auxiliary recurrences (the reference builds its auxiliary columns inside commit_to_trace_and_validate,
+    proving_worker.rs:323-332): the serial host evaluation in the middle of a device proof (the default: a dependent chain costs a host
+    core nanoseconds per link and a lone wavefront a microsecond, profiles/r5_general_recurrence.md), at 2^18 rows too, and
+    AERO_AIR_GENERAL_DEVICE=1, one wavefront per column on the device (air_general_column_kernel) - against the oracle's auxiliary columns
+    and proof bytes, in both fields, for two programs (one with three general columns that read each other)."""
+    run(tmp_path, GENERAL, {"AERO_TEST_LOG_N": str(log_n), "AERO_AIR_GENERAL_DEVICE": device}, timeout=1500)

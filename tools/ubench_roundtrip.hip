@@ -3,6 +3,9 @@
 //   B  the kernel stores to mapped pinned memory, hipStreamSynchronize, parameters by value in the kernel arguments
 //   C  as B, but the host polls a sequence word in pinned memory instead of synchronising the stream
 //   D  as A with hipDeviceScheduleSpin
+//   E  the kernel stores to mapped pinned memory, hipStreamWriteValue32 of a sequence word behind it, the host polls the word; parameters
+//      by hipMemcpyAsync H2D as in A (what the prover can do without touching its kernels' argument lists)
+//   G  the kernel stores to mapped pinned memory, hipStreamSynchronize, parameters by hipMemcpyAsync H2D
 // build: hipcc --offload-arch=gfx950 -O3 tools/ubench_roundtrip.hip -o tools/ubench_roundtrip
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -17,6 +20,9 @@ __global__ void produce_host(uint64_t* out, volatile uint64_t* host, volatile ui
     if (threadIdx.x < 4) { uint64_t v = p.v[threadIdx.x] * 3 + 1; out[threadIdx.x] = v; host[threadIdx.x] = v; }
     __syncthreads();
     if (threadIdx.x == 0) { __threadfence_system(); *flag = seq; }
+}
+__global__ void produce_host_plain(uint64_t* out, volatile uint64_t* host, const uint64_t* in) {      // E / G: results straight to mapped pinned memory, no flag
+    if (threadIdx.x < 4) { uint64_t v = in[threadIdx.x] * 3 + 1; out[threadIdx.x] = v; host[threadIdx.x] = v; }
 }
 __global__ void busy(uint64_t* x, int n) { uint64_t v = x[0]; for (int i = 0; i < n; i++) v = v * 6364136223846793005ull + 1; x[1] = v; }
 int main(int argc, char** argv) {
@@ -52,6 +58,25 @@ int main(int argc, char** argv) {
             CK(hipStreamSynchronize(s));
             double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters;
             if (rep) printf("mode %c: %.2f us per round trip\n", "ABC"[mode], us);
+        }
+    }
+    for (int mode = 0; mode < 2; mode++) {
+        bool ok = true;
+        for (int rep = 0; rep < 2 && ok; rep++) {
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 1; i <= iters; i++) {
+                const uint32_t seq = (uint32_t)(i + 100000 * (rep + 1) + 1000000 * mode);
+                hipLaunchKernelGGL(produce_host_plain, 1, 64, 0, s, d_out, (volatile uint64_t*)h_out, d_in);
+                if (mode == 0) {
+                    if (hipStreamWriteValue32(s, h_flag, seq, 0) != hipSuccess) { printf("mode E: hipStreamWriteValue32 refused\n"); (void)hipGetLastError(); ok = false; break; }
+                    while (*(volatile uint32_t*)h_flag != seq) { }
+                } else CK(hipStreamSynchronize(s));
+                for (int k = 0; k < 8; k++) h_in[k] = h_out[k & 3] + k;
+                CK(hipMemcpyAsync(d_in, h_in, 64, hipMemcpyHostToDevice, s));
+            }
+            CK(hipStreamSynchronize(s));
+            double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters;
+            if (rep) printf("mode %c: %.2f us per round trip\n", "EG"[mode], us);
         }
     }
     // the same with a 50 us kernel in front (the wake-up after a longer wait)
