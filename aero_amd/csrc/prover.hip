@@ -629,6 +629,74 @@ Commitment Prover::commit_exchange_rows(const Matrix& lde) {
     finish_exchange(c);
     return c;
 }
+// Chunked form of the two commitments above ("all-to-all issued per chunk behind the row hashing of the next chunk"). Every
+// peer's piece of `per` leaves is cut into K sub-pieces; sub-piece k of ALL peers travels in one all-to-all of per / K leaves (or rows) per
+// peer. The exchanges stay on the proving stream S, where the communicator enqueues them (RCCL and the in-process group are stream-ordered
+// on the context's stream); the row hashing runs on the context's second stream H, tied to S by events:
+//   digests:  H  hash(0) e0 | hash(1) e1 | hash(2) ...          rows:  S  pack(0) a2a(0) f0 | pack(1) a2a(1) f1 | ...
+//             S  wait e0, a2a(0), place(0) | wait e1, a2a(1) ...        H  wait f0, hash(0) | wait f1, hash(1) | ...
+// so piece k + 1 is hashed while piece k is on the links (digest path), or piece k is hashed while piece k + 1 is on the links (row path).
+// The leaves land in the same arrival-order slots as in the unchunked forms: the tree, the openings and the proof bytes do not change. On
+// one GPU (ranks sharing the device) this can only be checked for parity; whether it pays is a question for a node with links.
+Commitment Prover::commit_exchange_chunked(const Matrix& lde, int K, bool rows_path) {
+    Context* ctx = ctx_;
+    const int G = comm_.world;
+    const size_t L = lde.rows, per = L / G, W = (size_t)lde.cols, sub = per / (size_t)K;
+    if (L % G || per % (size_t)K || sub == 0) fail("sharded prove: commitment does not divide into this many exchange chunks", ST_INTERNAL);
+    Commitment c;
+    c.sharded = true;
+    c.n_global = L * G;
+    c.tree = MerkleTree(ctx, L);
+    hipStream_t S = ctx->stream, H = ctx->get_copy_stream();
+    struct OnStream { Context* c; hipStream_t old; OnStream(Context* c_, hipStream_t s) : c(c_), old(c_->stream) { c->stream = s; } ~OnStream() { c->stream = old; } };
+    const size_t ev0 = 40;      // events of this function (the pipelined hand-over and the pool prefetch use lower ones)
+    AERO_HIP(hipEventRecord(ctx->sync_event(ev0), S));                 // H starts behind everything S carries (the LDE)
+    AERO_HIP(hipStreamWaitEvent(H, ctx->sync_event(ev0), 0));
+    if (!rows_path) {
+        // send block k: [peer r][sub digests] contiguous, as the all-to-all wants it; receive block k likewise, then placed with one strided copy
+        DevBuf<Digest> send(ctx, (size_t)K * G * sub), recv(ctx, (size_t)K * G * sub);
+        for (int k = 0; k < K; k++) {
+            {
+                OnStream h(ctx, H);
+                for (int r = 0; r < G; r++)
+                    ctx->hash_rows(lde.data.get() + (size_t)r * per + (size_t)k * sub, L, (int)W, sub, send.get() + ((size_t)k * G + r) * sub);
+            }
+            AERO_HIP(hipEventRecord(ctx->sync_event(ev0 + 1 + (k & 1)), H));
+            AERO_HIP(hipStreamWaitEvent(S, ctx->sync_event(ev0 + 1 + (k & 1)), 0));
+            comm_all_to_all(send.get() + (size_t)k * G * sub, recv.get() + (size_t)k * G * sub, sub * sizeof(Digest));
+            // piece q of block k -> leaf slots [q per + k sub, q per + (k + 1) sub)
+            AERO_HIP(hipMemcpy2DAsync(c.tree.leaves() + (size_t)k * sub, per * sizeof(Digest), recv.get() + (size_t)k * G * sub, sub * sizeof(Digest),
+                                      sub * sizeof(Digest), G, hipMemcpyDeviceToDevice, S));
+        }
+    } else {
+        DevBuf<uint64_t> send(ctx, W * L), recv(ctx, W * L);
+        for (int k = 0; k < K; k++) {
+            uint64_t* sk = send.get() + (size_t)k * G * W * sub;
+            uint64_t* rk = recv.get() + (size_t)k * G * W * sub;
+            // block k, chunk p = my rows [p per + k sub, p per + (k + 1) sub) of every column, column-major inside the chunk
+            for (int p = 0; p < G; p++)
+                AERO_HIP(hipMemcpy2DAsync(sk + (size_t)p * W * sub, sub * 8, lde.data.get() + (size_t)p * per + (size_t)k * sub, L * 8, sub * 8, W, hipMemcpyDeviceToDevice, S));
+            comm_all_to_all(sk, rk, W * sub * 8);
+            AERO_HIP(hipEventRecord(ctx->sync_event(ev0 + 1 + (k & 1)), S));
+            AERO_HIP(hipStreamWaitEvent(H, ctx->sync_event(ev0 + 1 + (k & 1)), 0));
+            OnStream h(ctx, H);
+            for (int q = 0; q < G; q++) ctx->hash_rows(rk + (size_t)q * W * sub, sub, (int)W, sub, c.tree.leaves() + (size_t)q * per + (size_t)k * sub);
+        }
+        // `send` / `recv` go back to the allocator when this scope ends: everything H still reads of them must be behind S by then (below)
+        AERO_HIP(hipEventRecord(ctx->sync_event(ev0 + 3), H));
+        AERO_HIP(hipStreamWaitEvent(S, ctx->sync_event(ev0 + 3), 0));
+        c.leaf_parts_log = ilog2(G);
+        ctx->merkle_build_parts(c.tree.nodes.get(), L, c.leaf_parts_log);
+        finish_exchange(c);
+        return c;
+    }
+    AERO_HIP(hipEventRecord(ctx->sync_event(ev0 + 3), H));
+    AERO_HIP(hipStreamWaitEvent(S, ctx->sync_event(ev0 + 3), 0));
+    c.leaf_parts_log = ilog2(G);
+    ctx->merkle_build_parts(c.tree.nodes.get(), L, c.leaf_parts_log);
+    finish_exchange(c);
+    return c;
+}
 // all-gather of the G subtree roots (the only collective on the transcript's critical path); the top log2 G levels on the host
 void Prover::finish_exchange(Commitment& c) {
     Context* ctx = ctx_;
@@ -931,7 +999,14 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             c.root = c.tree.root();
             return c;
         }
-        if (exchange_rows && (size_t)lde.cols * 8 < sizeof(Digest) && lde.rows >= 8 * (size_t)G && lde.rows % G == 0) return commit_exchange_rows(lde);
+        const bool rows_path = exchange_rows && (size_t)lde.cols * 8 < sizeof(Digest) && lde.rows >= 8 * (size_t)G && lde.rows % G == 0;
+        if (exchange_chunks > 1 && lde.rows % G == 0 && lde.rows / G >= 8) {
+            // as many chunks as asked for, as long as a chunk keeps at least 8 leaves per peer (K and the piece are powers of two)
+            int K = 1;
+            while (K * 2 <= exchange_chunks && (lde.rows / G) / (size_t)(K * 2) >= 8) K *= 2;
+            if (K > 1) return commit_exchange_chunked(lde, K, rows_path);
+        }
+        if (rows_path) return commit_exchange_rows(lde);
         DevBuf<Digest> local(ctx, lde.rows);
         ctx->hash_rows(lde.data.get(), lde.rows, lde.cols, lde.rows, local.get());
         return commit_exchange(local, lde.rows);

@@ -192,6 +192,7 @@ public:
     bool compact_rows = getenv("AERO_COMPACT_ROWS") ? getenv("AERO_COMPACT_ROWS")[0] != '0' : true;   // compact every-k-th-row LDE copies for constraints / DEEP
     bool low_level_skip = true;         // large trees: the 3 lowest Merkle levels are not stored but recomputed by the openings
     bool exchange_rows = getenv("AERO_EXCHANGE_ROWS") ? getenv("AERO_EXCHANGE_ROWS")[0] != '0' : true;   // sharded: rows instead of digests when shorter
+    int exchange_chunks = getenv("AERO_EXCHANGE_CHUNKS") ? atoi(getenv("AERO_EXCHANGE_CHUNKS")) : 1;   // sharded: pieces per peer of a commitment's exchange, overlapped with hashing (1 = one exchange)
     bool h2d_pipeline = getenv("AERO_H2D_PIPELINE") ? getenv("AERO_H2D_PIPELINE")[0] != '0' : true;   // wide host traces travel in column groups behind the transforms
 
     // ---- stage-level entry points (the reference's split API; also what the C ABI exposes) ----
@@ -229,6 +230,9 @@ private:
     // sharded commitment: `local` = this rank's coset leaves (count L); returns the subtree over global leaves [rank*L, (rank+1)*L)
     Commitment commit_exchange(DevBuf<Digest>& local, size_t L);
     Commitment commit_exchange_rows(const Matrix& lde);    // rows shorter than a digest: exchange the rows, hash on arrival
+    // the same two commitments with the exchange cut into `chunks` pieces per peer, every piece's all-to-all on the proving stream while the row
+    // hashing of the neighbouring piece runs on the context's second stream (AERO_EXCHANGE_CHUNKS)
+    Commitment commit_exchange_chunked(const Matrix& lde, int chunks, bool rows_path);
     void finish_exchange(Commitment& c);
     void comm_all_to_all(const void* send, void* recv, size_t bytes);
     void comm_all_gather(const void* send, void* recv, size_t bytes);

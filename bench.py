@@ -538,8 +538,13 @@ def main():
     ap.add_argument("--shard-comm", default="auto", choices=["auto", "rccl", "torch"],
                     help="exchanges of a sharded proof: rccl = the library's native communicator (aero_rccl_*), torch = torch.distributed "
                          "collectives on the device buffers, auto = rccl when every rank has its own GPU")
+    ap.add_argument("--exchange-chunks", type=int, default=0,
+                    help="sharded proofs: cut every commitment's exchange into this many pieces per peer, overlapped with the row hashing "
+                         "(AERO_EXCHANGE_CHUNKS; 0 = the library's default, one exchange) - for an A/B on a node with links")
     ap.add_argument("--shard-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.exchange_chunks > 0:
+        os.environ["AERO_EXCHANGE_CHUNKS"] = str(args.exchange_chunks)      # read by every rank's prover (children inherit it)
     if args.shard_worker:
         return shard_worker_main(args)
 
@@ -594,7 +599,7 @@ def main():
                            "hand_over": "trace in pinned host memory; every rank copies its share of the columns inside the timed region (aero_prove_fib_sharded_host)",
                            "parallelism": f"ONE proof sharded over {world} GPUs by LDE coset; every rank copies and interpolates W / {world} columns, all-gather of the "
                                           "coefficients; per commitment: all-to-all of rows or leaf digests + all-gather of subtree roots; one all-reduce for the openings"},
-                "sharded_proof": res,
+                "sharded_proof": res, "exchange_chunks": int(os.environ.get("AERO_EXCHANGE_CHUNKS", "1")),
                 "path_roofline": {"bytes_per_cell": bpc, "achieved_GBps": res["value"] * bpc / 1e9 / world,
                                   "frac_of_hbm_peak": res["value"] * bpc / 1e9 / world / HBM_PEAK_GBS},
             }), flush=True)

@@ -62,6 +62,49 @@ def test_rows_travel_instead_of_digests_when_they_are_shorter(ctx):
     assert sent["1"] < sent["0"] - 1.5e6, sent           # 2 commitments x 16 B x 2^16 rows x 7/8 less per rank
 
 
+@pytest.mark.parametrize("chunks", ["4", "16", "3"])
+@pytest.mark.parametrize("width,log_n,aux,opt,worlds", [
+    (2, 14, (0, 0, 2), [27, 8, 16, 4, 1, 8, 8], (2, 4, 8)),          # rows exchanged, hashed on arrival while the next piece travels
+    (8, 13, (0, 0, 2), [27, 8, 8, 4, 1, 8, 6], (2, 4, 8)),           # digests: piece k + 1 hashed while piece k travels
+    (16, 12, (4, 3, 5), [27, 8, 8, 4, 2, 4, 7], (8,)),               # auxiliary segment, quadratic extension, fold 4
+])
+def test_chunked_exchange_gives_the_single_gpu_proof(ctx, oracle, chunks, width, log_n, aux, opt, worlds):
+    """AERO_EXCHANGE_CHUNKS: every commitment's all-to-all cut into pieces, each piece's exchange on the proving stream while the row hashing
+    of the neighbouring piece runs on the context's second stream. Same leaves in the same slots: same bytes. (3 is not a
+    power of two: the library rounds down to 2.) Ranks sharing one GPU can show parity only; whether it pays needs a node with links."""
+    trace = aero_amd.fib_trace(width, log_n)
+    o = aero_amd.ProofOptions(*opt)
+    want, pub = ctx.prove_fib_aux(trace, aux[0], aux[1], o, aux_degree=aux[2])
+    ref, _, _ = oracle.prove_fib_aux(width, log_n, aux[0], aux[1], opt, D=aux[2]) if aux[0] else oracle.prove_fib(width, log_n, opt)
+    assert want == ref
+    os.environ["AERO_EXCHANGE_CHUNKS"] = chunks
+    try:
+        for world in worlds:
+            proofs, pub2, ms, sent = aero_amd.prove_fib_sharded_local(trace, o, world, aux)
+            assert pub2 == pub and all(p == want for p in proofs), f"world {world}, chunks {chunks}"
+    finally:
+        os.environ.pop("AERO_EXCHANGE_CHUNKS", None)
+
+
+def test_chunked_exchange_of_a_program_air(oracle):
+    from aero_amd.shard import LocalGroup
+    log_n, pairs, aux, opt = 12, 26, 9, [27, 8, 16, 4, 1, 4, 8]
+    program = aero_amd.synth_vm_program(log_n, pairs, aux, 16)
+    trace, pub = aero_amd.synth_vm_trace(log_n, pairs)
+    air = aero_amd.Air(program)
+    want, _ = oracle.prove_air(program, trace, pub, opt)
+    os.environ["AERO_EXCHANGE_CHUNKS"] = "8"
+    try:
+        g = LocalGroup(4, min_peer_digests=64)
+        try:
+            proofs = g.run(lambda r, c, comm: c.prove_air(air, c.trace_upload(trace), pub, aero_amd.ProofOptions(*opt), comm=comm))
+        finally:
+            g.close()
+    finally:
+        os.environ.pop("AERO_EXCHANGE_CHUNKS", None)
+    assert all(p == want for p in proofs)
+
+
 def test_non_canonical_trace_is_refused_by_every_rank():
     trace = aero_amd.fib_trace(8, 12)
     trace[5][100] = 0xFFFFFFFF00000001 + 1           # rank 2 of 4 copies this column: the verdict is all-reduced
