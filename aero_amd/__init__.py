@@ -104,27 +104,58 @@ class PinnedTrace:
     trace aliased one buffer and a user-pointer registration lived on pages whose lifetime was the allocator's. A Rust host does the
     equivalent by filling a buffer from aero_host_alloc, or registers the Vec it owns with aero_host_register.)"""
 
-    def __init__(self, trace: np.ndarray):
+    def __init__(self, trace: np.ndarray, device=None):
+        """device: allocate the buffer on the NUMA node of that GPU (aero_host_alloc_near; falls back to aero_host_alloc)."""
         src = np.ascontiguousarray(trace, np.uint64)
         self.width, n = src.shape
         self.log_n = int(n).bit_length() - 1
-        self._ptr = C.c_void_p()
-        rc = lib().aero_host_alloc(C.c_size_t(src.nbytes), C.byref(self._ptr))
+        ptr = C.c_void_p()
+        if device is None:
+            rc = lib().aero_host_alloc(C.c_size_t(src.nbytes), C.byref(ptr))
+        else:
+            rc = lib().aero_host_alloc_near(C.c_size_t(src.nbytes), C.c_int32(device), C.byref(ptr))
         if rc != 0:
             raise AeroError(rc, lib().aero_last_error(None).decode())
-        flat = np.ctypeslib.as_array((C.c_uint64 * src.size).from_address(self._ptr.value))
+        # The numpy views are built over an owner object whose finaliser frees the memory: a view the caller still holds (`t = pinned.array`,
+        # a slice of it) keeps the buffer alive after release() / after this object is gone - no use-after-free in the host process.
+        self._owner = _PinnedBlock.from_address(ptr.value, src.nbytes)
+        flat = np.frombuffer(self._owner, dtype=np.uint64)
         self.array = flat.reshape(src.shape)
         self.array[...] = src
 
     def release(self):
-        if getattr(self, "_ptr", None) is not None and self._ptr.value:
-            self.array = None
-            lib().aero_host_free(self._ptr)
-            self._ptr = C.c_void_p()
+        """Drops this object's reference; the memory is freed once no numpy view of it is alive any more."""
+        self.array = None
+        self._owner = None
 
     def __del__(self):
         try:
             self.release()
+        except Exception:
+            pass
+
+
+class _PinnedBlock:
+    """Owner of one aero_host_alloc'd block, exposed through the buffer protocol (a ctypes array over the address); freed when the last
+    numpy view of it is gone."""
+
+    @staticmethod
+    def from_address(addr, nbytes):
+        holder = _PinnedHolder(addr)
+        arr = (C.c_uint8 * nbytes).from_address(addr)
+        arr._aero_holder = holder          # the ctypes array is the base object of every view: it carries the finaliser
+        return arr
+
+
+class _PinnedHolder:
+    def __init__(self, addr):
+        self.addr = addr
+
+    def __del__(self):
+        try:
+            if self.addr:
+                lib().aero_host_free(C.c_void_p(self.addr))
+                self.addr = 0
         except Exception:
             pass
 
@@ -643,6 +674,12 @@ class Pool:
 
     def ctx(self, slot) -> Context:
         return self.ctxs[slot]
+
+    def placement(self):
+        """(NUMA node of the pool's device or -1, number of worker threads bound to that node's CPUs) - aero_pool_placement."""
+        node, pinned = C.c_int32(-1), C.c_uint32(0)
+        lib().aero_pool_placement(self.h, C.byref(node), C.byref(pinned))
+        return node.value, pinned.value
 
     def prove_fib(self, traces, options: ProofOptions, aux=(0, 0, 2), rounds=1):
         """traces[i] = Matrix resident on slot i's context. Every slot proves its trace `rounds` times back to back; returns

@@ -22,10 +22,23 @@ struct ParamPack {
         return items.size() - 1;
     }
     void commit() {
-        uint8_t* host = (uint8_t*)ctx->stage_alloc(total + 16);
-        for (auto& it : items) if (it.bytes) memcpy(host + it.off, it.src, it.bytes);
         dev = (uint8_t*)ctx->scratch_alloc(total + 16);
-        AERO_HIP(hipMemcpyAsync(dev, host, total + 16, hipMemcpyHostToDevice, ctx->stream));
+        constexpr size_t PIECE = (size_t)2 << 20;      // the context's pinned staging block is 8 MiB and is shared with every other small copy
+        if (total + 16 <= PIECE) {
+            uint8_t* host = (uint8_t*)ctx->stage_alloc(total + 16);
+            for (auto& it : items) if (it.bytes) memcpy(host + it.off, it.src, it.bytes);
+            AERO_HIP(hipMemcpyAsync(dev, host, total + 16, hipMemcpyHostToDevice, ctx->stream));
+            return;
+        }
+        // a large pack (the raw values of long sequence assertions: 2^20 and more entries) travels piece by piece through the staging block
+        // (stage_alloc waits for the earlier copies when the block wraps) instead of failing with "staging request too large"
+        for (auto& it : items)
+            for (size_t off = 0; off < it.bytes; off += PIECE) {
+                const size_t len = it.bytes - off < PIECE ? it.bytes - off : PIECE;
+                uint8_t* host = (uint8_t*)ctx->stage_alloc(len);
+                memcpy(host, static_cast<const uint8_t*>(it.src) + off, len);
+                AERO_HIP(hipMemcpyAsync(dev + it.off + off, host, len, hipMemcpyHostToDevice, ctx->stream));
+            }
     }
     template <class T> const T* ptr(size_t id) const { return reinterpret_cast<const T*>(dev + items[id].off); }
 };
@@ -58,7 +71,7 @@ void air_build_aux(Context* ctx, const air::Program& p, const uint64_t* trace_de
 
 // `Trace::validate(&air)` on the device (run-time compiled kernel, air_jit.hip mode 2): trace = W x n main segment, aux = (A * DEG) x n
 // component columns or null (then only the main constraints and assertions are checked). Returns ~0 when every constraint holds, else
-// row << 16 | id of the first failure (id = transition index in the program's order, or 0x8000 | assertion index, main first).
+// row << 24 | id of the first failure (id = transition index in the program's order, or 0x800000 | assertion index, main first).
 template <class F>
 uint64_t air_validate_trace(Context* ctx, const air::Program& p, const air::Instance& in, const uint64_t* trace_dev, const uint64_t* aux_dev,
                             const uint64_t* pub, const typename F::T* rands);

@@ -19,6 +19,7 @@
 #include "air_kernels.hpp"
 
 #include <hip/hiprtc.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -447,11 +448,22 @@ struct CacheHeader {
     uint64_t src_len, code_len;
     b2s::Digest src_hash, code_hash;
 };
-// a cache directory that others can write to is a way to inject kernels into the prover: refused
+// A cache directory that anybody else can write to is a way to inject kernels into the prover (the header's digests are unkeyed: whoever can
+// write the directory can forge a valid entry). Trusted = a real directory (not a symbolic link: lstat), owned by this process's user, not
+// writable by group or others. Entries are opened with O_NOFOLLOW and must be regular files of the same owner (open_cache_entry).
 bool cache_dir_trusted(const char* dir) {
     struct stat st;
-    if (stat(dir, &st) != 0 || !S_ISDIR(st.st_mode)) return false;
-    return (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+    if (lstat(dir, &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+static FILE* open_cache_entry(const std::string& path) {
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return nullptr;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0) { close(fd); return nullptr; }
+    FILE* f = fdopen(fd, "rb");
+    if (!f) close(fd);
+    return f;
 }
 
 std::string structure_key(const Program& p, const Instance& in, int DEG, int mode, int R) {
@@ -478,7 +490,7 @@ std::shared_ptr<Blob> compile(const Program& p, const Instance& in, int DEG, int
     const char* dir = getenv("AERO_AIR_JIT_CACHE");
     if (dir && *dir && !cache_dir_trusted(dir)) {
         std::lock_guard<std::mutex> lk(g_mu);
-        g_last_error = std::string("AERO_AIR_JIT_CACHE ignored: ") + dir + " is not a directory or is group/world-writable";
+        g_last_error = std::string("AERO_AIR_JIT_CACHE ignored: ") + dir + " is not a directory of this user, is a symbolic link, or is group/world-writable";
         dir = nullptr;
     }
     if (dir && *dir) {
@@ -489,7 +501,7 @@ std::shared_ptr<Blob> compile(const Program& p, const Instance& in, int DEG, int
         char name[64];
         snprintf(name, sizeof name, "/aero_air_%016llx%016llx.co", (unsigned long long)h1, (unsigned long long)h2);
         cache_path = std::string(dir) + name;
-        if (FILE* f = fopen(cache_path.c_str(), "rb")) {
+        if (FILE* f = open_cache_entry(cache_path)) {
             fseek(f, 0, SEEK_END);
             const long sz = ftell(f);
             fseek(f, 0, SEEK_SET);
@@ -535,7 +547,10 @@ std::shared_ptr<Blob> compile(const Program& p, const Instance& in, int DEG, int
     hiprtcDestroyProgram(&prog);
     if (!cache_path.empty() && blob->error.empty()) {         // written under a temporary name, then renamed: readers never see a partial file
         const std::string tmp = cache_path + ".tmp" + std::to_string((unsigned long long)blob->id) + "_" + std::to_string((long)getpid());
-        if (FILE* f = fopen(tmp.c_str(), "wb")) {
+        const int tfd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+        FILE* f = tfd >= 0 ? fdopen(tfd, "wb") : nullptr;
+        if (!f && tfd >= 0) close(tfd);
+        if (f) {
             CacheHeader hd;
             memcpy(hd.magic, "AEROJIT1", 8);
             hd.src_len = src.size(); hd.code_len = blob->code.size();
@@ -632,10 +647,13 @@ template <class F> bool launch_air_jit(Context* ctx, const air::Program& p, cons
         if (!load(blob)) {
             // not retried on every launch; a cache entry that does not load (built for another chip or runtime) is dropped and the
             // program compiled afresh, once (the entry is gone, so this cannot loop)
+            // A load failure is a fact about THIS context at this moment (out of memory, a device in a bad state), not about the program: the
+            // shared blob is not marked failed - other contexts of a pool read blob->error without a lock, and a transient failure here must
+            // not switch every later proof of the process to the interpreter. Only a compile error (set once, before the blob is published) is
+            // permanent. This context gets the interpreter for this launch and tries again at its next one.
             const bool from_cache = !blob->cache_file.empty();
             if (from_cache) remove(blob->cache_file.c_str());
-            blob->error = "hipModuleLoadData refused the code object";
-            { std::lock_guard<std::mutex> lk(g_mu); g_last_error = blob->error; }
+            { std::lock_guard<std::mutex> lk(g_mu); g_last_error = "hipModuleLoadData refused the code object"; }
             if (!from_cache) return false;
             {
                 auto cache = std::static_pointer_cast<Cache>(p.jit_cache);

@@ -552,9 +552,18 @@ template <class F> __global__ __launch_bounds__(256) void air_fac_apply_kernel(c
         T rd = totals[(size_t)(2 * c + 1) * gridDim.x + blockIdx.x];
         if (threadIdx.x) rd = F::mul(rd, sh[threadIdx.x - 1]);
         // rd = prefix before this lane's first row; 1 / prefix_k = (1 / prefix_8) * fd[k] * ... * fd[7]
-        T inv = F::inv(F::mul(rd, pd));
+        const T tot = F::mul(rd, pd);
+        if (F::comp(tot, 0) == 0 && (F::DEG == 1 || F::comp(tot, 1) == 0)) {
+            // a zero denominator among this lane's rows (or before them): element by element, 1 / 0 = 0 as winter-math's inversion has it - the rows
+            // BEFORE the zero keep their values (one shared inversion of the lane's whole product would zero them too), the rows behind it are zero
+            T pre = rd;
 #pragma unroll
-        for (int k = SCAN_K - 1; k >= 0; k--) { inv = F::mul(inv, fd[k]); val[k] = F::mul(val[k], inv); }
+            for (int k = 0; k < SCAN_K; k++) { val[k] = F::mul(val[k], F::inv(pre)); pre = F::mul(pre, fd[k]); }
+        } else {
+            T inv = F::inv(tot);
+#pragma unroll
+            for (int k = SCAN_K - 1; k >= 0; k--) { inv = F::mul(inv, fd[k]); val[k] = F::mul(val[k], inv); }
+        }
     }
 #pragma unroll
     for (int k = 0; k < SCAN_K; k++)
@@ -601,11 +610,21 @@ template <class F> __global__ __launch_bounds__(256) void air_aff_ratio_kernel(u
         den[k] = hd ? air_fac_at<F>(fac, n, 2 * c + 1, first + k) : F::one();
         den[SCAN_K + k] = ad ? air_fac_at<F>(fac, n, 2 * A + 2 * c + 1, first + k) : F::one();
     }
+    // one inversion for the lane's 2 SCAN_K denominators; a ZERO among them is skipped in the product and inverted to zero (winter-math's
+    // batch_inversion does the same): only the offending row is affected, not every row of the lane
+    bool zero[2 * SCAN_K];
 #pragma unroll
-    for (int k = 0; k < 2 * SCAN_K; k++) { pre[k] = run; run = F::mul(run, den[k]); }
+    for (int k = 0; k < 2 * SCAN_K; k++) {
+        zero[k] = F::comp(den[k], 0) == 0 && (F::DEG == 1 || F::comp(den[k], 1) == 0);
+        pre[k] = run;
+        if (!zero[k]) run = F::mul(run, den[k]);
+    }
     T inv = F::inv(run);
 #pragma unroll
-    for (int k = 2 * SCAN_K - 1; k >= 0; k--) { const T di = F::mul(inv, pre[k]); inv = F::mul(inv, den[k]); den[k] = di; }     // den[k] <- 1 / den[k]
+    for (int k = 2 * SCAN_K - 1; k >= 0; k--) {                                                     // den[k] <- 1 / den[k]
+        if (zero[k]) { den[k] = F::zero(); continue; }
+        const T di = F::mul(inv, pre[k]); inv = F::mul(inv, den[k]); den[k] = di;
+    }
 #pragma unroll
     for (int k = 0; k < SCAN_K; k++) {
         if (first + k >= n) continue;

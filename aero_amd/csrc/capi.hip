@@ -7,6 +7,7 @@
 #include <mutex>
 #include <thread>
 
+#include <atomic>
 #include "capi_internal.hpp"
 #include "../../include/aero_air.h"
 #include "proof_format.hpp"
@@ -816,7 +817,12 @@ struct aero_pool {
     uint32_t rounds = 1;
     uint32_t host_width = 0, host_log_n = 0;
 
+    int numa_node = -1;                     // of the pool's device (numa.hip); -1 = unknown
+    std::atomic<uint32_t> pinned{0};        // worker threads bound to that node's CPUs
+
     void worker(Slot* s) {
+        // this thread issues every launch and every copy of its slot: it runs on the GPU's own socket where the box tells which that is
+        if (numa_node >= 0 && bind_thread_to_node(numa_node) > 0) pinned++;
         uint64_t seen = 0;
         for (;;) {
             {
@@ -913,6 +919,7 @@ int32_t aero_pool_create(int32_t device_id, uint32_t slots, aero_pool** out) {
         p->slots.back()->ctx = c;
         c->c->copy_gate = p->gate;
     }
+    p->numa_node = numa_node_of_device(device_id);
     for (auto& s : p->slots) s->th = std::thread(&aero_pool::worker, p.get(), s.get());
     *out = p.release();
     return AERO_OK;
@@ -927,6 +934,12 @@ void aero_pool_destroy(aero_pool* pool) {
     for (auto& s : pool->slots) if (s->th.joinable()) s->th.join();
     for (auto& s : pool->slots) aero_ctx_destroy(s->ctx);
     delete pool;
+}
+int32_t aero_pool_placement(const aero_pool* pool, int32_t* node_out, uint32_t* pinned_out) {
+    if (!pool) return AERO_E_BAD_ARG;
+    if (node_out) *node_out = pool->numa_node;
+    if (pinned_out) *pinned_out = pool->pinned.load();
+    return AERO_OK;
 }
 uint32_t aero_pool_slots(const aero_pool* pool) { return pool ? (uint32_t)pool->slots.size() : 0; }
 aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot) { return (pool && slot < pool->slots.size()) ? pool->slots[slot]->ctx : nullptr; }

@@ -80,3 +80,9 @@ template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
 static inline int ilog2u(uint64_t x) { int r = 0; while ((1ull << r) < x) r++; return r; }
 
 
+
+// numa.hip: placement of a rank's host side next to its GPU
+namespace aero {
+int numa_node_of_device(int device);        // -1 = unknown (or AERO_NUMA=0)
+int bind_thread_to_node(int node);          // calling thread -> the node's CPUs the process may use; returns their number, 0 = left alone
+}

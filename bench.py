@@ -629,7 +629,7 @@ def main():
         trace = aero_amd.fib_trace(width, log_n)      # synthetic data, pure function of (width, log_n)
     # the hand-over the metric is defined on: trace in (pinned) HOST memory -> proof bytes in
     # host memory; every proof starts with the host-to-device copy of its trace on its own stream. One pinned buffer per slot.
-    hosts = [aero_amd.PinnedTrace(trace.copy()) for _ in range(S)]
+    hosts = [aero_amd.PinnedTrace(trace, device=local_rank) for _ in range(S)]      # on the GPU's NUMA node where the box names one
     devs = [c.trace_upload(trace) for c in ctxs]      # HBM-resident copies for the secondary figure and the traced pass
     del trace
     ctx, dev = ctxs[0], devs[0]
@@ -754,6 +754,9 @@ def main():
     out["pcie"] = {"h2d_pinned_GBps_measured": link_GBps, "achieved_GBps": link_used, "frac": link_used / link_GBps if link_GBps else None,
                    "what": "8 B per trace cell of the H2D-inclusive figure / this box's pinned host-to-device rate on the same buffer (one copy at a time, best of 5)",
                    "binds": bool(link_GBps and link_used / link_GBps >= 0.9)}
+    numa_node, workers_pinned = pool.placement()
+    out["host_placement"] = {"gpu_numa_node": numa_node, "worker_threads_bound": workers_pinned, "of": S,
+                             "what": "pool worker threads bound to the CPUs of the GPU's NUMA node, pinned trace buffers allocated with that node preferred (inside the rank process: no numactl, no re-exec); -1 = the box names no node"}
     if rank == 0:
         calls, ms, abytes = dom_rep
         achieved = (abytes / (ms * 1e-3)) / 1e9 if ms > 0 else 0.0

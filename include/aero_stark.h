@@ -246,6 +246,23 @@ int32_t aero_host_unregister(void* p);
  * buffer and hands it to the *_host entry points. aero_host_free(NULL) is a no-op. Text on failure: aero_last_error(NULL). */
 int32_t aero_host_alloc(size_t bytes, void** out);
 int32_t aero_host_free(void* p);
+/* ---- host placement on a multi-socket node -------------------------------------------------------------------------------- */
+/* The reference sizes its worker pool by `navigator.hardwareConcurrency` and has no notion of where a worker runs
+ * (aero-sdk/miden-wasm/src/pool.rs:28-45,105-124). A rank process that drives ONE GPU of a two-socket 8-GPU node wants its worker
+ * threads and its pinned trace buffers on the GPU's own NUMA node; a process that has touched the GPU must not re-exec under
+ * numactl, so the library does it from inside:
+ *   aero_numa_device_node ... NUMA node of the device (sysfs: /sys/bus/pci/devices/<bdf>/numa_node), -1 = unknown / AERO_NUMA=0
+ *   aero_numa_bind_thread ... binds the CALLING thread to that node's CPUs (those the process is allowed to use); *n_cpus_out = how
+ *                             many it now runs on, 0 = left alone. aero_pool_create does this for its worker threads by itself.
+ *   aero_host_alloc_near .... aero_host_alloc with the pages placed on the device's node (falls back to aero_host_alloc)
+ *   aero_numa_query ......... the sysfs parsing alone, against a sysfs tree rooted at `sysfs_root_dir` ("/sys"): node of the PCI
+ *                             device `pci_bdf` and the CPUs of that node (cpus_out may be NULL; *n_cpus_out = their number)
+ *   aero_numa_parse_cpulist . "0-15,32-47" -> CPU numbers (the kernel's cpulist format); AERO_E_BAD_ARG on malformed text */
+int32_t aero_numa_device_node(int32_t device_id, int32_t* node_out);
+int32_t aero_numa_bind_thread(int32_t device_id, uint32_t* n_cpus_out);
+int32_t aero_host_alloc_near(size_t bytes, int32_t device_id, void** out);
+int32_t aero_numa_query(const char* sysfs_root_dir, const char* pci_bdf, int32_t* node_out, int32_t* cpus_out, uint32_t cpus_cap, uint32_t* n_cpus_out);
+int32_t aero_numa_parse_cpulist(const char* text, int32_t* cpus_out, uint32_t cpus_cap, uint32_t* n_cpus_out);
 /* ---- one proof sharded over the GPUs of a node ------------------------------------------------------------------------------ */
 /* The exchange steps of a sharded proof, supplied by the host (one process per GPU; torch.distributed over RCCL in this
  * repo's harness, `ncclSend/Recv`-style bindings from Rust). The reference has no multi-device prover; its parallel
@@ -379,6 +396,8 @@ int32_t aero_pool_create(int32_t device_id, uint32_t slots, aero_pool** out);
 void aero_pool_destroy(aero_pool* pool);
 uint32_t aero_pool_slots(const aero_pool* pool);
 aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot);
+/* where the pool's worker threads ended up: node_out = NUMA node of the device (-1 unknown), pinned_out = workers bound to its CPUs */
+int32_t aero_pool_placement(const aero_pool* pool, int32_t* node_out, uint32_t* pinned_out);
 int32_t aero_pool_prove_fib(aero_pool* pool, const aero_matrix* const* traces, uint32_t count, const aero_fib_air* air,
                             const aero_proof_options* options, uint32_t rounds, uint8_t** proofs, size_t* proof_lens, uint64_t* pubs);
 /* Same with the traces in HOST memory (host_traces[i] = column-major width x 2^log_n, ideally pinned): every proof of every

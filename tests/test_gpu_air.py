@@ -391,3 +391,50 @@ def test_version2_program_sharded_over_thread_ranks(world, oracle):
     finally:
         g.close()
     assert all(p == want for p in proofs)
+
+
+# ---- round-4 review items ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ext", [1, 2])
+def test_zero_denominator_in_an_aux_builder_affects_its_own_row_only(ctx, oracle, ext):
+    """A builder's denominator that vanishes on one row: 1 / 0 = 0 element by element (winter-math's inversion; the oracle inverts each
+    row on its own). The device shares one inversion between the rows of a lane: a zero must not zero the lane's other rows - the rows
+    BEFORE it keep their values (running product) / only the offending row's term vanishes (affine forms)."""
+    log_n = 10
+    n = 1 << log_n
+    b = A.AirBuilder(1, 3, 1, num_pub=0)
+    m, mn, a, an = b.main, b.main_next, b.aux, b.aux_next
+    b.transition(mn(0) - m(0) - 1, 1)
+    b.aux_transition(an(0) * (m(0) - 5) - a(0) * (m(0) + 1), 2)               # p' = p (m + 1) / (m - 5): the denominator vanishes on row 5
+    b.aux_transition((an(1) - a(1)) * (m(0) - 9) - m(0), 2)                   # s' = s + m / (m - 9): row 9
+    b.aux_transition((an(2) - a(2) * (m(0) + 2)) * (m(0) - 700) - 3, 2)       # u' = u (m + 2) + 3 / (m - 700): row 700 (another lane, another block)
+    b.assert_single(0, 0, 0)
+    b.aux_assert_single(0, 0, 1)
+    b.aux_assert_single(1, 0, 0)
+    b.aux_assert_single(2, 0, 1)
+    b.aux_builder(0, 1, m(0) + 1, m(0) - 5)
+    b.aux_builder(1, 0, 1, None, m(0), m(0) - 9)
+    b.aux_builder(2, 1, m(0) + 2, None, 3, m(0) - 700)
+    trace = np.arange(n, dtype=np.uint64)[None, :]
+    program = b.to_bytes()
+    air = aero_amd.Air(program)
+    opt = [27, 8, 8, 4, ext, 8, 6]
+    oracle.prove_air(program, trace, [], opt, keep_artifacts=True)           # the trace violates the program where 1 / 0 = 0: a prover does not care
+    rands = oracle.artifact("aux_rands", ext * 1)
+    want = oracle.artifact("aux_cols", 3 * ext * n).reshape(3 * ext, n)
+    got = ctx.aux_columns_program(air, ctx.trace_upload(trace), [], rands, ext).download()
+    assert (want[0][:6] != 0).all() and (want[0][6:] == 0).all()             # what "its own row only" means for a running product
+    assert (got == want).all(), [int(np.argmax(g != w)) for g, w in zip(got, want) if (g != w).any()]
+
+
+def test_sequence_assertions_of_a_million_values_are_validated(ctx):
+    """Trace::validate with the raw values of long sequence assertions (2^21 rows, a sequence on every second step = 2^20 values + two more
+    sequences): the parameter pack outgrows the context's 8 MiB pinned staging block and travels in pieces."""
+    log_n = 21
+    b, trace, pub = ex.v2_air(log_n, 2)
+    air = aero_amd.Air(b.to_bytes())
+    dev = ctx.trace_upload(trace)
+    assert ctx.validate_trace(air, dev, pub) is None
+    bad = trace.copy()
+    bad[2][1 + 2 * 777777] ^= 1                                               # the 777 778th value of the counter's sequence
+    got = ctx.validate_trace(air, ctx.trace_upload(bad), pub)
+    assert got is not None and got[0] in (1 + 2 * 777777 - 1, 1 + 2 * 777777)

@@ -66,3 +66,24 @@ def test_non_canonical_element_in_a_host_trace_is_refused(ctx, width, col, row):
     assert e.value.code == -1 and "non-canonical" in str(e.value)
     again, _ = ctx.prove_fib(trace, aero_amd.ProofOptions.with_96_bit_security())     # the context is still usable
     assert again == good
+
+
+def test_pinned_views_outlive_release_and_near_allocation_works(ctx):
+    """PinnedTrace.array is a view over library-owned pinned memory (aero_host_alloc / aero_host_alloc_near): a view the caller still holds
+    keeps the buffer alive after release(); a buffer allocated near the device proves like any other."""
+    t = aero_amd.fib_trace(4, 10)
+    want, _ = ctx.prove_fib(t, aero_amd.ProofOptions.with_96_bit_security())
+    p = aero_amd.PinnedTrace(t, device=0)
+    got, _ = ctx.prove_fib(p, aero_amd.ProofOptions.with_96_bit_security())
+    assert got == want
+    view, row = p.array, p.array[3]
+    p.release()
+    assert p.array is None and (view == t).all() and (row == t[3]).all()
+    del p, view
+    assert int(row[5]) == int(t[3][5])
+    node = aero_amd.C.c_int32(-9)
+    assert aero_amd.lib().aero_numa_device_node(aero_amd.C.c_int32(0), aero_amd.C.byref(node)) == 0 and node.value >= -1
+    pool = aero_amd.Pool(0, 2)
+    n, pinned = pool.placement()
+    assert n == node.value and (pinned == 0 if n < 0 else pinned <= 2)
+    pool.close()
