@@ -844,11 +844,11 @@ struct aero_pool {
             // With several rounds ahead the copy of trace r + 1 runs on the copy stream, into the other of two landing buffers, WHILE
             // trace r is proven; every trace still crosses the link inside the call. Narrow traces (< 32 MiB) keep the in-stream copy:
             // their copy is short and hides behind the other proofs as it is. AERO_POOL_PREFETCH_MIN_MB overrides the size, 0 = never.
-            static const long prefetch_mb = getenv("AERO_POOL_PREFETCH_MIN_MB") ? atol(getenv("AERO_POOL_PREFETCH_MIN_MB")) : 32;
+            static const double prefetch_mb = getenv("AERO_POOL_PREFETCH_MIN_MB") ? atof(getenv("AERO_POOL_PREFETCH_MIN_MB")) : 32.0;
             uint32_t trace_w = host_width;
             if (program) { uint32_t info[16] = {0}; if (aero_air_info(program, info) == AERO_OK) trace_w = info[0]; }      // main_width
             const size_t trace_bytes = s->host_trace ? ((size_t)trace_w << host_log_n) * 8 : 0;
-            const bool prefetch = s->host_trace && rounds > 1 && prefetch_mb > 0 && trace_bytes >= ((size_t)prefetch_mb << 20);
+            const bool prefetch = s->host_trace && rounds > 1 && prefetch_mb > 0 && (double)trace_bytes >= prefetch_mb * 1048576.0;
             Context* const c = s->ctx->c;
             DevBuf<uint64_t> land[2];
             hipStream_t cs = nullptr;

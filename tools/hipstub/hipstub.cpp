@@ -97,6 +97,7 @@ hipError_t hipSetDevice(int d) { if (d < 0 || d >= device_count()) return hipErr
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "hipstub error"; }
 hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+hipError_t hipDeviceGetPCIBusId(char* buf, int len, int d) { snprintf(buf, (size_t)len, "0000:%02x:00.0", 0xc1 + d); return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 
 hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }

@@ -336,7 +336,9 @@ static void pool_batches() {
         uint8_t* proofs[3] = {nullptr, nullptr, nullptr};
         size_t lens[3] = {0, 0, 0};
         std::vector<uint64_t> pubs(3 * w);
-        const int32_t rc = aero_pool_prove_fib_host(pool, hosts, w, log_n, 3, nullptr, &opt, 2, proofs, lens, pubs.data());
+        // rounds >= 2 with AERO_POOL_PREFETCH_MIN_MB below the trace size (main): the copy of round r + 1 on the copy stream, gated between the slots,
+        // while round r is proven from the other landing buffer
+        const int32_t rc = aero_pool_prove_fib_host(pool, hosts, w, log_n, 3, nullptr, &opt, 2 + it, proofs, lens, pubs.data());
         CHECK(rc == AERO_OK || aero_last_error(aero_pool_ctx(pool, 0))[0] != 0);
         for (uint8_t* p : proofs) aero_free(p);
     }
@@ -347,6 +349,7 @@ extern "C" uint64_t hipstub_launches();
 extern "C" uint64_t hipstub_copies();
 
 int main() {
+    setenv("AERO_POOL_PREFETCH_MIN_MB", "0.0005", 1);      // the pool prefetches its 1 KiB traces too
     {
         std::vector<std::thread> th;
         for (int t = 0; t < 4; t++) th.emplace_back(lifetimes, t);
@@ -358,6 +361,9 @@ int main() {
     for (uint32_t world : {2u, 4u, 8u}) local_group(world, 24, false);
     local_group(4, 12, true);                 // one rank leaves: its peers must come back with an error, not hang
     sharded_proofs();
+    setenv("AERO_EXCHANGE_CHUNKS", "4", 1);        // the same proofs with every commitment's exchange in pieces: the second stream and its events
+    sharded_proofs();
+    unsetenv("AERO_EXCHANGE_CHUNKS");
     sharded_program_proofs();
     version2_program_proofs();
     pool_batches();

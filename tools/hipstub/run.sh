@@ -10,7 +10,7 @@ SRC=aero_amd/csrc
 make -s -C $SRC gl_field_src.inc
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 pids=()
-for f in ntt hash stark air_kernels air_jit air_host prover capi capi_air verify comm_rccl comm_local export diag; do
+for f in ntt hash stark air_kernels air_jit air_host prover capi capi_air verify comm_rccl comm_local export diag numa; do
   if [ ! -f $OUT/$f.o ] || [ $SRC/$f.hip -nt $OUT/$f.o ] || [ -n "$(find $SRC include -name '*.h*' -newer $OUT/$f.o 2>/dev/null | head -1)" ]; then
     # host side only: the kernels' device code is not needed (they never run here)
     hipcc --offload-host-only --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wno-unused-result -fsanitize=$SAN -fno-omit-frame-pointer -Wno-option-ignored -c $SRC/$f.hip -o $OUT/$f.o &
