@@ -89,7 +89,10 @@ struct CoinStep {
     Digest* seed_io = nullptr;   // coin seed: reseeded in place with the root
     uint64_t* alpha_out = nullptr;   // `deg` u64: the drawn element
     int deg = 1;
-    Digest* root_out = nullptr;  // the root once more, in the block the host reads after the last layer
+    Digest* root_out = nullptr;  // the root once more, in the block the host reads after the last layer (mapped pinned memory)
+    Digest* seed_out = nullptr;  // the reseeded coin seed once more (mapped pinned memory): the host checks its own replay against the last one
+    uint32_t* flag_out = nullptr;   // mapped pinned word: the launch that produces the root stores flag_seq there behind everything else it wrote for
+    uint32_t flag_seq = 0;          // the host, which polls the word instead of waiting for the stream (Context::wait_flag)
 };
 
 // The small end of the FRI commit phase in ONE launch (hash.hip: fri_tail_kernel): every layer whose domain has at most
@@ -107,8 +110,28 @@ struct FriTailArgs {
     Digest* nodes[FRI_TAIL_MAX_LAYERS];         // tree of tail layer i: 2 * rows_i slots (rows_i = 1: the root in slot 1)
     Digest* roots_out;                          // n_layers roots
     Digest* seed_io;                            // coin seed, reseeded with every root
+    Digest* seed_out;                           // the seed once more after every step (mapped pinned memory; may be null)
+    uint32_t* flag_out;                         // mapped pinned word, receives flag_seq at the very end (may be null): Context::wait_flag
+    uint32_t flag_seq;
     uint64_t* alphas_out;                       // deg u64 per layer
     uint64_t gen_inv, fold_inv, w_inv0;         // 1 / domain offset, 1 / fold, w_dom0^-1
+};
+
+// Arguments of the fused opening launch (hash.hip: openings_kernel)
+constexpr int OPEN_MAX_JOBS = 4;
+struct OpeningArgs {
+    const uint64_t* addr = nullptr;      // n_u64 element addresses, then n_dig digest addresses (0 = leave zeros); mapped pinned memory
+    uint32_t n_u64 = 0, n_dig = 0, gather_blocks = 0;
+    uint64_t* out = nullptr;             // value block: n_u64 u64, then 4 u64 per digest; mapped pinned memory
+    struct Job {                         // unstored low nodes of one row-matrix tree, recomputed from the matrix
+        RowSrc src;
+        size_t n = 0;                    // leaves of the tree
+        const uint64_t* idx = nullptr;   // heap indices (mapped pinned memory)
+        int count = 0;
+        uint32_t blocks = 0;
+        Digest* out = nullptr;           // `count` digests (mapped pinned memory)
+    } jobs[OPEN_MAX_JOBS];
+    int n_jobs = 0;
 };
 
 // One context = one device + one stream. Not thread-safe: one host thread drives it (SURVEY 8b "Threading").
@@ -151,7 +174,23 @@ public:
     // pinned host staging (bump allocator) for small async H2D parameter blocks and D2H results; a block stays valid
     // until stage_reset(), which callers issue only after a stream synchronisation
     void* stage_alloc(size_t bytes);
+    // Completion word in mapped pinned memory. A single-workgroup launch at a transcript point (tree top, FRI tail) stores a sequence number there
+    // behind its results (system-scope fence); the host polls the word instead of waiting for the stream's completion signal - 5 us less per
+    // round trip (tools/ubench_roundtrip.hip, modes B / C). wait_flag() also returns when the stream has drained (hipStreamQuery every so often):
+    // correctness never rests on the word, a kernel that died shows up as the stream's error.
+    uint32_t* flag_host = nullptr;
+    uint32_t* flag_dev = nullptr;
+    uint32_t flag_seq = 0;
+    uint32_t next_flag();                 // a fresh sequence number (allocates the word at first use)
+    void wait_flag(uint32_t seq);
+    unsigned long long* grind_slots = nullptr;   // two words the grinding launches take their minimum in, in turn (stark.hip: run_grind)
+    int grind_parity = 0;
     void stage_reset() { stage_off = 0; }
+    // The staging block is mapped pinned memory: a kernel can read and write it through this alias (hipHostGetDevicePointer). The few bytes a
+    // proof hands to the host at each transcript point (roots, the OOD frame, the opened values) are stored there by the kernels that
+    // produce them - the host waits for the stream and finds them, no copy kernel in between (round 5; tools/ubench_roundtrip.hip: 18.6 ->
+    // 16.1 us per round trip, and one blit launch less on the proof's own timeline). Only for data the device writes once and never reads.
+    template <class T> T* stage_dev(T* host_ptr) { return reinterpret_cast<T*>(stage_dev_base + (reinterpret_cast<uint8_t*>(host_ptr) - stage_base)); }
     unsigned int* pinned_word();         // one pinned 32-bit word that outlives stage_reset() (deferred input-check verdict)
     size_t bytes_in_use = 0, bytes_peak = 0;
     // AERO_POOL_GUARD=1 (diagnosis): every block is mapped by itself at the END of its own virtual-address reservation with an unmapped
@@ -215,8 +254,9 @@ public:
     void fri_tail(const FriTailArgs& a, int fold);
     // levels above a stored level of c nodes (heap indices [c, 2c)) up to the root
     void merkle_upper(Digest* nodes, size_t c, const CoinStep* coin = nullptr);
+    void openings(const OpeningArgs& a);
     // fused leaf hashing + whole tree; the lowest `skip` (0 or 3) levels are not stored (nodes holds 2n >> skip slots)
-    template <class Src> void merkle_commit(const Src& src, size_t n, Digest* nodes, int skip);
+    template <class Src> void merkle_commit(const Src& src, size_t n, Digest* nodes, int skip = 0, const CoinStep* coin = nullptr);
     // digests of unstored low nodes (heap indices >= 2n >> skip), recomputed from the leaf source
     template <class Src> void merkle_recompute(const Src& src, size_t n, const uint64_t* idx_dev, int count, Digest* out_dev);
 
@@ -245,6 +285,8 @@ private:
     std::vector<void*> persistent, scratch;
     std::vector<hipEvent_t> sync_events;
     uint8_t* stage_base = nullptr;
+    uint8_t* stage_dev_base = nullptr;
+
     unsigned int* pinned_flag = nullptr;
     size_t stage_cap = 0, stage_off = 0;
 };

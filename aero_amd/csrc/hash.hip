@@ -18,8 +18,9 @@
 //   * upper levels are built 3 levels per launch (8 child digests -> 7 nodes per thread), the top 9 levels by one
 //     workgroup staged through LDS: a compression has ~1.2 us of serial latency, so small trees are bound by
 //     (levels x latency + launch boundaries), and 3 levels per launch removes two of every three boundaries;
-//   * optionally (skip = 3) the three lowest levels are not stored and the openings recompute the few low nodes they
-//     need from the committed data; this only saves memory (measured: no time gain), so it is off by default.
+//   * trees of large narrow matrices (the fused kernel's) do not store their three lowest levels (skip = 3: 7/8 of the digest writes and
+//     of the tree's memory, 0.1 ms per 2^23-leaf tree) - the openings recompute the few low nodes they need from the committed matrix
+//     (merkle_recompute_kernel, 8 lanes per node). Prover::low_level_skip, on by default (prover.hip: commit_to_rows).
 // Measured on MI355X (tools/bench_hash.hip, 2^23 x 2 matrix): every variant lands at 30-36 G compressions/s against
 // 40-42 G/s for compressions that never leave registers (tools/ubench_valu.hip).
 #include <type_traits>
@@ -232,6 +233,7 @@ __device__ __forceinline__ void coin_step(const CoinStep& cs, const Digest& root
     if (cs.root_out) *cs.root_out = root;
     const Digest seed = b2s::merge(*cs.seed_io, root);
     *cs.seed_io = seed;
+    if (cs.seed_out) *cs.seed_out = seed;
     for (uint64_t ctr = 1; ctr < 1000; ctr++) {
         const Digest d = b2s::merge_with_int(seed, ctr);
         const uint64_t v0 = (uint64_t)d.w[0] | ((uint64_t)d.w[1] << 32), v1 = (uint64_t)d.w[2] | ((uint64_t)d.w[3] << 32);
@@ -255,7 +257,11 @@ __global__ __launch_bounds__(256) void merkle_multi_kernel(Digest* nodes, size_t
         if (tid < w) { buf[tid] = v; store_digest(&nodes[(r << d) + tid], v); }
         __syncthreads();
     }
-    if (cs.seed_io && m == 1 && tid == 0) coin_step(cs, buf[0]);
+    if (m == 1 && tid == 0) {
+        if (cs.seed_io) coin_step(cs, buf[0]);
+        else if (cs.root_out) *cs.root_out = buf[0];       // no coin step: only the root, once more, where the host reads it
+        if (cs.flag_out) { __threadfence_system(); *(volatile uint32_t*)cs.flag_out = cs.flag_seq; }      // everything above is thread 0's own
+    }
 }
 
 // Same subtree build with FOUR lanes per compression (a quad holds one column of the 4 x 4 BLAKE2s state each: lane j has
@@ -309,7 +315,7 @@ __device__ __forceinline__ void quad_merge(const uint32_t* msg, int j, const uin
 // lone lane needs 2.4 us per compression and the step is 2 of them on the critical path of every layer.
 // scratch: 24 words of LDS, words [0, 8) = the root on entry. Returns the challenge (both components) to every thread.
 __device__ __forceinline__ void coin_step_quad(Digest* seed_io, int deg, uint32_t* scratch, int tid, int j, const uint32_t (&pk)[10],
-                                               uint64_t& a0, uint64_t& a1) {
+                                               uint64_t& a0, uint64_t& a1, Digest* seed_out = nullptr) {
     const uint32_t r_lo = scratch[j], r_hi = scratch[4 + j];
     const uint32_t s_lo = seed_io->w[j], s_hi = seed_io->w[4 + j];
     __syncthreads();
@@ -321,6 +327,7 @@ __device__ __forceinline__ void coin_step_quad(Digest* seed_io, int deg, uint32_
     if (tid < 4) {
         scratch[j] = lo; scratch[4 + j] = hi; scratch[8 + j] = 0; scratch[12 + j] = 0;
         seed_io->w[j] = lo; seed_io->w[4 + j] = hi;
+        if (seed_out) { seed_out->w[j] = lo; seed_out->w[4 + j] = hi; }
     }
     a0 = a1 = 0;
     for (uint32_t ctr = 1; ctr < 1000; ctr++) {               // draw: first 8 (16) bytes of BLAKE2s(seed || LE64(ctr)), retried while >= p
@@ -370,11 +377,16 @@ __global__ __launch_bounds__(256) void merkle_multi_quad_kernel(Digest* nodes, s
             __syncthreads();
         }
     }
+    if (m == 1 && tid == 0 && cs.root_out) store_digest(cs.root_out, buf[0]);      // also without a coin step: the root, once more, where the host reads it (mapped memory)
     if (cs.seed_io && m == 1) {       // uniform over the (single) workgroup
         uint64_t a0, a1;
-        if (tid == 0 && cs.root_out) store_digest(cs.root_out, buf[0]);
-        coin_step_quad(cs.seed_io, cs.deg, words, tid, j, pk, a0, a1);
+        coin_step_quad(cs.seed_io, cs.deg, words, tid, j, pk, a0, a1, cs.seed_out);
         if (tid == 0) { cs.alpha_out[0] = a0; if (cs.deg > 1) cs.alpha_out[1] = a1; }
+    }
+    if (m == 1 && cs.flag_out) {      // uniform: the host's completion word, behind everything this workgroup stored for the host
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) *(volatile uint32_t*)cs.flag_out = cs.flag_seq;
     }
 }
 
@@ -436,7 +448,7 @@ template <int LOGF> __global__ __launch_bounds__(512) void fri_tail_kernel(FriTa
         {
             if (tid == 0) store_digest(&a.roots_out[L], dig[0]);
             uint64_t a0, a1;
-            coin_step_quad(a.seed_io, deg, words, tid, j, pk, a0, a1);     // words [0, 8) = the root; the level buffer is free again
+            coin_step_quad(a.seed_io, deg, words, tid, j, pk, a0, a1, a.seed_out);     // words [0, 8) = the root; the level buffer is free again
             if (tid == 0) {
                 s_alpha[0] = a0; s_alpha[1] = a1;
                 a.alphas_out[(size_t)L * deg] = a0;
@@ -489,6 +501,11 @@ template <int LOGF> __global__ __launch_bounds__(512) void fri_tail_kernel(FriTa
         for (int k = 0; k < LOGF; k++) wn = gl::sqr(wn);
         w_inv = wn;
     }
+    if (a.flag_out) {             // the host's completion word, behind every root / seed this workgroup stored for it (Context::wait_flag)
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) *(volatile uint32_t*)a.flag_out = a.flag_seq;
+    }
 }
 void Context::fri_tail(const FriTailArgs& a, int fold) {
     if (a.dom0 > (uint32_t)FRI_TAIL_MAX_DOM || a.dom0 / (uint32_t)fold > (uint32_t)FRI_TAIL_MAX_ROWS || a.n_layers < 1 || a.n_layers > FRI_TAIL_MAX_LAYERS)
@@ -528,6 +545,57 @@ template <class Src> __global__ __launch_bounds__(256) void merkle_recompute_ker
         if (lvl < h && ((lane8 >> lvl) & 1) == 0) d = b2s::merge(d, o);
     }
     if (live && lane8 == 0) out[q] = d;
+}
+
+// Every opened value and tree node of a proof in ONE launch (round 5): the first blocks gather through the host-built address list (as
+// gather_addr_kernel in stark.hip does), the blocks behind them recompute the unstored low nodes of up to OPEN_MAX_JOBS trees of row
+// matrices (as merkle_recompute_kernel does, 8 lanes per node). The address list and the node indices are READ from mapped pinned memory and
+// the value block is WRITTEN to mapped pinned memory: no upload, no download, one launch instead of three to four - the opening phase of one
+// proof alone was a copy, a 4 us gather and two 12 us recomputations in a row, then a copy back (47 us, AERO_QUERY_TIMING).
+__global__ __launch_bounds__(256) void openings_kernel(OpeningArgs a) {
+    if (blockIdx.x < a.gather_blocks) {
+        const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+        if (t < a.n_u64) {
+            const uint64_t* p = reinterpret_cast<const uint64_t*>(a.addr[t]);
+            a.out[t] = p ? *p : 0;
+        } else if (t < a.n_u64 + a.n_dig) {
+            const uint32_t i = t - a.n_u64;
+            const ulonglong2* p = reinterpret_cast<const ulonglong2*>(a.addr[t]);
+            ulonglong2 x = make_ulonglong2(0, 0), y = x;
+            if (p) { x = p[0]; y = p[1]; }
+            uint64_t* o = a.out + a.n_u64 + 4 * (size_t)i;
+            o[0] = x.x; o[1] = x.y; o[2] = y.x; o[3] = y.y;
+        }
+        return;
+    }
+    uint32_t b = blockIdx.x - a.gather_blocks;
+    int job = 0;
+    while (job + 1 < a.n_jobs && b >= a.jobs[job].blocks) { b -= a.jobs[job].blocks; job++; }
+    const OpeningArgs::Job& J = a.jobs[job];
+    const int t = (int)b * 256 + (int)threadIdx.x;
+    const int q = t >> 3, lane8 = t & 7;
+    const bool live = q < J.count;
+    const size_t n = J.n;
+    uint64_t node = live ? J.idx[q] : n;
+    int h = 0;
+    while ((node << h) < n) h++;              // node << h lands in [n, 2n); h <= 3
+    const size_t first = (node << h) - n;
+    const int cnt = 1 << h;
+    Digest d = leaf_digest(J.src, first + (lane8 < cnt ? lane8 : 0));
+    for (int lvl = 0; lvl < 3; lvl++) {       // uniform trip count: every lane takes part in the shuffles
+        Digest o;
+#pragma unroll
+        for (int k = 0; k < 8; k++) o.w[k] = __shfl_xor((int)d.w[k], 1 << lvl);
+        if (lvl < h && ((lane8 >> lvl) & 1) == 0) d = b2s::merge(d, o);
+    }
+    if (live && lane8 == 0) store_digest(&J.out[q], d);
+}
+void Context::openings(const OpeningArgs& a) {
+    uint32_t blocks = a.gather_blocks;
+    for (int j = 0; j < a.n_jobs; j++) blocks += a.jobs[j].blocks;
+    if (!blocks) return;
+    AERO_LAUNCH(this, "openings_kernel", 0, openings_kernel, dim3(blocks), dim3(256), 0, a);
+    check_launch("openings");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -615,7 +683,7 @@ template <> size_t src_leaf_bytes<RowSrc>(const RowSrc& s) { return (size_t)s.nc
 template <> size_t src_leaf_bytes<FriSrc>(const FriSrc& s) { return (size_t)s.fold * s.deg * 8; }
 
 // leaves + whole tree from a leaf source; the lowest `skip` levels (0 or 3) are not stored.
-template <class Src> void Context::merkle_commit(const Src& src, size_t n, Digest* nodes, int skip) {
+template <class Src> void Context::merkle_commit(const Src& src, size_t n, Digest* nodes, int skip, const CoinStep* coin) {
     if (n < 8 || (n & (n - 1))) fail("merkle_commit: leaf count must be a power of two >= 8");
     if (skip != 0 && skip != 3) fail("merkle_commit: skip must be 0 or 3", ST_INTERNAL);
     const size_t stored = skip ? (n / 8) * 32 : (n + n / 2 + n / 4 + n / 8) * 32;
@@ -631,10 +699,10 @@ template <class Src> void Context::merkle_commit(const Src& src, size_t n, Diges
         else done = false;
     }
     if (!done) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_kernel<Src>), grid, block, 0, src, nodes, n, skip);
-    merkle_upper(nodes, n / 8);
+    merkle_upper(nodes, n / 8, coin);
 }
-template void Context::merkle_commit<RowSrc>(const RowSrc&, size_t, Digest*, int);
-template void Context::merkle_commit<FriSrc>(const FriSrc&, size_t, Digest*, int);
+template void Context::merkle_commit<RowSrc>(const RowSrc&, size_t, Digest*, int, const CoinStep*);
+template void Context::merkle_commit<FriSrc>(const FriSrc&, size_t, Digest*, int, const CoinStep*);
 
 template <class Src> void Context::merkle_recompute(const Src& src, size_t n, const uint64_t* idx_dev, int count, Digest* out_dev) {
     if (count <= 0) return;

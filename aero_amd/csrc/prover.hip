@@ -44,6 +44,7 @@ Context::~Context() {
     for (void* p : persistent) (void)hipFree(p);
     unload_jit_modules(this);   // may run on whichever host thread drops the last handle: not while another thread loads a module
     if (stage_base) (void)hipHostFree(stage_base);
+    if (flag_host) (void)hipHostFree(flag_host);
     if (pinned_flag) (void)hipHostFree(pinned_flag);
     for (auto& r : kt_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (hipEvent_t e : kt_pool) (void)hipEventDestroy(e);
@@ -168,6 +169,7 @@ void* Context::stage_alloc(size_t bytes) {
     if (!stage_base) {
         stage_cap = (size_t)8 << 20;
         AERO_HIP(hipHostMalloc((void**)&stage_base, stage_cap, hipHostMallocDefault));
+        AERO_HIP(hipHostGetDevicePointer((void**)&stage_dev_base, stage_base, 0));
     }
     if (bytes > stage_cap) fail("staging request too large", ST_INTERNAL);
     if (stage_off + bytes > stage_cap) { sync(); stage_off = 0; }   // wrap only when every earlier copy has completed
@@ -186,6 +188,29 @@ void Context::check_launch(const char* what) {
 void Context::sync() {
     hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess) throw Error(ST_HIP, std::string("stream synchronize: ") + hipGetErrorString(e));
+}
+
+uint32_t Context::next_flag() {
+    if (!flag_host) {
+        AERO_HIP(hipHostMalloc((void**)&flag_host, 64, hipHostMallocDefault));
+        AERO_HIP(hipHostGetDevicePointer((void**)&flag_dev, flag_host, 0));
+        *flag_host = 0;
+    }
+    if (++flag_seq == 0) ++flag_seq;
+    return flag_seq;
+}
+void Context::wait_flag(uint32_t seq) {
+    static const bool poll = !(getenv("AERO_POLL_FLAGS") && getenv("AERO_POLL_FLAGS")[0] == '0');
+    if (!poll) { sync(); return; }
+    volatile uint32_t* f = flag_host;
+    for (uint32_t spin = 1;; spin++) {
+        if (*f == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return; }
+        if ((spin & 2047u) == 0) {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e == hipSuccess) return;                   // drained: whatever the kernels wrote is visible
+            if (e != hipErrorNotReady) throw Error(ST_HIP, std::string("stream query: ") + hipGetErrorString(e));
+        }
+    }
 }
 
 void Context::fetch(void* dst, const void* dev_src, size_t bytes) {
@@ -488,13 +513,21 @@ MerkleTree Prover::commit_to_rows(const Matrix& lde, bool keep_low_levels) {
     const int skip = (fused && !keep_low_levels && low_level_skip) ? 3 : 0;   // never stores 7/8 of the digests
     MerkleTree t(ctx_, lde.rows, skip);
     if (skip) { t.src_kind = 1; t.row_src = src; }
+    // the launch that produces the root stores it a second time, in mapped pinned memory: the host waits for the stream and reads it there
+    // (no copy kernel between the tree and the transcript); a tree so small that no upper-level launch runs is fetched the old way
+    Digest* h_root = (Digest*)ctx_->stage_alloc(sizeof(Digest));
+    CoinStep cs;
+    cs.root_out = ctx_->stage_dev(h_root);
+    cs.flag_seq = ctx_->next_flag(); cs.flag_out = ctx_->flag_dev;
+    const bool mapped = (fused ? lde.rows / 8 : lde.rows) > 1;
     if (fused) {
-        ctx_->merkle_commit(src, lde.rows, t.nodes.get(), skip);
+        ctx_->merkle_commit(src, lde.rows, t.nodes.get(), skip, mapped ? &cs : nullptr);
     } else {
         ctx_->hash_rows(lde.data.get(), lde.rows, lde.cols, lde.rows, t.leaves());
-        ctx_->merkle_build(t.nodes.get(), t.n);
+        ctx_->merkle_build(t.nodes.get(), t.n, mapped ? &cs : nullptr);
     }
-    ctx_->fetch(&t.root_host, t.nodes.get() + 1, sizeof(Digest));
+    if (mapped) { ctx_->wait_flag(cs.flag_seq); t.root_host = *h_root; }
+    else ctx_->fetch(&t.root_host, t.nodes.get() + 1, sizeof(Digest));
     return t;
 }
 MerkleTree Prover::commit_fri_layer(const FriSrc& src, bool keep_low_levels) {
@@ -511,13 +544,17 @@ MerkleTree Prover::commit_fri_layer(const FriSrc& src, bool keep_low_levels) {
     (void)keep_low_levels;
     MerkleTree t(ctx_, rows, skip);
     if (skip) { t.src_kind = 2; t.fri_src = src; }
+    Digest* h_root = (Digest*)ctx_->stage_alloc(sizeof(Digest));
+    CoinStep cs;
+    cs.root_out = ctx_->stage_dev(h_root);
     if (fused) {
-        ctx_->merkle_commit(src, rows, t.nodes.get(), skip);
+        ctx_->merkle_commit(src, rows, t.nodes.get(), skip, &cs);
     } else {
         ctx_->hash_fri_rows(src, t.leaves());
-        ctx_->merkle_build(t.nodes.get(), rows);
+        ctx_->merkle_build(t.nodes.get(), rows, &cs);        // rows >= 2: the launch that writes node 1 exists
     }
-    ctx_->fetch(&t.root_host, t.nodes.get() + 1, sizeof(Digest));
+    ctx_->sync();
+    t.root_host = *h_root;
     return t;
 }
 
@@ -529,7 +566,9 @@ MerkleTree Prover::commit_fri_layer_async(const FriSrc& src, const CoinStep* coi
         if (coin) {
             if (coin->deg == 1) launch_fri_coin_step<FB>(ctx_, coin->seed_io, t.nodes.get() + 1, coin->alpha_out);
             else launch_fri_coin_step<FQ>(ctx_, coin->seed_io, t.nodes.get() + 1, reinterpret_cast<gl::E2*>(coin->alpha_out));
-            if (coin->root_out) AERO_HIP(hipMemcpyAsync(coin->root_out, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDeviceToDevice, ctx_->stream));
+            // root_out / seed_out may be mapped pinned memory (the block the host reads after the last layer): hipMemcpyDefault
+            if (coin->root_out) AERO_HIP(hipMemcpyAsync(coin->root_out, t.nodes.get() + 1, sizeof(Digest), hipMemcpyDefault, ctx_->stream));
+            if (coin->seed_out) AERO_HIP(hipMemcpyAsync(coin->seed_out, coin->seed_io, sizeof(Digest), hipMemcpyDefault, ctx_->stream));
         }
         return t;
     }
@@ -798,8 +837,11 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
     const uint64_t gen_inv = gl::inv(gl::GEN);
     // The transcript steps of the commit phase (reseed with the root, draw alpha) run on the device, so every layer is enqueued
     // without a host round trip; the roots come back with ONE copy at the end and the host replays the coin to stay in step.
-    Digest* d_roots = (Digest*)ctx->scratch_alloc(sizeof(Digest) * (fl.layers + 2));   // roots of all layers, then the final seed
-    Digest* d_seed = d_roots + fl.layers + 1;
+    // the roots (and, after every step, the coin's seed) are ALSO stored in mapped pinned memory by the launches that produce them: after the
+    // last layer the host waits for the stream and finds them - no copy. The seed the device steps stays in device memory.
+    Digest* h_block = (Digest*)ctx->stage_alloc(sizeof(Digest) * (fl.layers + 2));      // roots of all layers, then the final seed
+    Digest* d_roots = ctx->stage_dev(h_block);
+    Digest* d_seed = (Digest*)ctx->scratch_alloc(sizeof(Digest));
     T* d_alpha = (T*)ctx->scratch_alloc(sizeof(T) * (fl.layers + 1));
     Digest* h_seed = (Digest*)ctx->stage_alloc(sizeof(Digest));
     *h_seed = coin.seed;
@@ -808,6 +850,7 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
     uint64_t dom = N;
     // layers of at most FRI_TAIL_MAX_DOM points are pure latency: they all go into ONE single-workgroup launch (Context::fri_tail)
     int tail0 = fl.layers + 1;
+    uint32_t fri_flag = 0;
     if (fri_tail && (Fd == 2 || Fd == 4 || Fd == 8)) {
         uint64_t d = N;
         for (int l = 0; l <= fl.layers; l++, d /= Fd)
@@ -817,7 +860,7 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
         const size_t rows = dom / Fd;
         const FriSrc fsrc{fl.vals[l].get(), fl.vals[l].get() + (F::DEG > 1 ? dom : 0), F::DEG, rows, (int)Fd};
         Commitment c;
-        const CoinStep cs{d_seed, reinterpret_cast<uint64_t*>(d_alpha + l), F::DEG, d_roots + l};
+        const CoinStep cs{d_seed, reinterpret_cast<uint64_t*>(d_alpha + l), F::DEG, d_roots + l, d_roots + fl.layers + 1};
         c.tree = commit_fri_layer_async(fsrc, &cs);
         c.n_global = rows;
         fl.coms.push_back(std::move(c));
@@ -852,11 +895,14 @@ template <class F> FriLayers Prover::fri_build_layers(DevBuf<uint64_t>&& evals, 
             }
             dd = rows;
         }
-        t.roots_out = d_roots + tail0; t.seed_io = d_seed; t.alphas_out = reinterpret_cast<uint64_t*>(d_alpha + tail0);
+        t.flag_seq = fri_flag = ctx->next_flag(); t.flag_out = ctx->flag_dev;
+        t.roots_out = d_roots + tail0; t.seed_io = d_seed; t.seed_out = d_roots + fl.layers + 1; t.alphas_out = reinterpret_cast<uint64_t*>(d_alpha + tail0);
         t.gen_inv = gen_inv; t.fold_inv = gl::inv(Fd); t.w_inv0 = gl::inv(gl::root_of_unity(ilog2(dom)));
         ctx->fri_tail(t, (int)Fd);
     }
-    ctx->fetch(h_roots.data(), d_roots, sizeof(Digest) * (fl.layers + 2));
+    if (fri_flag) ctx->wait_flag(fri_flag);      // the tail launch is the last one and a single workgroup: it signals through the completion word
+    else ctx->sync();
+    memcpy(h_roots.data(), h_block, sizeof(Digest) * (fl.layers + 2));
     *h_seed = h_roots[fl.layers + 1];
     for (int l = 0; l <= fl.layers; l++) {
         Commitment& c = fl.coms[l];
@@ -977,13 +1023,11 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     if (host_trace_) {
         for (uint32_t c = 0; c < W; c++) h_last_row[c] = host_trace_[(size_t)c * n + (n - 1)];
     } else {
+        // position and row both live in mapped pinned memory: the gather reads its one position from the host and stores the row where
+        // the host reads it after the first commitment's synchronisation (two copy launches less at the start of every proof)
         uint64_t* h_pos = (uint64_t*)ctx->stage_alloc(8);
         *h_pos = n - 1;
-        uint64_t* d_pos = (uint64_t*)ctx->scratch_alloc(8);
-        uint64_t* d_row = (uint64_t*)ctx->scratch_alloc((size_t)W * 8);
-        AERO_HIP(hipMemcpyAsync(d_pos, h_pos, 8, hipMemcpyHostToDevice, ctx->stream));
-        launch_gather_rows(ctx, trace_dev, n, (int)W, d_pos, 1, d_row);
-        AERO_HIP(hipMemcpyAsync(h_last_row, d_row, (size_t)W * 8, hipMemcpyDeviceToHost, ctx->stream));
+        launch_gather_rows(ctx, trace_dev, n, (int)W, ctx->stage_dev(h_pos), 1, ctx->stage_dev(h_last_row));
     }
     StarkProof proof;
     proof.main_width = (uint8_t)W; proof.aux_width = (uint8_t)A; proof.aux_rands = (uint8_t)R; proof.log_n = (uint8_t)log_n; proof.options = opt_;
@@ -1330,20 +1374,39 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     const T z_next = F::mulb(z, g), z_c = gl::fpow<F>(z, C);
     std::vector<T> ood(2 * W + C + 2 * A);
     {
-        DevBuf<T> d_out(ctx, 2 * W + C + 2 * A);
-        if (A) launch_eval_bitrev<F>(ctx, apolys.data.get(), (size_t)F::DEG * n, n, (int)A, F::DEG, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get() + 2 * W + C);
-        if (G > 1 && W >= (uint32_t)G && W % (uint32_t)G == 0) {
+        // one GPU: the reductions store the frame in mapped pinned memory (the host waits for the stream, no copy); sharded: a device buffer,
+        // the all-gather writes into it
+        T* h_ood = (T*)ctx->stage_alloc(ood.size() * sizeof(T));
+        DevBuf<T> d_ood_buf;
+        if (G > 1) d_ood_buf = DevBuf<T>(ctx, 2 * W + C + 2 * A);
+        struct { T* p; T* get() const { return p; } } d_out{G > 1 ? d_ood_buf.get() : ctx->stage_dev(h_ood)};
+        const bool split_ood = G > 1 && W >= (uint32_t)G && W % (uint32_t)G == 0;
+        if (A && split_ood) launch_eval_bitrev<F>(ctx, apolys.data.get(), (size_t)F::DEG * n, n, (int)A, F::DEG, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get() + 2 * W + C);
+        if (split_ood) {
             // the value of a column polynomial at z does not depend on the coset a rank holds its coefficients for: every rank
             // evaluates W / G columns, one small all-gather (2 W / G elements per rank) completes the frame everywhere
             const uint32_t cpr = W / (uint32_t)G;
             DevBuf<T> part(ctx, 2 * cpr);
             launch_eval_bitrev<F>(ctx, polys.data.get() + (size_t)rank * cpr * n, n, 0, (int)cpr, 1, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, part.get());
             comm_all_gather(part.get(), d_out.get(), 2 * cpr * sizeof(T));
+            launch_eval_bitrev<F>(ctx, hbuf.get(), n, ceN, (int)C, F::DEG, log_n, F::mulb(z_c, h_inv), F::zero(), 1, d_out.get() + 2 * W);
         } else {
-            launch_eval_bitrev<F>(ctx, polys.data.get(), n, 0, (int)W, 1, log_n, F::mulb(z, h_inv), F::mulb(z_next, h_inv), 2, d_out.get());
+            // one GPU: the whole frame in three launches (tables, block sums, reduction) - trace polynomials at (z, z g), composition columns at
+            // z^C and, below, nothing more; a sharded proof keeps the separate evaluations (its trace part is all-gathered)
+            EvalJob<F> jobs[EVAL_MAX_JOBS];
+            int nj = 0;
+            jobs[nj].coeffs = polys.data.get(); jobs[nj].col_stride = n; jobs[nj].comp_stride = 0; jobs[nj].ncols = (int)W; jobs[nj].comps = 1; jobs[nj].npts = 2;
+            jobs[nj].y0 = F::mulb(z, h_inv); jobs[nj].y1 = F::mulb(z_next, h_inv); jobs[nj].out_off = 0; nj++;
+            jobs[nj].coeffs = hbuf.get(); jobs[nj].col_stride = n; jobs[nj].comp_stride = ceN; jobs[nj].ncols = (int)C; jobs[nj].comps = F::DEG; jobs[nj].npts = 1;
+            jobs[nj].y0 = F::mulb(z_c, h_inv); jobs[nj].y1 = F::zero(); jobs[nj].out_off = 2 * W; nj++;
+            if (A) {
+                jobs[nj].coeffs = apolys.data.get(); jobs[nj].col_stride = (size_t)F::DEG * n; jobs[nj].comp_stride = n; jobs[nj].ncols = (int)A; jobs[nj].comps = F::DEG; jobs[nj].npts = 2;
+                jobs[nj].y0 = F::mulb(z, h_inv); jobs[nj].y1 = F::mulb(z_next, h_inv); jobs[nj].out_off = 2 * W + (uint32_t)C; nj++;
+            }
+            launch_eval_multi<F>(ctx, jobs, nj, log_n, d_out.get());
         }
-        launch_eval_bitrev<F>(ctx, hbuf.get(), n, ceN, (int)C, F::DEG, log_n, F::mulb(z_c, h_inv), F::zero(), 1, d_out.get() + 2 * W);
-        ctx->fetch(ood.data(), d_out.get(), ood.size() * sizeof(T));
+        if (G > 1) ctx->fetch(ood.data(), d_out.get(), ood.size() * sizeof(T));
+        else { ctx->sync(); memcpy(ood.data(), h_ood, ood.size() * sizeof(T)); }
     }
     std::vector<T> ood_cur(TW), ood_next(TW), ood_h(C);
     for (uint32_t c = 0; c < W; c++) { ood_cur[c] = ood[2 * c]; ood_next[c] = ood[2 * c + 1]; }
@@ -1567,6 +1630,32 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             for (auto& v : low_idx) { memcpy(h_addr + o, v.data(), v.size() * 8); o += v.size(); }
         }
         uint64_t* h_val = (uint64_t*)ctx->stage_alloc((voff + 4 * n_low) * 8);
+        // One GPU, row-matrix trees only (every proof of this library but a sharded one): ONE launch gathers the values and recomputes the
+        // unstored low nodes, reading the lists from and writing the block to mapped pinned memory (hash.hip: openings_kernel)
+        bool fused_open = G == 1;
+        {
+            int jobs = 0;
+            for (size_t t = 0; t < coms.size(); t++) if (!low_idx[t].empty()) { jobs++; fused_open = fused_open && coms[t]->tree.src_kind == 1; }
+            fused_open = fused_open && jobs <= OPEN_MAX_JOBS;
+        }
+        if (fused_open) {
+            OpeningArgs oa;
+            oa.addr = ctx->stage_dev(h_addr); oa.n_u64 = (uint32_t)n_u64; oa.n_dig = (uint32_t)n_dig; oa.gather_blocks = (uint32_t)((n_u64 + n_dig + 255) / 256);
+            oa.out = ctx->stage_dev(h_val);
+            size_t o = 0;
+            for (size_t t = 0; t < coms.size(); t++) {
+                const int nl = (int)low_idx[t].size();
+                if (!nl) continue;
+                OpeningArgs::Job& J = oa.jobs[oa.n_jobs++];
+                J.src = coms[t]->tree.row_src; J.n = coms[t]->tree.n; J.idx = ctx->stage_dev(h_addr) + addr.size() + o; J.count = nl;
+                J.blocks = (uint32_t)((nl * 8 + 255) / 256); J.out = reinterpret_cast<Digest*>(ctx->stage_dev(h_val) + voff) + o;
+                o += nl;
+            }
+            ctx->openings(oa);
+            q_lap("enqueue");
+            ctx->sync();
+            q_lap("device_round_trip");
+        } else {
         DevBuf<uint64_t> d_addr(ctx, addr.size() + n_low), d_val(ctx, voff + 4 * n_low);
         AERO_HIP(hipMemcpyAsync(d_addr.get(), h_addr, (addr.size() + n_low) * 8, hipMemcpyHostToDevice, ctx->stream));
         launch_gather_addr(ctx, d_addr.get(), (uint32_t)n_u64, (uint32_t)n_dig, d_val.get());
@@ -1585,8 +1674,12 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         }
         q_lap("enqueue");
         if (G > 1) comm_all_reduce(d_val.get(), voff);
-        ctx->fetch(h_val, d_val.get(), (voff + 4 * n_low) * 8);
+        {   // straight into h_val (fetch() would stage the block a second time)
+            AERO_HIP(hipMemcpyAsync(h_val, d_val.get(), (voff + 4 * n_low) * 8, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->sync();
+        }
         q_lap("device_round_trip");
+        }
         {
             size_t o = 0;
             for (size_t t = 0; t < coms.size(); t++)

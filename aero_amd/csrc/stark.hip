@@ -263,6 +263,81 @@ template <class F> __global__ __launch_bounds__(256) void eval_reduce_kernel(con
     }
     if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
+// ---- the same for several jobs of one length at once (stark_kernels.hpp: EvalMultiArgs) ----
+template <class F> __global__ void eval_ktab_multi_kernel(EvalMultiArgs<F> a) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, job = blockIdx.y;
+    if (k >= (1u << a.r)) return;
+    const uint32_t e = gl::bitrev(k, a.r);
+    typename F::T* tab = a.ktab + ((size_t)job * 2 << a.r);
+    tab[k] = gl::fpow<F>(a.b0[job], e);
+    if (a.jobs[job].npts > 1) tab[(1u << a.r) + k] = gl::fpow<F>(a.b1[job], e);
+}
+template <class F> __global__ __launch_bounds__(256) void eval_bitrev_multi_kernel(EvalMultiArgs<F> a) {
+    typedef typename F::T T;
+    __shared__ T red[2][256];
+    const uint32_t blk = blockIdx.x;
+    uint32_t col = blockIdx.y;
+    int job = 0;
+    while (job + 1 < a.n_jobs && col >= (uint32_t)a.jobs[job].ncols) { col -= (uint32_t)a.jobs[job].ncols; job++; }
+    const EvalJob<F>& J = a.jobs[job];
+    const int R = 1 << a.r;
+    const T* ktab = a.ktab + ((size_t)job * 2 << a.r);
+    const uint64_t* c0 = J.coeffs + (size_t)col * J.col_stride + ((size_t)blk << a.r);
+    const uint64_t* c1 = J.comps > 1 ? c0 + J.comp_stride : c0;
+    T acc0 = F::zero(), acc1 = F::zero();
+    for (int k = threadIdx.x; k < R; k += 256) {
+        if (J.comps == 1) {
+            const uint64_t c = c0[k];
+            acc0 = F::add(acc0, F::mulb(ktab[k], c));
+            if (J.npts > 1) acc1 = F::add(acc1, F::mulb(ktab[R + k], c));
+        } else {
+            const T c = F::make(c0[k], c1[k]);
+            acc0 = F::add(acc0, F::mul(ktab[k], c));
+            if (J.npts > 1) acc1 = F::add(acc1, F::mul(ktab[R + k], c));
+        }
+    }
+    red[0][threadIdx.x] = acc0; red[1][threadIdx.x] = acc1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] = F::add(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+            red[1][threadIdx.x] = F::add(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < (unsigned)J.npts) {
+        const uint32_t rb = gl::bitrev(blk, a.L - a.r);
+        const T y = threadIdx.x == 0 ? J.y0 : J.y1;
+        const T v = F::mul(red[threadIdx.x][0], gl::fpow<F>(y, rb));
+        a.partials[((size_t)J.out_off + (size_t)col * J.npts + threadIdx.x) * gridDim.x + blk] = v;
+    }
+}
+template <class F> void launch_eval_multi(Context* ctx, const EvalJob<F>* jobs, int n_jobs, int L, typename F::T* out) {
+    typedef typename F::T T;
+    if (n_jobs < 1 || n_jobs > EVAL_MAX_JOBS) fail("eval_multi: bad job count", ST_INTERNAL);
+    EvalMultiArgs<F> a;
+    a.n_jobs = n_jobs; a.L = L; a.r = L < 10 ? L : 10;
+    const uint32_t nblk = 1u << (L - a.r);
+    uint32_t cols = 0, outs = 0;
+    size_t abytes = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        a.jobs[j] = jobs[j];
+        a.b0[j] = gl::fpow<F>(jobs[j].y0, 1ull << (L - a.r));
+        a.b1[j] = jobs[j].npts > 1 ? gl::fpow<F>(jobs[j].y1, 1ull << (L - a.r)) : F::zero();
+        cols += (uint32_t)jobs[j].ncols; outs += (uint32_t)(jobs[j].ncols * jobs[j].npts);
+        abytes += ((size_t)jobs[j].ncols * jobs[j].comps * 8) << L;
+    }
+    for (int j = n_jobs; j < EVAL_MAX_JOBS; j++) { a.jobs[j] = EvalJob<F>{}; a.jobs[j].y0 = a.jobs[j].y1 = F::zero(); a.b0[j] = a.b1[j] = F::zero(); }
+    a.ktab = (T*)ctx->scratch_alloc(sizeof(T) * 2 * (size_t)n_jobs * ((size_t)1 << a.r));
+    a.partials = (T*)ctx->scratch_alloc(sizeof(T) * (size_t)outs * nblk);
+    AERO_LAUNCH(ctx, "eval_ktab_kernel", 0, (eval_ktab_multi_kernel<F>), dim3(((1u << a.r) + 255) / 256, n_jobs), dim3(256), 0, a);
+    AERO_LAUNCH(ctx, "eval_bitrev_kernel", abytes, (eval_bitrev_multi_kernel<F>), dim3(nblk, cols), dim3(256), 0, a);
+    AERO_LAUNCH(ctx, "eval_reduce_kernel", 0, (eval_reduce_kernel<F>), dim3(outs), dim3(256), 0, a.partials, nblk, out);
+    ctx->check_launch("eval_multi");
+}
+template void launch_eval_multi<FB>(Context*, const EvalJob<FB>*, int, int, FB::T*);
+template void launch_eval_multi<FQ>(Context*, const EvalJob<FQ>*, int, int, FQ::T*);
+
 // out (device, ncols*npts values, index col*npts + pt)
 template <class F>
 void launch_eval_bitrev(Context* ctx, const uint64_t* coeffs, size_t col_stride, size_t comp_stride, int ncols, int comps, int L,
@@ -536,24 +611,33 @@ __device__ __forceinline__ uint32_t leading_zeros_be(const Digest& d) {
     if (w1) return 32 + __clz(w1);
     return 64;
 }
-__global__ __launch_bounds__(256) void grind_kernel(Digest seed, uint32_t bits, uint64_t first, unsigned long long* best) {
+__global__ __launch_bounds__(256) void grind_kernel(Digest seed, uint32_t bits, uint64_t first, unsigned long long* best, unsigned long long* reset) {
     const uint64_t nonce = first + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reset = ~0ull;         // the slot the NEXT launch takes its minimum in
     Digest d = b2s::merge_with_int(seed, nonce);
     if (leading_zeros_be(d) >= bits) atomicMin(best, (unsigned long long)nonce);
 }
-// Returns the smallest nonce >= 1 with the required leading zeros (synchronises the stream once per batch).
+// Returns the smallest nonce >= 1 with the required leading zeros (synchronises the stream once per batch). The minimum is taken in one of
+// two device words that the launches use in turn: every launch also resets the OTHER word, so no launch needs a fill in front of it (one
+// small launch less on the critical path of every proof).
 uint64_t run_grind(Context* ctx, const Digest& seed, uint32_t bits) {
     if (bits == 0) return 1;
-    DevBuf<unsigned long long> d_best(ctx, 1);
-    AERO_HIP(hipMemsetAsync(d_best.get(), 0xff, 8, ctx->stream));
+    if (!ctx->grind_slots) {
+        ctx->grind_slots = (unsigned long long*)ctx->dev_alloc(16);
+        AERO_HIP(hipMemsetAsync(ctx->grind_slots, 0xff, 16, ctx->stream));
+        ctx->grind_parity = 0;
+    }
     // batch = 4x the expected number of trials (a batch without a hit has probability e^-4), at least 2^16
     uint64_t batch = 1ull << (bits + 2 < 16 ? 16 : bits + 2);
     if (batch > (1ull << 30)) batch = 1ull << 30;
     for (uint64_t first = 1;; first += batch) {
-        AERO_LAUNCH(ctx, "grind_kernel", 0, grind_kernel, dim3((unsigned)(batch / 256)), dim3(256), 0, seed, bits, first, d_best.get());
+        unsigned long long* slot = ctx->grind_slots + ctx->grind_parity;
+        unsigned long long* other = ctx->grind_slots + (ctx->grind_parity ^ 1);
+        ctx->grind_parity ^= 1;
+        AERO_LAUNCH(ctx, "grind_kernel", 0, grind_kernel, dim3((unsigned)(batch / 256)), dim3(256), 0, seed, bits, first, slot, other);
         ctx->check_launch("grind");
         unsigned long long best = 0;
-        ctx->fetch(&best, d_best.get(), 8);
+        ctx->fetch(&best, slot, 8);
         if (best != ~0ull) return best;
         if (first > (1ull << 40)) fail("grind: no nonce found", ST_INTERNAL);
     }

@@ -59,6 +59,28 @@ template <class F>
 void launch_eval_bitrev(Context* ctx, const uint64_t* coeffs, size_t col_stride, size_t comp_stride, int ncols, int comps, int L,
                         typename F::T y0, typename F::T y1, int npts, typename F::T* out);
 
+// Several evaluations of the same length in THREE launches (tables, block sums, reduction) instead of three each: the OOD frame of a proof is
+// the trace polynomials at (z, z g), the auxiliary ones at the same points and the composition columns at z^C - nine small launches in a row on
+// the critical path of one proof. out index of (job, column, point) = job.out_off + column * npts + point.
+constexpr int EVAL_MAX_JOBS = 3;
+template <class F> struct EvalJob {
+    typedef typename F::T T;
+    const uint64_t* coeffs = nullptr;
+    size_t col_stride = 0, comp_stride = 0;
+    int ncols = 0, comps = 1, npts = 1;
+    T y0, y1;                      // evaluation points (y1 unused when npts = 1)
+    uint32_t out_off = 0;          // first output index of this job
+};
+template <class F> struct EvalMultiArgs {
+    typedef typename F::T T;
+    EvalJob<F> jobs[EVAL_MAX_JOBS];
+    T b0[EVAL_MAX_JOBS], b1[EVAL_MAX_JOBS];     // y^(2^(L - r)) per job: bases of the in-block tables
+    int n_jobs, L, r;
+    T* ktab;                       // [job][2][2^r]
+    T* partials;                   // [output index][block]
+};
+template <class F> void launch_eval_multi(Context* ctx, const EvalJob<F>* jobs, int n_jobs, int L, typename F::T* out);
+
 template <class F> struct DeepArgs {
     typedef typename F::T T;
     const uint64_t* tlde;   // W x N

@@ -61,7 +61,12 @@ typedef struct aero_fib_air {
 
 /* ---- context --------------------------------------------------------------------------------------------------- */
 /* One context = one GPU + one HIP stream + a device memory pool. (Reference has no analogue: its workers are
- * web workers, aero-sdk/miden-wasm/src/pool.rs:28-45.) */
+ * web workers, aero-sdk/miden-wasm/src/pool.rs:28-45.)
+ * A context is SINGLE-device on purpose. SURVEY 8(b) sketched `ctx_create(device list)`; what was built instead keeps the
+ * one-process-per-GPU model of the launch contract intact and composes from the outside: several GPUs work on ONE proof through an
+ * aero_comm handed to the *_sharded entry points - RCCL between processes (aero_rccl_*), or the in-process group for a host that
+ * drives several devices from one process with a context per device (aero_local_group_*); several proofs in flight on one GPU
+ * are an aero_pool. A multi-device context would have had to own that choice (threads or processes, which exchange library) itself. */
 int32_t aero_device_count(void);
 int32_t aero_ctx_create(int32_t device_id, aero_ctx** out);
 void aero_ctx_destroy(aero_ctx* ctx);

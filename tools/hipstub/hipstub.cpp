@@ -104,6 +104,7 @@ hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, (n + 255) & ~(size_t)2
 hipError_t hipFree(void* p) { sync_all(); free(p); return hipSuccess; }      // hipFree synchronises the device
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { sync_all(); free(p); return hipSuccess; }
+hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
 hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 hipError_t hipHostUnregister(void*) { return hipSuccess; }
 
@@ -124,6 +125,11 @@ hipError_t hipStreamDestroy(hipStream_t s) {
     return hipSuccess;       // the worker thread ends with the last owner
 }
 hipError_t hipStreamSynchronize(hipStream_t s) { S(s)->sync(); return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t s) {
+    Stream* st = &*S(s);
+    std::lock_guard<std::mutex> lk(st->m);
+    return (st->q.empty() && !st->busy) ? hipSuccess : hipErrorNotReady;
+}
 
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(new Event()); return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0); }

@@ -15,7 +15,7 @@ def short(n):
 def main(path, min_gap=2.0):
     rows = [r for r in csv.DictReader(open(path))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ends = [i for i, r in enumerate(rows) if "gather_addr_kernel" in r["Kernel_Name"]]
+    ends = [i for i, r in enumerate(rows) if "gather_addr_kernel" in r["Kernel_Name"] or "openings_kernel" in r["Kernel_Name"]]
     if len(ends) < 2:
         raise SystemExit("need two proofs in the trace")
     seq = rows[ends[-2] + 1:ends[-1] + 1]
