@@ -77,7 +77,7 @@ bool cpus_of_node(const std::string& root, int node, std::vector<int>& out) {
     if (node < 0 || !read_text(root + "/devices/system/node/node" + std::to_string(node) + "/cpulist", text)) return false;
     return parse_cpulist(text.c_str(), out);
 }
-static const char* sysfs_root() { const char* e = getenv("AERO_SYSFS_ROOT"); return e && *e ? e : "/sys"; }
+static const char* sysfs_root() { return "/sys"; }
 int numa_node_of_device(int device) {
     static const bool off = getenv("AERO_NUMA") && getenv("AERO_NUMA")[0] == '0';
     if (off) return -1;

@@ -245,3 +245,29 @@ def test_general_aux_recurrences(tmp_path, log_n, device):
     AERO_AIR_GENERAL_DEVICE=1, one wavefront per column on the device (air_general_column_kernel) - against the oracle's auxiliary columns
     and proof bytes, in both fields, for two programs (one with three general columns that read each other)."""
     run(tmp_path, GENERAL, {"AERO_TEST_LOG_N": str(log_n), "AERO_AIR_GENERAL_DEVICE": device}, timeout=1500)
+
+
+POLL = r'''
+for width, log_n, aux, opt in ((2, 16, (0, 0, 2), [27, 8, 16, 4, 1, 8, 8]), (6, 12, (2, 3, 4), [20, 8, 4, 4, 2, 4, 5]), (72, 12, (0, 0, 2), [27, 8, 8, 4, 1, 8, 6])):
+    want = orc.prove_fib_aux(width, log_n, aux[0], aux[1], opt, D=aux[2])[0] if aux[0] else orc.prove_fib(width, log_n, opt)[0]
+    dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
+    for _ in range(3):
+        got, _ = ctx.prove_fib_aux(dev, aux[0], aux[1], aero_amd.ProofOptions(*opt), aux_degree=aux[2])
+        assert got == want
+pool = aero_amd.Pool(0, 4)
+node, pinned = pool.placement()
+assert (node, pinned) == (-1, 0) if os.environ.get("AERO_NUMA") == "0" else (node >= -1 and pinned <= 4), (node, pinned)
+trace = aero_amd.fib_trace(2, 14)
+want = orc.prove_fib(2, 14, [27, 8, 16, 4, 1, 8, 8])[0]
+for p, _ in pool.prove_fib([pool.ctx(i).trace_upload(trace) for i in range(4)], aero_amd.ProofOptions(27, 8, 16, 4, 1, 8, 8), rounds=3):
+    assert p == want
+pool.close()
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("env", [{"AERO_POLL_FLAGS": "0"}, {"AERO_POLL_FLAGS": "1"}, {"AERO_NUMA": "0"}])
+def test_completion_word_and_placement_switches(tmp_path, env):
+    """AERO_POLL_FLAGS=0: the host waits for the stream at the tree roots and the FRI tail instead of polling the completion word the
+    producing launch stores in mapped pinned memory; AERO_NUMA=0: no thread binding, no node preference for pinned buffers."""
+    run(tmp_path, POLL, env)

@@ -1,5 +1,5 @@
 """Per-kernel HIP-event time of interpolate + 8x LDE for the shapes given ("20x2 20x72"), for A/B runs of NTT variants selected
-through the environment (AERO_NTT_R6, AERO_INV_2PHASE_MIN, ...). Prints one JSON line.   usage: ntt_ab.py [shape ...]"""
+through the environment (AERO_NTT_R128, AERO_NTT_2PHASE, ...) or a whole other build (AERO_LIB_PATH=<libaero_stark_<variant>.so>, `make VARIANT=...`). Prints one JSON line.   usage: ntt_ab.py [shape ...]"""
 import json
 import os
 import sys
