@@ -19,11 +19,11 @@ from collections import defaultdict
 # device function -> the name its launches carry in bench.py's per-kernel table (AERO_LAUNCH name)
 ALIASES = {
     "merkle_leaf8_rows_kernel": "merkle_leaf8_kernel",
-    "ntt_fwd_strided_reg": "ntt_fwd_pass", "ntt_fwd_strided_reg6x2": "ntt_fwd_pass", "ntt_fwd_strided_reg6x2_v": "ntt_fwd_pass", "ntt_fwd_strided_reg7x2": "ntt_fwd_pass", "ntt_inv_last_pass_11": "ntt_inv_pass", "ntt_fwd_first_pass": "ntt_fwd_pass", "ntt_fwd_first_pass_8": "ntt_fwd_pass",
+    "ntt_fwd_strided_reg": "ntt_fwd_pass", "ntt_fwd_strided_reg6x2": "ntt_fwd_pass", "ntt_fwd_strided_reg6x2_v": "ntt_fwd_pass", "ntt_fwd_strided_reg6x2_buf": "ntt_fwd_pass", "ntt_fwd_strided_reg7x2": "ntt_fwd_pass", "ntt_inv_last_pass_11": "ntt_inv_pass", "ntt_fwd_first_pass": "ntt_fwd_pass", "ntt_fwd_first_pass_8": "ntt_fwd_pass",
     "merkle_multi_quad_kernel": "merkle_multi_kernel",
     "ntt_inv_strided_reg": "ntt_inv_pass",
     "merkle_up3_parts_kernel": "merkle_up3_kernel",
-    "fri_fold_fft_kernel": "fri_fold_kernel",
+    "fri_fold_fft_kernel": "fri_fold_kernel", "eval_bitrev_multi_kernel": "eval_bitrev_kernel", "eval_ktab_multi_kernel": "eval_ktab_kernel",
     "aux_block_totals_kernel": "aux_columns_kernel", "aux_scan_totals_kernel": "aux_columns_kernel", "aux_apply_kernel": "aux_columns_kernel",
 }
 
