@@ -427,9 +427,75 @@ def median(xs):
     return xs[m] if len(xs) % 2 else 0.5 * (xs[m - 1] + xs[m])
 
 
+CPU_CHILD = r'''
+import hashlib, json, os, sys, time
+sys.path.insert(0, %(root)r)
+from tests import oracle_lib
+a = json.loads(sys.argv[1])
+orc = oracle_lib.load()
+width, log_n, aux, opt, probe_log, cands = a["width"], a["log_n"], a["aux"], a["opt"], a["probe_log"], a["candidates"]
+def prove(ln):
+    return orc.prove_fib_aux(width, ln, aux[0], aux[1], opt, D=aux[2])
+best = None
+for t in cands:
+    orc.set_threads(t)
+    prove(min(12, log_n))
+    probe = prove(probe_log)[2]
+    if best is None or probe["total"] < best[1]:
+        best = (t, probe["total"])
+cores = best[0]
+orc.set_threads(cores)
+s_log_n = a["sample_log_n"]
+if not s_log_n:
+    projected, s_log_n = best[1] * (1 << max(log_n - probe_log, 0)) * 1.3, log_n
+    while s_log_n > probe_log and projected > 5.0:
+        s_log_n -= 1
+        projected /= 2
+runs, walls, proof = [], [], None
+for i in range(6):                                # run 0 = warm-up
+    t1 = time.perf_counter()
+    proof, _, times = prove(s_log_n)
+    if i:
+        runs.append(times["total"]); walls.append(time.perf_counter() - t1)
+orc.set_threads(1)
+st = prove(a["st_log"])[2]
+print(json.dumps({"cores": cores, "s_log_n": s_log_n, "runs": runs, "walls": walls, "sha256": hashlib.sha256(proof).hexdigest(), "single_total": st["total"]}))
+'''
+
+
 def cpu_baseline_leg(args, log_n, width, over, opt, first_proof):
     """The CPU oracle (oracle/, kind "port") on this box's host cores: thread count picked on a probe, then 1 warm-up + the
-    MEDIAN of 5 complete proofs of the sample (SURVEY 8d / BASELINE.md section 2)."""
+    MEDIAN of 5 complete proofs of the sample (SURVEY 8d / BASELINE.md section 2). The built-in AIR's oracle runs in a process of its own
+    (no torch, no HIP runtime, no pool threads next to its OpenMP team: inside this process the same runs took 1.57 s instead of 1.15 s);
+    the proof's SHA-256 comes back and is compared with the GPU's."""
+    if not over.get("program"):
+        import hashlib
+        import subprocess
+        ncpu = os.cpu_count() or 1
+        aux = over.get("aux") or (0, 0, 2)
+        cols = trace_cols(width, over)
+        probe_log = min(14 if width > 8 else 18, log_n)
+        st_log = min(log_n, 16 if width <= 8 else 13)
+        job = {"width": width, "log_n": log_n, "aux": list(aux), "opt": opt.to_list(), "probe_log": probe_log, "candidates": cpu_thread_candidates(ncpu),
+               "sample_log_n": min(args.cpu_sample_log_n, log_n) if args.cpu_sample_log_n else 0, "st_log": st_log}
+        env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS",)}
+        r = subprocess.run([sys.executable, "-c", CPU_CHILD % {"root": ROOT}, json.dumps(job)], capture_output=True, text=True, timeout=1800, env=env, cwd=ROOT)
+        if r.returncode != 0:
+            raise RuntimeError("cpu baseline child failed: " + r.stderr[-400:])
+        c = json.loads(r.stdout.strip().splitlines()[-1])
+        if c["s_log_n"] == log_n:
+            assert c["sha256"] == hashlib.sha256(first_proof).hexdigest(), "GPU and CPU proofs differ"
+        med = median(c["runs"])
+        return {
+            "value": (1 << c["s_log_n"]) * cols / med, "unit": "cells/s", "cores": c["cores"], "kind": "port",
+            "sample": f"complete proofs of a 2^{c['s_log_n']} x {cols} trace of the same AIR with the same options: 1 warm-up + median of 5 runs "
+                      f"(prover time per run {', '.join(f'{x:.2f}' for x in c['runs'])} s; median {med:.2f} s; wall incl. trace generation {median(c['walls']):.2f} s); "
+                      f"OpenMP port in a process of its own, single-run thread sweep over {cpu_thread_candidates(ncpu)} on a 2^{probe_log} probe picked {c['cores']}; "
+                      f"host has {ncpu} logical CPUs" + ("; proof bytes identical to the GPU's (SHA-256)" if c["s_log_n"] == log_n else ""),
+            "runs_s": c["runs"],
+            "single_thread": {"value": (1 << st_log) * cols / c["single_total"], "unit": "cells/s",
+                              "sample": f"one complete proof of a 2^{st_log} x {cols} trace, 1 thread (the reference binary runs Winterfell single-threaded)"},
+        }
     from tests import oracle_lib
     orc = oracle_lib.load()
     ncpu = os.cpu_count() or 1
@@ -456,7 +522,7 @@ def cpu_baseline_leg(args, log_n, width, over, opt, first_proof):
                 real.set_threads(t)
 
         orc = _ProgramOracle()
-    probe_log = min(14 if width > 8 else 16, log_n)
+    probe_log = min(14 if width > 8 else 18, log_n)      # large enough for the transforms' inner parallelism to show (a 2^16 probe picked 16 threads of 256)
     best = None
     for t in cpu_thread_candidates(ncpu):
         orc.set_threads(t)

@@ -145,7 +145,12 @@ static Bytes prove_model(const M& air, const std::vector<Col>& trace, int log_n,
     for (int k = 0; k < F::DEG; k++) intt_coset(hcomp[k].data(), ceN, GEN, true);
     // split: coefficient i -> column i mod C (H(x) = sum_c x^c H_c(x^C); stark_verifier.cairo:166-176)
     std::vector<Col> cpolys(C * F::DEG, Col(n));   // index c*DEG + k
-    for (size_t c = 0; c < C; c++) for (int k = 0; k < F::DEG; k++) for (size_t i = 0; i < n; i++) cpolys[c * F::DEG + k][i] = hcomp[k][i * C + c];
+    for (size_t c = 0; c < C; c++) for (int k = 0; k < F::DEG; k++) {
+        Col& dst = cpolys[c * F::DEG + k];
+        const Col& src = hcomp[k];
+#pragma omp parallel for schedule(static) if (n >= 65536)
+        for (size_t i = 0; i < n; i++) dst[i] = src[i * C + c];
+    }
     t1 = now_s(); tm.composition = t1 - t0; t0 = t1;
     // 6. composition commitment [a12]
     std::vector<Col> clde(C * F::DEG);

@@ -30,6 +30,9 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "blake2s.hpp"
 #include "gl.hpp"
@@ -426,9 +429,10 @@ template <class F> static typename F::T lagrange_eval(const uint64_t* xs, const 
 
 // ------------------------------------------------------------------------------------------------
 // NTT (natural order in, natural order out). Radix-2 DIT after a bit-reversal; twiddles w^k, k < n/2.
-static void bit_reverse(uint64_t* a, size_t n) {
+static void bit_reverse(uint64_t* a, size_t n, bool par = false) {
     int lg = ilog2(n);
     if (lg == 0) return;
+#pragma omp parallel for schedule(static) if (par && n >= 16384)      // every swap touches its own pair (i, rev(i)), done by the smaller index only
     for (size_t i = 0; i < n; i++) {
         uint64_t x = i;   // byte-swap + bit tricks: reverse 64 bits, keep the top lg
         x = __builtin_bswap64(x);
@@ -439,14 +443,28 @@ static void bit_reverse(uint64_t* a, size_t n) {
         if (i < j) std::swap(a[i], a[j]);
     }
 }
+// out[i] = c0 * base^i, i < count: chunks that start from their own power (parallel for long tables; the same values)
+static void geometric(uint64_t* out, size_t count, uint64_t c0, uint64_t base) {
+#pragma omp parallel if (count >= 65536)
+    {
+#ifdef _OPENMP
+        const size_t nt = (size_t)omp_get_num_threads(), t = (size_t)omp_get_thread_num();
+#else
+        const size_t nt = 1, t = 0;
+#endif
+        const size_t lo = count * t / nt, hi = count * (t + 1) / nt;
+        uint64_t w = gl_mul(c0, gl_pow(base, lo));
+        for (size_t i = lo; i < hi; i++) { out[i] = w; w = gl_mul(w, base); }
+    }
+}
 static Col twiddles(size_t n, uint64_t root) {
     Col tw(n / 2 ? n / 2 : 1);
-    uint64_t w = 1;
-    for (size_t i = 0; i < n / 2; i++) { tw[i] = w; w = gl_mul(w, root); }
+    tw[0] = 1;
+    geometric(tw.data(), n / 2, 1, root);
     return tw;
 }
 static void ntt_core(uint64_t* a, size_t n, const Col& tw, bool par = false) {
-    bit_reverse(a, n);
+    bit_reverse(a, n, par);
     for (size_t len = 2; len <= n; len <<= 1) {
         size_t half = len / 2, step = n / len;
 #pragma omp parallel for schedule(static) if (par && n >= 16384)
@@ -474,6 +492,28 @@ static Col lde(const uint64_t* coeffs, size_t n, size_t blowup, uint64_t offset)
     Col out(N);
     uint64_t wN = gl_root_of_unity(ilog2(N));
     Col tw = twiddles(n, gl_root_of_unity(ilog2(n)));
+#ifdef _OPENMP
+    // More threads than cosets (a column's LDE has only `blowup` independent transforms: 8 threads' worth): the cosets one after the other,
+    // every transform parallel over its butterflies, the coefficient scaling over chunks that start from their own power - what keeps an
+    // all-core host busy on narrow traces (the CPU baseline of bench.py; same values, same order of field operations per element).
+    if (n >= 16384 && (size_t)omp_get_max_threads() > blowup) {
+        Col tmp(n);
+        for (size_t k = 0; k < blowup; k++) {
+            const uint64_t s = gl_mul(offset, gl_pow(wN, k));
+#pragma omp parallel
+            {
+                const size_t nt = (size_t)omp_get_num_threads(), t = (size_t)omp_get_thread_num();
+                const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+                uint64_t acc = gl_pow(s, lo);
+                for (size_t i = lo; i < hi; i++) { tmp[i] = gl_mul(coeffs[i], acc); acc = gl_mul(acc, s); }
+            }
+            ntt_core(tmp.data(), n, tw, true);
+#pragma omp parallel for schedule(static)
+            for (size_t m = 0; m < n; m++) out[k + blowup * m] = tmp[m];
+        }
+        return out;
+    }
+#endif
 #pragma omp parallel for schedule(dynamic, 1) if (n >= 4096)
     for (size_t k = 0; k < blowup; k++) {
         Col tmp(n);
@@ -487,7 +527,15 @@ static Col lde(const uint64_t* coeffs, size_t n, size_t blowup, uint64_t offset)
 // evaluations on offset * <w_n> -> coefficients (interpolate_poly_with_offset).
 static void intt_coset(uint64_t* a, size_t n, uint64_t offset, bool par = false) {
     intt(a, n, par);
-    uint64_t oi = gl_inv(offset), acc = 1;
+    const uint64_t oi = gl_inv(offset);
+    if (par && n >= 65536) {
+        Col pw(n);
+        geometric(pw.data(), n, 1, oi);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n; i++) a[i] = gl_mul(a[i], pw[i]);
+        return;
+    }
+    uint64_t acc = 1;
     for (size_t i = 0; i < n; i++) { a[i] = gl_mul(a[i], acc); acc = gl_mul(acc, oi); }
 }
 template <class F> static typename F::T horner(const uint64_t* c, size_t n, typename F::T x) {
