@@ -675,6 +675,51 @@ class Pool:
     def ctx(self, slot) -> Context:
         return self.ctxs[slot]
 
+    def prove_fib_queue(self, host_traces, options: ProofOptions, aux=(0, 0, 2)):
+        """A queue of DIFFERENT host traces of one shape (PinnedTrace or C-contiguous (width, n) uint64 arrays): trace t goes to slot
+        t mod slots, every proof comes back (aero_pool_prove_fib_queue). Returns [(proof_bytes, public_inputs)] in queue order."""
+        arrs = [t.array if isinstance(t, PinnedTrace) else np.ascontiguousarray(t, np.uint64) for t in host_traces]
+        n = len(arrs)
+        w, rows = arrs[0].shape
+        assert all(a.shape == (w, rows) for a in arrs), "the traces of one queue must have one shape"
+        ptrs = (u64p * n)(*[_p64(a) for a in arrs])
+        proofs = (u8p * n)()
+        lens = (C.c_size_t * n)()
+        pubs = np.zeros(n * (w // 2), np.uint64)
+        air = FibAirDesc(aux[0], aux[1], aux[2])
+        rc = lib().aero_pool_prove_fib_queue(self.h, ptrs, C.c_uint32(n), C.c_uint32(w), C.c_uint32(int(rows).bit_length() - 1), C.byref(air),
+                                             C.byref(options), proofs, lens, _p64(pubs))
+        if rc != 0:
+            msgs = [lib().aero_last_error(c.h).decode() for c in self.ctxs]
+            raise AeroError(rc, "; ".join(m for m in msgs if m))
+        out = []
+        for i in range(n):
+            out.append((C.string_at(proofs[i], lens[i]), pubs[i * (w // 2):(i + 1) * (w // 2)].tolist()))
+            lib().aero_free(proofs[i])
+        return out
+
+    def prove_air_queue(self, air: "Air", host_traces, pubs, options: ProofOptions):
+        """The same for a constraint program: pubs[t] = the statement of trace t (aero_pool_prove_air_queue). Returns the proofs in queue order."""
+        arrs = [t.array if isinstance(t, PinnedTrace) else np.ascontiguousarray(t, np.uint64) for t in host_traces]
+        n = len(arrs)
+        w, rows = arrs[0].shape
+        assert all(a.shape == (w, rows) for a in arrs) and len(pubs) == n
+        npub = len(pubs[0])
+        pb = np.array([list(p) for p in pubs], dtype=np.uint64).reshape(-1) if npub else np.zeros(1, np.uint64)
+        ptrs = (u64p * n)(*[_p64(a) for a in arrs])
+        proofs = (u8p * n)()
+        lens = (C.c_size_t * n)()
+        rc = lib().aero_pool_prove_air_queue(self.h, air.h, ptrs, C.c_uint32(n), C.c_uint32(int(rows).bit_length() - 1), _p64(pb), C.c_uint32(npub),
+                                             C.byref(options), proofs, lens)
+        if rc != 0:
+            msgs = [lib().aero_last_error(c.h).decode() for c in self.ctxs]
+            raise AeroError(rc, "; ".join(m for m in msgs if m))
+        out = []
+        for i in range(n):
+            out.append(C.string_at(proofs[i], lens[i]))
+            lib().aero_free(proofs[i])
+        return out
+
     def placement(self):
         """(NUMA node of the pool's device or -1, number of worker threads bound to that node's CPUs) - aero_pool_placement."""
         node, pinned = C.c_int32(-1), C.c_uint32(0)

@@ -796,6 +796,10 @@ struct aero_pool {
         // job (written by the caller under `mu`, read by the worker)
         const aero_matrix* trace = nullptr;
         const uint64_t* host_trace = nullptr;   // host-trace batch (aero_pool_prove_fib_host): copied in before every proof
+        // queue mode (aero_pool_prove_*_queue): this slot's share of a queue of DIFFERENT host traces, in order; result k of the slot goes to
+        // entry queue_out[k] of the caller's arrays (the reference deals its batches the same way: batch_idx % concurrency, pool.rs:105-124)
+        std::vector<const uint64_t*> queue;
+        std::vector<uint32_t> queue_out;
         uint8_t* proof = nullptr;
         size_t proof_len = 0;
         std::vector<uint64_t> pub;
@@ -816,6 +820,11 @@ struct aero_pool {
     aero_proof_options opt{};
     uint32_t rounds = 1;
     uint32_t host_width = 0, host_log_n = 0;
+    // queue mode: the caller's result arrays (one entry per queued trace) and, for programs, one statement per trace
+    uint8_t** q_proofs = nullptr;
+    size_t* q_lens = nullptr;
+    uint64_t* q_pubs = nullptr;                 // built-in AIR: width / 2 results per trace
+    const uint64_t* q_program_pubs = nullptr;   // programs: n_pub elements per trace (null: program_pub for all)
 
     int numa_node = -1;                     // of the pool's device (numa.hip); -1 = unknown
     std::atomic<uint32_t> pinned{0};        // worker threads bound to that node's CPUs
@@ -838,7 +847,10 @@ struct aero_pool {
             // an exception that leaves a thread body ends the whole host process (std::terminate): whatever is thrown here
             // (the entry points below catch their own) becomes the slot's status
             try {
-            pub.resize((size_t)(s->host_trace ? host_width : (uint32_t)s->trace->m.cols) / 2);
+            const bool queued = !s->queue.empty();
+            const uint32_t rounds = queued ? (uint32_t)s->queue.size() : this->rounds;        // shadows the batch parameter
+            auto trace_of = [&](uint32_t r) { return queued ? s->queue[r] : s->host_trace; };
+            pub.resize((size_t)((s->host_trace || queued) ? host_width : (uint32_t)s->trace->m.cols) / 2);
             // Prefetch (round 5): a slot whose stream sits behind a 10 ms copy is a slot that does not compute - eight slots of 2^20 x 72
             // proofs behaved like four or five (3.5 against 4.2 G cells/s resident with the link at half its rate, profiles/r5_h2d.md).
             // With several rounds ahead the copy of trace r + 1 runs on the copy stream, into the other of two landing buffers, WHILE
@@ -847,8 +859,8 @@ struct aero_pool {
             static const double prefetch_mb = getenv("AERO_POOL_PREFETCH_MIN_MB") ? atof(getenv("AERO_POOL_PREFETCH_MIN_MB")) : 32.0;
             uint32_t trace_w = host_width;
             if (program) { uint32_t info[16] = {0}; if (aero_air_info(program, info) == AERO_OK) trace_w = info[0]; }      // main_width
-            const size_t trace_bytes = s->host_trace ? ((size_t)trace_w << host_log_n) * 8 : 0;
-            const bool prefetch = s->host_trace && rounds > 1 && prefetch_mb > 0 && (double)trace_bytes >= prefetch_mb * 1048576.0;
+            const size_t trace_bytes = (s->host_trace || queued) ? ((size_t)trace_w << host_log_n) * 8 : 0;
+            const bool prefetch = (s->host_trace || queued) && rounds > 1 && prefetch_mb > 0 && (double)trace_bytes >= prefetch_mb * 1048576.0;
             Context* const c = s->ctx->c;
             DevBuf<uint64_t> land[2];
             hipStream_t cs = nullptr;
@@ -857,7 +869,7 @@ struct aero_pool {
                 // apart and they stay out of phase - proofs that run in lockstep queue their latency-bound stages behind each other
                 std::lock_guard<std::mutex> lk(gate->mu);
                 if (gate->last) AERO_HIP(hipStreamWaitEvent(cs, gate->last, 0));
-                AERO_HIP(hipMemcpyAsync(land[r & 1].get(), s->host_trace, trace_bytes, hipMemcpyHostToDevice, cs));
+                AERO_HIP(hipMemcpyAsync(land[r & 1].get(), trace_of(r), trace_bytes, hipMemcpyHostToDevice, cs));
                 AERO_HIP(hipEventRecord(c->sync_event(32 + (r & 1)), cs));
                 gate->last = c->sync_event(32 + (r & 1));
             };
@@ -876,14 +888,21 @@ struct aero_pool {
                     if (rc != AERO_OK) break;
                     c->landed.dev = land[r & 1].get(); c->landed.ready = c->sync_event(32 + (r & 1));
                 }
+                const uint64_t* ht = trace_of(r);
                 if (program) {
                     const uint32_t np = (uint32_t)program_pub.size();
-                    if (s->host_trace) rc = aero_prove_air_host(s->ctx, program, s->host_trace, host_log_n, program_pub.data(), np, &opt, &out, &len);
-                    else rc = aero_prove_air(s->ctx, nullptr, program, s->trace, program_pub.data(), np, &opt, &out, &len);
+                    const uint64_t* pb = (queued && q_program_pubs) ? q_program_pubs + (size_t)s->queue_out[r] * np : program_pub.data();
+                    if (ht) rc = aero_prove_air_host(s->ctx, program, ht, host_log_n, pb, np, &opt, &out, &len);
+                    else rc = aero_prove_air(s->ctx, nullptr, program, s->trace, pb, np, &opt, &out, &len);
                 }
-                else if (s->host_trace) rc = aero_prove_fib_air_host(s->ctx, s->host_trace, host_width, host_log_n, &air, &opt, &out, &len, pub.data());
+                else if (ht) rc = aero_prove_fib_air_host(s->ctx, ht, host_width, host_log_n, &air, &opt, &out, &len, pub.data());
                 else rc = aero_prove_fib_air(s->ctx, nullptr, s->trace, &air, &opt, &out, &len, pub.data());
                 c->landed = Context::LandedTrace{};
+                if (queued && rc == AERO_OK) {        // every proof of a queue goes back to the caller, in the caller's order
+                    const uint32_t o = s->queue_out[r];
+                    q_proofs[o] = out; q_lens[o] = len; out = nullptr; len = 0;
+                    if (q_pubs && !program) memcpy(q_pubs + (size_t)o * (host_width / 2), pub.data(), (size_t)(host_width / 2) * 8);
+                }
             }
             if (prefetch) {     // nothing of this job is left on the copy stream when the landing buffers go back to the context's allocator
                 c->landed = Context::LandedTrace{};
@@ -1015,6 +1034,68 @@ int32_t aero_pool_prove_air_host(aero_pool* pool, const aero_air* air, const uin
     if (log_n < 3 || log_n > 29) return AERO_E_BAD_ARG;
     for (uint32_t i = 0; i < count; i++) if (!host_traces[i]) return AERO_E_BAD_ARG;
     return pool_run(pool, nullptr, host_traces, 2, log_n, count, nullptr, options, rounds, proofs, proof_lens, nullptr, air, pub, n_pub);
+}
+// A queue of DIFFERENT host traces of one shape through the pool: trace t goes to slot t mod slots (the reference's pool deals its batches the
+// same way, pool.rs:105-124), every slot proves its share in order - copying its next trace while it proves the current one when they are large
+// enough to be worth it - and EVERY proof comes back: proofs[t] (malloc'd, aero_free), proof_lens[t], pubs + t * width / 2.
+static int32_t pool_run_queue(aero_pool* pool, const uint64_t* const* host_traces, uint32_t n_traces, uint32_t width, uint32_t log_n, const aero_fib_air* air,
+                              const aero_proof_options* options, uint8_t** proofs, size_t* proof_lens, uint64_t* pubs, const aero_air* program,
+                              const uint64_t* program_pubs, uint32_t n_pub) {
+    const uint32_t S = (uint32_t)pool->slots.size(), used = n_traces < S ? n_traces : S;
+    for (uint32_t t = 0; t < n_traces; t++) { proofs[t] = nullptr; proof_lens[t] = 0; }
+    if (program) (void)aero_air_prepare(program, log_n, options, 1);
+    {
+        std::lock_guard<std::mutex> lk(pool->mu);
+        pool->program = program;
+        pool->program_pub.assign(n_pub, 0);
+        if (program && program_pubs) pool->program_pub.assign(program_pubs, program_pubs + n_pub);
+        pool->q_program_pubs = program ? program_pubs : nullptr;
+        pool->air = air ? *air : aero_fib_air{0, 0, 2};
+        pool->opt = *options;
+        pool->rounds = 1;
+        pool->host_width = width; pool->host_log_n = log_n;
+        pool->q_proofs = proofs; pool->q_lens = proof_lens; pool->q_pubs = pubs;
+        for (uint32_t i = 0; i < used; i++) {
+            aero_pool::Slot& s = *pool->slots[i];
+            s.trace = nullptr; s.host_trace = nullptr;
+            s.queue.clear(); s.queue_out.clear();
+            for (uint32_t t = i; t < n_traces; t += S) { s.queue.push_back(host_traces[t]); s.queue_out.push_back(t); }
+            s.ctx->concurrent_peers = used > 1;
+            s.has_job = true;
+        }
+        pool->pending = (int)used;
+        pool->generation++;
+    }
+    pool->cv_job.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(pool->mu);
+        pool->cv_done.wait(lk, [&] { return pool->pending == 0; });
+        for (uint32_t i = 0; i < used; i++) { pool->slots[i]->ctx->concurrent_peers = false; pool->slots[i]->queue.clear(); pool->slots[i]->queue_out.clear(); }
+        pool->q_proofs = nullptr; pool->q_lens = nullptr; pool->q_pubs = nullptr; pool->q_program_pubs = nullptr;
+    }
+    int32_t first = AERO_OK;
+    for (uint32_t i = 0; i < used; i++) {
+        aero_pool::Slot& s = *pool->slots[i];
+        if (first == AERO_OK && s.status != AERO_OK) first = s.status;
+        if (s.proof) { free(s.proof); s.proof = nullptr; }      // a slot that failed mid-queue may hold a last buffer
+    }
+    if (first != AERO_OK)        // all or nothing: the caller gets no partial result set to sort out
+        for (uint32_t t = 0; t < n_traces; t++) if (proofs[t]) { free(proofs[t]); proofs[t] = nullptr; proof_lens[t] = 0; }
+    return first;
+}
+int32_t aero_pool_prove_fib_queue(aero_pool* pool, const uint64_t* const* host_traces, uint32_t n_traces, uint32_t width, uint32_t log_n,
+                                  const aero_fib_air* air, const aero_proof_options* options, uint8_t** proofs, size_t* proof_lens, uint64_t* pubs) {
+    if (!pool || !host_traces || !options || !proofs || !proof_lens || n_traces == 0 || n_traces > (1u << 24)) return AERO_E_BAD_ARG;
+    if (width < 2 || width > 254 || log_n < 3 || log_n > 29) return AERO_E_BAD_ARG;
+    for (uint32_t t = 0; t < n_traces; t++) if (!host_traces[t]) return AERO_E_BAD_ARG;
+    return pool_run_queue(pool, host_traces, n_traces, width, log_n, air, options, proofs, proof_lens, pubs, nullptr, nullptr, 0);
+}
+int32_t aero_pool_prove_air_queue(aero_pool* pool, const aero_air* air, const uint64_t* const* host_traces, uint32_t n_traces, uint32_t log_n,
+                                  const uint64_t* pubs_per_trace, uint32_t n_pub, const aero_proof_options* options, uint8_t** proofs, size_t* proof_lens) {
+    if (!pool || !air || !host_traces || !options || !proofs || !proof_lens || (n_pub && !pubs_per_trace) || n_traces == 0 || n_traces > (1u << 24)) return AERO_E_BAD_ARG;
+    if (log_n < 3 || log_n > 29) return AERO_E_BAD_ARG;
+    for (uint32_t t = 0; t < n_traces; t++) if (!host_traces[t]) return AERO_E_BAD_ARG;
+    return pool_run_queue(pool, host_traces, n_traces, 2, log_n, nullptr, options, proofs, proof_lens, nullptr, air, pubs_per_trace, n_pub);
 }
 // ---- the reference's worker seam at the message level (worker_messages.hpp) ------------------------------------------------------
 // hashing_worker.rs:12-26: every row of the work item -> Blake2s_256::hash_elements, answered in row order with the batch index.

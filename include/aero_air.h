@@ -142,6 +142,10 @@ int32_t aero_pool_prove_air(struct aero_pool* pool, const aero_air* air, const a
 int32_t aero_pool_prove_air_host(struct aero_pool* pool, const aero_air* air, const uint64_t* const* host_traces, uint32_t log_n, uint32_t count,
                                  const uint64_t* pub, uint32_t n_pub, const aero_proof_options* options, uint32_t rounds, uint8_t** proofs,
                                  size_t* proof_lens);
+/* The same for a QUEUE of different host traces (aero_pool_prove_fib_queue in aero_stark.h): trace t to slot t mod slots, one statement per
+ * trace (pubs_per_trace holds n_traces x n_pub elements), every proof comes back in proofs[t] / proof_lens[t]; all or nothing. */
+int32_t aero_pool_prove_air_queue(aero_pool* pool, const aero_air* air, const uint64_t* const* host_traces, uint32_t n_traces, uint32_t log_n,
+                                  const uint64_t* pubs_per_trace, uint32_t n_pub, const aero_proof_options* options, uint8_t** proofs, size_t* proof_lens);
 
 /* The evaluation kernel the library generates from the program and compiles at run time (hiprtc, gfx950) when the first proof of a
  * (program, trace length, field) arrives - straight-line HIP over the expression DAG, same arithmetic as the interpreter, same

@@ -401,6 +401,13 @@ int32_t aero_pool_create(int32_t device_id, uint32_t slots, aero_pool** out);
 void aero_pool_destroy(aero_pool* pool);
 uint32_t aero_pool_slots(const aero_pool* pool);
 aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot);
+/* A QUEUE of different host traces of one shape (column-major width x 2^log_n each, pinned or pageable): trace t is dealt to slot
+ * t mod slots - the reference's pool deals its batches the same way (`batch_idx % concurrency`, aero-sdk/miden-wasm/src/pool.rs:105-124) -,
+ * every slot proves its share in order, copying its next trace while it proves the current one (traces of >= 32 MiB), and EVERY proof
+ * comes back: proofs[t] (malloc'd: aero_free), proof_lens[t], pubs + t * width / 2 (pubs may be NULL). All or nothing: on a non-zero
+ * status every proofs[t] is NULL. n_traces may be smaller or (much) larger than the number of slots. */
+int32_t aero_pool_prove_fib_queue(aero_pool* pool, const uint64_t* const* host_traces, uint32_t n_traces, uint32_t width, uint32_t log_n,
+                                  const aero_fib_air* air, const aero_proof_options* options, uint8_t** proofs, size_t* proof_lens, uint64_t* pubs);
 /* where the pool's worker threads ended up: node_out = NUMA node of the device (-1 unknown), pinned_out = workers bound to its CPUs */
 int32_t aero_pool_placement(const aero_pool* pool, int32_t* node_out, uint32_t* pinned_out);
 int32_t aero_pool_prove_fib(aero_pool* pool, const aero_matrix* const* traces, uint32_t count, const aero_fib_air* air,

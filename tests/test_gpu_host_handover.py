@@ -12,6 +12,7 @@ from tests import air_examples as ex
 
 pytestmark = pytest.mark.gpu
 P = 0xFFFFFFFF00000001
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -87,3 +88,62 @@ def test_pinned_views_outlive_release_and_near_allocation_works(ctx):
     n, pinned = pool.placement()
     assert n == node.value and (pinned == 0 if n < 0 else pinned <= 2)
     pool.close()
+
+
+@pytest.mark.parametrize("prefetch_mb", ["32", "0.01"])
+def test_pool_queue_of_different_traces(oracle, prefetch_mb, tmp_path):
+    """aero_pool_prove_*_queue: a queue of DIFFERENT traces dealt to the slots round-robin (pool.rs:105-124), every proof back in queue
+    order - fewer traces than slots, more traces than slots, with the prefetch of the next trace (threshold lowered) and without; a
+    constraint program with one statement per trace; a bad trace fails the whole call and leaves the pool usable."""
+    import json, subprocess, sys
+    body = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import aero_amd
+from aero_amd import air as A
+from tests import oracle_lib
+P = 0xFFFFFFFF00000001
+orc = oracle_lib.load(); orc.set_threads(16)
+opt = [27, 8, 8, 4, 1, 8, 6]
+o = aero_amd.ProofOptions(*opt)
+pool = aero_amd.Pool(0, 3)
+W, log_n = 4, 12
+base = aero_amd.fib_trace(W, log_n)
+rng = np.random.default_rng(5)
+# different traces: the valid one, and copies with one cell changed (they violate the AIR: a prover does not care, the bytes are still a
+# pure function of the trace, and the oracle is handed the same trace)
+traces = [base.copy() for _ in range(8)]
+for t in range(1, 8):
+    traces[t][t %% W][100 + t] = int(rng.integers(1, 1 << 62))
+want = [orc.prove_fib(W, log_n, opt, trace=tr)[0] for tr in traces]
+assert len(set(want)) == 8
+for count in (2, 3, 8):
+    got = pool.prove_fib_queue([aero_amd.PinnedTrace(tr) for tr in traces[:count]], o)
+    assert [g[0] for g in got] == want[:count], count
+    assert all(g[1] == [int(tr[2 * k + 1][-1]) for k in range(W // 2)] for g, tr in zip(got, traces))
+bad = [tr.copy() for tr in traces[:5]]
+bad[3][1][7] = P + 1
+try:
+    pool.prove_fib_queue(bad, o)
+    raise SystemExit("non-canonical element went unnoticed")
+except aero_amd.AeroError as e:
+    assert "non-canonical" in str(e)
+assert [g[0] for g in pool.prove_fib_queue(traces[:4], o)] == want[:4]
+# a program whose statement differs per trace: one doubling column started at pub(0)
+n = 1 << 10
+b = A.AirBuilder(1, num_pub=1)
+b.transition(b.main_next(0) - 2 * b.main(0), 1)
+b.assert_single(0, 0, b.pub(0))
+air = aero_amd.Air(b.to_bytes())
+starts = [3, 5, 7, 11, 13]
+ptraces = [np.array([[pow(2, i, P) * s0 %% P for i in range(n)]], dtype=np.uint64) for s0 in starts]
+pwant = [orc.prove_air(b.to_bytes(), tr, [s0], opt)[0] for tr, s0 in zip(ptraces, starts)]
+assert pool.prove_air_queue(air, ptraces, [[s0] for s0 in starts], o) == pwant
+pool.close()
+print("ok")
+''' % ROOT
+    script = tmp_path / "queue.py"
+    script.write_text(body)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=dict(os.environ, AERO_POOL_PREFETCH_MIN_MB=prefetch_mb), cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])

@@ -342,6 +342,16 @@ static void pool_batches() {
         CHECK(rc == AERO_OK || aero_last_error(aero_pool_ctx(pool, 0))[0] != 0);
         for (uint8_t* p : proofs) aero_free(p);
     }
+    {   // a queue of 7 traces over 3 slots: every proof comes back, every slot prefetches its next trace
+        const uint64_t* q[7];
+        uint8_t* qp[7];
+        size_t ql[7];
+        std::vector<uint64_t> qpub(7 * (w / 2));
+        for (auto& x : q) x = t.data();
+        const int32_t rc = aero_pool_prove_fib_queue(pool, q, 7, w, log_n, nullptr, &opt, qp, ql, qpub.data());
+        CHECK(rc == AERO_OK || aero_last_error(aero_pool_ctx(pool, 0))[0] != 0);
+        for (uint8_t* p : qp) aero_free(p);
+    }
     aero_pool_destroy(pool);
 }
 
