@@ -432,7 +432,7 @@ template <class F> static typename F::T lagrange_eval(const uint64_t* xs, const 
 static void bit_reverse(uint64_t* a, size_t n, bool par = false) {
     int lg = ilog2(n);
     if (lg == 0) return;
-#pragma omp parallel for schedule(static) if (par && n >= 16384)      // every swap touches its own pair (i, rev(i)), done by the smaller index only
+#pragma omp parallel for schedule(static) if (par && n >= 65536)      // every swap touches its own pair (i, rev(i)), done by the smaller index only
     for (size_t i = 0; i < n; i++) {
         uint64_t x = i;   // byte-swap + bit tricks: reverse 64 bits, keep the top lg
         x = __builtin_bswap64(x);
@@ -496,7 +496,8 @@ static Col lde(const uint64_t* coeffs, size_t n, size_t blowup, uint64_t offset)
     // More threads than cosets (a column's LDE has only `blowup` independent transforms: 8 threads' worth): the cosets one after the other,
     // every transform parallel over its butterflies, the coefficient scaling over chunks that start from their own power - what keeps an
     // all-core host busy on narrow traces (the CPU baseline of bench.py; same values, same order of field operations per element).
-    if (n >= 16384 && (size_t)omp_get_max_threads() > blowup) {
+    // (only for long transforms: at 2^14 points a parallel region per butterfly stage costs more than the stage, most of all with 128 - 256 threads)
+    if (n >= ((size_t)1 << 18) && (size_t)omp_get_max_threads() > blowup) {
         Col tmp(n);
         for (size_t k = 0; k < blowup; k++) {
             const uint64_t s = gl_mul(offset, gl_pow(wN, k));

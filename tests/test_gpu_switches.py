@@ -219,7 +219,7 @@ for name, (b, trace, pub), nrand in (("v2", ex.v2_air(log_n), 4), ("chain", ex.g
     air = aero_amd.Air(program)
     info = air.info()
     n, A_ = 1 << log_n, info["aux_width"]
-    for ext in (1, 2):
+    for ext in ((1, 2) if log_n < 16 else (1,)):      # the long case once per program: the oracle's proof is what takes the time
         opt = [27, 8, 8, 4, ext, 8, 6]
         want, _ = orc.prove_air(program, trace, pub, opt, keep_artifacts=True)
         rands = orc.artifact("aux_rands", ext * nrand)
@@ -230,7 +230,7 @@ for name, (b, trace, pub), nrand in (("v2", ex.v2_air(log_n), 4), ("chain", ex.g
         ctx.set_kernel_timing(False)
         assert ("air_general_column_kernel" in names) == (os.environ.get("AERO_AIR_GENERAL_DEVICE") == "1"), names
         assert (auxm.download() == orc.artifact("aux_cols", A_ * ext * n).reshape(A_ * ext, n)).all(), (name, ext, "auxiliary columns differ from the oracle")
-        for src in (dev, trace):                      # resident, and from host memory (the builders read the kept copy)
+        for src in ((dev, trace) if log_n < 16 else (dev,)):      # resident, and from host memory (the builders read the kept copy)
             assert ctx.prove_air(air, src, pub, aero_amd.ProofOptions(*opt)) == want, (name, ext)
         auxm.free(); dev.free()
 print("ok")
