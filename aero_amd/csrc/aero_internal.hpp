@@ -273,7 +273,7 @@ public:
     std::map<std::vector<uint64_t>, uint64_t*> ktab_cache;
    // final-pass scale tables of ntt_inverse, keyed by their parameters
     uint64_t *tw4096_fwd = nullptr, *tw4096_inv = nullptr;
-    uint64_t *twmt_fwd = nullptr, *twmt_inv = nullptr;   // [r * 64 + k] = w_2048^(+-r k), r < 32
+    uint64_t *twmt_fwd = nullptr, *twmt_inv = nullptr, *twmt12_inv = nullptr;   // [r * 64 + k] = w_2048^(+-r k), r < 32
 
 private:
     struct KtRec { const char* name; size_t abytes; hipEvent_t start, stop; };

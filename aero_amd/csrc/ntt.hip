@@ -411,95 +411,196 @@ template <int NT> __global__ __launch_bounds__(NT) void ntt_inv_pass(PassArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Contiguous LAST pass of the inverse transform (log_r = 11, 2048-point tiles) as the mirror of ntt_fwd_first_pass_8: two register
-// transforms around one exchange, one wavefront per tile, 32 values per lane, decimation in frequency with the inverse roots:
-//   B' lane k holds positions k + 64 i: pass-boundary twiddle w^-(rev(tile) p) as a geometric progression in i (its start carries
-//      the tile's share of the output scaling, which is uniform over the tile and therefore commutes with the transform), the
-//      32-point inverse transform (shift twiddles), one table multiplication per element (w_2048^-(k rev(i)));
-//   -- 32 x 64 transpose through XOR-swizzled LDS in two rounds of 16 rows (8 KiB per wave) --
-//   A' lane (h, half) holds columns [32 half, 32 half + 32) of row h: the 64-point inverse transform shared by two lanes - the first
-//      stage pairs column c with c + 32 across the halves (one V_PERMLANE32_SWAP round to form the pairs, the factor
-//      w_64^-16 = -2^48 of the upper half's twiddles as a select, a second round to hand each lane a complete 32-block), then the
-//      32-point inverse transform of each half; outputs (bit-reversed order, as everywhere) times the per-position scale table.
-// Against the LDS rounds of ntt_inv_pass (12 bits): 4 full multiplications per element instead of 6.6, no workgroup barrier.
-template <int I> __device__ __forceinline__ void first_stage_pairs_inv(uint64_t (&y)[32]) {
-    bfly_w64_inv<I>(y[I], y[16 + I]);
-    if constexpr (I + 1 < 16) first_stage_pairs_inv<I + 1>(y);
+// Contiguous LAST pass of the inverse transform (log_r = 11, 2048-point tiles), decimation in frequency with the inverse roots: TWO
+// wavefronts per tile, 16 values per lane. The tile as 16 x 16 x 8, position p = 128 j + 8 s + u, three register transforms around two
+// exchanges through LDS and no cross-lane step:
+//   1  thread t < 128 holds p = t + 128 j: boundary twiddle w^-(rev(tile) p) as a geometric progression in j (its start carries the tile's
+//      share of the output scaling, uniform over the tile), 16-point inverse transform over j (-> f2 = rev4(j')), times
+//      w_2048^-(f2 t) = table[f2][t mod 64] * (w_32^-f2, a shift, in the wavefront that holds t >= 64);
+//   2  thread (j', u) holds t = u + 8 s: 16-point inverse transform over s (-> g1 = rev4(s')), times w_128^-(g1 u) = table[2 g1][8 u];
+//   3  thread (j', m) holds rows s' = 2 m, 2 m + 1 with their eight u each: two 8-point inverse transforms (-> g0 = rev3(u')), then the
+//      per-position scale table; frequency f2 + 16 g1 + 256 g0 lands at position 128 j' + 8 s' + u' = 16 thread + 8 (s' & 1) + u'.
+// Exchange buffer: row j' at j' * 144 slots (the 16 extra slots put consecutive rows into opposite bank halves); first exchange (j', t) at
+// ((t + 8 j') mod 128) of the row, second exchange in output order with the 16-byte pairs of a thread's 128 bytes XOR-permuted.
+// Until round 5 this pass mirrored ntt_fwd_first_pass_8 (one wavefront per tile, 32 values per lane, a 32-point and a 64-point transform, the
+// latter shared by two lanes through V_PERMLANE32_SWAP rounds: 168 VGPRs with 20 spilled, three waves per SIMD). This form has one full
+// multiplication per element more (5 against 4) and measured faster on every launch (profiles/r5_inv_last11.md): 41.2 -> 33.2 us on one
+// column of 2^21 points (1024 tiles: the one-wave form left one wavefront per SIMD), 706 -> 596 us on 72 columns of 2^20.
+constexpr int I2_ROW = 144;
+constexpr int rev4c(int j) { return ((j & 1) << 3) | ((j & 2) << 1) | ((j & 4) >> 1) | ((j & 8) >> 3); }
+template <int E> __device__ __forceinline__ uint64_t mul_w64_inv(uint64_t x) {      // x * w_64^-E
+    constexpr int K = (192 - (39 * E) % 192) % 192;
+    if constexpr (K < 96) return mul_pow2<K>(x);
+    else return gl::neg(mul_pow2<K - 96>(x));
 }
-__global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_inv_last_pass_11(PassArgs a, const uint64_t* __restrict__ bftab) {
-    __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS / 2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t* lds = f8_lds + wave * (F8_TILE_LDS / 2);
-    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * F8_WAVES + wave;
+template <int J> __device__ __forceinline__ void upper_wave_factors(uint64_t (&y)[16]) {   // y[j'] *= w_32^-rev4(j')
+    y[J] = mul_w64_inv<2 * rev4c(J)>(y[J]);
+    if constexpr (J + 1 < 16) upper_wave_factors<J + 1>(y);
+}
+__global__ __launch_bounds__(128) void ntt_inv_last_pass_11(PassArgs a, const uint64_t* __restrict__ bftab) {
+    __shared__ __attribute__((aligned(16))) uint64_t lds[16 * I2_ROW];
+    const int tid = threadIdx.x;
+    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x);
     uint64_t* data = a.out + (size_t)blockIdx.y * a.out_col_stride + ((size_t)b << 11);
-    const uint64_t* src = a.in + (size_t)blockIdx.y * a.in_col_stride + ((size_t)b << 11);    // = data unless the caller transforms out of place
-    const int h = lane & 31;
-    const uint32_t half = (uint32_t)lane >> 5;
+    const uint64_t* src = a.in + (size_t)blockIdx.y * a.in_col_stride + ((size_t)b << 11);
     const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
     const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
-    uint64_t y[32];
+    uint64_t y[16];
 #pragma unroll
-    for (int i = 0; i < 32; i++) y[i] = src[lane + 64 * i];
+    for (int j = 0; j < 16; j++) y[j] = src[tid + 128 * j];
     if (a.bad) {
         bool any = false;
 #pragma unroll
-        for (int i = 0; i < 32; i++) any |= y[i] >= gl::P;
+        for (int j = 0; j < 16; j++) any |= y[j] >= gl::P;
         if (any) atomicOr(a.bad, 1u);
     }
     {
-        // input side: w^-(rbk p), p = lane + 64 i, times the tile's output factor
         uint64_t cur = bftab[b];
         if (!a.first && rbk) {
-            cur = mul(cur, tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)lane) & nmask), a.tw_h));
-            const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
+            cur = mul(cur, tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)tid) & nmask), a.tw_h));
+            const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 128u) & nmask), a.tw_h);
 #pragma unroll
-            for (int i = 0; i < 32; i++) { y[i] = mul(y[i], cur); cur = mul(cur, step); }
+            for (int j = 0; j < 16; j++) { y[j] = mul(y[j], cur); if (j < 15) cur = mul(cur, step); }
         } else {
 #pragma unroll
-            for (int i = 0; i < 32; i++) y[i] = mul(y[i], cur);
+            for (int j = 0; j < 16; j++) y[j] = mul(y[j], cur);
         }
     }
-    dft_dif_inv_reg<5>(y);                                   // natural i -> bit-reversed i'
+    dft_dif_inv_reg<4>(y);
+    {
+        const uint64_t* mt = a.tw_mt + (tid & 63);
 #pragma unroll
-    for (int i = 1; i < 32; i++) y[i] = mul(y[i], a.tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane]);
-    // exchange: register i' of lane k -> (row i', column k); lane (h, half) then reads columns [32 half, 32 half + 32) of row h
-    uint64_t v[32];
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) lds[i * 64 + (lane ^ ((2 * (16 * r + i)) & 63))] = y[16 * r + i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if ((h >> 4) == r) {
-            const uint64_t* row = lds + (h & 15) * 64;
-            const int sw = (2 * h) & 63;
-#pragma unroll
-            for (int j = 0; j < 32; j++) v[j] = row[(32 * (int)half + j) ^ sw];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        for (int j = 1; j < 16; j++) y[j] = mul(y[j], mt[rev4c(j) * 64]);
+        if (tid >= 64) upper_wave_factors<1>(y);              // uniform over the wavefront
     }
-    // 64-point inverse transform of row h over the two halves: v = columns 32 half + j
 #pragma unroll
-    for (int i = 0; i < 16; i++) swap_halves(v[i], v[16 + i]);           // lower half: (u, v) of columns i, upper: of columns 16 + i
-    first_stage_pairs_inv<0>(v);                                         // (u + v, (u - v) w_64^-i)
+    for (int j = 0; j < 16; j++) lds[j * I2_ROW + ((tid + 8 * j) & 127)] = y[j];
+    __syncthreads();
+    const int jr = tid >> 3, u = tid & 7;
+    {
+        const uint64_t* row = lds + jr * I2_ROW;
 #pragma unroll
-    for (int i = 0; i < 16; i++) { const uint64_t t = gl::neg(mul_w4(v[16 + i])); v[16 + i] = half ? t : v[16 + i]; }    // upper: * w_64^-16 = -2^48
+        for (int s = 0; s < 16; s++) y[s] = row[(u + 8 * s + 8 * jr) & 127];
+    }
+    __syncthreads();                                          // the buffer is written again below
+    dft_dif_inv_reg<4>(y);
+    {
+        const uint64_t* mt = a.tw_mt + 8 * u;
 #pragma unroll
-    for (int i = 0; i < 16; i++) swap_halves(v[i], v[16 + i]);           // lower half: the 32 sums, upper: the 32 twiddled differences
-    dft_dif_inv_reg<5>(v);
-    // position 64 h + 32 half + m of the tile (bit-reversed coefficient order), scaled per position
-    const size_t q0 = (size_t)64 * h + 32 * half;
-    const ulonglong2* kt = reinterpret_cast<const ulonglong2*>(a.ktab + q0);
-    ulonglong2* dst = reinterpret_cast<ulonglong2*>(data + q0);
+        for (int s = 1; s < 16; s++) y[s] = mul(y[s], mt[2 * rev4c(s) * 64]);
+    }
+    {
+        // element (s', u) of row j' is element e = 8 (s' & 1) + u of thread (j', s' >> 1) of phase 3; its 16-byte pair e >> 1 sits at
+        // pair (e >> 1) ^ sigma, sigma = (s' >> 1) ^ (bit 1 of j') << 2
+        uint64_t* row = lds + jr * I2_ROW + (u & 1);
+        const int jb = ((jr >> 1) & 1) << 2;
 #pragma unroll
-    for (int m = 0; m < 16; m++) {
-        const ulonglong2 k2 = kt[m];
+        for (int s = 0; s < 16; s++) row[(s >> 1) * 16 + 2 * ((((s & 1) << 2) + (u >> 1)) ^ (s >> 1) ^ jb)] = y[s];
+    }
+    __syncthreads();
+    uint64_t p0[8], p1[8];
+    {
+        const int m = tid & 7, sigma = m ^ (((jr >> 1) & 1) << 2);
+        const ulonglong2* rp = reinterpret_cast<const ulonglong2*>(lds + jr * I2_ROW + m * 16);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const ulonglong2 t0 = rp[q ^ sigma], t1 = rp[(4 + q) ^ sigma];
+            p0[2 * q] = t0.x; p0[2 * q + 1] = t0.y; p1[2 * q] = t1.x; p1[2 * q + 1] = t1.y;
+        }
+    }
+    dft_dif_inv_reg<3>(p0);
+    dft_dif_inv_reg<3>(p1);
+    const ulonglong2* kt = reinterpret_cast<const ulonglong2*>(a.ktab + 16 * tid);
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(data + 16 * tid);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const ulonglong2 k0 = kt[q], k1 = kt[4 + q];
+        ulonglong2 o0, o1;
+        o0.x = mul(p0[2 * q], k0.x); o0.y = mul(p0[2 * q + 1], k0.y);
+        o1.x = mul(p1[2 * q], k1.x); o1.y = mul(p1[2 * q + 1], k1.y);
+        dst[q] = o0; dst[4 + q] = o1;
+    }
+}
+// The 12-bit contiguous last pass (4096-point tiles: every transform of 2^13 points and more whose launch is too small for the 11-bit
+// plan) in the same form: 16 x 16 x 16, position p = 256 j + 16 s + u, four wavefronts per tile and 16 values per lane, three 16-point
+// register transforms, the twiddles between them from one [16][256] table mt[f][t] = w_4096^-(f t) (w_256^-(g u) = mt[g][16 u]).
+// Exchange buffer: row j' at j' * 272 slots; first exchange (j', t) at slot t, second in output order (thread (j', s') owns 16
+// consecutive slots) with the 16-byte pairs XOR-permuted by s'. Against the LDS rounds of ntt_inv_pass (four rounds of three bits, a
+// table multiplication per element and round): 5 full multiplications per element instead of 6.6 and two barriers less.
+constexpr int I3_ROW = 272;
+__global__ __launch_bounds__(256) void ntt_inv_last_pass_12(PassArgs a, const uint64_t* __restrict__ bftab, const uint64_t* __restrict__ mt) {
+    __shared__ __attribute__((aligned(16))) uint64_t lds[16 * I3_ROW];
+    const int tid = threadIdx.x;
+    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x);
+    uint64_t* data = a.out + (size_t)blockIdx.y * a.out_col_stride + ((size_t)b << 12);
+    const uint64_t* src = a.in + (size_t)blockIdx.y * a.in_col_stride + ((size_t)b << 12);
+    const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
+    const uint32_t rbk = gl::bitrev(b, a.log_n - 12);
+    uint64_t y[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) y[j] = src[tid + 256 * j];
+    if (a.bad) {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 16; j++) any |= y[j] >= gl::P;
+        if (any) atomicOr(a.bad, 1u);
+    }
+    {
+        uint64_t cur = bftab[b];
+        if (!a.first && rbk) {
+            cur = mul(cur, tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)tid) & nmask), a.tw_h));
+            const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 256u) & nmask), a.tw_h);
+#pragma unroll
+            for (int j = 0; j < 16; j++) { y[j] = mul(y[j], cur); if (j < 15) cur = mul(cur, step); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) y[j] = mul(y[j], cur);
+        }
+    }
+    dft_dif_inv_reg<4>(y);
+#pragma unroll
+    for (int j = 1; j < 16; j++) y[j] = mul(y[j], mt[rev4c(j) * 256 + tid]);
+#pragma unroll
+    for (int j = 0; j < 16; j++) lds[j * I3_ROW + tid] = y[j];
+    __syncthreads();
+    const int jr = tid >> 4, u = tid & 15;
+    {
+        const uint64_t* row = lds + jr * I3_ROW + u;
+#pragma unroll
+        for (int s = 0; s < 16; s++) y[s] = row[16 * s];
+    }
+    __syncthreads();                                          // the buffer is written again below
+    dft_dif_inv_reg<4>(y);
+#pragma unroll
+    for (int s = 1; s < 16; s++) y[s] = mul(y[s], mt[rev4c(s) * 256 + 16 * u]);
+    {
+        uint64_t* row = lds + jr * I3_ROW + (u & 1);
+#pragma unroll
+        for (int s = 0; s < 16; s++) row[s * 16 + 2 * ((u >> 1) ^ (s & 7))] = y[s];
+    }
+    __syncthreads();
+    {
+        const int sr = tid & 15;
+        const ulonglong2* rp = reinterpret_cast<const ulonglong2*>(lds + jr * I3_ROW + sr * 16);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const ulonglong2 t = rp[q ^ (sr & 7)]; y[2 * q] = t.x; y[2 * q + 1] = t.y; }
+    }
+    dft_dif_inv_reg<4>(y);
+    const ulonglong2* kt = reinterpret_cast<const ulonglong2*>(a.ktab + 16 * tid);
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(data + 16 * tid);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const ulonglong2 k2 = kt[q];
         ulonglong2 o;
-        o.x = mul(v[2 * m], k2.x); o.y = mul(v[2 * m + 1], k2.y);
-        dst[m] = o;
+        o.x = mul(y[2 * q], k2.x); o.y = mul(y[2 * q + 1], k2.y);
+        dst[q] = o;
     }
+}
+// tab[r << log_cols | k] = root^(r k), r < rows
+__global__ void fill_mul_table(uint64_t* tab, uint32_t rows, int log_cols, uint64_t root) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (rows << log_cols)) return;
+    tab[i] = gl::pow(root, (uint64_t)((i >> log_cols) * (i & ((1u << log_cols) - 1))));
 }
 // tab[b] = a^rev(b) * b2^(rev(b) >> shift), rev over `bits` bits: the tile factors of the inverse transform's output scaling
 __global__ void fill_block_factors(uint64_t* tab, int bits, uint64_t abase, uint64_t bbase, int shift) {
@@ -815,6 +916,9 @@ void Context::ensure_small_twiddles() {
     const uint64_t w2048 = gl::mul(w, w);
     AERO_LAUNCH(this, "fill_mul_table64", 0, fill_mul_table64, dim3(8), dim3(256), 0, twmt_fwd, 32u, w2048);
     AERO_LAUNCH(this, "fill_mul_table64", 0, fill_mul_table64, dim3(8), dim3(256), 0, twmt_inv, 32u, gl::inv(w2048));
+    // 12-bit contiguous inverse pass: [f * 256 + t] = w_4096^-(f t), f < 16
+    twmt12_inv = (uint64_t*)dev_alloc(4096 * 8);
+    AERO_LAUNCH(this, "fill_mul_table", 0, fill_mul_table, dim3(16), dim3(256), 0, twmt12_inv, 16u, 8, gl::inv(w));
     check_launch("small twiddles");
 }
 
@@ -1004,9 +1108,10 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
             }
             continue;
         }
-        if (inv2p && qi == 0 && a.log_r == 11) {
+        const bool last12 = this->reg_passes && qi == 0 && a.log_r == 12 && a.log_s == 0 && a.log_tl == 0 && log_n >= 13;
+        if ((inv2p && qi == 0 && a.log_r == 11) || last12) {
             // per-tile factors a^rev(b) * b^(rev(b) >> shift): built once per (size, scale parameters) and kept
-            const int bbits = log_n - 11;
+            const int bbits = log_n - a.log_r;
             const std::vector<uint64_t> key{(uint64_t)(0x100 + bbits), sa, sb, (uint64_t)shift, 0};
             uint64_t* bftab = nullptr;
             auto it = ktab_cache.find(key);
@@ -1017,10 +1122,15 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
                 AERO_LAUNCH(this, "fill_block_factors", 0, fill_block_factors, dim3(((1u << bbits) + 255) / 256), dim3(256), 0, bftab, bbits, sa, sb, shift);
                 if (keep) ktab_cache[key] = bftab;
             }
+            if (last12) {
+                AERO_LAUNCH(this, pass_names ? "ntt_inv_last12" : "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_last_pass_12, dim3((unsigned)(((size_t)1 << log_n) >> 12), ncols),
+                            dim3(256), 0, a, (const uint64_t*)bftab, (const uint64_t*)twmt12_inv);
+                continue;
+            }
             a.tw_mt = twmt_inv;
             const size_t tiles = ((size_t)1 << log_n) >> 11;
-            AERO_LAUNCH(this, pass_names ? "ntt_inv_last11" : "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_last_pass_11, dim3((unsigned)(tiles / F8_WAVES), ncols),
-                        dim3(64 * F8_WAVES), 0, a, (const uint64_t*)bftab);
+            AERO_LAUNCH(this, pass_names ? "ntt_inv_last11" : "ntt_inv_pass", (size_t)ncols * 16 * ((size_t)1 << log_n), ntt_inv_last_pass_11, dim3((unsigned)tiles, ncols),
+                        dim3(128), 0, a, (const uint64_t*)bftab);
             continue;
         }
         size_t E = (size_t)1 << (a.log_r + a.log_tl);

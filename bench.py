@@ -728,7 +728,14 @@ def main():
 
     # single-proof wall-clock (one stream, nothing else on the GPU): the "proof-gen wall-clock" half of the metric, trace in
     # pinned host memory -> proof bytes (H2D included), and the same with the trace already resident
-    def one_proof_ms(src, reps=7):
+    def one_proof_ms(src, reps=0):
+        # median of enough repetitions to spend about 0.2 s (7 at least, 60 at most): seven runs of a 2.3 ms proof right behind a batch
+        # read 2 - 3 % high and noisy against tools/single_latency.py's 300
+        if not reps:
+            t1 = time.perf_counter()
+            prove_call(ctx, src, opt, over) if program else ctx.prove_fib_aux(src, aux[0], aux[1], opt, aux_degree=aux[2])
+            first = time.perf_counter() - t1
+            reps = int(max(7, min(60, 0.2 / max(first, 1e-4))))
         ts = []
         for _ in range(reps):
             t1 = time.perf_counter()

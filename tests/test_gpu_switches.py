@@ -45,7 +45,7 @@ PLANS = r'''
 SHAPES = json.loads(os.environ.get("AERO_TEST_SHAPES", "null"))
 # (log_n, columns, log_blowup): interpolate + LDE; columns beyond the first two repeat them, so that the oracle transforms two columns
 # whatever the width and every other column is checked against its twin on the device
-shapes = SHAPES or [(3, 2, 3), (8, 2, 1), (10, 4, 3), (12, 2, 3), (13, 2, 3), (16, 2, 3), (18, 1, 3), (20, 2, 3), (20, 72, 3), (21, 1, 3), (22, 1, 3), (22, 2, 1)]
+shapes = SHAPES or [(3, 2, 3), (8, 2, 1), (10, 4, 3), (12, 2, 3), (13, 2, 3), (16, 2, 3), (18, 1, 3), (20, 2, 3), (20, 72, 3), (21, 1, 3), (22, 1, 3), (22, 2, 1), (14, 128, 1)]
 seen = {}
 for log_n, cols, lb in shapes:
     rng = np.random.default_rng(77 + log_n + cols)
@@ -77,8 +77,9 @@ EXPECTED = {
     "ntt_fwd_reg6_mid_buf", "ntt_fwd_reg6_last_buf", "ntt_fwd_reg6_last",      # two-lane radix 64: buffer form / pointer form from 16 columns on
     "ntt_fwd_reg7",              # two-lane radix 128 (2^24- and 2^25-point transforms)
     "ntt_fwd_reg5", "ntt_fwd_reg4", "ntt_fwd_reg123",
-    "ntt_inv_last11",            # two-phase contiguous last pass (launches of >= 2^21 elements)
-    "ntt_inv_lds_512", "ntt_inv_lds_strided_512",          # LDS rounds (small launches); the two-launch plan of 2^18..2^20-point small launches
+    "ntt_inv_last11",            # contiguous last pass, 2048-point tiles (launches of >= 2^21 elements)
+    "ntt_inv_last12",            # contiguous last pass, 4096-point tiles (smaller launches of transforms of >= 2^13 points)
+    "ntt_inv_lds_512", "ntt_inv_lds_strided_512",          # LDS rounds (transforms of <= 2^12 points); the strided half of the two-launch plan of 2^18..2^20-point small launches
     "ntt_inv_reg6", "ntt_inv_reg5", "ntt_inv_reg4", "ntt_inv_reg123",
 }
 
