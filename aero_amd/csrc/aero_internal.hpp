@@ -61,7 +61,7 @@ struct CompactOut {
     int log_step = 0;
     int log_split = 0;
 };
-std::vector<NttPass> plan_passes(int log_n, bool reg_passes, int first_bits = 12, bool radix128 = false);
+std::vector<NttPass> plan_passes(int log_n, bool reg_passes, int first_bits = 12, bool radix128 = false, int lds_max_r = 8);
 
 typedef b2s::Digest Digest;   // 8 x u32, byte order = digest byte order (little-endian words)
 

@@ -933,13 +933,13 @@ static bool lds_wide(int ncols, int log_n) { return ((size_t)ncols << log_n) <= 
 // passes every strided pass has radix <= 64 (one more pass over HBM beats a radix-128/256 pass through LDS: measured 2^25
 // points, 4 columns: 1162 us for the LDS radix-128 pass against 550 us for a register radix-64 pass); without them the
 // strided passes take up to 8 bits each through LDS tiles of R x TL = 4096 elements.
-std::vector<NttPass> plan_passes(int L, bool reg, int first_bits, bool radix128) {
+std::vector<NttPass> plan_passes(int L, bool reg, int first_bits, bool radix128, int lds_max_r) {
     std::vector<NttPass> p;
     int r1 = L < first_bits ? L : first_bits;
     p.push_back(NttPass{0, r1, 0});
     int rem = L - r1, s = r1;
     if (rem == 0) return p;
-    int max_r = reg ? 6 : 8;
+    int max_r = reg ? 6 : lds_max_r;
     // forward register passes: radix 128 (two lanes per transform) where it saves a whole pass over radix <= 64
     if (reg && radix128 && (rem + 6) / 7 < (rem + 5) / 6) max_r = 7;
     int npass = (rem + max_r - 1) / max_r;
@@ -966,7 +966,7 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
     ensure_small_twiddles();
     bool compact_written = false;
     NttTables* t = ntt_tables(log_out);
-    std::vector<NttPass> plan = plan_passes(log_out, reg_passes, fwd_two_phase(log_out, log_pad) ? 11 : 12, radix128);
+    std::vector<NttPass> plan = plan_passes(log_out, reg_passes, fwd_two_phase(log_out, log_pad) ? 11 : 12, radix128, 8);
     if (plan[0].log_r < log_pad) fail("ntt_forward: transform too small for the requested padding");
     for (size_t q = 0; q < plan.size(); q++) {
         PassArgs a{};
@@ -1044,18 +1044,19 @@ void Context::ntt_inverse(uint64_t* data, size_t stride, int ncols, int log_n, u
                           const uint64_t* src, size_t src_stride) {
     ensure_small_twiddles();
     NttTables* t = ntt_tables(log_n);
-    // Two-phase contiguous pass (11 bits) on launches of at least 2^21 elements (measured: -20 % on 72 columns x 2^20 and on 2 x 2^24, -7 % on
-    // 2 x 2^21, -8 % on 2 x 2^20 (75.9 -> 69.9 us, round 4: fewer VALU instructions matter with several proofs in flight even where one proof
-    // alone is latency-bound); below that the LDS rounds keep the launch (profiles/r4_inv_threshold_ab.txt).
-    // Small launches (lds_wide) of 2^18 .. 2^20 points: the 6 - 8 bits behind the 12-bit contiguous pass as ONE strided pass through LDS tiles
-    // (512 threads) instead of one or two register passes - two launches instead of three where every launch is latency. Measured
-    // (profiles/r4_inv_lds_plan_ab.txt): 2 columns 2^20 76.0 -> 63.4 us, 1 column 2^20 52.4 -> 46.7, 2 columns 2^18 49.6 -> 43.7, 2^19 50.9 -> 48.5;
-    // 2 columns 2^16 (4 bits behind the first pass: one radix-16 register pass) 30.5 -> 33.5, so shorter transforms keep the register pass.
-    // One proof alone: 2.30 - 2.35 -> 2.28 - 2.31 ms; eight in flight: unchanged (1.251 / 1.265 against 1.263 / 1.260 G cells/s).
-    const bool lds_plan = this->reg_passes && log_n >= 18 && log_n <= 20 && lds_wide(ncols, log_n);
+    // Small launches (lds_wide: up to 2^21 elements) of 2^18 .. 2^21 points: the 6 - 9 bits behind the 12-bit contiguous pass as ONE strided pass
+    // through LDS tiles (512 threads, R x TL = 4096 elements) instead of two register passes - two launches instead of three where every launch
+    // is latency. Measured (profiles/r4_inv_lds_plan_ab.txt, round 4): 2 columns 2^20 76.0 -> 63.4 us, 1 column 2^20 52.4 -> 46.7, 2 columns 2^18
+    // 49.6 -> 43.7, 2^19 50.9 -> 48.5; 2 columns 2^16 (4 bits behind the first pass: one radix-16 register pass) 30.5 -> 33.5, so shorter
+    // transforms keep the register pass; eight proofs in flight: unchanged. Round 5 (profiles/r5_inv_last11.md): one column of 2^21 points (the
+    // composition polynomial of a 2^20-row proof) the same way with 9 bits in the strided pass (512 x 8 tiles): 66.5 -> 51.6 us.
+    const bool lds_plan = this->reg_passes && log_n >= 18 && log_n <= 21 && lds_wide(ncols, log_n);
     const bool reg_passes = this->reg_passes && !lds_plan;          // shadows the member for the rest of this transform
-    const bool inv2p = reg_passes && log_n >= 13 && ((size_t)ncols << log_n) >= ((size_t)1 << 21);
-    std::vector<NttPass> plan = plan_passes(log_n, reg_passes, inv2p ? 11 : 12, false);
+    // 2048-point tiles on launches of at least 2^21 elements - except where 4096-point tiles save a whole strided pass (radix <= 64: the bits
+    // behind the contiguous pass are 6 k + 1 with 2048-point tiles, i.e. 2^18- and 2^24-point transforms): 72 columns 2^18 287 -> 260 us,
+    // 2 columns 2^24 594 -> 556 us, the other sizes within 2 % either way (profiles/r5_inv_last11.md)
+    const bool inv2p = reg_passes && log_n >= 13 && ((size_t)ncols << log_n) >= ((size_t)1 << 21) && (log_n - 11) % 6 != 1;
+    std::vector<NttPass> plan = plan_passes(log_n, reg_passes, inv2p ? 11 : 12, false, lds_plan ? 9 : 8);
     const int r1 = plan[0].log_r;
     // per-k table for the final (contiguous) pass
     uint64_t ninv = gl::inv((uint64_t)1 << log_n);

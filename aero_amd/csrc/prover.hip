@@ -599,6 +599,25 @@ struct StageClock {
     }
 };
 
+// AERO_HOST_GAPS=1 (diagnosis): host wall-clock between the points of one proof where the device waits for the host or the host for the device,
+// one line per proof on stderr. "x->y" = time from mark x to mark y.
+struct GapLog {
+    bool on;
+    std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> marks;
+    GapLog() { static const bool e = getenv("AERO_HOST_GAPS") != nullptr; on = e; }
+    void mark(const char* what) { if (on) marks.emplace_back(what, std::chrono::steady_clock::now()); }
+    ~GapLog() {
+        if (!on || marks.size() < 2) return;
+        std::string line = "host gaps (us):";
+        char buf[96];
+        for (size_t i = 1; i < marks.size(); i++) {
+            snprintf(buf, sizeof buf, " %s->%s %.1f", marks[i - 1].first, marks[i].first, std::chrono::duration<double, std::micro>(marks[i].second - marks[i - 1].second).count());
+            line += buf;
+        }
+        fprintf(stderr, "%s\n", line.c_str());
+    }
+};
+
 // ---- exchange helpers (sharded proof only) -----------------------------------------------------------
 void Prover::comm_all_to_all(const void* send, void* recv, size_t bytes) {
     if (!comm_.stream_ordered) ctx_->sync();
@@ -1007,6 +1026,8 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     ctx->sync();
     ctx->stage_reset();
     StageClock clk(ctx, collect_stage_times);
+    GapLog gaps;
+    gaps.mark("start");
     auto t_start = std::chrono::steady_clock::now();
 
     // 0. AIR, public inputs, channel [proving_worker.rs:248-268]. The public inputs (results[k] = trace[2k+1][n-1]) seed the coin, but
@@ -1212,7 +1233,9 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     }
     ms.lde = clk.lap();
     // 3. row hashes, Merkle tree, commit [a5, a6, a8]
+    gaps.mark("lde_enqueued");
     Commitment tcom = commit_matrix(tlde);          // synchronises the stream: the last trace row has arrived as well
+    gaps.mark("root1");
     if (prog) air.results = program_pub_;      // a program's public inputs are the caller's (FibAir reads its own off the trace)
     else for (uint32_t k = 0; k < W / 2; k++) air.results[k] = h_last_row[2 * k + 1];
     if (pub_out) *pub_out = air.results;
@@ -1336,6 +1359,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             }
         }
     }
+    gaps.mark("cons_enqueued");
     ms.constraints = clk.lap();
     // 5. composition polynomial: interpolate over the coset; coefficient I gets h^-I (coset) * h^(I >> log C)
     //    (pre-scaling of column coefficient i = I >> log C for the column LDE). In bit-reversed order the C column
@@ -1364,7 +1388,9 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             }
         }
     }
+    gaps.mark("clde_enqueued");
     Commitment ccom = commit_matrix(clde);
+    gaps.mark("root2");
     wdigest(proof.commitments, ccom.root);
     coin.reseed(ccom.root);
     ms.comp_commit = clk.lap();
@@ -1406,7 +1432,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             launch_eval_multi<F>(ctx, jobs, nj, log_n, d_out.get());
         }
         if (G > 1) ctx->fetch(ood.data(), d_out.get(), ood.size() * sizeof(T));
-        else { ctx->sync(); memcpy(ood.data(), h_ood, ood.size() * sizeof(T)); }
+        else { gaps.mark("ood_enqueued"); ctx->sync(); gaps.mark("ood_back"); memcpy(ood.data(), h_ood, ood.size() * sizeof(T)); }
     }
     std::vector<T> ood_cur(TW), ood_next(TW), ood_h(C);
     for (uint32_t c = 0; c < W; c++) { ood_cur[c] = ood[2 * c]; ood_next[c] = ood[2 * c + 1]; }
@@ -1444,6 +1470,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         if (have_cc) { dc_src.c = clde_c.data.get(); dc_src.c_log = cc_log; }
         fri_vals.push_back(deep_compose<F>(tlde.data.get(), clde.data.get(), A ? alde.data.get() : nullptr, W, A, (uint32_t)C, log_n, log_Bl, h, in, &dc_src));
     }
+    gaps.mark("deep_enqueued");
     ms.deep = clk.lap();
 
     // 9. FRI commit phase [a15]: layers + 1 rounds (the last commits the remainder). A sharded layer of global domain Dom
@@ -1505,6 +1532,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             Dom /= Fd;
         }
     }
+    gaps.mark("fri_back");
     ms.fri = clk.lap();
 
     // 10. grinding [a16]
@@ -1513,6 +1541,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         proof.pow_nonce = nonce;
         coin.reseed_with_int(nonce);
     }
+    gaps.mark("grind_back");
     ms.grind = clk.lap();
 
     // 11. queries [a17]: every position / node index is known up front, so all gathers are issued behind ONE upload and
@@ -1722,6 +1751,7 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         for (size_t i = 0; i < rem_dom; i++) for (int d = 0; d < F::DEG; d++) w64(proof.fri_remainder, h_val[off_rem + (size_t)d * rem_dom + i]);
     }
     q_lap("serialise");
+    gaps.mark("done");
     ms.queries = clk.lap();
     ctx->scratch_reset();
     ms.total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
