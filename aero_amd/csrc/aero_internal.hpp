@@ -271,6 +271,10 @@ public:
     std::map<int, NttTables> ntt_tabs;
     std::map<uint64_t, uint64_t*> pass_tabs;
     std::map<std::vector<uint64_t>, uint64_t*> ktab_cache;
+    // FibAir constraint evaluation: the boundary-divisor inverses of a constraint domain (2 x rows words, key = rows, offset, w_last), built by
+    // the first proof of a shape and kept (at most two shapes and 2^23 rows each; AERO_CONS_INV_TABLE=0: every proof inverts per thread)
+    std::map<std::vector<uint64_t>, uint64_t*> cons_inv_cache;
+    bool cons_inv_table = true;
    // final-pass scale tables of ntt_inverse, keyed by their parameters
     uint64_t *tw4096_fwd = nullptr, *tw4096_inv = nullptr;
     uint64_t *twmt_fwd = nullptr, *twmt_inv = nullptr, *twmt12_inv = nullptr;   // [r * 64 + k] = w_2048^(+-r k), r < 32

@@ -162,14 +162,24 @@ GL_HD uint64_t pow(uint64_t b, uint64_t e) {
     return r;
 }
 // a^(p-2), p - 2 = 2^64 - 2^32 - 1 = (2^32 - 2) * 2^32 + (2^32 - 1). inv(0) = 0 (winter-math convention).
+GL_HD uint64_t sqr_n(uint64_t x, int n) {
+#pragma unroll 1
+    for (int i = 0; i < n; i++) x = sqr(x);
+    return x;
+}
+// a^(p - 2), p - 2 = (2^32 - 2) 2^32 + (2^32 - 1): a^(2^31 - 1) by the chain 1, 2, 4, 5, 10, 15, 30, 31 (exponents 2^k - 1), then 33 squarings:
+// 63 squarings + 9 multiplications (the square-and-multiply ladder this replaces took 63 + 32)
 GL_HD uint64_t inv(uint64_t a) {
-    uint64_t x31 = a;                              // a^(2^1 - 1)
-#pragma unroll 1
-    for (int i = 1; i < 31; i++) x31 = mul(sqr(x31), a);   // a^(2^31 - 1)
+    const uint64_t x2 = mul(sqr(a), a);
+    const uint64_t x4 = mul(sqr_n(x2, 2), x2);
+    const uint64_t x5 = mul(sqr(x4), a);
+    const uint64_t x10 = mul(sqr_n(x5, 5), x5);
+    const uint64_t x15 = mul(sqr_n(x10, 5), x5);
+    const uint64_t x30 = mul(sqr_n(x15, 15), x15);
+    const uint64_t x31 = mul(sqr(x30), a);         // a^(2^31 - 1)
     uint64_t y = sqr(x31);                         // a^(2^32 - 2)
-    uint64_t t = mul(y, a);                        // a^(2^32 - 1)
-#pragma unroll 1
-    for (int i = 0; i < 32; i++) y = sqr(y);       // a^((2^32 - 2) * 2^32)
+    const uint64_t t = mul(y, a);                  // a^(2^32 - 1)
+    y = sqr_n(y, 32);                              // a^((2^32 - 2) * 2^32)
     return mul(y, t);
 }
 GL_HD uint64_t root_of_unity(int log_n) { return pow(ROOT_2_32, 1ULL << (TWO_ADICITY - log_n)); }

@@ -30,6 +30,7 @@ Context::Context(int dev) : device(dev) {
     if (const char* e = getenv("AERO_QUAD_TOPS")) quad_tops = e[0] != '0';
     if (const char* e = getenv("AERO_AIR_JIT")) air_jit = e[0] != '0';
     if (const char* e = getenv("AERO_NTT_R128")) radix128 = e[0] != '0';
+    if (const char* e = getenv("AERO_CONS_INV_TABLE")) cons_inv_table = e[0] != '0';
     if (const char* e = getenv("AERO_POOL_GUARD")) guard_mode = e[0] == '1';
 }
 Context::~Context() {
@@ -1347,6 +1348,17 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             a.out_cols = nullptr;
             if (!gather_h) {
                 for (int d = 0; d < F::DEG; d++) a.out_h[d] = hbuf.get() + (size_t)d * ceN;
+                if (ctx->cons_inv_table && rows_eval <= ((size_t)1 << 23) && rows_eval % 4 == 0) {
+                    // (x - 1)^-1 and (x - w^(n-1))^-1 over the constraint domain do not depend on the proof: one table per shape, built once
+                    const std::vector<uint64_t> key{(uint64_t)rows_eval, h, a.w_last};
+                    auto it = ctx->cons_inv_cache.find(key);
+                    if (it == ctx->cons_inv_cache.end() && ctx->cons_inv_cache.size() < 2) {
+                        uint64_t* tab = (uint64_t*)ctx->dev_alloc(2 * rows_eval * 8);
+                        launch_fib_inverse_table(ctx, tab, rows_eval, h, a.w_last, tce->lo_fwd, tce->hi_fwd, tce->h);
+                        it = ctx->cons_inv_cache.emplace(key, tab).first;
+                    }
+                    if (it != ctx->cons_inv_cache.end()) { a.inv_tab = it->second; a.inv_tab_n = rows_eval; }
+                }
                 launch_fib_constraints<F>(ctx, a, 1);
             } else {
                 DevBuf<uint64_t> hloc(ctx, (size_t)F::DEG * M), hall(ctx, (size_t)F::DEG * N);

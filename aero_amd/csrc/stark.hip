@@ -127,8 +127,18 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
         }
     }
     if (MODE == 1) {
+        uint64_t den[2 * K];
+        if (a.inv_tab) {
+            // (x - 1)^-1, (x - w_n^(n-1))^-1 from the per-domain table: 16 bytes per row instead of 27 multiplications
+#pragma unroll
+            for (int q = 0; q < K; q++) {
+                const size_t s = a.first + t + (size_t)q * nthreads;
+                den[2 * q] = a.inv_tab[s];
+                den[2 * q + 1] = a.inv_tab[a.inv_tab_n + s];
+            }
+        } else {
         // batch-invert (x - 1), (x - w_n^(n-1)) for the K points
-        uint64_t den[2 * K], pre[2 * K];
+        uint64_t pre[2 * K];
         uint64_t run = 1;
 #pragma unroll
         for (int q = 0; q < K; q++) {
@@ -140,6 +150,7 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
         uint64_t ia = gl::inv(run);
 #pragma unroll
         for (int i = 2 * K - 1; i >= 0; i--) { uint64_t v = gl::mul(ia, pre[i]); ia = gl::mul(ia, den[i]); den[i] = v; }
+        }
 #pragma unroll
         for (int q = 0; q < K; q++) {
             const size_t s = a.first + t + (size_t)q * nthreads;
@@ -151,6 +162,34 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
             for (int d = 0; d < F::DEG; d++) a.out_h[d][s] = F::comp(h, d);
         }
     }
+}
+
+// out[s] = (x_s - 1)^-1, out[rows + s] = (x_s - w_last)^-1, x_s = offset * w_rows^s: four points per thread share one inversion
+__global__ __launch_bounds__(256) void fib_inverse_table_kernel(uint64_t* __restrict__ out, size_t rows, uint64_t offset, uint64_t w_last,
+                                                                  const uint64_t* __restrict__ tw_lo, const uint64_t* __restrict__ tw_hi, int tw_h) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = rows / 4;
+    if (t >= nthreads) return;
+    uint64_t den[8], pre[8], run = 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint64_t x = gl::mul(offset, tw2(tw_lo, tw_hi, (uint32_t)(t + (size_t)q * nthreads), tw_h));
+        den[2 * q] = gl::sub(x, 1);
+        den[2 * q + 1] = gl::sub(x, w_last);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { pre[i] = run; run = gl::mul(run, den[i]); }
+    uint64_t ia = gl::inv(run);
+#pragma unroll
+    for (int i = 7; i >= 0; i--) { const uint64_t v = gl::mul(ia, pre[i]); ia = gl::mul(ia, den[i]); den[i] = v; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        out[t + (size_t)q * nthreads] = den[2 * q];
+        out[rows + t + (size_t)q * nthreads] = den[2 * q + 1];
+    }
+}
+void launch_fib_inverse_table(Context* ctx, uint64_t* out, size_t rows, uint64_t offset, uint64_t w_last, const uint64_t* tw_lo, const uint64_t* tw_hi, int tw_h) {
+    AERO_LAUNCH(ctx, "fib_inverse_table_kernel", 0, fib_inverse_table_kernel, dim3((unsigned)((rows / 4 + 255) / 256)), dim3(256), 0, out, rows, offset, w_last, tw_lo, tw_hi, tw_h);
+    ctx->check_launch("fib_inverse_table");
 }
 
 template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F>& a, int mode) {
@@ -165,6 +204,9 @@ template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F
         // with the 160-bit sums 2 rows per thread: 6 sums x 5 limbs per row are live, 4 rows cost the occupancy (2^20 x 72: 0.81 ms with 4
         // rows, 0.56 with 2, 0.54 with 1; 2^20 x 8: 0.195 / 0.176 / 0.232)
         if (wide) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 2, true>), dim3((unsigned)((cnt / 2 + 255) / 256)), dim3(256), 0, a);
+        // with the divisor inverses from the per-shape table nothing is shared between a thread's rows: one row per thread (2^21 rows x 2 columns:
+        // 56 / 50 / 46 us for 4 / 2 / 1 rows, 89 us with the per-thread inversions; profiles/r5_cons_inv_table.txt)
+        else if (a.inv_tab) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG + 2), (fib_constraints_kernel<F, 1, 1, false>), g1, dim3(256), 0, a);
         else AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 4, false>), g4, dim3(256), 0, a);
     } else {
         if (wide) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 1, true>), g1, dim3(256), 0, a);

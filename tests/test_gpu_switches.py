@@ -272,3 +272,28 @@ def test_completion_word_and_placement_switches(tmp_path, env):
     """AERO_POLL_FLAGS=0: the host waits for the stream at the tree roots and the FRI tail instead of polling the completion word the
     producing launch stores in mapped pinned memory; AERO_NUMA=0: no thread binding, no node preference for pinned buffers."""
     run(tmp_path, POLL, env)
+
+
+CONS_TABLE = r'''
+# three shapes on one context (the table cache holds two: the third shape inverts per thread), each proved three times (first proof builds the table)
+for width, log_n, aux, opt in ((2, 16, (0, 0, 2), [27, 8, 16, 4, 1, 8, 8]), (6, 12, (2, 3, 4), [20, 8, 4, 4, 2, 4, 5]), (2, 13, (0, 0, 2), [27, 4, 8, 4, 1, 8, 6]),
+                              (8, 10, (0, 0, 2), [16, 16, 0, 4, 2, 8, 7])):
+    want = orc.prove_fib_aux(width, log_n, aux[0], aux[1], opt, D=aux[2])[0] if aux[0] else orc.prove_fib(width, log_n, opt)[0]
+    dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
+    ctx.set_kernel_timing(True)
+    for _ in range(3):
+        got, _ = ctx.prove_fib_aux(dev, aux[0], aux[1], aero_amd.ProofOptions(*opt), aux_degree=aux[2])
+        assert got == want, (width, log_n)
+    names = set(ctx.kernel_timing_report())
+    ctx.set_kernel_timing(False)
+    if os.environ.get("AERO_CONS_INV_TABLE") == "0": assert "fib_inverse_table_kernel" not in names, names
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("flag", ["1", "0"])
+def test_constraint_divisor_inverse_table(tmp_path, flag):
+    """AERO_CONS_INV_TABLE=0: the FibAir constraint kernel inverts its two boundary divisors per thread (batched over four rows) instead of
+    reading them from the per-shape table the first proof of a shape builds (stark.hip: fib_inverse_table_kernel); proof bytes against the
+    oracle in both fields, with and without an auxiliary segment, more shapes than the table cache holds."""
+    run(tmp_path, CONS_TABLE, {"AERO_CONS_INV_TABLE": flag})
