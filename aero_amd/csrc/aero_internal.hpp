@@ -275,6 +275,7 @@ public:
     // the first proof of a shape and kept (at most two shapes and 2^23 rows each; AERO_CONS_INV_TABLE=0: every proof inverts per thread)
     std::map<std::vector<uint64_t>, uint64_t*> cons_inv_cache;
     bool cons_inv_table = true;
+    bool deep_coeff = true;    // DEEP composition in coefficient form (base field, one GPU); AERO_DEEP_COEFF=0: evaluated on the trace-length coset and interpolated
    // final-pass scale tables of ntt_inverse, keyed by their parameters
     uint64_t *tw4096_fwd = nullptr, *tw4096_inv = nullptr;
     uint64_t *twmt_fwd = nullptr, *twmt_inv = nullptr, *twmt12_inv = nullptr;   // [r * 64 + k] = w_2048^(+-r k), r < 32

@@ -31,6 +31,7 @@ Context::Context(int dev) : device(dev) {
     if (const char* e = getenv("AERO_AIR_JIT")) air_jit = e[0] != '0';
     if (const char* e = getenv("AERO_NTT_R128")) radix128 = e[0] != '0';
     if (const char* e = getenv("AERO_CONS_INV_TABLE")) cons_inv_table = e[0] != '0';
+    if (const char* e = getenv("AERO_DEEP_COEFF")) deep_coeff = e[0] != '0';
     if (const char* e = getenv("AERO_POOL_GUARD")) guard_mode = e[0] == '1';
 }
 Context::~Context() {
@@ -1480,6 +1481,35 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
         if (have_tc && (!A || have_ac)) { dc_src.t = tlde_c.data.get(); dc_src.t_log = tc_log + tc_split; dc_src.t_stride = M >> tc_log;
                                           if (A) { dc_src.a = alde_c.data.get(); dc_src.a_log = tc_log + tc_split; dc_src.a_stride = M >> tc_log; } }
         if (have_cc) { dc_src.c = clde_c.data.get(); dc_src.c_log = cc_log; }
+        bool coeff_form = false;
+        if constexpr (F::DEG == 1) {
+            // base field, one GPU, narrow traces: the quotients as synthetic divisions of the column polynomials (stark.hip: launch_deep_coeff) - no
+            // inversions, no interpolation of the result (2^20 x 2: deep kernel + inverse transform 93 us -> 85 us in five short launches, one proof
+            // alone 2.155 -> 2.13 ms, eight in flight +0.8 %). From 8 columns on the evaluation form's single fused pass over the rows wins
+            // (2^20 x 72: 0.46 ms against 0.53 - 0.60), profiles/r5_deep_coeff.md
+            if (ctx->deep_coeff && G == 1 && log_Bl > 0 && log_n >= 3 && W + A < 8) {
+                coeff_form = true;
+                std::vector<uint64_t> dc_chunk(C);
+                for (size_t q = 0; q < C; q++) dc_chunk[q] = dc[gl::bitrev((uint32_t)q, log_C)];       // chunk q of hbuf is column bitrev(q)
+                ParamPack pp(ctx);
+                const size_t i_a = pp.add(da), i_b = pp.add(db), i_c = pp.add(dc_chunk);
+                pp.commit();
+                DeepCoeffArgs ca{};
+                ca.tpolys = polys.data.get(); ca.t_stride = n; ca.W = W;
+                ca.apolys = A ? apolys.data.get() : nullptr; ca.a_stride = n; ca.A = A;
+                ca.hpolys = hbuf.get(); ca.h_stride = n; ca.C = (uint32_t)C;
+                ca.da = pp.ptr<uint64_t>(i_a); ca.db = pp.ptr<uint64_t>(i_b); ca.dc = pp.ptr<uint64_t>(i_c);
+                ca.log_n = log_n;
+                ca.y[0] = gl::mul(z, h_inv); ca.y[1] = gl::mul(z_next, h_inv); ca.y[2] = gl::mul(z_c, h_inv);
+                ca.lam = gl::mul(lambda, h_inv); ca.mu = mu;
+                DevBuf<uint64_t> blocks(ctx, deep_coeff_scratch_words(log_n)), dsm(ctx, n), out(ctx, M);
+                ca.blocks = blocks.get(); ca.out = dsm.get();
+                launch_deep_coeff(ctx, ca);
+                ctx->ntt_forward(dsm.get(), n, out.get(), M, 1, log_M, log_Bl);
+                fri_vals.push_back(std::move(out));
+            }
+        }
+        if (!coeff_form)
         fri_vals.push_back(deep_compose<F>(tlde.data.get(), clde.data.get(), A ? alde.data.get() : nullptr, W, A, (uint32_t)C, log_n, log_Bl, h, in, &dc_src));
     }
     gaps.mark("deep_enqueued");

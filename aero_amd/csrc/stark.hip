@@ -477,6 +477,186 @@ template void launch_deep<FB>(Context*, const DeepArgs<FB>&);
 template void launch_deep<FQ>(Context*, const DeepArgs<FQ>&);
 
 // ------------------------------------------------------------------------------------------------
+// DEEP composition in coefficient form (DeepCoeffArgs). Synthetic division q_(m-1) = c_m + y q_m is a suffix scan over the coefficient index.
+// Coefficient k = a B + b of a bit-reversed vector sits at position rev(b) (n / B) + rev(a): a thread that walks the B coefficients of block a
+// serially reads, together with its neighbours (consecutive rev(a)), contiguous segments - and the vector of block values, indexed by rev(a), is
+// again a bit-reversed vector, so the scheme nests. Every serial walk fetches its values eight steps ahead (a lone dependent chain per thread would
+// otherwise pay one memory latency per step: 133 us instead of 25 for the first kernel). Launches for 2^20 coefficients (blocks of 8, then 8,
+// then one workgroup per quotient over 2^14 values):
+//   deep_coeff_combine_kernel   the three combined polynomials P_j (stored: the way down reads them again) and their block values E1;
+//   deep_coeff_up_kernel        block values E2 of E1 at the points y^8;
+//   deep_coeff_mid_kernel       E2 -> carries: serial per thread, log-step scan over the threads through LDS, serial again; one workgroup per
+//                               quotient (all three on one CU took 71 us, on three 31);
+//   deep_coeff_down_kernel      carries of the level below from the carries of this one (in place over the block values);
+//   deep_coeff_down_kernel<FINAL> the quotients from the carries down, their sum times (lam + mu y) on the way out.
+constexpr int DC_CHUNK = 8;
+struct DeepLevel {            // one level of the scan over three chains stored as [3][1 << log_len] (bit-reversed order)
+    uint64_t* vals;           // values of this level (up: read; down: read, then overwritten by the carries unless FINAL)
+    uint64_t* blocks;         // [3][len >> log_b]: block values (up: written), carries (down: read)
+    int log_len, log_b;
+    uint64_t y[3];            // the level's point per chain
+};
+__device__ __forceinline__ size_t dc_pos(int b, int log_b, int log_len, size_t ra) { return ((size_t)gl::bitrev((uint32_t)b, log_b) << (log_len - log_b)) + ra; }
+
+__global__ __launch_bounds__(256) void deep_coeff_combine_kernel(DeepCoeffArgs a, DeepLevel lv) {
+    const size_t nb = (size_t)1 << (lv.log_len - lv.log_b), ra = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)1 << lv.log_len;
+    if (ra >= nb) return;
+    uint64_t acc[3] = {0, 0, 0};
+    const int B = 1 << lv.log_b, step = B < DC_CHUNK ? B : DC_CHUNK;
+    for (int b0 = B - step; b0 >= 0; b0 -= step) {
+        uint64_t p[DC_CHUNK][3];
+        size_t pos[DC_CHUNK];
+#pragma unroll
+        for (int i = 0; i < DC_CHUNK; i++) { pos[i] = i < step ? dc_pos(b0 + i, lv.log_b, lv.log_len, ra) : 0; p[i][0] = p[i][1] = p[i][2] = 0; }
+        for (uint32_t c = 0; c < a.W + a.A; c++) {
+            const uint64_t ka = a.da[c], kb = a.db[c];
+            const uint64_t* col = c < a.W ? a.tpolys + (size_t)c * a.t_stride : a.apolys + (size_t)(c - a.W) * a.a_stride;
+#pragma unroll
+            for (int i = 0; i < DC_CHUNK; i++) if (i < step) { const uint64_t v = col[pos[i]]; p[i][0] = gl::add(p[i][0], gl::mul(ka, v)); p[i][1] = gl::add(p[i][1], gl::mul(kb, v)); }
+        }
+        for (uint32_t c = 0; c < a.C; c++) {
+            const uint64_t kc = a.dc[c];
+#pragma unroll
+            for (int i = 0; i < DC_CHUNK; i++) if (i < step) p[i][2] = gl::add(p[i][2], gl::mul(kc, a.hpolys[(size_t)c * a.h_stride + pos[i]]));
+        }
+#pragma unroll
+        for (int i = DC_CHUNK - 1; i >= 0; i--) if (i < step) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { lv.vals[(size_t)j * n + pos[i]] = p[i][j]; acc[j] = gl::add(p[i][j], gl::mul(lv.y[j], acc[j])); }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) lv.blocks[(size_t)j * nb + ra] = acc[j];
+}
+__global__ __launch_bounds__(256) void deep_coeff_up_kernel(DeepLevel lv) {
+    const size_t nb = (size_t)1 << (lv.log_len - lv.log_b), ra = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)1 << lv.log_len;
+    if (ra >= nb) return;
+    uint64_t acc[3] = {0, 0, 0};
+    const int B = 1 << lv.log_b, step = B < DC_CHUNK ? B : DC_CHUNK;
+    for (int b0 = B - step; b0 >= 0; b0 -= step) {
+        uint64_t p[DC_CHUNK][3];
+#pragma unroll
+        for (int i = 0; i < DC_CHUNK; i++) if (i < step) {
+            const size_t pos = dc_pos(b0 + i, lv.log_b, lv.log_len, ra);
+#pragma unroll
+            for (int j = 0; j < 3; j++) p[i][j] = lv.vals[(size_t)j * n + pos];
+        }
+#pragma unroll
+        for (int i = DC_CHUNK - 1; i >= 0; i--) if (i < step) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) acc[j] = gl::add(p[i][j], gl::mul(lv.y[j], acc[j]));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) lv.blocks[(size_t)j * nb + ra] = acc[j];
+}
+// carries of this level's values from the carries of its blocks. FINAL (level of the polynomials themselves): instead of the carries, the DEEP
+// coefficients lam S_m + mu S_(m-1), S = sum of the three quotients, go to `out`
+template <bool FINAL> __global__ __launch_bounds__(256) void deep_coeff_down_kernel(DeepLevel lv, uint64_t lam, uint64_t mu, uint64_t* __restrict__ out) {
+    const size_t nb = (size_t)1 << (lv.log_len - lv.log_b), ra = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)1 << lv.log_len;
+    if (ra >= nb) return;
+    uint64_t acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) acc[j] = lv.blocks[(size_t)j * nb + ra];
+    uint64_t s_hi = FINAL ? gl::add(gl::add(acc[0], acc[1]), acc[2]) : 0;      // S_m at the top coefficient m of the block
+    const int B = 1 << lv.log_b, step = B < DC_CHUNK ? B : DC_CHUNK;
+    for (int b0 = B - step; b0 >= 0; b0 -= step) {
+        uint64_t p[DC_CHUNK][3];
+        size_t pos[DC_CHUNK];
+#pragma unroll
+        for (int i = 0; i < DC_CHUNK; i++) if (i < step) {
+            pos[i] = dc_pos(b0 + i, lv.log_b, lv.log_len, ra);
+#pragma unroll
+            for (int j = 0; j < 3; j++) p[i][j] = lv.vals[(size_t)j * n + pos[i]];
+        }
+#pragma unroll
+        for (int i = DC_CHUNK - 1; i >= 0; i--) if (i < step) {
+            if (!FINAL) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) { lv.vals[(size_t)j * n + pos[i]] = acc[j]; acc[j] = gl::add(p[i][j], gl::mul(lv.y[j], acc[j])); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; j++) acc[j] = gl::add(p[i][j], gl::mul(lv.y[j], acc[j]));
+                uint64_t s_lo = gl::add(gl::add(acc[0], acc[1]), acc[2]);   // S_(m-1); below coefficient 0 there is the remainder, not a quotient term
+                if (b0 + i == 0 && ra == 0) s_lo = 0;
+                out[pos[i]] = gl::add(gl::mul(lam, s_hi), gl::mul(mu, s_lo));
+                s_hi = s_lo;
+            }
+        }
+    }
+}
+// vals[j][rev(a)] = E_a  ->  carry_a = sum_(a' > a) E_a' y^(a' - a - 1), in place; workgroup j (one CU) scans chain j. Thread t owns the
+// 2^log_per consecutive a of block rev(t) - their positions are rev(i) * threads + t, contiguous over the threads like everywhere else - and
+// the scan over the blocks runs through LDS in block order with the host's step multipliers w[j][s] = (y_j^per)^(2^s).
+struct DeepMidW { uint64_t w[3][10]; };
+__global__ __launch_bounds__(1024) void deep_coeff_mid_kernel(DeepLevel lv, int log_threads, DeepMidW mw) {
+    __shared__ uint64_t sh[1024];
+    const int j = blockIdx.x;
+    const int log_per = lv.log_len - log_threads;
+    uint64_t* vals = lv.vals + ((size_t)j << lv.log_len);
+    const int per = 1 << log_per, tid = threadIdx.x, threads = 1 << log_threads, step = per < DC_CHUNK ? per : DC_CHUNK;
+    const int blk = (int)gl::bitrev((uint32_t)tid, log_threads);
+    const uint64_t y = lv.y[j];
+    uint64_t acc = 0;
+    for (int i0 = per - step; i0 >= 0; i0 -= step) {
+        uint64_t p[DC_CHUNK];
+#pragma unroll
+        for (int i = 0; i < DC_CHUNK; i++) if (i < step) p[i] = vals[dc_pos(i0 + i, log_per, lv.log_len, (size_t)tid)];
+#pragma unroll
+        for (int i = DC_CHUNK - 1; i >= 0; i--) if (i < step) acc = gl::add(p[i], gl::mul(y, acc));
+    }
+    sh[blk] = acc;
+    __syncthreads();
+    // inclusive suffix scan over the blocks: S_t = sum_(t' >= t) v_t' w^(t' - t)
+    for (int d = 1, st = 0; d < threads; d <<= 1, st++) {
+        const uint64_t add = blk + d < threads ? gl::mul(mw.w[j][st], sh[blk + d]) : 0;
+        __syncthreads();
+        sh[blk] = gl::add(sh[blk], add);
+        __syncthreads();
+    }
+    acc = blk + 1 < threads ? sh[blk + 1] : 0;       // carry into this block's top value
+    for (int i0 = per - step; i0 >= 0; i0 -= step) {
+        uint64_t p[DC_CHUNK];
+        size_t pos[DC_CHUNK];
+#pragma unroll
+        for (int i = 0; i < DC_CHUNK; i++) if (i < step) { pos[i] = dc_pos(i0 + i, log_per, lv.log_len, (size_t)tid); p[i] = vals[pos[i]]; }
+#pragma unroll
+        for (int i = DC_CHUNK - 1; i >= 0; i--) if (i < step) { vals[pos[i]] = acc; acc = gl::add(p[i], gl::mul(y, acc)); }
+    }
+}
+void launch_deep_coeff(Context* ctx, const DeepCoeffArgs& a) {
+    // levels: the polynomials (2^log_n, blocks of 2^b1), then - when more than 2^14 blocks remain - their block values (blocks of 2^b2), then one
+    // workgroup per quotient (2^14 values: 2^12 measured the same, 2^10 slower, profiles/r5_deep_coeff.md)
+    const int L = a.log_n;
+    const int b1 = L >= 6 ? 3 : (L + 1) / 2;
+    const int L1 = L - b1;
+    const int b2 = L1 > 14 ? L1 - 14 : 0;
+    const int L2 = L1 - b2;
+    const size_t n = (size_t)1 << L;
+    // scratch layout (a.blocks): [3][n] combined polynomials | [3][2^L1] | [3][2^L2]
+    uint64_t* comb = a.blocks;
+    uint64_t* e1 = comb + 3 * n;
+    uint64_t* e2 = e1 + ((size_t)3 << L1);
+    DeepLevel lv1{comb, e1, L, b1, {a.y[0], a.y[1], a.y[2]}};
+    DeepLevel lv2{e1, e2, L1, b2, {0, 0, 0}}, lvm{b2 ? e2 : e1, nullptr, L2, 0, {0, 0, 0}};
+    for (int j = 0; j < 3; j++) { lv2.y[j] = gl::pow(a.y[j], 1ull << b1); lvm.y[j] = gl::pow(lv2.y[j], 1ull << b2); }
+    const size_t bytes = ((size_t)a.W + a.A + a.C + 3) * 8 << L;
+    const dim3 g1((unsigned)((((size_t)1 << L1) + 255) / 256)), g2((unsigned)((((size_t)1 << L2) + 255) / 256));
+    AERO_LAUNCH(ctx, "deep_coeff_combine_kernel", bytes, deep_coeff_combine_kernel, g1, dim3(256), 0, a, lv1);
+    if (b2) AERO_LAUNCH(ctx, "deep_coeff_up_kernel", 0, deep_coeff_up_kernel, g2, dim3(256), 0, lv2);
+    const int log_threads = L2 < 10 ? L2 : 10;
+    DeepMidW mw;
+    for (int j = 0; j < 3; j++) {
+        mw.w[j][0] = gl::pow(lvm.y[j], 1ull << (L2 - log_threads));
+        for (int st = 1; st < 10; st++) mw.w[j][st] = gl::mul(mw.w[j][st - 1], mw.w[j][st - 1]);
+    }
+    AERO_LAUNCH(ctx, "deep_coeff_mid_kernel", 0, deep_coeff_mid_kernel, dim3(3), dim3(1u << log_threads), 0, lvm, log_threads, mw);
+    if (b2) AERO_LAUNCH(ctx, "deep_coeff_down_kernel", 0, deep_coeff_down_kernel<false>, g2, dim3(256), 0, lv2, (uint64_t)0, (uint64_t)0, (uint64_t*)nullptr);
+    AERO_LAUNCH(ctx, "deep_coeff_quotient_kernel", (size_t)32 << L, deep_coeff_down_kernel<true>, g1, dim3(256), 0, lv1, a.lam, a.mu, a.out);
+    ctx->check_launch("deep_coeff");
+}
+
+// ------------------------------------------------------------------------------------------------
 // FRI fold by `fold` (fri_verifier.cairo:305-315 mirror; winter-fri apply_drp): row i = (v[i + j*rows])_j lies on
 // x_i * <w_F>, x_i = 7 * w_dom^i (the offset stays 7 at every layer: fri_verifier.cairo:23,308). With c_k = inverse
 // DFT of the row, the interpolant evaluated at alpha is (1/F) * sum_k (alpha / x_i)^k * sum_j v_j w_F^(-jk).

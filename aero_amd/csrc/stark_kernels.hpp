@@ -108,6 +108,25 @@ template <class F> struct DeepArgs {
 };
 template <class F> void launch_deep(Context* ctx, const DeepArgs<F>& a);
 
+// DEEP composition in COEFFICIENT form (base field, one GPU): the quotients (P(x) - P(z)) / (x - z) are synthetic divisions of the combined
+// column polynomials - no field inversion and no interpolation of the result. All arrays are bit-reversed coefficient vectors pre-scaled by
+// h^k (what the interpolation stage leaves and the LDE takes), so the divisions run at the points z / h:
+//   out_k = lam * S_k + mu * S_(k-1),  S = Q_1 + Q_2 + Q_3,  Q_j = synthetic quotient of P_j at y_j,
+//   P_1 = sum da_i T_i, P_2 = sum db_i T_i (main then aux columns), P_3 = sum dc_c H_(chunk c)        (lam = lambda / h, mu as drawn)
+struct DeepCoeffArgs {
+    const uint64_t* tpolys; size_t t_stride; uint32_t W;      // main segment polynomials
+    const uint64_t* apolys; size_t a_stride; uint32_t A;      // auxiliary segment polynomials (base field: one component), or A = 0
+    const uint64_t* hpolys; size_t h_stride; uint32_t C;      // composition column c = chunk c of this buffer (dc is given in chunk order)
+    const uint64_t *da, *db, *dc;                             // device: W + A, W + A, C coefficients
+    uint64_t y[3];                                            // division points z / h, z g / h, z^C / h
+    uint64_t lam, mu;
+    int log_n;                                                // n = 2^log_n coefficients
+    uint64_t* blocks;                                         // scratch: deep_coeff_scratch_words(log_n) words
+    uint64_t* out;                                            // n coefficients of the DEEP polynomial
+};
+inline size_t deep_coeff_scratch_words(int log_n) { return (size_t)5 << log_n; }   // [3][n] combined polynomials + two levels of block values (at most n / 4 each)
+void launch_deep_coeff(Context* ctx, const DeepCoeffArgs& a);
+
 template <class F> struct FoldArgs {
     typedef typename F::T T;
     const uint64_t* in[2];

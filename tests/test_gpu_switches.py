@@ -297,3 +297,30 @@ def test_constraint_divisor_inverse_table(tmp_path, flag):
     reading them from the per-shape table the first proof of a shape builds (stark.hip: fib_inverse_table_kernel); proof bytes against the
     oracle in both fields, with and without an auxiliary segment, more shapes than the table cache holds."""
     run(tmp_path, CONS_TABLE, {"AERO_CONS_INV_TABLE": flag})
+
+
+DEEP_FORM = r'''
+for width, log_n, aux, opt in ((2, 16, (0, 0, 2), [27, 8, 16, 4, 1, 8, 8]), (4, 12, (2, 3, 4), [20, 8, 4, 4, 1, 4, 5]), (6, 11, (2, 3, 4), [20, 8, 4, 4, 1, 4, 5]), (2, 13, (0, 0, 2), [27, 4, 8, 4, 1, 8, 6]),
+                              (8, 10, (0, 0, 2), [16, 16, 0, 4, 2, 8, 7]), (72, 12, (0, 0, 2), [27, 8, 8, 4, 1, 8, 6]), (2, 3, (0, 0, 2), [4, 8, 0, 4, 1, 2, 3]),
+                              (4, 7, (0, 0, 2), [8, 2, 0, 4, 1, 4, 4])):
+    want = orc.prove_fib_aux(width, log_n, aux[0], aux[1], opt, D=aux[2])[0] if aux[0] else orc.prove_fib(width, log_n, opt)[0]
+    dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
+    ctx.set_kernel_timing(True)
+    got, _ = ctx.prove_fib_aux(dev, aux[0], aux[1], aero_amd.ProofOptions(*opt), aux_degree=aux[2])
+    names = set(ctx.kernel_timing_report())
+    ctx.set_kernel_timing(False)
+    assert got == want, (width, log_n)
+    base_field = opt[4] == 1
+    narrow = width + aux[0] < 8           # from 8 columns on the evaluation form is the default too
+    assert ("deep_coeff_quotient_kernel" in names) == (base_field and narrow and os.environ.get("AERO_DEEP_COEFF") != "0"), (names, opt)
+    assert ("deep_kernel" in names) != ("deep_coeff_quotient_kernel" in names), names
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("flag", ["1", "0"])
+def test_deep_composition_form(tmp_path, flag):
+    """AERO_DEEP_COEFF=0: the DEEP composition evaluated on the trace-length coset (per-row inversions) and interpolated, instead of the
+    synthetic divisions of the coefficient vectors (base field, one GPU, fewer than 8 columns; F_p^2 and wide proofs take the evaluation form either way): proof bytes
+    against the oracle for narrow, wide, auxiliary-segment and tiny traces, and the launch labels say which form ran."""
+    run(tmp_path, DEEP_FORM, {"AERO_DEEP_COEFF": flag})
