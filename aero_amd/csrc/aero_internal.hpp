@@ -271,7 +271,7 @@ public:
     std::map<int, NttTables> ntt_tabs;
     std::map<uint64_t, uint64_t*> pass_tabs;
     std::map<std::vector<uint64_t>, uint64_t*> ktab_cache;
-    // FibAir constraint evaluation: the boundary-divisor inverses of a constraint domain (2 x rows words, key = rows, offset, w_last), built by
+    // FibAir constraint evaluation: the divisor inverses and degree-adjustment powers of a constraint domain (5 x rows words), built by
     // the first proof of a shape and kept (at most two shapes and 2^23 rows each; AERO_CONS_INV_TABLE=0: every proof inverts per thread)
     std::map<std::vector<uint64_t>, uint64_t*> cons_inv_cache;
     bool cons_inv_table = true;

@@ -1350,12 +1350,13 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             if (!gather_h) {
                 for (int d = 0; d < F::DEG; d++) a.out_h[d] = hbuf.get() + (size_t)d * ceN;
                 if (ctx->cons_inv_table && rows_eval <= ((size_t)1 << 23) && rows_eval % 4 == 0) {
-                    // (x - 1)^-1 and (x - w^(n-1))^-1 over the constraint domain do not depend on the proof: one table per shape, built once
-                    const std::vector<uint64_t> key{(uint64_t)rows_eval, h, a.w_last};
+                    // the divisor inverses and the degree-adjustment powers of a constraint-domain point do not depend on the proof: one table per
+                    // shape (5 words per row), built by the first proof of the shape
+                    const std::vector<uint64_t> key{(uint64_t)rows_eval, h, a.w_last, (uint64_t)xcount, (uint64_t)n};
                     auto it = ctx->cons_inv_cache.find(key);
                     if (it == ctx->cons_inv_cache.end() && ctx->cons_inv_cache.size() < 2) {
-                        uint64_t* tab = (uint64_t*)ctx->dev_alloc(2 * rows_eval * 8);
-                        launch_fib_inverse_table(ctx, tab, rows_eval, h, a.w_last, tce->lo_fwd, tce->hi_fwd, tce->h);
+                        uint64_t* tab = (uint64_t*)ctx->dev_alloc(5 * rows_eval * 8);
+                        launch_fib_inverse_table<F>(ctx, tab, a);
                         it = ctx->cons_inv_cache.emplace(key, tab).first;
                     }
                     if (it != ctx->cons_inv_cache.end()) { a.inv_tab = it->second; a.inv_tab_n = rows_eval; }

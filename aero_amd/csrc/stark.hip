@@ -51,16 +51,20 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
             r = (r & pm) * part_len + (r >> a.split_log);
             rn = (rn & pm) * part_len + (rn >> a.split_log);
         }
-        const uint64_t w = tw2(a.tw_lo, a.tw_hi, (uint32_t)s, a.tw_h);       // w_ce^s
-        const uint64_t wi = tw2(a.twi_lo, a.twi_hi, (uint32_t)s, a.tw_h);    // w_ce^-s
-        const uint64_t x = gl::mul(a.offset, w);
-        xs[q] = x;
         // degree adjustments without exponentiation: x^ce_n = 7^ce_n is constant on the coset
         //   x^adj_t = x^(ce_n - 1)     = K7 * x^-1
         //   x^adj_b = x^(ce_n - n + 1) = K7 * x * (x^n)^-1,   x^n = 7^n * w_C^(s mod C)
-        const uint64_t xinv = gl::mul(a.gen_inv, wi);
-        const uint64_t xt = gl::mul(a.k7, xinv);
-        const uint64_t xb = gl::mul(gl::mul(a.k7, x), a.xn_inv[s & a.xmask]);
+        // - functions of the domain point only: with the per-shape table (MODE 1) they are two loads, and x itself is needed by the auxiliary group only
+        uint64_t x = 0, xt, xb;
+        const bool tab = MODE == 1 && a.inv_tab != nullptr;
+        if (!tab || a.A) x = gl::mul(a.offset, tw2(a.tw_lo, a.tw_hi, (uint32_t)s, a.tw_h));       // h w_ce^s
+        if (tab) { xt = a.inv_tab[3 * a.inv_tab_n + s]; xb = a.inv_tab[4 * a.inv_tab_n + s]; }
+        else {
+            const uint64_t xinv = gl::mul(a.gen_inv, tw2(a.twi_lo, a.twi_hi, (uint32_t)s, a.tw_h));    // (h w_ce^s)^-1
+            xt = gl::mul(a.k7, xinv);
+            xb = gl::mul(gl::mul(a.k7, x), a.xn_inv[s & a.xmask]);
+        }
+        xs[q] = x;
         T acc = F::zero(), g0 = F::zero(), g1 = F::zero();
         if (WIDE) {
             // sum_k (alpha_k + beta_k x^adj) c_k = sum alpha_k c_k + x^adj sum beta_k c_k: the two sums per divisor are accumulated as
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
         for (int q = 0; q < K; q++) {
             const size_t s = a.first + t + (size_t)q * nthreads;
             // 1 / ((x^n - 1) / (x - w^(n-1))) = (x - w^(n-1)) * zinv[s mod C]
-            const uint64_t tdiv = gl::mul(gl::sub(xs[q], a.w_last), a.zn_inv[s & a.xmask]);
+            const uint64_t tdiv = a.inv_tab ? a.inv_tab[2 * a.inv_tab_n + s] : gl::mul(gl::sub(xs[q], a.w_last), a.zn_inv[s & a.xmask]);
             T h = F::mulb(num[q][0], tdiv);
             h = F::add(h, F::mulb(num[q][1], den[2 * q]));
             h = F::add(h, F::mulb(num[q][2], den[2 * q + 1]));
@@ -164,17 +168,25 @@ __global__ __launch_bounds__(256) void fib_constraints_kernel(FibConsArgs<F> a) 
     }
 }
 
-// out[s] = (x_s - 1)^-1, out[rows + s] = (x_s - w_last)^-1, x_s = offset * w_rows^s: four points per thread share one inversion
-__global__ __launch_bounds__(256) void fib_inverse_table_kernel(uint64_t* __restrict__ out, size_t rows, uint64_t offset, uint64_t w_last,
-                                                                  const uint64_t* __restrict__ tw_lo, const uint64_t* __restrict__ tw_hi, int tw_h) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = rows / 4;
+// Everything the constraint kernel needs of a domain point x_s = offset * w_rows^s that does not depend on the proof, out[k * rows + s]:
+//   k = 0: (x - 1)^-1   1: (x - w_last)^-1   2: (x - w_last) * zn_inv[s & xmask] (inverse of the transition divisor)
+//   3: k7 * x^-1 (x^adj of the transition group)   4: k7 * x * xn_inv[s & xmask] (x^adj of the boundary groups)
+// four points per thread share one inversion
+struct FibTableArgs {
+    uint64_t* out; size_t rows; uint64_t offset, gen_inv, k7, w_last;
+    const uint64_t *tw_lo, *tw_hi, *twi_lo, *twi_hi; int tw_h;
+    const uint64_t *xn_inv, *zn_inv; uint32_t xmask;
+};
+__global__ __launch_bounds__(256) void fib_inverse_table_kernel(FibTableArgs a) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = a.rows / 4;
     if (t >= nthreads) return;
-    uint64_t den[8], pre[8], run = 1;
+    uint64_t den[8], pre[8], xs[4], run = 1;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint64_t x = gl::mul(offset, tw2(tw_lo, tw_hi, (uint32_t)(t + (size_t)q * nthreads), tw_h));
+        const uint64_t x = gl::mul(a.offset, tw2(a.tw_lo, a.tw_hi, (uint32_t)(t + (size_t)q * nthreads), a.tw_h));
+        xs[q] = x;
         den[2 * q] = gl::sub(x, 1);
-        den[2 * q + 1] = gl::sub(x, w_last);
+        den[2 * q + 1] = gl::sub(x, a.w_last);
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) { pre[i] = run; run = gl::mul(run, den[i]); }
@@ -183,14 +195,21 @@ __global__ __launch_bounds__(256) void fib_inverse_table_kernel(uint64_t* __rest
     for (int i = 7; i >= 0; i--) { const uint64_t v = gl::mul(ia, pre[i]); ia = gl::mul(ia, den[i]); den[i] = v; }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        out[t + (size_t)q * nthreads] = den[2 * q];
-        out[rows + t + (size_t)q * nthreads] = den[2 * q + 1];
+        const size_t s = t + (size_t)q * nthreads;
+        a.out[s] = den[2 * q];
+        a.out[a.rows + s] = den[2 * q + 1];
+        a.out[2 * a.rows + s] = gl::mul(gl::sub(xs[q], a.w_last), a.zn_inv[s & a.xmask]);
+        a.out[3 * a.rows + s] = gl::mul(a.k7, gl::mul(a.gen_inv, tw2(a.twi_lo, a.twi_hi, (uint32_t)s, a.tw_h)));
+        a.out[4 * a.rows + s] = gl::mul(gl::mul(a.k7, xs[q]), a.xn_inv[s & a.xmask]);
     }
 }
-void launch_fib_inverse_table(Context* ctx, uint64_t* out, size_t rows, uint64_t offset, uint64_t w_last, const uint64_t* tw_lo, const uint64_t* tw_hi, int tw_h) {
-    AERO_LAUNCH(ctx, "fib_inverse_table_kernel", 0, fib_inverse_table_kernel, dim3((unsigned)((rows / 4 + 255) / 256)), dim3(256), 0, out, rows, offset, w_last, tw_lo, tw_hi, tw_h);
+template <class F> void launch_fib_inverse_table(Context* ctx, uint64_t* out, const FibConsArgs<F>& c) {
+    FibTableArgs a{out, c.count, c.offset, c.gen_inv, c.k7, c.w_last, c.tw_lo, c.tw_hi, c.twi_lo, c.twi_hi, c.tw_h, c.xn_inv, c.zn_inv, c.xmask};
+    AERO_LAUNCH(ctx, "fib_inverse_table_kernel", 0, fib_inverse_table_kernel, dim3((unsigned)((a.rows / 4 + 255) / 256)), dim3(256), 0, a);
     ctx->check_launch("fib_inverse_table");
 }
+template void launch_fib_inverse_table<FB>(Context*, uint64_t*, const FibConsArgs<FB>&);
+template void launch_fib_inverse_table<FQ>(Context*, uint64_t*, const FibConsArgs<FQ>&);
 
 template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F>& a, int mode) {
     size_t cnt = a.count;
@@ -206,7 +225,7 @@ template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F
         if (wide) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 2, true>), dim3((unsigned)((cnt / 2 + 255) / 256)), dim3(256), 0, a);
         // with the divisor inverses from the per-shape table nothing is shared between a thread's rows: one row per thread (2^21 rows x 2 columns:
         // 56 / 50 / 46 us for 4 / 2 / 1 rows, 89 us with the per-thread inversions; profiles/r5_cons_inv_table.txt)
-        else if (a.inv_tab) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG + 2), (fib_constraints_kernel<F, 1, 1, false>), g1, dim3(256), 0, a);
+        else if (a.inv_tab) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG + 5), (fib_constraints_kernel<F, 1, 1, false>), g1, dim3(256), 0, a);
         else AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 4, false>), g4, dim3(256), 0, a);
     } else {
         if (wide) AERO_LAUNCH(ctx, "fib_constraints_kernel", cnt * 8 * (in_cols + F::DEG), (fib_constraints_kernel<F, 1, 1, true>), g1, dim3(256), 0, a);

@@ -21,8 +21,8 @@ template <class F> struct FibConsArgs {
     const uint64_t* xn_inv;       // C entries: (h^n w_C^k)^-1
     const uint64_t* zn_inv;       // C entries: (h^n w_C^k - 1)^-1
     uint64_t w_last;              // w_n^(n-1)
-    const uint64_t* inv_tab;      // MODE 1, optional: [s] = (x_s - 1)^-1, [inv_tab_n + s] = (x_s - w_last)^-1 over the whole domain (fib_inverse_table);
-    size_t inv_tab_n;             //   nullptr = the kernel inverts per thread (batched over its K rows)
+    const uint64_t* inv_tab;      // MODE 1, optional: the per-shape table of fib_inverse_table_kernel, five arrays of inv_tab_n words - (x - 1)^-1,
+    size_t inv_tab_n;             //   (x - w_last)^-1, the transition divisor's inverse, the two x^adj; nullptr = the kernel computes them per row
     // auxiliary segment (A = 0: none): A columns over E stored as A*DEG base columns (index c*DEG + d) with the same row
     // count / stride as `lde`; p_c' = p_c * (rands[c mod R] + main[c mod W]); p_c(0) = 1
     const uint64_t* aux;
@@ -33,8 +33,9 @@ template <class F> struct FibConsArgs {
     uint64_t* out_h[2];           // MODE 1: DEG component arrays of ce_n values
 };
 template <class F> void launch_fib_constraints(Context* ctx, const FibConsArgs<F>& a, int mode);
-// the two boundary-divisor inverses of every point x_s = offset * w_rows^s, s < rows (they depend on the domain only, not on the proof): out[2 * rows]
-void launch_fib_inverse_table(Context* ctx, uint64_t* out, size_t rows, uint64_t offset, uint64_t w_last, const uint64_t* tw_lo, const uint64_t* tw_hi, int tw_h);
+// what the constraint kernel needs of every point x_s = offset * w_rows^s, s < c.count, that depends on the domain only: out[5 * c.count] (c: the
+// launch's arguments with first = 0 and the device tables xn_inv / zn_inv in place)
+template <class F> void launch_fib_inverse_table(Context* ctx, uint64_t* out, const FibConsArgs<F>& c);
 
 // The division step of `ConstraintEvaluationTable::into_poly` for FibAir: H(x) = sum over the three divisor columns of
 // numerator / divisor on the constraint-evaluation domain (row s <-> x = offset * w_ce^s).
