@@ -170,6 +170,7 @@ public:
     void pool_free(void* p);
     void* dev_alloc(size_t bytes);       // lives until the context dies (tables)
     void* scratch_alloc(size_t bytes);   // released by scratch_reset() (stream-ordered reuse)
+    void poison_block(void* p, size_t bytes);   // AERO_POISON_ALLOC=1: fill a block that is being handed out (diagnosis of reads of unwritten words)
     void scratch_reset();
     // pinned host staging (bump allocator) for small async H2D parameter blocks and D2H results; a block stays valid
     // until stage_reset(), which callers issue only after a stream synchronisation

@@ -140,6 +140,7 @@ void* Context::pool_alloc(size_t bytes) {
     live_blocks[p] = bytes;
     bytes_in_use += bytes;
     if (bytes_in_use > bytes_peak) bytes_peak = bytes_in_use;
+    poison_block(p, bytes);
     return p;
 }
 void Context::pool_free(void* p) {
@@ -161,6 +162,13 @@ void* Context::scratch_alloc(size_t bytes) {
     void* p = pool_alloc(bytes);
     scratch.push_back(p);
     return p;
+}
+// AERO_POISON_ALLOC=1 (diagnosis): every pool block is filled with a non-canonical pattern when it is handed out, on the context's stream - a
+// kernel that reads a word nobody wrote then fails the same way every time instead of depending on what the block held before
+void Context::poison_block(void* p, size_t bytes) {
+    static const bool on = getenv("AERO_POISON_ALLOC") != nullptr && getenv("AERO_POISON_ALLOC")[0] != '0';
+    // (completed before the call returns: a block may be written next from another stream of the context that is only ordered behind EARLIER work of this one)
+    if (on && p && bytes) { AERO_HIP(hipMemsetAsync(p, 0xA5, bytes, stream)); AERO_HIP(hipStreamSynchronize(stream)); }
 }
 void Context::scratch_reset() {
     for (void* p : scratch) pool_free(p);
