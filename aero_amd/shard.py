@@ -55,10 +55,19 @@ class TorchComm:
             self.last_error = e
             return 1
 
+    # gloo (ranks sharing one test GPU): the collectives run on HOST copies made and written back here, synchronously - gloo's own
+    # handling of device tensors (its staging copies on streams of its own) is not something a byte-exact test should depend on
+    # (profiles/r5_sharded_anomaly.md). nccl (= RCCL): device tensors, as a multi-GPU node runs them.
     def _all_to_all(self, _user, send, recv, nbytes):
         def run():
             n = int(nbytes) * self.world
-            self.dist.all_to_all_single(self._t(recv, n), self._t(send, n), group=self.group)
+            if self.gather_into_tensor:
+                self.dist.all_to_all_single(self._t(recv, n), self._t(send, n), group=self.group)
+            else:
+                s = self._t(send, n).cpu()
+                r = self.torch.empty_like(s)
+                self.dist.all_to_all_single(r, s, group=self.group)
+                self._t(recv, n).copy_(r)
             self.calls["all_to_all"] += 1
             self.bytes_sent += int(nbytes) * (self.world - 1)
         return self._guard(run)
@@ -69,7 +78,10 @@ class TorchComm:
             if self.gather_into_tensor:
                 self.dist.all_gather_into_tensor(out, inp, group=self.group)
             else:
-                self.dist.all_gather(list(out.chunk(self.world)), inp, group=self.group)
+                h = inp.cpu()
+                parts = [self.torch.empty_like(h) for _ in range(self.world)]
+                self.dist.all_gather(parts, h, group=self.group)
+                out.copy_(self.torch.cat(parts))
             self.calls["all_gather"] += 1
             self.bytes_sent += int(nbytes) * (self.world - 1)
         return self._guard(run)
@@ -77,7 +89,12 @@ class TorchComm:
     def _all_reduce(self, _user, buf, count):
         def run():
             t = self._t(buf, int(count) * 8).view(self.torch.int64)   # wrapping two's-complement sum == u64 sum
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.gather_into_tensor:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            else:
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
             self.calls["all_reduce"] += 1
             self.bytes_sent += int(count) * 8
         return self._guard(run)
