@@ -299,6 +299,25 @@ class Context:
     def synchronize(self):
         self._ck(lib().aero_ctx_synchronize(self.h))
 
+    def set_self_verify(self, mode):
+        """aero_ctx_set_self_verify: -1 / "auto" (default: on for proofs made by more than one rank), 0 / False off, 1 / True on. A proof the
+        library's own verifier rejects then comes back as AeroError(code -8, AERO_E_SELF_VERIFY) instead of bytes."""
+        m = -1 if mode in (-1, "auto", None) else int(bool(mode))
+        self._ck(lib().aero_ctx_set_self_verify(self.h, C.c_int32(m)))
+
+    def commit_trace(self, trace: "Matrix", options: ProofOptions, comm=None):
+        """aero_commit_trace_sharded: the main segment's commitment alone (interpolate, extend, exchange, subtree, root all-gather).
+        Returns (root, [subtree roots]) as bytes."""
+        world = comm.world if comm is not None else 1
+        root = (C.c_uint8 * 32)()
+        subs = (C.c_uint8 * (32 * world))()
+        rc = lib().aero_commit_trace_sharded(self.h, C.byref(comm.struct) if comm is not None else None, trace.h, C.byref(options), root, subs)
+        if rc != 0 and getattr(comm, "last_error", None) is not None:
+            raise AeroError(rc, f"{lib().aero_last_error(self.h).decode()} ({comm.last_error!r})")
+        self._ck(rc)
+        b = bytes(subs)
+        return bytes(root), [b[32 * r:32 * r + 32] for r in range(world)]
+
     # ---- matrices / stage 1
     def trace_upload(self, trace: np.ndarray) -> Matrix:
         t = np.ascontiguousarray(trace, np.uint64)
@@ -674,6 +693,13 @@ class Pool:
 
     def ctx(self, slot) -> Context:
         return self.ctxs[slot]
+
+    def set_self_verify(self, mode):
+        """aero_pool_set_self_verify: Context.set_self_verify for every slot (between batches)."""
+        m = -1 if mode in (-1, "auto", None) else int(bool(mode))
+        rc = lib().aero_pool_set_self_verify(self.h, C.c_int32(m))
+        if rc != 0:
+            raise AeroError(rc, "aero_pool_set_self_verify")
 
     def prove_fib_queue(self, host_traces, options: ProofOptions, aux=(0, 0, 2)):
         """A queue of DIFFERENT host traces of one shape (PinnedTrace or C-contiguous (width, n) uint64 arrays): trace t goes to slot

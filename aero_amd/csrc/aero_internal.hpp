@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -159,6 +160,7 @@ public:
     struct LandedTrace {
         const uint64_t* dev = nullptr;
         hipEvent_t ready = nullptr;
+        size_t bytes = 0;                // of the landing buffer's trace: a call that picks it up checks it against its own shape
     } landed;
     // second stream + events for the host-to-device copy of a wide trace: column group g + 1 travels while group g is transformed
     hipStream_t copy_stream = nullptr;
@@ -274,7 +276,18 @@ public:
     std::map<std::vector<uint64_t>, uint64_t*> ktab_cache;
     // FibAir constraint evaluation: the divisor inverses and degree-adjustment powers of a constraint domain (5 x rows words), built by
     // the first proof of a shape and kept (at most two shapes and 2^23 rows each; AERO_CONS_INV_TABLE=0: every proof inverts per thread)
-    std::map<std::vector<uint64_t>, uint64_t*> cons_inv_cache;
+    // One table per (device, shape) for ALL contexts of the process (the eight slots of a pool used to hold eight copies: 8 x 5 x 2^23 x 8 B):
+    // a context keeps the two shapes it used last (least recently used out first), a table lives while any context holds it, its bytes count
+    // in bytes_in_use / bytes_peak of every holder, and an allocation that fails is not an error - the kernel then inverts per row.
+    struct SharedTable {
+        int device = 0;
+        uint64_t* ptr = nullptr;
+        size_t bytes = 0;
+        hipEvent_t ready = nullptr;      // recorded behind the build on the building context's stream; other contexts wait for it once
+        ~SharedTable();
+    };
+    std::vector<std::pair<std::vector<uint64_t>, std::shared_ptr<SharedTable>>> cons_inv_cache;     // most recently used first
+    const uint64_t* cons_inv_table_for(const std::vector<uint64_t>& key, size_t bytes, const std::function<void(uint64_t*)>& build);   // nullptr: no table
     bool cons_inv_table = true;
     bool deep_coeff = true;    // DEEP composition in coefficient form (base field, one GPU); AERO_DEEP_COEFF=0: evaluated on the trace-length coset and interpolated
    // final-pass scale tables of ntt_inverse, keyed by their parameters

@@ -31,6 +31,7 @@ int32_t aero_ctx_create(int32_t device_id, aero_ctx** out) {
     try {
         aero_ctx* h = new aero_ctx();
         try { h->keep = std::make_shared<Context>(device_id); h->c = h->keep.get(); } catch (...) { delete h; throw; }
+        if (const char* e = getenv("AERO_SELF_VERIFY")) if (e[0] == '0' || e[0] == '1') h->self_verify = e[0] - '0';
         *out = h;
         return AERO_OK;
     } catch (const Error& e) { g_create_err = e.what(); return e.code; }
@@ -39,6 +40,11 @@ int32_t aero_ctx_create(int32_t device_id, aero_ctx** out) {
 void aero_ctx_destroy(aero_ctx* ctx) {
     if (!ctx) return;
     delete ctx;   // the Context itself dies with the last matrix / tree that still references it
+}
+int32_t aero_ctx_set_self_verify(aero_ctx* ctx, int32_t mode) {
+    if (!ctx || mode < AERO_SELF_VERIFY_AUTO || mode > AERO_SELF_VERIFY_ON) return AERO_E_BAD_ARG;
+    ctx->self_verify = mode;
+    return AERO_OK;
 }
 int32_t aero_selftest(aero_ctx* ctx, uint32_t samples, uint64_t seed) {
     return guard(ctx, [&] {
@@ -523,28 +529,27 @@ static void do_prove(aero_ctx* ctx, const uint64_t* trace_dev, uint32_t width, i
                      size_t* proof_len, uint64_t* pub_out, const aero_comm* comm = nullptr, uint32_t aux_width = 0, uint32_t aux_rands = 0,
                      uint32_t aux_degree = 2, const uint64_t* trace_host = nullptr, unsigned int* verdict = nullptr) {
     REQUIRE(o && proof && proof_len, "prove: null argument");
+    *proof = nullptr; *proof_len = 0;       // whatever goes wrong below, the caller is not left with a stale pointer
     ProofOptions po{o->num_queries, o->blowup_factor, o->grinding_factor, o->hash_fn, o->field_extension, o->fri_folding_factor, o->fri_log_max_remainder};
     Prover p(ctx->c, po);
     p.set_aux_segment(aux_width, aux_rands, aux_degree);
     if (trace_host) {
-        if (ctx->c->landed.dev && !(comm && comm->world > 1)) { trace_dev = ctx->c->landed.dev; p.set_landed_trace(trace_host, ctx->c->landed.ready, verdict); }
+        if (ctx->c->landed.dev && !(comm && comm->world > 1)) {
+            if (ctx->c->landed.bytes != ((size_t)width << log_n) * 8) fail("prove: the landed trace does not have this call's shape", ST_INTERNAL);
+            trace_dev = ctx->c->landed.dev; p.set_landed_trace(trace_host, ctx->c->landed.ready, verdict); }
         else p.set_host_trace(trace_host, verdict);
     }
-    if (comm) {
-        REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "prove_fib_sharded: bad rank / world");
-        REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "prove_fib_sharded: missing exchange callback");
-        ShardComm sc;
-        sc.rank = comm->rank; sc.world = comm->world; sc.user = comm->user;
-        sc.all_to_all = comm->all_to_all; sc.all_gather = comm->all_gather; sc.all_reduce_sum_u64 = comm->all_reduce_sum_u64; sc.send_recv = comm->send_recv;
-        sc.min_peer_digests = comm->min_peer_digests ? comm->min_peer_digests : 2048;
-        sc.stream_ordered = (comm->flags & AERO_COMM_STREAM_ORDERED) != 0;
-        p.set_comm(sc);
-    }
+    if (comm) p.set_comm(shard_comm_of(comm, "prove_fib_sharded"));
     p.collect_stage_times = ctx->stage_timing;
     if (ctx->concurrent_peers) p.h2d_pipeline = false;      // column groups on a second stream: no gain under other proofs (profiles/r5_h2d.md)
     std::vector<uint64_t> pub;
     Bytes b = p.prove(trace_dev, width, log_n, &pub);
     ctx->last_ms = p.last_stage_ms;
+    // prove-then-verify (main.rs:47, proving_worker.rs:196-203); a trace that failed the canonical-form check is the caller's error, reported by it
+    if (self_verify_wanted(ctx, comm) && !(verdict && *verdict != 0)) {
+        const aero_fib_air a{aux_width, aux_width ? aux_rands : 0, aux_width ? aux_degree : 2};
+        run_self_verify(ctx, b, pub, &a, nullptr, (uint32_t)log_n, *o);
+    }
     uint8_t* buf = (uint8_t*)malloc(b.size());
     if (!buf) throw std::bad_alloc();
     memcpy(buf, b.data(), b.size());
@@ -568,6 +573,22 @@ int32_t aero_prove_fib_sharded(aero_ctx* ctx, const aero_comm* comm, const aero_
         REQUIRE(trace, "prove_fib_sharded: null trace");
         REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0, "prove_fib_sharded: trace length must be a power of two");
         do_prove(ctx, trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows), options, proof, proof_len, pub_out, comm);
+    });
+}
+int32_t aero_commit_trace_sharded(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_proof_options* o, uint8_t root_out[32],
+                                  uint8_t* subtree_roots_out) {
+    return guard(ctx, [&] {
+        REQUIRE(trace && o && root_out, "commit_trace_sharded: null argument");
+        REQUIRE((trace->m.rows & (trace->m.rows - 1)) == 0, "commit_trace_sharded: trace length must be a power of two");
+        ProofOptions po{o->num_queries, o->blowup_factor, o->grinding_factor, o->hash_fn, o->field_extension, o->fri_folding_factor, o->fri_log_max_remainder};
+        Prover p(ctx->c, po);
+        if (comm) p.set_comm(shard_comm_of(comm, "commit_trace_sharded"));
+        p.trace_commit_only = true;
+        const Bytes b = p.prove(trace->m.data.get(), (uint32_t)trace->m.cols, ilog2u(trace->m.rows), nullptr);
+        const size_t G = comm ? (size_t)comm->world : 1;
+        REQUIRE(b.size() == 32 * (1 + G), "commit_trace_sharded: unexpected result size");
+        memcpy(root_out, b.data(), 32);
+        if (subtree_roots_out) memcpy(subtree_roots_out, b.data() + 32, 32 * G);
     });
 }
 int32_t aero_prove_fib_aux(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, uint32_t aux_width, uint32_t aux_rands,
@@ -864,6 +885,19 @@ struct aero_pool {
             Context* const c = s->ctx->c;
             DevBuf<uint64_t> land[2];
             hipStream_t cs = nullptr;
+            // Declared behind the landing buffers, so it runs BEFORE they return to the context's allocator on every way out of this block
+            // (an exception included): nothing of this job is left on the copy stream, the context offers no landed trace any more, and the
+            // pool's gate does not keep pointing at an event of this context.
+            struct PrefetchEnd {
+                Context* c; hipStream_t* cs; Context::CopyGate* gate; bool on;
+                ~PrefetchEnd() {
+                    if (!on) return;
+                    c->landed = Context::LandedTrace{};
+                    if (*cs) (void)hipStreamSynchronize(*cs);
+                    std::lock_guard<std::mutex> lk(gate->mu);      // a fired event is a no-op to wait on, but it is this context's: leave none behind
+                    if (gate->last == c->sync_event(32) || gate->last == c->sync_event(33)) gate->last = nullptr;
+                }
+            } prefetch_end{c, &cs, gate.get(), prefetch};
             auto send = [&](uint32_t r) {       // the copy of round r's trace, behind whatever the copy stream still carries
                 // one copy at a time per pool, in the order the slots ask (Context::CopyGate): the first fills then start the slots one copy
                 // apart and they stay out of phase - proofs that run in lockstep queue their latency-bound stages behind each other
@@ -886,7 +920,7 @@ struct aero_pool {
                     // round r - 1 has returned (the calls below are synchronous): its landing buffer is free for round r + 1
                     if (r + 1 < rounds) rc = guard(s->ctx, [&] { send(r + 1); });
                     if (rc != AERO_OK) break;
-                    c->landed.dev = land[r & 1].get(); c->landed.ready = c->sync_event(32 + (r & 1));
+                    c->landed.dev = land[r & 1].get(); c->landed.ready = c->sync_event(32 + (r & 1)); c->landed.bytes = trace_bytes;
                 }
                 const uint64_t* ht = trace_of(r);
                 if (program) {
@@ -903,12 +937,6 @@ struct aero_pool {
                     q_proofs[o] = out; q_lens[o] = len; out = nullptr; len = 0;
                     if (q_pubs && !program) memcpy(q_pubs + (size_t)o * (host_width / 2), pub.data(), (size_t)(host_width / 2) * 8);
                 }
-            }
-            if (prefetch) {     // nothing of this job is left on the copy stream when the landing buffers go back to the context's allocator
-                c->landed = Context::LandedTrace{};
-                if (cs) (void)hipStreamSynchronize(cs);
-                std::lock_guard<std::mutex> lk(gate->mu);      // a fired event is a no-op to wait on, but it is this context's: leave none behind
-                if (gate->last == c->sync_event(32) || gate->last == c->sync_event(33)) gate->last = nullptr;
             }
             } catch (const std::bad_alloc&) { rc = AERO_E_OOM; s->ctx->err = "pool worker: host allocation failed"; }
             catch (...) { rc = AERO_E_INTERNAL; s->ctx->err = "pool worker: unexpected exception"; }
@@ -953,6 +981,13 @@ void aero_pool_destroy(aero_pool* pool) {
     for (auto& s : pool->slots) if (s->th.joinable()) s->th.join();
     for (auto& s : pool->slots) aero_ctx_destroy(s->ctx);
     delete pool;
+}
+int32_t aero_pool_set_self_verify(aero_pool* pool, int32_t mode) {
+    if (!pool || mode < AERO_SELF_VERIFY_AUTO || mode > AERO_SELF_VERIFY_ON) return AERO_E_BAD_ARG;
+    std::lock_guard<std::mutex> lk(pool->mu);
+    if (pool->pending) return AERO_E_BAD_ARG;      // a batch is running
+    for (auto& s : pool->slots) s->ctx->self_verify = mode;
+    return AERO_OK;
 }
 int32_t aero_pool_placement(const aero_pool* pool, int32_t* node_out, uint32_t* pinned_out) {
     if (!pool) return AERO_E_BAD_ARG;

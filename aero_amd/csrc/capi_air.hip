@@ -137,6 +137,7 @@ static void prove_program(aero_ctx* ctx, const aero_comm* comm, const aero_air* 
                           unsigned int* verdict, uint32_t width, int log_n, const uint64_t* pub, uint32_t n_pub, const aero_proof_options* o,
                           uint8_t** proof, size_t* proof_len) {
     REQUIRE(air && o && proof && proof_len, "prove_air: null argument");
+    *proof = nullptr; *proof_len = 0;
     const air::Program& p = air->prog;
     const std::vector<uint64_t> pubv = read_pub(p, pub, n_pub, "prove_air");
     REQUIRE(width == p.W, "prove_air: the trace does not have the program's main width");
@@ -144,23 +145,17 @@ static void prove_program(aero_ctx* ctx, const aero_comm* comm, const aero_air* 
     Prover pr(ctx->c, to_options(o));
     pr.set_program(&p, pubv);
     if (trace_host) {
-        if (ctx->c->landed.dev && !(comm && comm->world > 1)) { trace_dev = ctx->c->landed.dev; pr.set_landed_trace(trace_host, ctx->c->landed.ready, verdict); }
+        if (ctx->c->landed.dev && !(comm && comm->world > 1)) {
+            if (ctx->c->landed.bytes != ((size_t)width << log_n) * 8) fail("prove_air: the landed trace does not have this call's shape", ST_INTERNAL);
+            trace_dev = ctx->c->landed.dev; pr.set_landed_trace(trace_host, ctx->c->landed.ready, verdict); }
         else pr.set_host_trace(trace_host, verdict);
     }
-    if (comm) {
-        REQUIRE(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world, "prove_air: bad rank / world");
-        REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "prove_air: missing exchange callback");
-        ShardComm sc;
-        sc.rank = comm->rank; sc.world = comm->world; sc.user = comm->user;
-        sc.all_to_all = comm->all_to_all; sc.all_gather = comm->all_gather; sc.all_reduce_sum_u64 = comm->all_reduce_sum_u64; sc.send_recv = comm->send_recv;
-        sc.min_peer_digests = comm->min_peer_digests ? comm->min_peer_digests : 2048;
-        sc.stream_ordered = (comm->flags & AERO_COMM_STREAM_ORDERED) != 0;
-        pr.set_comm(sc);
-    }
+    if (comm) pr.set_comm(shard_comm_of(comm, "prove_air"));
     pr.collect_stage_times = ctx->stage_timing;
     if (ctx->concurrent_peers) pr.h2d_pipeline = false;      // column groups on a second stream: no gain under other proofs (profiles/r5_h2d.md)
     const Bytes b = pr.prove(trace_dev, width, log_n, nullptr);
     ctx->last_ms = pr.last_stage_ms;
+    if (self_verify_wanted(ctx, comm) && !(verdict && *verdict != 0)) run_self_verify(ctx, b, pubv, nullptr, &p, (uint32_t)log_n, *o);
     *proof = to_malloc(b, proof_len);
 }
 

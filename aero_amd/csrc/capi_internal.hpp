@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <memory>
 
 #include "../../include/aero_stark.h"
@@ -19,6 +20,8 @@ struct aero_ctx {
     // set by a pool while several of its slots prove at once: other proofs' kernels then overlap this proof's host-to-device copy,
     // and a second stream per proof only adds cross-stream waits (measured, 2^20 x 72, 8 in flight: 3.85 G cells/s against 3.3)
     bool concurrent_peers = false;
+    int self_verify = AERO_SELF_VERIFY_AUTO;     // aero_ctx_set_self_verify
+    double last_self_verify_ms = 0;
 };
 struct aero_matrix {
     std::shared_ptr<Context> keep;   // declared first: destroyed after `m`, whose buffers return to the context pool
@@ -76,6 +79,35 @@ template <class Fn> static int32_t guard(aero_ctx* ctx, Fn&& fn) {
     }
 }
 #define REQUIRE(cond, msg) do { if (!(cond)) fail(msg); } while (0)
+
+// the aero_comm of a *_sharded call as the prover takes it
+static inline ShardComm shard_comm_of(const aero_comm* comm, const char* who) {
+    if (!(comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world)) fail(std::string(who) + ": bad rank / world");
+    if (!(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64))) fail(std::string(who) + ": missing exchange callback");
+    ShardComm sc;
+    sc.rank = comm->rank; sc.world = comm->world; sc.user = comm->user;
+    sc.all_to_all = comm->all_to_all; sc.all_gather = comm->all_gather; sc.all_reduce_sum_u64 = comm->all_reduce_sum_u64; sc.send_recv = comm->send_recv;
+    sc.min_peer_digests = comm->min_peer_digests ? comm->min_peer_digests : 2048;
+    sc.stream_ordered = (comm->flags & AERO_COMM_STREAM_ORDERED) != 0;
+    return sc;
+}
+// prove-then-verify at the boundary (include/aero_stark.h: aero_ctx_set_self_verify)
+static inline bool self_verify_wanted(const aero_ctx* ctx, const aero_comm* comm) {
+    if (ctx->self_verify == AERO_SELF_VERIFY_AUTO) return comm && comm->world > 1;
+    return ctx->self_verify != AERO_SELF_VERIFY_OFF;
+}
+namespace aero {
+// verify.hip: the library's verifier on the bytes a prove call is about to return, the proof's options and trace length pinned to the
+// call's; throws Error(AERO_E_SELF_VERIFY) with the verifier's reason when it rejects. Exactly one of air / prog is non-null.
+void self_verify_or_throw(const uint8_t* proof, size_t len, const std::vector<uint64_t>& pub, const aero_fib_air* air, const air::Program* prog,
+                          uint32_t log_n, const aero_proof_options& opt);
+}
+static inline void run_self_verify(aero_ctx* ctx, const Bytes& b, const std::vector<uint64_t>& pub, const aero_fib_air* air, const air::Program* prog,
+                                   uint32_t log_n, const aero_proof_options& opt) {
+    const auto t0 = std::chrono::steady_clock::now();
+    self_verify_or_throw(b.data(), b.size(), pub, air, prog, log_n, opt);
+    ctx->last_self_verify_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 
 static inline int ilog2u(uint64_t x) { int r = 0; while ((1ull << r) < x) r++; return r; }
 

@@ -97,18 +97,32 @@ int bind_thread_to_node(int node) {
     if (k == 0) return 0;                       // the node's CPUs are not ours (cgroup cpuset): stay where we are
     return sched_setaffinity(0, sizeof want, &want) == 0 ? k : 0;
 }
-// memory policy of the calling thread: prefer `node` (mode 1 = MPOL_PREFERRED), or back to the default (node < 0)
-static void prefer_node(int node) {
-#ifdef SYS_set_mempolicy
-    if (node < 0) { (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0); return; }
-    unsigned long mask[64] = {0};
-    if (node >= (int)(64 * 8 * sizeof(unsigned long))) return;
-    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
-    (void)syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 64 * 8 * sizeof(unsigned long));
+// Memory policy of the calling thread for the length of one allocation: prefer `node` (MPOL_PREFERRED), then back to whatever the thread
+// had before - a policy the host application or `numactl --membind / --interleave` set is the caller's, not ours to reset.
+struct ScopedPreferNode {
+    static constexpr unsigned long MAXNODE = 64 * 8 * sizeof(unsigned long);
+    int saved_mode = 0;
+    unsigned long saved_mask[64] = {0};
+    bool saved = false, set = false;
+    explicit ScopedPreferNode(int node) {
+#if defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
+        if (node < 0 || node >= (int)MAXNODE) return;
+        saved = syscall(SYS_get_mempolicy, &saved_mode, saved_mask, MAXNODE, nullptr, 0ul) == 0;
+        unsigned long mask[64] = {0};
+        mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+        set = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, MAXNODE) == 0;
 #else
-    (void)node;
+        (void)node;
 #endif
-}
+    }
+    ~ScopedPreferNode() {
+#if defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
+        if (!set) return;
+        if (saved && saved_mode != 0) { if (syscall(SYS_set_mempolicy, saved_mode, saved_mask, MAXNODE) == 0) return; }
+        (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0);
+#endif
+    }
+};
 
 }  // namespace aero
 
@@ -152,10 +166,13 @@ int32_t aero_host_alloc_near(size_t bytes, int32_t device_id, void** out) {
     *out = nullptr;
     const int node = numa_node_of_device(device_id);
     if (node < 0) return aero_host_alloc(bytes, out);
-    prefer_node(node);
-    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocNumaUser);
-    if (e == hipSuccess) memset(*out, 0, bytes);      // first touch under the policy: the pages are placed now, not by whoever writes first later
-    prefer_node(-1);
+    hipError_t e;
+    {
+        // pinning faults the pages in: they are placed by THIS call, under the policy in force here (no pass over the buffer to touch them -
+        // the caller is about to fill it anyway); the thread's own policy is back when the scope ends
+        ScopedPreferNode prefer(node);
+        e = hipHostMalloc(out, bytes, hipHostMallocNumaUser);
+    }
     if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return aero_host_alloc(bytes, out); }
     return AERO_OK;
 }

@@ -1,6 +1,8 @@
 // Host pipeline of the MI355X STARK prover (see prover.hpp for the reference interface it mirrors).
 #include "prover.hpp"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -158,6 +160,53 @@ void* Context::dev_alloc(size_t bytes) {
     persistent.push_back(p);
     return p;
 }
+// ---- tables shared by the contexts of one device (aero_internal.hpp: SharedTable) ----
+namespace {
+std::mutex g_shared_tab_mu;
+std::map<std::vector<uint64_t>, std::weak_ptr<Context::SharedTable>> g_shared_tabs;      // key + device
+}
+Context::SharedTable::~SharedTable() {
+    // the last holder is gone; kernels of its earlier proofs may still read the table
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    if (ready) (void)hipEventDestroy(ready);
+    if (ptr) (void)hipFree(ptr);
+    (void)hipGetLastError();
+}
+const uint64_t* Context::cons_inv_table_for(const std::vector<uint64_t>& key, size_t bytes, const std::function<void(uint64_t*)>& build) {
+    for (size_t i = 0; i < cons_inv_cache.size(); i++)
+        if (cons_inv_cache[i].first == key) {
+            if (i) std::rotate(cons_inv_cache.begin(), cons_inv_cache.begin() + i, cons_inv_cache.begin() + i + 1);
+            return cons_inv_cache.front().second->ptr;
+        }
+    // make room first (the peak is then two tables, not three); the evicted table dies here unless another context still holds it
+    while (cons_inv_cache.size() >= 2) { bytes_in_use -= cons_inv_cache.back().second->bytes; cons_inv_cache.pop_back(); }
+    std::shared_ptr<SharedTable> t;
+    {
+        std::lock_guard<std::mutex> lk(g_shared_tab_mu);
+        std::vector<uint64_t> gkey = key;
+        gkey.push_back((uint64_t)device);
+        auto it = g_shared_tabs.find(gkey);
+        if (it != g_shared_tabs.end()) t = it->second.lock();
+        if (!t) {
+            static const bool refuse = getenv("AERO_TEST_TABLE_OOM") != nullptr;     // tests: the allocation fails, the proof must not
+            void* p = nullptr;
+            const hipError_t e = refuse ? hipErrorOutOfMemory : hipMalloc(&p, bytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            t = std::make_shared<SharedTable>();
+            t->device = device; t->ptr = (uint64_t*)p; t->bytes = bytes;
+            AERO_HIP(hipEventCreateWithFlags(&t->ready, hipEventDisableTiming));
+            build(t->ptr);
+            AERO_HIP(hipEventRecord(t->ready, stream));
+            g_shared_tabs[gkey] = t;
+        }
+    }
+    AERO_HIP(hipStreamWaitEvent(stream, t->ready, 0));        // built on another context's stream, perhaps
+    cons_inv_cache.insert(cons_inv_cache.begin(), {key, t});
+    bytes_in_use += bytes;
+    if (bytes_in_use > bytes_peak) bytes_peak = bytes_in_use;
+    return t->ptr;
+}
 void* Context::scratch_alloc(size_t bytes) {
     void* p = pool_alloc(bytes);
     scratch.push_back(p);
@@ -178,7 +227,7 @@ void* Context::stage_alloc(size_t bytes) {
     bytes = (bytes + 63) & ~(size_t)63;
     if (!stage_base) {
         stage_cap = (size_t)8 << 20;
-        AERO_HIP(hipHostMalloc((void**)&stage_base, stage_cap, hipHostMallocDefault));
+        AERO_HIP(hipHostMalloc((void**)&stage_base, stage_cap, hipHostMallocCoherent | hipHostMallocMapped));     // kernels store results here, the host reads them behind a flag
         AERO_HIP(hipHostGetDevicePointer((void**)&stage_dev_base, stage_base, 0));
     }
     if (bytes > stage_cap) fail("staging request too large", ST_INTERNAL);
@@ -202,7 +251,8 @@ void Context::sync() {
 
 uint32_t Context::next_flag() {
     if (!flag_host) {
-        AERO_HIP(hipHostMalloc((void**)&flag_host, 64, hipHostMallocDefault));
+        // the protocol (a kernel's system-scope store observed by a polling host) rests on coherent, mapped host memory: asked for by name
+        AERO_HIP(hipHostMalloc((void**)&flag_host, 64, hipHostMallocCoherent | hipHostMallocMapped));
         AERO_HIP(hipHostGetDevicePointer((void**)&flag_dev, flag_host, 0));
         *flag_host = 0;
     }
@@ -212,14 +262,20 @@ uint32_t Context::next_flag() {
 void Context::wait_flag(uint32_t seq) {
     static const bool poll = !(getenv("AERO_POLL_FLAGS") && getenv("AERO_POLL_FLAGS")[0] == '0');
     if (!poll) { sync(); return; }
+    // A polite spin: `pause` in every iteration (the sibling hyper-thread and the memory pipeline get the cycles); the stream's own state is
+    // looked at every 2048 polls; and a wait that has lasted longer than a root's round trip ever does on an idle GPU (the word is then behind
+    // OTHER proofs' kernels: a pool with more slots than the process may use CPUs would otherwise starve the slots that still have launches
+    // to enqueue) gives its time slice away between polls.
     volatile uint32_t* f = flag_host;
     for (uint32_t spin = 1;; spin++) {
         if (*f == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return; }
+        __builtin_ia32_pause();
         if ((spin & 2047u) == 0) {
             const hipError_t e = hipStreamQuery(stream);
             if (e == hipSuccess) return;                   // drained: whatever the kernels wrote is visible
             if (e != hipErrorNotReady) throw Error(ST_HIP, std::string("stream query: ") + hipGetErrorString(e));
         }
+        if (spin > 16384u) sched_yield();
     }
 }
 
@@ -1246,6 +1302,16 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
     gaps.mark("lde_enqueued");
     Commitment tcom = commit_matrix(tlde);          // synchronises the stream: the last trace row has arrived as well
     gaps.mark("root1");
+    if (trace_commit_only) {
+        Bytes out;
+        wdigest(out, tcom.root);
+        if (G > 1) for (int r = 0; r < G; r++) wdigest(out, tcom.top[(size_t)G + r]);
+        else wdigest(out, tcom.root);
+        if (pub_out) pub_out->clear();
+        ctx->sync();
+        ctx->scratch_reset();
+        return out;
+    }
     if (prog) air.results = program_pub_;      // a program's public inputs are the caller's (FibAir reads its own off the trace)
     else for (uint32_t k = 0; k < W / 2; k++) air.results[k] = h_last_row[2 * k + 1];
     if (pub_out) *pub_out = air.results;
@@ -1361,13 +1427,8 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
                     // the divisor inverses and the degree-adjustment powers of a constraint-domain point do not depend on the proof: one table per
                     // shape (5 words per row), built by the first proof of the shape
                     const std::vector<uint64_t> key{(uint64_t)rows_eval, h, a.w_last, (uint64_t)xcount, (uint64_t)n};
-                    auto it = ctx->cons_inv_cache.find(key);
-                    if (it == ctx->cons_inv_cache.end() && ctx->cons_inv_cache.size() < 2) {
-                        uint64_t* tab = (uint64_t*)ctx->dev_alloc(5 * rows_eval * 8);
-                        launch_fib_inverse_table<F>(ctx, tab, a);
-                        it = ctx->cons_inv_cache.emplace(key, tab).first;
-                    }
-                    if (it != ctx->cons_inv_cache.end()) { a.inv_tab = it->second; a.inv_tab_n = rows_eval; }
+                    const uint64_t* tab = ctx->cons_inv_table_for(key, 5 * rows_eval * 8, [&](uint64_t* out) { launch_fib_inverse_table<F>(ctx, out, a); });
+                    if (tab) { a.inv_tab = tab; a.inv_tab_n = rows_eval; }
                 }
                 launch_fib_constraints<F>(ctx, a, 1);
             } else {

@@ -193,6 +193,9 @@ public:
     bool low_level_skip = true;         // large trees: the 3 lowest Merkle levels are not stored but recomputed by the openings
     bool exchange_rows = getenv("AERO_EXCHANGE_ROWS") ? getenv("AERO_EXCHANGE_ROWS")[0] != '0' : true;   // sharded: rows instead of digests when shorter
     int exchange_chunks = getenv("AERO_EXCHANGE_CHUNKS") ? atoi(getenv("AERO_EXCHANGE_CHUNKS")) : 1;   // sharded: pieces per peer of a commitment's exchange, overlapped with hashing (1 = one exchange)
+    // stop behind the main segment's commitment (the first half of the reference's fork-only split `commit_to_trace_and_validate`,
+    // proving_worker.rs:323-332): prove() then returns root || subtree roots (world digests; the root itself on one GPU) instead of a proof
+    bool trace_commit_only = false;
     bool h2d_pipeline = getenv("AERO_H2D_PIPELINE") ? getenv("AERO_H2D_PIPELINE")[0] != '0' : true;   // wide host traces travel in column groups behind the transforms
 
     // ---- stage-level entry points (the reference's split API; also what the C ABI exposes) ----

@@ -400,6 +400,23 @@ static int32_t verify_entry(const uint8_t* proof, size_t proof_len, const uint64
     }
 }
 
+namespace aero {
+void self_verify_or_throw(const uint8_t* proof, size_t len, const std::vector<uint64_t>& pub, const aero_fib_air* air, const air::Program* prog,
+                          uint32_t log_n, const aero_proof_options& opt) {
+    aero_verify_policy pol{};
+    pol.min_query_security_bits = 0;        // the options are the caller's choice; what is checked is that the proof is a proof under them
+    pol.expected_log_n = log_n;
+    pol.require_options = 1;
+    pol.options = opt;
+    char err[384];
+    err[0] = 0;
+    const int32_t rc = verify_entry(proof, len, pub.data(), (uint32_t)pub.size(), air, prog, &pol, err, sizeof err);
+    if (rc != AERO_OK)
+        throw Error(AERO_E_SELF_VERIFY, std::string("self-verify: the proof this call produced is rejected by the library's own verifier (") + err +
+                                            "); no bytes are returned");
+}
+}  // namespace aero
+
 extern "C" int32_t aero_verify_fib(const uint8_t* proof, size_t proof_len, const uint64_t* pub_elements, uint32_t n_pub, const aero_fib_air* air,
                                    const aero_verify_policy* policy, char* err, size_t err_cap) {
     return verify_entry(proof, proof_len, pub_elements, n_pub, air, nullptr, policy, err, err_cap);

@@ -1,11 +1,17 @@
 """Exchange steps of a sharded proof (include/aero_stark.h: aero_comm) carried by torch.distributed.
 
-One process per GPU; backend "nccl" (= RCCL over xGMI) on a multi-GPU node, "gloo" when several ranks share one GPU
-(tests on a 1-GPU box). The library hands the callbacks raw DEVICE pointers; they are wrapped as torch tensors through
-`__cuda_array_interface__` (no copy), so the collectives run directly on the prover's buffers. This file is plumbing:
-the sharding itself (coset geometry, what is exchanged and when) lives in aero_amd/csrc/prover.hip.
+One process per GPU. On a multi-GPU node the product path is the library's NATIVE communicator (RcclComm below: RCCL over xGMI, exchanges
+enqueued on the prover's stream) or, for ranks that are threads of one process, the in-library local group (LocalGroup). TorchComm is the
+TEST data plane for ranks that are processes sharing one GPU (a 1-GPU box): the library hands the callbacks raw DEVICE pointers, which are
+wrapped as torch tensors through `__cuda_array_interface__` (no copy); with backend "nccl" (= RCCL) the collectives run directly on those
+tensors, with backend "gloo" they run by default on HOST copies made and written back here ("host" form), or - AERO_TORCHCOMM_GLOO=device,
+the form rounds 1-5 ran - on the device tensors themselves, which gloo stages through host memory on streams of its own. Both gloo forms
+are kept because one wrong proof was met under the device form in round 5 (profiles/r5_sharded_anomaly.md, r6_sharded_anomaly.md): the
+stress loop (tests/shard_stress_worker.py) runs them side by side. This file is plumbing: the sharding itself (coset geometry, what is
+exchanged and when) lives in aero_amd/csrc/prover.hip.
 """
 import ctypes as C
+import os
 
 _A2A = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 _AG = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -23,10 +29,29 @@ class _DevPtr:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3, "strides": None}
 
 
-class TorchComm:
-    """aero_comm whose callbacks run torch.distributed collectives on the default (or given) process group."""
+def chunk_digests(torch, t, chunks):
+    """32-byte fingerprints of the `chunks` equal pieces of a device byte tensor, computed ON the device (four wrapping 64-bit sums:
+    plain, index-weighted, index-squared-weighted, and of a xor-shifted copy with odd weights) - cheap enough to take on every exchange of
+    a stress loop (a 256 MiB buffer costs a few milliseconds), strong enough to tell any bit flip, any moved or missing piece. Not a hash."""
+    w = t.view(torch.int64).view(chunks, -1)
+    n = w.shape[1]
+    i = torch.arange(1, n + 1, dtype=torch.int64, device=w.device)
+    out = torch.stack([w.sum(1), (w * i).sum(1), (w * (i * i)).sum(1), ((w ^ (w >> 29)) * (2 * i + 1)).sum(1)], 1).cpu()
+    return [out[c].numpy().tobytes().hex() for c in range(chunks)]
 
-    def __init__(self, device=0, group=None, min_peer_digests=0):
+
+class TorchComm:
+    """aero_comm whose callbacks run torch.distributed collectives on the default (or given) process group.
+
+    gloo_tensors: "host" (default; env AERO_TORCHCOMM_GLOO) or "device" - see the module text; ignored for backend nccl.
+    evidence (env AERO_SHARD_EVIDENCE=1): every callback appends {"op", "bytes", "send": [...], "recv": [...]} to self.evidence - one
+        fingerprint (chunk_digests) per peer piece of what this rank sent and of what it received, taken after the collective. For a
+        commitment that is: the rows or leaf digests sent to / received from every peer (all_to_all), this rank's subtree root (the
+        all_gather's send) and the gathered top (its recv). tests/test_gpu_sharded.py: diagnose() lines them up across ranks.
+    fault (tests only): {"op": "all_gather", "call": k, "chunk": q, "byte": b} flips one bit of byte b of piece q of what the k-th call of
+        that kind received - the same on every rank that is given the fault."""
+
+    def __init__(self, device=0, group=None, min_peer_digests=0, gloo_tensors=None, evidence=None, fault=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -39,6 +64,11 @@ class TorchComm:
         # one collective per exchange, chosen ONCE by backend (a fallback taken by one rank only would desynchronise the ranks):
         # gloo has no all_gather_into_tensor for device tensors, nccl (= RCCL) has
         self.gather_into_tensor = dist.get_backend(group) == "nccl"
+        self.gloo_tensors = gloo_tensors or os.environ.get("AERO_TORCHCOMM_GLOO", "host")
+        assert self.gloo_tensors in ("host", "device")
+        self.keep_evidence = (os.environ.get("AERO_SHARD_EVIDENCE", "0") != "0") if evidence is None else bool(evidence)
+        self.evidence = []
+        self.fault = fault
         # keep the CFUNCTYPE objects alive for as long as the struct is in use
         self._a2a, self._ag, self._ar = _A2A(self._all_to_all), _AG(self._all_gather), _AR(self._all_reduce)
         self.struct = CommStruct(self.rank, self.world, None, self._a2a, self._ag, self._ar, min_peer_digests)
@@ -55,19 +85,29 @@ class TorchComm:
             self.last_error = e
             return 1
 
-    # gloo (ranks sharing one test GPU): the collectives run on HOST copies made and written back here, synchronously - gloo's own
-    # handling of device tensors (its staging copies on streams of its own) is not something a byte-exact test should depend on
-    # (profiles/r5_sharded_anomaly.md). nccl (= RCCL): device tensors, as a multi-GPU node runs them.
+    def _after(self, op, nbytes, send_t, send_chunks, recv_t, recv_chunks):
+        """fault injection and evidence, behind the collective and its synchronisation"""
+        f = self.fault
+        if f and f["op"] == op and f["call"] == self.calls[op]:
+            self.torch.cuda.synchronize(self.device)
+            recv_t[f["chunk"] * (recv_t.numel() // recv_chunks) + f.get("byte", 0)] ^= 1
+        if self.keep_evidence:
+            self.torch.cuda.synchronize(self.device)
+            self.evidence.append({"op": op, "bytes": int(nbytes), "send": chunk_digests(self.torch, send_t, send_chunks) if send_t is not None else [],
+                                  "recv": chunk_digests(self.torch, recv_t, recv_chunks)})
+
     def _all_to_all(self, _user, send, recv, nbytes):
         def run():
             n = int(nbytes) * self.world
-            if self.gather_into_tensor:
-                self.dist.all_to_all_single(self._t(recv, n), self._t(send, n), group=self.group)
-            else:
-                s = self._t(send, n).cpu()
-                r = self.torch.empty_like(s)
+            s, r = self._t(send, n), self._t(recv, n)
+            if self.gather_into_tensor or self.gloo_tensors == "device":
                 self.dist.all_to_all_single(r, s, group=self.group)
-                self._t(recv, n).copy_(r)
+            else:
+                hs = s.cpu()
+                hr = self.torch.empty_like(hs)
+                self.dist.all_to_all_single(hr, hs, group=self.group)
+                r.copy_(hr)
+            self._after("all_to_all", nbytes, s, self.world, r, self.world)
             self.calls["all_to_all"] += 1
             self.bytes_sent += int(nbytes) * (self.world - 1)
         return self._guard(run)
@@ -77,11 +117,14 @@ class TorchComm:
             out, inp = self._t(recv, int(nbytes) * self.world), self._t(send, int(nbytes))
             if self.gather_into_tensor:
                 self.dist.all_gather_into_tensor(out, inp, group=self.group)
+            elif self.gloo_tensors == "device":
+                self.dist.all_gather(list(out.chunk(self.world)), inp, group=self.group)
             else:
                 h = inp.cpu()
                 parts = [self.torch.empty_like(h) for _ in range(self.world)]
                 self.dist.all_gather(parts, h, group=self.group)
                 out.copy_(self.torch.cat(parts))
+            self._after("all_gather", nbytes, inp, 1, out, self.world)
             self.calls["all_gather"] += 1
             self.bytes_sent += int(nbytes) * (self.world - 1)
         return self._guard(run)
@@ -89,12 +132,13 @@ class TorchComm:
     def _all_reduce(self, _user, buf, count):
         def run():
             t = self._t(buf, int(count) * 8).view(self.torch.int64)   # wrapping two's-complement sum == u64 sum
-            if self.gather_into_tensor:
+            if self.gather_into_tensor or self.gloo_tensors == "device":
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
             else:
                 h = t.cpu()
                 self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
                 t.copy_(h)
+            self._after("all_reduce", int(count) * 8, None, 1, t.view(self.torch.uint8), 1)
             self.calls["all_reduce"] += 1
             self.bytes_sent += int(count) * 8
         return self._guard(run)

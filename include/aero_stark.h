@@ -31,6 +31,7 @@ extern "C" {
 #define AERO_E_UNSUPPORTED (-5)
 #define AERO_E_INTERNAL (-6)
 #define AERO_E_VERIFY (-7) /* aero_verify_fib: the proof was parsed and rejected */
+#define AERO_E_SELF_VERIFY (-8) /* a prove call's own proof was rejected by the library's verifier before it left: no bytes returned (aero_ctx_set_self_verify) */
 
 typedef struct aero_ctx aero_ctx;
 typedef struct aero_matrix aero_matrix; /* device, column-major u64 matrix */
@@ -70,6 +71,22 @@ typedef struct aero_fib_air {
 int32_t aero_device_count(void);
 int32_t aero_ctx_create(int32_t device_id, aero_ctx** out);
 void aero_ctx_destroy(aero_ctx* ctx);
+/* Prove-then-verify, as both reference callers do before a proof leaves the process (miden-proof-generator/src/main.rs:47
+ * `miden::verify(...)` right after `prove`; aero-sdk/miden-wasm/src/proving_worker.rs:196-203 verifies inside `prove` and turns a
+ * rejection into an error instead of a result). With the check on, every aero_prove_* call of this context runs the library's own
+ * host verifier (aero_verify_fib / aero_verify_air: every check of src/stark_verifier plus the out-of-domain constraint check, the
+ * proof's options and trace length pinned to the call's) on the bytes it is about to return; a rejection yields AERO_E_SELF_VERIFY,
+ * the reason in aero_last_error, and NO bytes (*proof = NULL). Modes:
+ *   AERO_SELF_VERIFY_AUTO (default)  on for every proof made by more than one rank (aero_comm world > 1: the *_sharded* entry points,
+ *                                    the local group, the RCCL communicator - each rank checks the bytes it returns), off on one GPU
+ *   AERO_SELF_VERIFY_OFF / _ON       never / always (1 - 2 ms of host time per proof, independent of the trace length)
+ * The environment variable AERO_SELF_VERIFY=0|1 sets the initial mode of contexts created afterwards (pools included).
+ * What the check can and cannot see: a proof the verifier accepts is a valid proof of the statement; a corrupted exchange whose damage
+ * none of the queries touches (one wrong leaf among 2^23) yields bytes that differ from the single-GPU proof and still verify. */
+#define AERO_SELF_VERIFY_AUTO (-1)
+#define AERO_SELF_VERIFY_OFF 0
+#define AERO_SELF_VERIFY_ON 1
+int32_t aero_ctx_set_self_verify(aero_ctx* ctx, int32_t mode);
 /* Field-arithmetic self test on the context's GPU: the device formulations of Goldilocks add / sub / mul / inverse, the
  * power-of-two multiplications of the NTT butterflies and the F_p^2 product, run inside one kernel on `samples` random operand
  * pairs plus the carry-boundary edge cases, against host results computed with 128-bit integers. AERO_OK, or AERO_E_INTERNAL with
@@ -328,6 +345,14 @@ void aero_rccl_destroy(aero_rccl* r);
  * aero_prove_fib's. */
 int32_t aero_prove_fib_sharded(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_proof_options* options,
                                uint8_t** proof, size_t* proof_len, uint64_t* pub_out);
+/* The main segment's commitment alone: interpolate, extend this rank's coset, exchange rows or digests, build the subtree, all-gather
+ * the subtree roots - everything aero_prove_fib_sharded does up to the first reseed of the coin, then stop. The first half of the
+ * reference's fork-only split `commit_to_trace_and_validate` (aero-sdk/miden-wasm/src/proving_worker.rs:323-332; the tree it is handed
+ * is built at :283-321). root_out = the trace commitment (bytes 24..55 of the proof); subtree_roots_out (may be NULL) = comm->world x 32
+ * bytes, subtree r = the leaves [r N / world, (r + 1) N / world). comm == NULL or world == 1: one GPU (subtree_roots_out = the root).
+ * Used by the exchange stress loop (tests/shard_stress_worker.py): thousands of exchanges per minute against a known root. */
+int32_t aero_commit_trace_sharded(aero_ctx* ctx, const aero_comm* comm, const aero_matrix* trace, const aero_proof_options* options,
+                                  uint8_t root_out[32], uint8_t* subtree_roots_out);
 
 /* The same with the trace in HOST memory - the hand-over the metric is defined on (`Prover::prove(trace)` receives a host
  * ExecutionTrace, proving_worker.rs:465-467): every rank is given the same column-major host buffer (one process per GPU on one
@@ -400,6 +425,8 @@ typedef struct aero_pool aero_pool;
 int32_t aero_pool_create(int32_t device_id, uint32_t slots, aero_pool** out);
 void aero_pool_destroy(aero_pool* pool);
 uint32_t aero_pool_slots(const aero_pool* pool);
+/* aero_ctx_set_self_verify for every slot's context (call between batches). */
+int32_t aero_pool_set_self_verify(aero_pool* pool, int32_t mode);
 aero_ctx* aero_pool_ctx(aero_pool* pool, uint32_t slot);
 /* A QUEUE of different host traces of one shape (column-major width x 2^log_n each, pinned or pageable): trace t is dealt to slot
  * t mod slots - the reference's pool deals its batches the same way (`batch_idx % concurrency`, aero-sdk/miden-wasm/src/pool.rs:105-124) -,

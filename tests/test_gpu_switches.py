@@ -275,7 +275,7 @@ def test_completion_word_and_placement_switches(tmp_path, env):
 
 
 CONS_TABLE = r'''
-# three shapes on one context (the table cache holds two: the third shape inverts per thread), each proved three times (first proof builds the table)
+# four shapes on one context (it keeps the two used last), each proved three times (first proof builds the table)
 for width, log_n, aux, opt in ((2, 16, (0, 0, 2), [27, 8, 16, 4, 1, 8, 8]), (6, 12, (2, 3, 4), [20, 8, 4, 4, 2, 4, 5]), (2, 13, (0, 0, 2), [27, 4, 8, 4, 1, 8, 6]),
                               (8, 10, (0, 0, 2), [16, 16, 0, 4, 2, 8, 7])):
     want = orc.prove_fib_aux(width, log_n, aux[0], aux[1], opt, D=aux[2])[0] if aux[0] else orc.prove_fib(width, log_n, opt)[0]
@@ -286,17 +286,37 @@ for width, log_n, aux, opt in ((2, 16, (0, 0, 2), [27, 8, 16, 4, 1, 8, 8]), (6, 
         assert got == want, (width, log_n)
     names = set(ctx.kernel_timing_report())
     ctx.set_kernel_timing(False)
-    if os.environ.get("AERO_CONS_INV_TABLE") == "0": assert "fib_inverse_table_kernel" not in names, names
+    if os.environ.get("AERO_CONS_INV_TABLE") == "0" or os.environ.get("AERO_TEST_TABLE_OOM"): assert "fib_inverse_table_kernel" not in names, names
+# the tables are shared by the contexts of a device and counted by every holder: a pool's slots and a second context build nothing new
+if os.environ.get("AERO_CONS_INV_TABLE") != "0" and not os.environ.get("AERO_TEST_TABLE_OOM"):
+    width, log_n, opt = 2, 16, [27, 8, 16, 4, 1, 8, 8]
+    want = orc.prove_fib(width, log_n, opt)[0]
+    other = aero_amd.Context(0)
+    dev = other.trace_upload(aero_amd.fib_trace(width, log_n))
+    before = other.memory_stats()[0]
+    other.set_kernel_timing(True)
+    first = aero_amd.Context(0)       # a third context builds the table (the main one has long evicted the shape) ...
+    d1 = first.trace_upload(aero_amd.fib_trace(width, log_n))
+    first.set_kernel_timing(True)
+    assert first.prove_fib(d1, aero_amd.ProofOptions(*opt))[0] == want
+    assert "fib_inverse_table_kernel" in set(first.kernel_timing_report())
+    assert other.prove_fib(dev, aero_amd.ProofOptions(*opt))[0] == want      # ... and this one finds it
+    assert "fib_inverse_table_kernel" not in set(other.kernel_timing_report())
+    assert other.memory_stats()[0] - before == 5 * 8 * (2 << log_n), (other.memory_stats(), before)     # counted by the holder: 5 words per constraint-domain row
+    d1.free(); first.close()
+    assert other.prove_fib(dev, aero_amd.ProofOptions(*opt))[0] == want      # the builder is gone, the table is not
+    dev.free(); other.close()
 print("ok")
 '''
 
 
-@pytest.mark.parametrize("flag", ["1", "0"])
-def test_constraint_divisor_inverse_table(tmp_path, flag):
+@pytest.mark.parametrize("env", [{"AERO_CONS_INV_TABLE": "1"}, {"AERO_CONS_INV_TABLE": "0"}, {"AERO_TEST_TABLE_OOM": "1"}])
+def test_constraint_divisor_inverse_table(tmp_path, env):
     """AERO_CONS_INV_TABLE=0: the FibAir constraint kernel inverts its two boundary divisors per thread (batched over four rows) instead of
     reading them from the per-shape table the first proof of a shape builds (stark.hip: fib_inverse_table_kernel); proof bytes against the
-    oracle in both fields, with and without an auxiliary segment, more shapes than the table cache holds."""
-    run(tmp_path, CONS_TABLE, {"AERO_CONS_INV_TABLE": flag})
+    oracle in both fields, with and without an auxiliary segment, more shapes than a context keeps (least recently used out). The table is
+    one per device and shape for all contexts; AERO_TEST_TABLE_OOM=1 makes its allocation fail: the proofs fall back to per-row inversion."""
+    run(tmp_path, CONS_TABLE, env)
 
 
 DEEP_FORM = r'''

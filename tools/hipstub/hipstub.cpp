@@ -125,6 +125,7 @@ hipError_t hipStreamDestroy(hipStream_t s) {
     return hipSuccess;       // the worker thread ends with the last owner
 }
 hipError_t hipStreamSynchronize(hipStream_t s) { S(s)->sync(); return hipSuccess; }
+hipError_t hipDeviceSynchronize() { sync_all(); return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t s) {
     Stream* st = &*S(s);
     std::lock_guard<std::mutex> lk(st->m);
