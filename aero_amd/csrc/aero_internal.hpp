@@ -195,6 +195,10 @@ public:
     // 16.1 us per round trip, and one blit launch less on the proof's own timeline). Only for data the device writes once and never reads.
     template <class T> T* stage_dev(T* host_ptr) { return reinterpret_cast<T*>(stage_dev_base + (reinterpret_cast<uint8_t*>(host_ptr) - stage_base)); }
     unsigned int* pinned_word();         // one pinned 32-bit word that outlives stage_reset() (deferred input-check verdict)
+    // One pinned host block kept by the context (grow-only; no allocation per proof) for host steps that exchange whole columns with the
+    // device (air_host.hip: general auxiliary recurrences). The caller orders its own reuse: copies still in flight from an earlier use
+    // must sit on this context's streams in front of whatever touches the block next. Growing it drains both streams first.
+    uint64_t* host_arena(size_t bytes);
     size_t bytes_in_use = 0, bytes_peak = 0;
     // AERO_POOL_GUARD=1 (diagnosis): every block is mapped by itself at the END of its own virtual-address reservation with an unmapped
     // granule behind it (hipMemAddressReserve / hipMemMap), nothing is reused - a kernel that reads or writes one byte past a buffer
@@ -307,6 +311,8 @@ private:
     uint8_t* stage_dev_base = nullptr;
 
     unsigned int* pinned_flag = nullptr;
+    uint64_t* arena_base = nullptr;
+    size_t arena_cap = 0;
     size_t stage_cap = 0, stage_off = 0;
 };
 

@@ -1,6 +1,9 @@
 // Per-proof device tables + launches of a program AIR (see air_host.hpp).
 #include "air_host.hpp"
+#include <atomic>
 #include <map>
+#include <mutex>
+#include <thread>
 
 namespace aero {
 
@@ -275,6 +278,13 @@ void air_build_aux(Context* ctx, const Program& p, const uint64_t* trace_dev, in
     a.code = pp.ptr<Insn>(i_code); a.pool = pp.ptr<uint64_t>(i_pool); a.slotsB = p.aux_slotsB; a.slotsE = p.aux_slotsE;
     a.ptab = pp.ptr<uint64_t>(i_pt);
     a.has_den = pp.ptr<uint8_t>(i_hd); a.has_add = pp.ptr<uint8_t>(i_ha); a.init = pp.ptr<T>(i_in); a.out = out;
+    bool any_general_col = false;
+    for (uint32_t c = 0; c < p.A; c++) any_general_col |= p.has_add[c] == 4;
+    hipEvent_t ev_trace_ready = nullptr;
+    if (any_general_col) {      // the main columns a general recurrence reads can leave for the host while the affine columns are scanned
+        ev_trace_ready = ctx->sync_event(48);
+        AERO_HIP(hipEventRecord(ev_trace_ready, ctx->stream));
+    }
     launch_air_aux<F>(ctx, a, p.has_den, p.has_add);
     // General recurrences (den = REF_GENERAL): column(i + 1) = expr(main row i, main row i + 1, aux row i of the columns up to its own).
     // Nothing about such a recurrence can be scanned, so it is evaluated row after row on the HOST, after the columns the device built:
@@ -290,59 +300,66 @@ void air_build_aux(Context* ctx, const Program& p, const uint64_t* trace_dev, in
     // nanoseconds; the two copies and the synchronisation the host step needs are noise next to that. A serial chain is the host's job: the host
     // evaluation stays the default, the kernel stays as the tested alternative for a host that must not be interrupted.
     static const bool general_host = !(getenv("AERO_AIR_GENERAL_DEVICE") && getenv("AERO_AIR_GENERAL_DEVICE")[0] == '1');
+    // Both forms run the same compiled recurrence: per general column the leaf operands it reads (loads -> slots), the nodes that do not
+    // depend on the column's own value (par: slot = op(slot | const, slot | const)) and the dependent chain (ser), in topological order.
+    struct Compiled { std::vector<GenLoad> loads; std::vector<GenInsn> par, ser; std::vector<T> consts; uint32_t res_kind = 0, res_idx = 0, n_slots = 0, n_serial = 0; };
+    std::vector<Compiled> progs(p.A);
+    for (uint32_t c = 0; c < p.A; c++) {
+        if (p.has_add[c] != 4) continue;
+        Compiled& g = progs[c];
+        std::map<uint64_t, uint32_t> load_slot, const_idx;       // (kind, index) -> slot / pool index
+        std::vector<int> node_slot(p.nodes.size(), -1), node_ser(p.nodes.size(), -1);
+        uint32_t n_slots = 0, n_serial = 0;
+        struct Op { uint32_t kind, idx; bool serial; };
+        auto scalar = [&](T v) {
+            g.consts.push_back(v);
+            return (uint32_t)g.consts.size() - 1;
+        };
+        auto resolve = [&](uint32_t ref) -> Op {
+            const uint32_t k = ref_kind(ref), j = ref_index(ref);
+            auto load = [&](uint32_t kind, uint32_t col, uint32_t mask) {
+                const uint64_t key = ((uint64_t)kind << 56) | ((uint64_t)mask << 28) | col;
+                auto it = load_slot.find(key);
+                if (it == load_slot.end()) { it = load_slot.emplace(key, n_slots++).first; g.loads.push_back(GenLoad{kind, col, it->second, mask}); }
+                return Op{GOP_SLOT, it->second, false};
+            };
+            auto constant = [&](uint32_t space, uint32_t idx, T v) {
+                const uint64_t key = ((uint64_t)space << 32) | idx;
+                auto it = const_idx.find(key);
+                if (it == const_idx.end()) it = const_idx.emplace(key, scalar(v)).first;
+                return Op{GOP_CONST, it->second, false};
+            };
+            switch (k) {
+                case K_NODE:
+                    if (p.scalar_of[j] >= 0) return constant(0, j, p.is_ext[j] ? sc.e[p.scalar_of[j]] : F::from(sc.b[p.scalar_of[j]]));
+                    if (node_ser[j] >= 0) return Op{GOP_SER, (uint32_t)node_ser[j], true};
+                    return Op{GOP_SLOT, (uint32_t)node_slot[j], false};
+                case K_MAIN_CUR: return load(GLD_MAIN_CUR, j, 0);
+                case K_MAIN_NXT: return load(GLD_MAIN_NXT, j, 0);
+                case K_AUX_CUR: return j == c ? Op{GOP_X, 0, true} : load(GLD_AUX_CUR, j, 0);
+                case K_PERIODIC: return load(GLD_PERIODIC, pt.off[j], pt.mask[j]);
+                case K_CONST: return constant(1, j, F::from(p.consts[j]));
+                case K_PUB: return constant(2, j, F::from(sc.b[p.consts.size() + j]));
+                case K_RAND: return constant(3, j, sc.e[j]);
+                default: fail("air program: operand not available to a general aux recurrence", ST_INTERNAL); return Op{0, 0, false};
+            }
+        };
+        for (uint32_t j : p.general_nodes[c]) {          // ascending = topological
+            const Node& nd = p.nodes[j];
+            const Op x = resolve(nd.a), y = resolve(nd.b);
+            if (x.serial || y.serial) { node_ser[j] = (int)n_serial++; g.ser.push_back(GenInsn{nd.op, (uint32_t)node_ser[j], x.kind, x.idx, y.kind, y.idx}); }
+            else { node_slot[j] = (int)n_slots++; g.par.push_back(GenInsn{nd.op, (uint32_t)node_slot[j], x.kind, x.idx, y.kind, y.idx}); }
+        }
+        const Op r = resolve(p.builders[c].num);
+        g.res_kind = r.kind; g.res_idx = r.idx;
+        g.n_slots = n_slots; g.n_serial = n_serial;
+    }
     if (!general_host) {
-        struct Compiled { std::vector<GenLoad> loads; std::vector<GenInsn> par, ser; std::vector<T> consts; uint32_t res_kind = 0, res_idx = 0; };
-        std::vector<Compiled> progs(p.A);
         bool fits = true;
-        for (uint32_t c = 0; c < p.A && fits; c++) {
+        for (uint32_t c = 0; c < p.A; c++) {
             if (p.has_add[c] != 4) continue;
             Compiled& g = progs[c];
-            std::map<uint64_t, uint32_t> load_slot, const_idx;       // (kind, index) -> slot / pool index
-            std::vector<int> node_slot(p.nodes.size(), -1), node_ser(p.nodes.size(), -1);
-            uint32_t n_slots = 0, n_serial = 0;
-            struct Op { uint32_t kind, idx; bool serial; };
-            auto scalar = [&](T v) {
-                g.consts.push_back(v);
-                return (uint32_t)g.consts.size() - 1;
-            };
-            auto resolve = [&](uint32_t ref) -> Op {
-                const uint32_t k = ref_kind(ref), j = ref_index(ref);
-                auto load = [&](uint32_t kind, uint32_t col, uint32_t mask) {
-                    const uint64_t key = ((uint64_t)kind << 56) | ((uint64_t)mask << 28) | col;
-                    auto it = load_slot.find(key);
-                    if (it == load_slot.end()) { it = load_slot.emplace(key, n_slots++).first; g.loads.push_back(GenLoad{kind, col, it->second, mask}); }
-                    return Op{GOP_SLOT, it->second, false};
-                };
-                auto constant = [&](uint32_t space, uint32_t idx, T v) {
-                    const uint64_t key = ((uint64_t)space << 32) | idx;
-                    auto it = const_idx.find(key);
-                    if (it == const_idx.end()) it = const_idx.emplace(key, scalar(v)).first;
-                    return Op{GOP_CONST, it->second, false};
-                };
-                switch (k) {
-                    case K_NODE:
-                        if (p.scalar_of[j] >= 0) return constant(0, j, p.is_ext[j] ? sc.e[p.scalar_of[j]] : F::from(sc.b[p.scalar_of[j]]));
-                        if (node_ser[j] >= 0) return Op{GOP_SER, (uint32_t)node_ser[j], true};
-                        return Op{GOP_SLOT, (uint32_t)node_slot[j], false};
-                    case K_MAIN_CUR: return load(GLD_MAIN_CUR, j, 0);
-                    case K_MAIN_NXT: return load(GLD_MAIN_NXT, j, 0);
-                    case K_AUX_CUR: return j == c ? Op{GOP_X, 0, true} : load(GLD_AUX_CUR, j, 0);
-                    case K_PERIODIC: return load(GLD_PERIODIC, pt.off[j], pt.mask[j]);
-                    case K_CONST: return constant(1, j, F::from(p.consts[j]));
-                    case K_PUB: return constant(2, j, F::from(sc.b[p.consts.size() + j]));
-                    case K_RAND: return constant(3, j, sc.e[j]);
-                    default: fail("air program: operand not available to a general aux recurrence", ST_INTERNAL); return Op{0, 0, false};
-                }
-            };
-            for (uint32_t j : p.general_nodes[c]) {          // ascending = topological
-                const Node& nd = p.nodes[j];
-                const Op x = resolve(nd.a), y = resolve(nd.b);
-                if (x.serial || y.serial) { node_ser[j] = (int)n_serial++; g.ser.push_back(GenInsn{nd.op, (uint32_t)node_ser[j], x.kind, x.idx, y.kind, y.idx}); }
-                else { node_slot[j] = (int)n_slots++; g.par.push_back(GenInsn{nd.op, (uint32_t)node_slot[j], x.kind, x.idx, y.kind, y.idx}); }
-            }
-            const Op r = resolve(p.builders[c].num);
-            g.res_kind = r.kind; g.res_idx = r.idx;
-            if (n_slots > GEN_MAX_SLOTS - 1 || n_serial > GEN_MAX_SERIAL) fits = false;      // the last slot is the dummies' (below)
+            if (g.n_slots > GEN_MAX_SLOTS - 1 || g.n_serial > GEN_MAX_SERIAL) fits = false;      // the last slot is the dummies' (below)
             // ParamPack keeps POINTERS to its sources until commit(): no section may be empty, none may be a temporary
             if (g.consts.empty()) g.consts.push_back(F::zero());
             if (g.loads.empty()) g.loads.push_back(GenLoad{GLD_MAIN_CUR, 0, GEN_MAX_SLOTS - 1, 0});
@@ -368,46 +385,144 @@ void air_build_aux(Context* ctx, const Program& p, const uint64_t* trace_dev, in
             return;
         }
     }
-    ctx->sync();
-    std::vector<std::vector<uint64_t>> mcols(p.W);
-    for (uint32_t c : p.general_main_cols) {
-        mcols[c].resize(n);
-        AERO_HIP(hipMemcpyAsync(mcols[c].data(), trace_dev + (size_t)c * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    std::vector<uint64_t> aux((size_t)p.A * F::DEG * n);
-    AERO_HIP(hipMemcpyAsync(aux.data(), out, aux.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->sync();
-    std::vector<T> vals(p.nodes.size(), F::zero());
+    // ---- the host step (round 6: two phases per chunk of rows, one thread per general column, copies on their own stream) ----
+    // Sums are exact in the field, so a dependent chain (((x x) + a) + b) is re-associated to (x x) + (a + b): everything that does not
+    // depend on the column's own value leaves the chain (v2 example: three dependent operations per row -> two).
     for (uint32_t c = 0; c < p.A; c++) {
         if (p.has_add[c] != 4) continue;
-        auto aux_at = [&](uint32_t col, uint64_t i) { return F::make(aux[((size_t)col * F::DEG) * n + i], F::DEG > 1 ? aux[((size_t)col * F::DEG + 1) * n + i] : 0); };
-        auto put = [&](uint64_t i, T v) { for (int d = 0; d < F::DEG; d++) aux[((size_t)c * F::DEG + d) * n + i] = F::comp(v, d); };
-        put(0, init[c]);
-        for (uint64_t i = 0; i + 1 < n; i++) {
-            auto operand = [&](uint32_t ref) -> T {
-                const uint32_t k = ref_kind(ref), j = ref_index(ref);
-                switch (k) {
-                    case K_NODE: return p.scalar_of[j] >= 0 ? (p.is_ext[j] ? sc.e[p.scalar_of[j]] : F::from(sc.b[p.scalar_of[j]])) : vals[j];
-                    case K_MAIN_CUR: return F::from(mcols[j][i]);
-                    case K_MAIN_NXT: return F::from(mcols[j][i + 1]);
-                    case K_AUX_CUR: return aux_at(j, i);
-                    case K_PERIODIC: return F::from(p.periodic[j][i % p.periodic[j].size()]);
-                    case K_CONST: return F::from(p.consts[j]);
-                    case K_PUB: return F::from(sc.b[p.consts.size() + j]);
-                    case K_RAND: return sc.e[j];
-                    default: fail("air program: operand not available to a general aux recurrence", ST_INTERNAL); return F::zero();
-                }
-            };
-            for (uint32_t j : p.general_nodes[c]) {
-                const Node& nd = p.nodes[j];
-                const T x = operand(nd.a), y = operand(nd.b);
-                vals[j] = nd.op == 1 ? F::add(x, y) : nd.op == 2 ? F::sub(x, y) : F::mul(x, y);
+        Compiled& g = progs[c];
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (size_t k = 0; k < g.ser.size() && !changed; k++) {
+                GenInsn& s2 = g.ser[k];
+                if ((s2.op != 1 && s2.op != 2) || s2.ka != GOP_SER || s2.kb == GOP_SER || s2.kb == GOP_X) continue;       // s2 = s1 +- q, q free of the chain
+                size_t k1 = g.ser.size();
+                for (size_t m = 0; m < k; m++) if (g.ser[m].dst == s2.ia) k1 = m;
+                if (k1 == g.ser.size()) continue;
+                const GenInsn s1 = g.ser[k1];
+                if ((s1.op != 1 && s1.op != 2) || s1.kb == GOP_SER || s1.kb == GOP_X || !(s1.ka == GOP_SER || s1.ka == GOP_X)) continue;   // s1 = s0 +- p
+                uint32_t uses = (g.res_kind == GOP_SER && g.res_idx == s1.dst) ? 1 : 0;
+                for (const GenInsn& u : g.ser) uses += (u.ka == GOP_SER && u.ia == s1.dst) + (u.kb == GOP_SER && u.ib == s1.dst);
+                if (uses != 1) continue;
+                // s2 = (s0 +- p) +- q = s0 + r,  r = (+-p) +- q as a chain-free node: r = p + q | p - q | q - p | -(p + q) -> s0 - (p + q)
+                const bool np = s1.op == 2, nq = s2.op == 2;
+                GenInsn r{1, g.n_slots++, s1.kb, s1.ib, s2.kb, s2.ib};
+                uint32_t top = 1;
+                if (!np && nq) r.op = 2;                                   // p - q
+                else if (np && !nq) { r.op = 2; std::swap(r.ka, r.kb); std::swap(r.ia, r.ib); }      // q - p
+                else if (np && nq) top = 2;                                // s0 - (p + q)
+                g.par.push_back(r);
+                s2 = GenInsn{top, s2.dst, s1.ka, s1.ia, GOP_SLOT, r.dst};
+                g.ser.erase(g.ser.begin() + (long)k1);
+                changed = true;
             }
-            put(i + 1, operand(p.builders[c].num));
         }
-        AERO_HIP(hipMemcpyAsync(out + (size_t)c * F::DEG * n, aux.data() + (size_t)c * F::DEG * n, (size_t)F::DEG * n * 8, hipMemcpyHostToDevice, ctx->stream));
     }
-    ctx->sync();          // `aux` is pageable host memory that dies with this frame
+    // what travels: the main columns and the device-built auxiliary columns the general builders read come down (the main columns on the
+    // copy stream, behind nothing but the trace itself - they do not wait for the kernel above), the general columns go up, each as soon
+    // as it is finished; everything through ONE pinned block kept by the context (true asynchronous copies, no allocation per proof)
+    std::vector<uint8_t> need_aux(p.A, 0);
+    for (uint32_t c = 0; c < p.A; c++) if (p.has_add[c] == 4) for (const GenLoad& l : progs[c].loads) if (l.kind == GLD_AUX_CUR) need_aux[l.col] = 1;
+    const size_t n_main = p.general_main_cols.size();
+    uint64_t* const arena = ctx->host_arena((n_main + (size_t)p.A * F::DEG) * n * 8);
+    std::vector<const uint64_t*> mcols(p.W, nullptr);
+    uint64_t* const aux = arena + n_main * n;
+    hipStream_t cs = ctx->get_copy_stream();
+    AERO_HIP(hipStreamWaitEvent(cs, ev_trace_ready, 0));
+    for (size_t k = 0; k < n_main; k++) {
+        const uint32_t c = p.general_main_cols[k];
+        mcols[c] = arena + k * n;
+        AERO_HIP(hipMemcpyAsync(arena + k * n, trace_dev + (size_t)c * n, n * 8, hipMemcpyDeviceToHost, cs));
+    }
+    for (uint32_t c = 0; c < p.A; c++)
+        if (need_aux[c] && p.has_add[c] != 4)
+            AERO_HIP(hipMemcpyAsync(aux + (size_t)c * F::DEG * n, out + (size_t)c * F::DEG * n, (size_t)F::DEG * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    AERO_HIP(hipStreamSynchronize(cs));
+    ctx->sync();
+    // done[c] = rows of auxiliary column c that exist on the host (device-built columns: all of them)
+    std::unique_ptr<std::atomic<uint64_t>[]> done(new std::atomic<uint64_t>[p.A]);
+    for (uint32_t c = 0; c < p.A; c++) done[c].store(p.has_add[c] == 4 ? 0 : n, std::memory_order_relaxed);
+    std::atomic<bool> failed{false};
+    constexpr uint64_t CH = 4096;          // rows per chunk: its slot arrays stay in the core's cache
+    auto run_column = [&](uint32_t c) {
+        const Compiled& g = progs[c];
+        std::vector<T> slots((size_t)(g.n_slots ? g.n_slots : 1) * CH), regs(g.n_serial ? g.n_serial : 1, F::zero());
+        auto comp = [&](uint32_t col, int d) { return aux + ((size_t)col * F::DEG + d) * n; };
+        auto put = [&](uint64_t i, T v) { for (int d = 0; d < F::DEG; d++) comp(c, d)[i] = F::comp(v, d); };
+        put(0, init[c]);
+        T x = init[c];
+        done[c].store(1, std::memory_order_release);
+        for (uint64_t i0 = 0; i0 + 1 < n; i0 += CH) {
+            const uint64_t cnt = std::min<uint64_t>(CH, n - 1 - i0);
+            // leaf operands of rows [i0, i0 + cnt) -> slot arrays; a column another thread is still building is waited for
+            for (const GenLoad& l : g.loads) {
+                T* s = slots.data() + (size_t)l.slot * CH;
+                switch (l.kind) {
+                    case GLD_MAIN_CUR: { const uint64_t* m = mcols[l.col] + i0; for (uint64_t k = 0; k < cnt; k++) s[k] = F::from(m[k]); break; }
+                    case GLD_MAIN_NXT: { const uint64_t* m = mcols[l.col] + i0 + 1; for (uint64_t k = 0; k < cnt; k++) s[k] = F::from(m[k]); break; }
+                    case GLD_AUX_CUR: {
+                        while (done[l.col].load(std::memory_order_acquire) < i0 + cnt) { if (failed.load(std::memory_order_relaxed)) return; std::this_thread::yield(); }
+                        const uint64_t* a0 = comp(l.col, 0) + i0;
+                        const uint64_t* a1 = comp(l.col, F::DEG - 1) + i0;
+                        for (uint64_t k = 0; k < cnt; k++) s[k] = F::make(a0[k], F::DEG > 1 ? a1[k] : 0);
+                        break;
+                    }
+                    default: { const uint64_t* t = pt.tab.data() + l.col; for (uint64_t k = 0; k < cnt; k++) s[k] = F::from(t[(i0 + k) & l.mask]); }
+                }
+            }
+            for (const GenInsn& I : g.par) {
+                T* d = slots.data() + (size_t)I.dst * CH;
+                const T* a = I.ka == GOP_SLOT ? slots.data() + (size_t)I.ia * CH : nullptr;
+                const T* b = I.kb == GOP_SLOT ? slots.data() + (size_t)I.ib * CH : nullptr;
+                const T ca = a ? F::zero() : g.consts[I.ia], cb = b ? F::zero() : g.consts[I.ib];
+                if (I.op == 1) for (uint64_t k = 0; k < cnt; k++) d[k] = F::add(a ? a[k] : ca, b ? b[k] : cb);
+                else if (I.op == 2) for (uint64_t k = 0; k < cnt; k++) d[k] = F::sub(a ? a[k] : ca, b ? b[k] : cb);
+                else for (uint64_t k = 0; k < cnt; k++) d[k] = F::mul(a ? a[k] : ca, b ? b[k] : cb);
+            }
+            // the chain, row after row
+            uint64_t* o0 = comp(c, 0) + i0 + 1;
+            uint64_t* o1 = comp(c, F::DEG - 1) + i0 + 1;
+            const GenInsn* ser = g.ser.data();
+            const size_t ns = g.ser.size();
+            for (uint64_t k = 0; k < cnt; k++) {
+                auto val = [&](uint32_t kind, uint32_t idx) -> T {
+                    return kind == GOP_SER ? regs[idx] : kind == GOP_X ? x : kind == GOP_SLOT ? slots[(size_t)idx * CH + k] : g.consts[idx];
+                };
+                for (size_t q = 0; q < ns; q++) {
+                    const GenInsn& I = ser[q];
+                    const T a = val(I.ka, I.ia), b = val(I.kb, I.ib);
+                    regs[I.dst] = I.op == 1 ? F::add(a, b) : I.op == 2 ? F::sub(a, b) : F::mul(a, b);
+                }
+                x = val(g.res_kind, g.res_idx);
+                o0[k] = F::comp(x, 0);
+                if (F::DEG > 1) o1[k] = F::comp(x, F::DEG - 1);
+            }
+            done[c].store(i0 + cnt + 1, std::memory_order_release);
+        }
+    };
+    std::vector<uint32_t> gcols;
+    for (uint32_t c = 0; c < p.A; c++) if (p.has_add[c] == 4) gcols.push_back(c);
+    auto upload = [&](uint32_t c) {
+        AERO_HIP(hipMemcpyAsync(out + (size_t)c * F::DEG * n, aux + (size_t)c * F::DEG * n, (size_t)F::DEG * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    };
+    if (gcols.size() == 1) { run_column(gcols[0]); upload(gcols[0]); }
+    else {
+        // a column reads only columns before it: the threads form a pipeline, each a chunk behind the ones it reads
+        std::vector<std::thread> th;
+        std::exception_ptr err;
+        std::mutex err_mu;
+        for (uint32_t c : gcols)
+            th.emplace_back([&, c] {
+                try { run_column(c); }
+                catch (...) { failed.store(true); std::lock_guard<std::mutex> lk(err_mu); if (!err) err = std::current_exception(); }
+            });
+        for (size_t k = 0; k < th.size(); k++) {
+            th[k].join();
+            if (!failed.load()) upload(gcols[k]);       // goes up while the later columns are still being computed
+        }
+        if (err) std::rethrow_exception(err);
+    }
+    // no synchronisation: the pinned block stays the context's, and its next use is ordered behind these copies (host_arena)
 }
 template void air_build_aux<FB>(Context*, const Program&, const uint64_t*, int, const uint64_t*, const uint64_t*, uint64_t*);
 template void air_build_aux<FQ>(Context*, const Program&, const uint64_t*, int, const uint64_t*, const gl::E2*, uint64_t*);

@@ -49,6 +49,10 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (aero_rccl_info): what the communicator itself reports
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
 };
 
 RcclApi g_api;
@@ -92,6 +96,9 @@ RcclApi* rccl_api() {
                     bind(h, "ncclGroupStart", a.GroupStart) && bind(h, "ncclGroupEnd", a.GroupEnd) && bind(h, "ncclSend", a.Send) && bind(h, "ncclRecv", a.Recv) &&
                     bind(h, "ncclAllGather", a.AllGather) && bind(h, "ncclAllReduce", a.AllReduce) && bind(h, "ncclGetErrorString", a.GetErrorString);
     if (!ok) { g_api.err = "RCCL library lacks a required entry point"; g_rccl_err = g_api.err; return nullptr; }
+    (void)bind(h, "ncclCommCount", a.CommCount);
+    (void)bind(h, "ncclCommUserRank", a.CommUserRank);
+    (void)bind(h, "ncclCommCuDevice", a.CommCuDevice);
     a.handle = h;
     g_api = a;
     return &g_api;
@@ -221,6 +228,19 @@ int32_t aero_rccl_comm(aero_rccl* r, uint32_t min_peer_digests, aero_comm* out) 
 int32_t aero_rccl_stats(const aero_rccl* r, uint64_t out[4]) {
     if (!r || !out) return AERO_E_BAD_ARG;
     out[0] = r->calls[0]; out[1] = r->calls[1]; out[2] = r->calls[2]; out[3] = r->bytes_sent;
+    return AERO_OK;
+}
+
+int32_t aero_rccl_info(const aero_rccl* r, int32_t out[4]) {
+    if (!r || !out) return AERO_E_BAD_ARG;
+    out[0] = out[1] = out[2] = -1;
+    out[3] = r->world;
+    if (r->comm && r->api) {
+        int v = -1;
+        if (r->api->CommCount && r->api->CommCount(r->comm, &v) == ncclSuccess) out[0] = v;
+        if (r->api->CommUserRank && r->api->CommUserRank(r->comm, &v) == ncclSuccess) out[1] = v;
+        if (r->api->CommCuDevice && r->api->CommCuDevice(r->comm, &v) == ncclSuccess) out[2] = v;
+    }
     return AERO_OK;
 }
 

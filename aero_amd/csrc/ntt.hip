@@ -282,18 +282,18 @@ constexpr int F8_WAVES = 4;                      // tiles per workgroup
 // depend on the lane and the row only). Dropped after measuring: a per-ELEMENT table of all pass-boundary twiddles (64 MiB, one
 // multiplication instead of the progression's two: 362 us against 252 us per proof), walking 4 tiles per wave (6 % slower), and
 // replacing the progression's serial chain by a per-tile table of the 32 step powers read through scalar loads (2 - 5 % slower).
-__global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArgs a) {
-    __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS / 2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t* lds = f8_lds + wave * (F8_TILE_LDS / 2);
-    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * F8_WAVES + wave;
-    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
-    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+// One column of one 2048-point tile by one wavefront. TW selects the pass-boundary twiddle (w_N^(rev(tile) (lane + 64 i)) for row i):
+//   0 = none (the transform's only pass, or tile 0);
+//   1 = the progression cur <- cur * step (two multiplications per element), as one or two interleaved chains;
+//   2 = the progression, and the factors of the rows i = `wave` (mod F8_WAVES) are ALSO stored to `tab` (32 x 64 words of LDS);
+//   3 = one multiplication per element, the factor read from `tab`.
+template <int TW>
+__device__ __forceinline__ void first8_column(const PassArgs& a, const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t* lds,
+                                              int lane, int wave, uint32_t b, uint32_t rbk, uint64_t* tab, const uint64_t* __restrict__ tw_mt) {
     const int h = lane & 31;
     const bool upper = lane >= 32;
     const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
     const size_t base = (size_t)b << 11;
-    const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
     uint64_t y[32];
     {
         uint64_t c[8];
@@ -328,12 +328,18 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArg
         }
     }
 #pragma unroll
-    for (int i = 1; i < 32; i++) y[i] = mul(y[i], a.tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane]);
+    for (int i = 1; i < 32; i++) y[i] = mul(y[i], tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane]);
     dft_dit_reg<5>(y);
-    if (!a.first && rbk) {
+    if constexpr (TW == 0) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = y[i];
+    } else if constexpr (TW == 3) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = mul(y[i], tab[i * 64 + lane]);
+    } else {
         uint64_t cur = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)lane) & nmask), a.tw_h);
         const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
-        if (a.chains == 2) {
+        if (TW == 1 && a.chains == 2) {
             // two interleaved progressions (even and odd rows): the serial chain cur <- cur * step is half as deep
             uint64_t cur1 = mul(cur, step);
             const uint64_t step2 = mul(step, step);
@@ -345,14 +351,58 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArg
             }
         } else {
 #pragma unroll
-        for (int i = 0; i < 32; i++) {
-            out[base + lane + 64 * i] = mul(y[i], cur);
-            cur = mul(cur, step);
+            for (int i = 0; i < 32; i++) {
+                if (TW == 2 && (i & (F8_WAVES - 1)) == wave) tab[i * 64 + lane] = cur;       // wave-uniform
+                out[base + lane + 64 * i] = mul(y[i], cur);
+                cur = mul(cur, step);
+            }
         }
+    }
+}
+__global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArgs a) {
+    __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS / 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t* lds = f8_lds + wave * (F8_TILE_LDS / 2);
+    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x) * F8_WAVES + wave;
+    const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+    const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
+    if (!a.first && rbk) first8_column<1>(a, in, out, lds, lane, wave, b, rbk, nullptr, a.tw_mt);
+    else first8_column<0>(a, in, out, lds, lane, wave, b, rbk, nullptr, a.tw_mt);
+}
+// Wide launches (round 6): the pass-boundary factors depend on the tile, the lane and the row - NOT on the column. A workgroup takes ONE tile
+// and F8_WAVES * K columns of it (wave w: columns w, w + F8_WAVES, ...): each wave's first column runs the progression and leaves a quarter
+// of the 32 x 64 factors in LDS (16 KiB per workgroup, next to the four 8 KiB exchange buffers: three workgroups per CU as before), one
+// workgroup barrier, and the remaining K - 1 columns of every wave spend ONE multiplication per element on the boundary instead of two
+// (193 -> about 167 VALU instructions per element at K = 9). a.chains = columns of the launch here; grid = (tiles, columns / (F8_WAVES K)).
+__global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8w(PassArgs a, int K) {
+    __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS / 2];
+    __shared__ __attribute__((aligned(16))) uint64_t f8_tab[F8_TILE_LDS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // scalar: the column pointers stay in SGPRs
+    uint64_t* lds = f8_lds + wave * (F8_TILE_LDS / 2);
+    const uint32_t b = xcd_tile(blockIdx.x, gridDim.x);
+    const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
+    const int col0 = (int)blockIdx.y * F8_WAVES * K + wave;
+    const uint64_t* in = a.in + (size_t)col0 * a.in_col_stride;
+    uint64_t* out = a.out + (size_t)col0 * a.out_col_stride;
+    // the table twiddles and the boundary factors do not change from column to column: left to itself the compiler hoists all 31 + 32 loads
+    // out of the column loop and spills a hundred registers; the pointers are laundered per iteration so that every column reads them where
+    // it uses them (L1 / LDS hits)
+    const uint64_t* mt = a.tw_mt;
+    uint64_t* tab = f8_tab;
+    if (a.first || !rbk) {       // uniform over the workgroup
+        for (int j = 0; j < K; j++) {
+            asm volatile("" : "+s"(mt));
+            first8_column<0>(a, in + (size_t)j * F8_WAVES * a.in_col_stride, out + (size_t)j * F8_WAVES * a.out_col_stride, lds, lane, wave, b, rbk, nullptr, mt);
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = y[i];
+        return;
+    }
+    first8_column<2>(a, in, out, lds, lane, wave, b, rbk, tab, mt);
+    __syncthreads();
+    for (int j = 1; j < K; j++) {
+        asm volatile("" : "+s"(mt));
+        asm volatile("" : "+v"(tab));
+        first8_column<3>(a, in + (size_t)j * F8_WAVES * a.in_col_stride, out + (size_t)j * F8_WAVES * a.out_col_stride, lds, lane, wave, b, rbk, tab, mt);
     }
 }
 // Round 5 measured this pass with TWO wavefronts per tile and 16 values per lane (74 VGPRs, five waves per SIMD instead of three, commit
@@ -1022,7 +1072,14 @@ bool Context::ntt_forward(const uint64_t* in, size_t in_stride, uint64_t* out, s
             a.chains = ncols < 16 ? 2 : 1;
             const size_t tiles = ((size_t)1 << log_out) >> 11;
             const char* nm = pass_names ? "ntt_fwd_first8" : "ntt_fwd_pass";
-            AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8, dim3((unsigned)(tiles / F8_WAVES), ncols), dim3(64 * F8_WAVES), 0, a);
+            // from 16 columns on, and when the columns split evenly: one tile and F8_WAVES * K columns per workgroup, the boundary factors
+            // generated once per tile (ntt_fwd_first_pass_8w); K = the largest divisor of columns / F8_WAVES up to 9. AERO_NTT_F8W=0: never.
+            static const bool f8w = !(getenv("AERO_NTT_F8W") && getenv("AERO_NTT_F8W")[0] == '0');
+            int K = 0;
+            if (f8w && ncols >= 16 && ncols % F8_WAVES == 0)
+                for (int k = 9; k >= 2; k--) if ((ncols / F8_WAVES) % k == 0) { K = k; break; }
+            if (K) AERO_LAUNCH(this, pass_names ? "ntt_fwd_first8w" : nm, abytes, ntt_fwd_first_pass_8w, dim3((unsigned)tiles, (unsigned)(ncols / (F8_WAVES * K))), dim3(64 * F8_WAVES), 0, a, K);
+            else AERO_LAUNCH(this, nm, abytes, ntt_fwd_first_pass_8, dim3((unsigned)(tiles / F8_WAVES), ncols), dim3(64 * F8_WAVES), 0, a);
             continue;
         }
         if (q == 0 && reg_passes && a.log_r > a.log_pad) {

@@ -50,6 +50,7 @@ Context::~Context() {
     if (stage_base) (void)hipHostFree(stage_base);
     if (flag_host) (void)hipHostFree(flag_host);
     if (pinned_flag) (void)hipHostFree(pinned_flag);
+    if (arena_base) (void)hipHostFree(arena_base);
     for (auto& r : kt_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (hipEvent_t e : kt_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : sync_events) (void)hipEventDestroy(e);
@@ -235,6 +236,19 @@ void* Context::stage_alloc(size_t bytes) {
     void* p = stage_base + stage_off;
     stage_off += bytes;
     return p;
+}
+uint64_t* Context::host_arena(size_t bytes) {
+    if (bytes > arena_cap) {
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+        sync();
+        if (arena_base) (void)hipHostFree(arena_base);
+        arena_base = nullptr; arena_cap = 0;
+        const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        const hipError_t e = hipHostMalloc((void**)&arena_base, want, hipHostMallocDefault);
+        if (e != hipSuccess) { (void)hipGetLastError(); arena_base = nullptr; throw Error(ST_OOM, "pinned host block of " + std::to_string(want) + " bytes: " + hipGetErrorString(e)); }
+        arena_cap = want;
+    }
+    return arena_base;
 }
 unsigned int* Context::pinned_word() {
     if (!pinned_flag) AERO_HIP(hipHostMalloc((void**)&pinned_flag, 64, hipHostMallocDefault));

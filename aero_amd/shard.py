@@ -218,6 +218,12 @@ class RcclComm:
     def bytes_sent(self):
         return self._stats()[3]
 
+    def info(self):
+        """aero_rccl_info: what RCCL itself reports about this communicator."""
+        out = (C.c_int32 * 4)()
+        self.lib.aero_rccl_info(self.h, out)
+        return {"ranks_counted_by_rccl": out[0], "rank_as_rccl_numbers_it": out[1], "device_rccl_bound": out[2], "world_asked_for": out[3]}
+
     def error_text(self):
         return self.lib.aero_rccl_last_error(self.h).decode() if self.h else ""
 

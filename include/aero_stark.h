@@ -335,6 +335,10 @@ int32_t aero_rccl_create(aero_ctx* ctx, int32_t rank, int32_t world, const uint8
 int32_t aero_rccl_comm(aero_rccl* r, uint32_t min_peer_digests, aero_comm* out);
 /* out = {all_to_all calls, all_gather calls, all_reduce calls, bytes sent by this rank} since creation */
 int32_t aero_rccl_stats(const aero_rccl* r, uint64_t out[4]);
+/* What the communicator itself reports: out = {ranks RCCL counts in it (ncclCommCount), this rank as RCCL numbers it (ncclCommUserRank),
+ * the device RCCL bound (ncclCommCuDevice), the world the caller asked for}; -1 where the bound librccl lacks the query. The first thing a
+ * first run on a multi-GPU node prints (tools/first_contact.sh). (No counterpart in the reference: single-device prover.) */
+int32_t aero_rccl_info(const aero_rccl* r, int32_t out[4]);
 const char* aero_rccl_last_error(const aero_rccl* r);   /* r may be NULL for errors of unique_id / create */
 void aero_rccl_destroy(aero_rccl* r);
 /* `Prover::prove` + `to_bytes` for ONE trace proven cooperatively by comm->world GPUs (BASELINE config 4). Rank k owns

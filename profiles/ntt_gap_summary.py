@@ -30,7 +30,8 @@ def main(d):
         for r in csv.DictReader(open(ks)):
             dur[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
     names = sorted(set(n for c in acc.values() for n in c))
-    kernels = [k for k in acc if k.startswith("ntt_")]
+    prefixes = tuple(os.environ.get("GAP_PREFIX", "ntt_").split(","))     # GAP_PREFIX=hash_,merkle_: other kernel families (tools/kernel_gap.sh)
+    kernels = [k for k in acc if k.startswith(prefixes)]
     print("per-wave counters (each from its own pass); avg_us from the kernel trace")
     for k in sorted(kernels, key=lambda k: -acc[k].get("SQ_INSTS_VALU", 0)):
         c = acc[k]

@@ -19,6 +19,7 @@ from collections import defaultdict
 # device function -> the name its launches carry in bench.py's per-kernel table (AERO_LAUNCH name)
 ALIASES = {
     "merkle_leaf8_rows_kernel": "merkle_leaf8_kernel",
+    "hash_fri_rows_fixed_kernel": "hash_fri_rows_kernel", "hash_fri_rows_fixed2_kernel": "hash_fri_rows_kernel", "hash_rows_wide_kernel": "hash_rows_kernel",
     "ntt_fwd_strided_reg": "ntt_fwd_pass", "ntt_fwd_strided_reg6x2": "ntt_fwd_pass", "ntt_fwd_strided_reg6x2_v": "ntt_fwd_pass", "ntt_fwd_strided_reg6x2_buf": "ntt_fwd_pass", "ntt_fwd_strided_reg7x2": "ntt_fwd_pass", "ntt_inv_last_pass_11": "ntt_inv_pass", "ntt_inv_last_pass_12": "ntt_inv_pass", "ntt_fwd_first_pass": "ntt_fwd_pass", "ntt_fwd_first_pass_8": "ntt_fwd_pass",
     "merkle_multi_quad_kernel": "merkle_multi_kernel",
     "ntt_inv_strided_reg": "ntt_inv_pass",

@@ -41,7 +41,7 @@ def opts(**kw):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # a5: row hashing — the HashingWorkItem -> HashingResult seam (hashing_worker.rs:12-26)
-@pytest.mark.parametrize("width", [1, 2, 3, 8, 9, 72, 81])
+@pytest.mark.parametrize("width", [1, 2, 3, 7, 8, 9, 15, 16, 17, 23, 24, 25, 72, 81])      # 8 and up: the software-pipelined wide kernel, whole and ragged chunks
 def test_hash_rows_matches_oracle(ctx, oracle, width):
     rng = np.random.default_rng(width)
     rows = rand_felts(rng, (300, width))

@@ -73,6 +73,7 @@ print("ok")
 # AERO_NTT_REG=0 and the 12-bit forward first pass of a blowup-8 LDE under AERO_NTT_2PHASE=0: tests/test_gpu_fallback_paths.py)
 EXPECTED = {
     "ntt_fwd_first8",            # two-phase contiguous first pass of a blowup-8 LDE
+    "ntt_fwd_first8w",           # the same from 16 columns on: one tile and 4 K columns per workgroup, boundary factors generated once per tile
     "ntt_fwd_first_512", "ntt_fwd_first_256",      # LDS-round first pass (small transforms, other blowups), 512 / 256 threads per tile
     "ntt_fwd_reg6_mid_buf", "ntt_fwd_reg6_last_buf", "ntt_fwd_reg6_last",      # two-lane radix 64: buffer form / pointer form from 16 columns on
     "ntt_fwd_reg7",              # two-lane radix 128 (2^24- and 2^25-point transforms)
@@ -109,7 +110,46 @@ def test_ntt_without_two_phase_passes_on_large_launches(tmp_path):
     assert "ntt_fwd_first8" not in reached and {"ntt_fwd_first_256", "ntt_fwd_first_512"} <= reached, seen
 
 
+@pytest.mark.parametrize("flag", ["1", "0"])
+def test_ntt_first_pass_shared_boundary_factors(tmp_path, flag):
+    """AERO_NTT_F8W=0: wide launches of the two-phase first pass keep one column per wave with the two-multiplication progression instead of
+    sharing the tile's boundary factors through LDS (ntt_fwd_first_pass_8w). Widths with K = 4, 5, 9, 9 columns per wave, one that does not
+    split (44 = 4 x 11: no K <= 9) and one below the threshold; every column against the oracle or its twin."""
+    shapes = "[[10, 16, 3], [13, 20, 3], [14, 36, 3], [12, 44, 3], [20, 72, 3], [16, 12, 3]]"
+    out = run(tmp_path, PLANS, {"AERO_NTT_NAMES": "1", "AERO_NTT_F8W": flag, "AERO_TEST_SHAPES": shapes}, timeout=1500)
+    seen = json.loads(out.strip().split("\n")[-2])
+    for shape, names in seen.items():
+        wide = shape.split("/")[0] in ("10x16", "13x20", "14x36", "20x72") and flag == "1"
+        assert ("ntt_fwd_first8w" in names) == wide and ("ntt_fwd_first8" in names) == (not wide), (shape, names)
+
+
 # ---- switches -----------------------------------------------------------------------------------------------------------------
+HASH_FORMS = r'''
+import hashlib
+rng = np.random.default_rng(11)
+for width in (1, 2, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 47, 48, 49, 72, 81):
+    rows = (rng.integers(0, 1 << 63, (777, width), dtype=np.uint64) % np.uint64(P)).astype(np.uint64)
+    got = ctx.hash_rows(rows)
+    assert (got == orc.hash_rows(np.ascontiguousarray(rows.T))).all(), width
+    blob = b"".join(int(v).to_bytes(8, "little") + bytes(24) for v in rows[776])
+    assert got[776].tobytes() == hashlib.blake2s(blob).digest(), width
+# FRI layers of 2^17 rows and more (what AERO_HASH_FRI2 switches), fold 8 and fold 4, inside whole proofs
+for width, log_n, opt in ((2, 17, [27, 8, 16, 4, 1, 8, 8]), (2, 16, [27, 8, 16, 4, 1, 4, 8])):
+    want = orc.prove_fib(width, log_n, opt)[0]
+    dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
+    assert ctx.prove_fib(dev, aero_amd.ProofOptions(*opt))[0] == want, (width, log_n)
+    dev.free()
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("env", [{"AERO_HASH_WIDE": "0"}, {"AERO_HASH_WIDE": "8"}, {"AERO_HASH_WIDE": "16"}, {"AERO_HASH_WIDE": "24"}, {"AERO_HASH_FRI2": "1"}])
+def test_row_hash_forms(tmp_path, env):
+    """AERO_HASH_WIDE: columns per software-pipelined chunk of the wide-row kernel (0 = the plain one-row-per-lane kernel at every width);
+    AERO_HASH_FRI2=1: two FRI rows per lane from 2^17 rows on. Digests against the oracle and hashlib at widths around every chunk size."""
+    run(tmp_path, HASH_FORMS, env)
+
+
 R128 = r'''
 for log_n in (21, 22):
     rng = np.random.default_rng(log_n)

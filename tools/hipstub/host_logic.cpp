@@ -322,6 +322,79 @@ static void version2_program_proofs() {
     }
 }
 
+// Three general recurrences that read each other (the shape of tests/air_examples.py: general_chain_air) over more rows than one chunk of
+// the host step: one thread per column, each a chunk behind the column it reads (air_host.hip: `done` counters), the finished columns
+// uploaded while the later ones are still computed. Base field: every value is recomputed here with plain 128-bit arithmetic.
+static uint64_t mulp(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % P); }
+static uint64_t addp(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + b) % P); }
+static void general_chain_columns() {
+    using aero_air_builder::Builder;
+    using aero_air_builder::Expr;
+    for (int log_n : {6, 14}) {
+        const size_t n = (size_t)1 << log_n;
+        std::vector<uint64_t> trace(2 * n);
+        uint64_t x = 1, y = 2;
+        for (size_t i = 0; i < n; i++) {
+            trace[i] = x; trace[n + i] = y;
+            const uint64_t nx = addp(x, y), ny = addp(y, nx);
+            x = nx; y = ny;
+        }
+        Builder b(2, 3, 2, 2);
+        Expr k = b.periodic({1, 2, 3, 4});
+        b.transition(b.main_next(0) - (b.main(0) + b.main(1)), 1);
+        b.transition(b.main_next(1) - (b.main(1) + b.main_next(0)), 1);
+        Expr e0 = b.aux(0) * b.aux(0) + b.main(0);
+        Expr e1 = b.aux(1) * b.aux(0) + k * b.main(1) + b.pub(0) + 5;
+        Expr e2 = (b.aux(2) + b.rand(0)) * (b.aux(1) + b.main_next(0));
+        b.aux_transition(b.aux_next(0) - e0, 2);
+        b.aux_transition(b.aux_next(1) - e1, 2);
+        b.aux_transition(b.aux_next(2) - e2, 2);
+        b.assert_single(0, 0, (uint64_t)1);
+        b.assert_single(1, -1, b.pub(1));
+        b.aux_assert_single(0, 0, (uint64_t)3);
+        b.aux_assert_single(1, 0, (uint64_t)4);
+        b.aux_assert_single(2, 0, (uint64_t)6);
+        b.aux_builder_general(0, b.constant(3), e0);
+        b.aux_builder_general(1, b.constant(4), e1);
+        b.aux_builder_general(2, b.constant(6), e2);
+        const std::vector<uint8_t> program = b.to_bytes();
+        char err[256] = {0};
+        aero_air* air = nullptr;
+        CHECK(aero_air_load(program.data(), program.size(), &air, err, sizeof err) == AERO_OK);
+        aero_ctx* ctx = nullptr;
+        CHECK(aero_ctx_create(0, &ctx) == AERO_OK);
+        const uint64_t pub[2] = {77, trace[n + n - 1]};
+        const uint64_t rands[4] = {11, 0, 13, 0};
+        for (uint8_t ext : {(uint8_t)1, (uint8_t)2}) {
+            for (int rep = 0; rep < 2; rep++) {          // twice: the second run reuses the context's pinned block behind the first run's uploads
+                aero_matrix *m = nullptr, *auxm = nullptr;
+                CHECK(aero_trace_upload(ctx, trace.data(), 2, (uint32_t)log_n, &m) == AERO_OK);
+                CHECK(aero_aux_columns_program(ctx, air, m, pub, 2, rands, ext, &auxm) == AERO_OK);
+                uint32_t cols = 0; uint64_t rows = 0;
+                aero_matrix_shape(auxm, &cols, &rows);
+                CHECK(cols == 3u * ext && rows == n);
+                std::vector<uint64_t> a((size_t)cols * n);
+                CHECK(aero_matrix_download(ctx, auxm, a.data()) == AERO_OK);
+                if (ext == 1) {
+                    uint64_t g0 = 3, g1 = 4, g2 = 6;
+                    for (size_t i = 0; i < n; i++) {
+                        CHECK(a[i] == g0 && a[n + i] == g1 && a[2 * n + i] == g2);
+                        if (i + 1 == n) break;
+                        const uint64_t kk = 1 + (i & 3);
+                        const uint64_t n0 = addp(mulp(g0, g0), trace[i]);
+                        const uint64_t n1 = addp(addp(addp(mulp(g1, g0), mulp(kk, trace[n + i])), pub[0]), 5);
+                        const uint64_t n2 = mulp(addp(g2, rands[0]), addp(g1, trace[i + 1]));
+                        g0 = n0; g1 = n1; g2 = n2;
+                    }
+                }
+                aero_matrix_free(ctx, auxm); aero_matrix_free(ctx, m);
+            }
+        }
+        aero_ctx_destroy(ctx);
+        aero_air_free(air);
+    }
+}
+
 // a batch through the pool: every slot's worker thread runs the host pipeline of a proof from host memory (copy gate between the slots),
 // the batch comes back with the workers' statuses
 static void pool_batches() {
@@ -376,6 +449,7 @@ int main() {
     unsetenv("AERO_EXCHANGE_CHUNKS");
     sharded_program_proofs();
     version2_program_proofs();
+    general_chain_columns();
     pool_batches();
     printf("host logic ok: %llu copies moved, %llu kernel launches skipped\n", (unsigned long long)hipstub_copies(), (unsigned long long)hipstub_launches());
     return 0;
