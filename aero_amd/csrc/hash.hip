@@ -224,42 +224,6 @@ template <class Src> __global__ __launch_bounds__(256) void hash_rows_kernel(Src
     store_digest(&leaves[j], leaf_digest(src, j));
 }
 
-// Wide rows (>= 8 columns: the 72-column Miden-width trace, 8 composition columns, FRI-width auxiliary segments): the same lane <-> row
-// mapping with the column loads SOFTWARE-PIPELINED one chunk of CH columns ahead - while the CH / 2 compressions of a chunk run (about a
-// thousand VALU instructions each), the next chunk's loads are in flight, so a lane meets the memory latency (and, with 64 MiB between the
-// columns of a 2^23-row matrix, a TLB miss per column) once per row instead of once per compression. The plain kernel above waits for its two
-// loads in front of every compression and sits at 0.84 of the in-register BLAKE2s rate on 72 columns (profiles/r5_all_workloads.txt).
-template <int CH> __global__ __launch_bounds__(256) void hash_rows_wide_kernel(RowSrc s, size_t rows, Digest* leaves) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= rows) return;
-    const int nc = s.ncols;
-    const uint64_t* const p = s.cols + j;
-    uint64_t cur[CH], nxt[CH];
-#pragma unroll
-    for (int k = 0; k < CH; k++) cur[k] = p[(size_t)(k < nc ? k : nc - 1) * s.stride];
-    b2s::State st;
-    b2s::init(st);
-    const uint32_t total = (uint32_t)nc * 32;
-    for (int c0 = 0; c0 < nc; c0 += CH) {
-        if (c0 + CH < nc) {       // uniform; columns past the end repeat the last one (a cache hit, never used)
-#pragma unroll
-            for (int k = 0; k < CH; k++) { const int c = c0 + CH + k; nxt[k] = p[(size_t)(c < nc ? c : nc - 1) * s.stride]; }
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k += 2) {
-            const int c = c0 + k;
-            if (c < nc) {         // uniform
-                const bool two = c + 1 < nc;
-                const uint32_t t = (uint32_t)(two ? c + 2 : c + 1) * 32;
-                b2s::compress_elems(st, cur[k], two ? cur[k + 1] : 0, two, t, t == total);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k++) cur[k] = nxt[k];
-    }
-    store_digest(&leaves[j], state_digest(st));
-}
-
 // L <= 9 levels in one launch, one workgroup per subtree: workgroup b owns node r = m + b and its 2^L descendants L
 // levels below (heap indices (r << L) + j), staged through LDS. Lane utilisation is poor (2^L - 1 compressions on
 // L * 2^(L-1) lane slots), so this is used only where a level has too few nodes to fill the chip anyway: there the cost
@@ -638,14 +602,11 @@ void Context::openings(const OpeningArgs& a) {
 void Context::hash_rows(const uint64_t* cols, size_t col_stride, int ncols, size_t rows, Digest* leaves) {
     if (ncols < 1) fail("hash_rows: empty rows");
     RowSrc src{cols, col_stride, ncols};
-    // AERO_HASH_WIDE: columns per software-pipelined chunk of the wide-row kernel (8, 16 or 24; 0 = the plain kernel for every width)
-    static const int wide = getenv("AERO_HASH_WIDE") ? atoi(getenv("AERO_HASH_WIDE")) : 8;
-    const dim3 grid((unsigned)((rows + 255) / 256));
-    const size_t abytes = rows * ((size_t)ncols * 8 + 32);
-    if (wide >= 24 && ncols >= 24) AERO_LAUNCH(this, "hash_rows_kernel", abytes, (hash_rows_wide_kernel<24>), grid, dim3(256), 0, src, rows, leaves);
-    else if (wide >= 16 && ncols >= 16) AERO_LAUNCH(this, "hash_rows_kernel", abytes, (hash_rows_wide_kernel<16>), grid, dim3(256), 0, src, rows, leaves);
-    else if (wide >= 8 && ncols >= 8) AERO_LAUNCH(this, "hash_rows_kernel", abytes, (hash_rows_wide_kernel<8>), grid, dim3(256), 0, src, rows, leaves);
-    else AERO_LAUNCH(this, "hash_rows_kernel", abytes, (hash_rows_kernel<RowSrc>), grid, dim3(256), 0, src, rows, leaves);
+    // Round 6 measured three other forms of this kernel on 2^23-row matrices (profiles/r6_hash_forms.md): column loads software-pipelined one
+    // chunk of 8 / 16 / 24 columns ahead, two rows per lane, R rows per thread in a loop - none faster at any width (72 columns: 0.93 of the
+    // in-register BLAKE2s rate in every form, 24 columns per chunk 0.92; 8 columns 0.80 - 0.81 in every form): the plain form stays.
+    AERO_LAUNCH(this, "hash_rows_kernel", rows * ((size_t)ncols * 8 + 32), (hash_rows_kernel<RowSrc>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                src, rows, leaves);
     check_launch("hash_rows");
 }
 
@@ -671,45 +632,11 @@ template <int FOLD, int DEG> __global__ __launch_bounds__(256) void hash_fri_row
     for (int q = 0; q < FOLD * DEG; q += 2) b2s::compress_elems(st, e[q], e[q + 1], true, (uint32_t)(q + 2) * 32, q + 2 == FOLD * DEG);
     store_digest(&leaves[i], state_digest(st));
 }
-// The same with TWO rows per lane (rows i and i + rows / 2): all loads of both rows are issued up front, the two hash states advance side by
-// side. Half the waves, twice the work per wave; AERO_HASH_FRI2=1 selects it for layers of >= 2^17 rows (measurement switch, tools/hash_ab.py).
-template <int FOLD, int DEG> __global__ __launch_bounds__(256) void hash_fri_rows_fixed2_kernel(FriSrc s, Digest* leaves) {
-    const size_t half = s.rows / 2;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= half) return;
-    uint64_t e[2][FOLD * DEG];
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-#pragma unroll
-        for (int j = 0; j < FOLD; j++) {
-            e[r][j * DEG] = s.c0[i + r * half + (size_t)j * s.rows];
-            if (DEG > 1) e[r][j * DEG + DEG - 1] = s.c1[i + r * half + (size_t)j * s.rows];
-        }
-    }
-    b2s::State st0, st1;
-    b2s::init(st0);
-    b2s::init(st1);
-#pragma unroll
-    for (int q = 0; q < FOLD * DEG; q += 2) {
-        b2s::compress_elems(st0, e[0][q], e[0][q + 1], true, (uint32_t)(q + 2) * 32, q + 2 == FOLD * DEG);
-        b2s::compress_elems(st1, e[1][q], e[1][q + 1], true, (uint32_t)(q + 2) * 32, q + 2 == FOLD * DEG);
-    }
-    store_digest(&leaves[i], state_digest(st0));
-    store_digest(&leaves[i + half], state_digest(st1));
-}
 void Context::hash_fri_rows(const FriSrc& src, Digest* leaves) {
     if ((src.fold * src.deg) & 1) fail("hash_fri_rows: odd element count");
     const size_t abytes = src.rows * ((size_t)src.fold * src.deg * 8 + 32);
     const dim3 grid((unsigned)((src.rows + 255) / 256));
     const int shape = src.fold * 4 + src.deg;
-    static const bool fri2 = getenv("AERO_HASH_FRI2") && getenv("AERO_HASH_FRI2")[0] == '1';
-    if (fri2 && src.rows >= ((size_t)1 << 17) && src.rows % 512 == 0 && (shape == 8 * 4 + 1 || shape == 4 * 4 + 1)) {
-        const dim3 g2((unsigned)(src.rows / 512));
-        if (shape == 8 * 4 + 1) AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_fri_rows_fixed2_kernel<8, 1>), g2, dim3(256), 0, src, leaves);
-        else AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_fri_rows_fixed2_kernel<4, 1>), g2, dim3(256), 0, src, leaves);
-        check_launch("hash_fri_rows");
-        return;
-    }
     switch (shape) {
         case 8 * 4 + 1: AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_fri_rows_fixed_kernel<8, 1>), grid, dim3(256), 0, src, leaves); break;
         case 8 * 4 + 2: AERO_LAUNCH(this, "hash_fri_rows_kernel", abytes, (hash_fri_rows_fixed_kernel<8, 2>), grid, dim3(256), 0, src, leaves); break;

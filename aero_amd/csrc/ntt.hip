@@ -289,7 +289,8 @@ constexpr int F8_WAVES = 4;                      // tiles per workgroup
 //   3 = one multiplication per element, the factor read from `tab`.
 template <int TW>
 __device__ __forceinline__ void first8_column(const PassArgs& a, const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t* lds,
-                                              int lane, int wave, uint32_t b, uint32_t rbk, uint64_t* tab, const uint64_t* __restrict__ tw_mt) {
+                                              int lane, int wave, uint32_t b, uint32_t rbk, uint64_t* tab, int z = 0) {
+    const uint64_t* __restrict__ tw_mt = a.tw_mt;
     const int h = lane & 31;
     const bool upper = lane >= 32;
     const uint64_t nmask = ((uint64_t)1 << a.log_n) - 1;
@@ -328,14 +329,14 @@ __device__ __forceinline__ void first8_column(const PassArgs& a, const uint64_t*
         }
     }
 #pragma unroll
-    for (int i = 1; i < 32; i++) y[i] = mul(y[i], tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane]);
+    for (int i = 1; i < 32; i++) y[i] = mul(y[i], tw_mt[(int)gl::bitrev((uint32_t)i, 5) * 64 + lane + z]);
     dft_dit_reg<5>(y);
     if constexpr (TW == 0) {
 #pragma unroll
         for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = y[i];
     } else if constexpr (TW == 3) {
 #pragma unroll
-        for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = mul(y[i], tab[i * 64 + lane]);
+        for (int i = 0; i < 32; i++) out[base + lane + 64 * i] = mul(y[i], tab[i * 64 + lane + z]);
     } else {
         uint64_t cur = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * (uint32_t)lane) & nmask), a.tw_h);
         const uint64_t step = tw_lookup(a.tw_lo, a.tw_hi, (uint32_t)(((uint64_t)rbk * 64u) & nmask), a.tw_h);
@@ -367,8 +368,8 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArg
     const uint64_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
     uint64_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
     const uint32_t rbk = gl::bitrev(b, a.log_n - 11);
-    if (!a.first && rbk) first8_column<1>(a, in, out, lds, lane, wave, b, rbk, nullptr, a.tw_mt);
-    else first8_column<0>(a, in, out, lds, lane, wave, b, rbk, nullptr, a.tw_mt);
+    if (!a.first && rbk) first8_column<1>(a, in, out, lds, lane, wave, b, rbk, nullptr);
+    else first8_column<0>(a, in, out, lds, lane, wave, b, rbk, nullptr);
 }
 // Wide launches (round 6): the pass-boundary factors depend on the tile, the lane and the row - NOT on the column. A workgroup takes ONE tile
 // and F8_WAVES * K columns of it (wave w: columns w, w + F8_WAVES, ...): each wave's first column runs the progression and leaves a quarter
@@ -386,23 +387,22 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8w(PassAr
     const uint64_t* in = a.in + (size_t)col0 * a.in_col_stride;
     uint64_t* out = a.out + (size_t)col0 * a.out_col_stride;
     // the table twiddles and the boundary factors do not change from column to column: left to itself the compiler hoists all 31 + 32 loads
-    // out of the column loop and spills a hundred registers; the pointers are laundered per iteration so that every column reads them where
-    // it uses them (L1 / LDS hits)
-    const uint64_t* mt = a.tw_mt;
-    uint64_t* tab = f8_tab;
+    // out of the column loop and spills a hundred registers. An index offset the compiler cannot see through (zero, re-laundered per
+    // iteration) keeps every column's reads where they are used (L1 / LDS hits) WITHOUT touching the pointers: laundering the pointers
+    // themselves loses their address space - every access became a flat load behind its own s_waitcnt vmcnt(0), +58 % on 72 columns.
+    int z = 0;
     if (a.first || !rbk) {       // uniform over the workgroup
         for (int j = 0; j < K; j++) {
-            asm volatile("" : "+s"(mt));
-            first8_column<0>(a, in + (size_t)j * F8_WAVES * a.in_col_stride, out + (size_t)j * F8_WAVES * a.out_col_stride, lds, lane, wave, b, rbk, nullptr, mt);
+            asm volatile("" : "+s"(z));
+            first8_column<0>(a, in + (size_t)j * F8_WAVES * a.in_col_stride, out + (size_t)j * F8_WAVES * a.out_col_stride, lds, lane, wave, b, rbk, nullptr, z);
         }
         return;
     }
-    first8_column<2>(a, in, out, lds, lane, wave, b, rbk, tab, mt);
+    first8_column<2>(a, in, out, lds, lane, wave, b, rbk, f8_tab);
     __syncthreads();
     for (int j = 1; j < K; j++) {
-        asm volatile("" : "+s"(mt));
-        asm volatile("" : "+v"(tab));
-        first8_column<3>(a, in + (size_t)j * F8_WAVES * a.in_col_stride, out + (size_t)j * F8_WAVES * a.out_col_stride, lds, lane, wave, b, rbk, tab, mt);
+        asm volatile("" : "+s"(z));
+        first8_column<3>(a, in + (size_t)j * F8_WAVES * a.in_col_stride, out + (size_t)j * F8_WAVES * a.out_col_stride, lds, lane, wave, b, rbk, f8_tab, z);
     }
 }
 // Round 5 measured this pass with TWO wavefronts per tile and 16 values per lane (74 VGPRs, five waves per SIMD instead of three, commit

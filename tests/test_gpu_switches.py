@@ -115,7 +115,7 @@ def test_ntt_first_pass_shared_boundary_factors(tmp_path, flag):
     """AERO_NTT_F8W=0: wide launches of the two-phase first pass keep one column per wave with the two-multiplication progression instead of
     sharing the tile's boundary factors through LDS (ntt_fwd_first_pass_8w). Widths with K = 4, 5, 9, 9 columns per wave, one that does not
     split (44 = 4 x 11: no K <= 9) and one below the threshold; every column against the oracle or its twin."""
-    shapes = "[[10, 16, 3], [13, 20, 3], [14, 36, 3], [12, 44, 3], [20, 72, 3], [16, 12, 3]]"
+    shapes = "[[10, 16, 3], [13, 20, 3], [14, 36, 3], [12, 44, 3], [20, 72, 3], [17, 12, 3]]"
     out = run(tmp_path, PLANS, {"AERO_NTT_NAMES": "1", "AERO_NTT_F8W": flag, "AERO_TEST_SHAPES": shapes}, timeout=1500)
     seen = json.loads(out.strip().split("\n")[-2])
     for shape, names in seen.items():
@@ -133,7 +133,12 @@ for width in (1, 2, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 47, 48, 49, 72,
     assert (got == orc.hash_rows(np.ascontiguousarray(rows.T))).all(), width
     blob = b"".join(int(v).to_bytes(8, "little") + bytes(24) for v in rows[776])
     assert got[776].tobytes() == hashlib.blake2s(blob).digest(), width
-# FRI layers of 2^17 rows and more (what AERO_HASH_FRI2 switches), fold 8 and fold 4, inside whole proofs
+# a launch of 2^16 rows: a 9-column matrix through the hashing seam ...
+big = (rng.integers(0, 1 << 63, (9, 1 << 16), dtype=np.uint64) % np.uint64(P)).astype(np.uint64)
+m = ctx.trace_upload(big)
+assert (ctx.hash_matrix_rows(m) == orc.hash_rows(big)).all()
+m.free()
+# ... and FRI layers of 2^17 rows, fold 8 and fold 4, inside whole proofs
 for width, log_n, opt in ((2, 17, [27, 8, 16, 4, 1, 8, 8]), (2, 16, [27, 8, 16, 4, 1, 4, 8])):
     want = orc.prove_fib(width, log_n, opt)[0]
     dev = ctx.trace_upload(aero_amd.fib_trace(width, log_n))
@@ -143,11 +148,11 @@ print("ok")
 '''
 
 
-@pytest.mark.parametrize("env", [{"AERO_HASH_WIDE": "0"}, {"AERO_HASH_WIDE": "8"}, {"AERO_HASH_WIDE": "16"}, {"AERO_HASH_WIDE": "24"}, {"AERO_HASH_FRI2": "1"}])
-def test_row_hash_forms(tmp_path, env):
-    """AERO_HASH_WIDE: columns per software-pipelined chunk of the wide-row kernel (0 = the plain one-row-per-lane kernel at every width);
-    AERO_HASH_FRI2=1: two FRI rows per lane from 2^17 rows on. Digests against the oracle and hashlib at widths around every chunk size."""
-    run(tmp_path, HASH_FORMS, env)
+def test_row_hashes_at_many_widths_and_sizes(tmp_path):
+    """The row-hash kernels by shape: widths around every even / odd / chunk boundary against the oracle and hashlib, a 2^16-row matrix through
+    the hashing seam, FRI layers of 2^17 rows (fold 8) and 2^16 (fold 4) inside whole proofs. (Round 6 tried three other forms of these kernels -
+    pipelined column loads, two rows per lane, R rows per thread - on this test; none was faster, none is kept: profiles/r6_hash_forms.md.)"""
+    run(tmp_path, HASH_FORMS, {})
 
 
 R128 = r'''

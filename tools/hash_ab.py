@@ -1,6 +1,4 @@
-"""Per-kernel HIP-event time of the row hashing kernels on the shapes the workloads commit to, for A/B runs of hashing variants selected through
-the environment (AERO_HASH_WIDE = columns per pipelined chunk of the wide-row kernel, 0 = plain kernel; AERO_HASH_FRI2=1 = two FRI rows per
-lane). Prints one JSON line: per shape the kernel's time and its BLAKE2s compressions per second against profiles/ceilings.json.
+"""Per-kernel HIP-event time of the row hashing kernels on the shapes the workloads commit to (A/B runs: another build of the library through AERO_LIB_PATH). Prints one JSON line: per shape the kernel's time and its BLAKE2s compressions per second against profiles/ceilings.json.
 usage: hash_ab.py [rowsLog2xcols ...] [friLog2Rows:fold ...]      default: 23x72 23x8 23x9 23x18 fri20:8 fri23:4"""
 import json
 import os
