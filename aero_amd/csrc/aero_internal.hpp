@@ -279,7 +279,7 @@ public:
     std::map<uint64_t, uint64_t*> pass_tabs;
     std::map<std::vector<uint64_t>, uint64_t*> ktab_cache;
     // FibAir constraint evaluation: the divisor inverses and degree-adjustment powers of a constraint domain (5 x rows words), built by
-    // the first proof of a shape and kept (at most two shapes and 2^23 rows each; AERO_CONS_INV_TABLE=0: every proof inverts per thread)
+    // the first proof of a shape and kept (a context keeps the two shapes it used last, up to 2^25 rows each; AERO_CONS_INV_TABLE=0: every proof inverts per thread)
     // One table per (device, shape) for ALL contexts of the process (the eight slots of a pool used to hold eight copies: 8 x 5 x 2^23 x 8 B):
     // a context keeps the two shapes it used last (least recently used out first), a table lives while any context holds it, its bytes count
     // in bytes_in_use / bytes_peak of every holder, and an allocation that fails is not an error - the kernel then inverts per row.

@@ -1437,7 +1437,9 @@ Bytes Prover::prove_impl(const uint64_t* trace_dev, uint32_t W, int log_n, std::
             a.out_cols = nullptr;
             if (!gather_h) {
                 for (int d = 0; d < F::DEG; d++) a.out_h[d] = hbuf.get() + (size_t)d * ceN;
-                if (ctx->cons_inv_table && rows_eval <= ((size_t)1 << 23) && rows_eval % 4 == 0) {
+                // up to 2^25 constraint-domain rows (2^24-row traces: 1.3 GB, one table per device and shape for all contexts; round 5 stopped at 2^23
+                // because every context held its own copy - config 4's constraint kernel then inverted per row, 1.17 ms of a 30 ms proof)
+                if (ctx->cons_inv_table && rows_eval <= ((size_t)1 << 25) && rows_eval % 4 == 0) {
                     // the divisor inverses and the degree-adjustment powers of a constraint-domain point do not depend on the proof: one table per
                     // shape (5 words per row), built by the first proof of the shape
                     const std::vector<uint64_t> key{(uint64_t)rows_eval, h, a.w_last, (uint64_t)xcount, (uint64_t)n};
