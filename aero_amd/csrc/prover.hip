@@ -289,7 +289,7 @@ void Context::wait_flag(uint32_t seq) {
             if (e == hipSuccess) return;                   // drained: whatever the kernels wrote is visible
             if (e != hipErrorNotReady) throw Error(ST_HIP, std::string("stream query: ") + hipGetErrorString(e));
         }
-        if (spin > 16384u) sched_yield();
+        if (spin > 16384u) sched_yield();       // (same-box A/B against the bare loop and against default host-memory flags: no difference on the headline, profiles/r6_headline_spin_flags_ab.txt)
     }
 }
 

@@ -54,7 +54,7 @@ try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     s = d["sharded_proof"]
     ranks = s.get("ranks") or []
-    counted = sorted({(r.get("rccl") or {}).get("ranks_counted_by_rccl") for r in ranks})
+    counted = sorted({(r.get("rccl") or {}).get("ranks_counted_by_rccl") for r in ranks if r.get("rccl")}) or "n/a (ranks share one GPU: exchanges over gloo)"
     print("%.1f ms per proof, %.2fx one GPU, identical on every rank: %s, RCCL counted %s ranks, NUMA nodes %s, CPUs bound %s" % (
         s["ms_per_proof"], s["speedup_vs_single_gpu"], s["proof_identical_to_single_gpu_on_every_rank"], counted,
         [r["gpu_numa_node"] for r in ranks], [r["cpus_bound_to"] for r in ranks]))
