@@ -4,6 +4,9 @@ the context's stream (RCCL refuses two ranks on one device, so world > 1 needs a
 there; tests/test_gpu_sharded.py checks the sharding itself at world 2/4/8 over gloo). No torch in this file: the
 communicator must work in a process that holds only this library and its HIP runtime."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -13,6 +16,14 @@ from aero_amd.shard import RcclComm
 
 pytestmark = pytest.mark.gpu
 P = aero_amd.P
+
+# The tests that call `ncclCommInitRank` INSIDE the test process run in a pytest child of their own (AERO_RCCL_INNER=1, started by
+# test_world_of_one_in_a_process_of_its_own below). Reason (profiles/r6_suite_abort.md): once in 8 runs of this stretch of the suite a GPU
+# memory fault was reported by the runtime's event thread while the main thread sat inside RCCL's initialisation - an abort() that takes the
+# whole suite's process and every result with it. In a child the same event is ONE failed test with its log; it also is what a deployment
+# looks like (one process per GPU creates its communicator early, not after 180 tests' worth of contexts).
+INNER = os.environ.get("AERO_RCCL_INNER") == "1"
+in_child = pytest.mark.skipif(not INNER, reason="runs inside test_world_of_one_in_a_process_of_its_own")
 
 
 @pytest.fixture(scope="module")
@@ -24,6 +35,7 @@ def env():
     ctx.close()
 
 
+@in_child
 def test_exchanges_run_on_the_context_stream(env):
     ctx, comm = env
     cs = comm.struct
@@ -46,6 +58,7 @@ def test_exchanges_run_on_the_context_stream(env):
         m.free()
 
 
+@in_child
 def test_world_of_one_proof_is_the_single_gpu_proof(env, oracle):
     ctx, comm = env
     opt = aero_amd.ProofOptions.with_96_bit_security()
@@ -56,6 +69,7 @@ def test_world_of_one_proof_is_the_single_gpu_proof(env, oracle):
     dev.free()
 
 
+@in_child
 def test_bad_arguments(env):
     ctx, comm = env
     L = aero_amd.lib()
@@ -66,6 +80,7 @@ def test_bad_arguments(env):
     assert L.aero_rccl_unique_id(None) == -1
 
 
+@in_child
 def test_pairwise_exchange_with_itself(env):
     ctx, comm = env
     cs = comm.struct
@@ -74,6 +89,37 @@ def test_pairwise_exchange_with_itself(env):
     src, dst = ctx.trace_upload(data), ctx.trace_upload(np.zeros((1, n), np.uint64))
     assert cs.send_recv(cs.user, src.device_ptr, 0, dst.device_ptr, 0, 8 * n) == 0, comm.error_text()
     assert (dst.download() == data).all()
+
+
+@pytest.mark.skipif(INNER, reason="this IS the child")
+def test_world_of_one_in_a_process_of_its_own():
+    """Runs the four in-process communicator tests above in a child pytest. A child that dies of the GPU memory fault described at the top of
+    this file is kept as evidence (gpurun_out/rccl_init_fault_<n>.log), reported as a warning and retried ONCE - the fault has never been
+    seen twice in a row, and nothing of this library runs between process start and `ncclCommInitRank` in the child; any other failure, and a
+    second fault, fail the test with the child's output."""
+    import warnings
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    last = None
+    for attempt in (1, 2):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                            "-k", "context_stream or world_of_one_proof_is or bad_arguments or pairwise_exchange"],
+                           env=dict(os.environ, AERO_RCCL_INNER="1"), capture_output=True, text=True, timeout=900, cwd=root, stdin=subprocess.DEVNULL)
+        last = r.stdout[-4000:] + "\n" + r.stderr[-4000:]
+        if r.returncode == 0:
+            assert "4 passed" in r.stdout, last
+            return
+        if attempt == 1 and "Memory access fault" in (r.stdout + r.stderr):
+            keep = os.path.join(os.environ.get("GRAFT_REPO_ROOT", root), "gpurun_out")
+            try:
+                os.makedirs(keep, exist_ok=True)
+                with open(os.path.join(keep, f"rccl_init_fault_{os.getpid()}.log"), "w") as f:
+                    f.write(r.stdout + "\n" + r.stderr)
+            except OSError:
+                pass
+            warnings.warn("GPU memory fault inside the RCCL child (profiles/r6_suite_abort.md); retrying once:\n" + last[-1500:])
+            continue
+        break
+    raise AssertionError("in-process RCCL tests failed in their child:\n" + last)
 
 
 RANK_WORKER = r'''
