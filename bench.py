@@ -966,8 +966,14 @@ def main():
                     "source": "profiles/r3_ubench_dft.txt (tools/ubench_dft.hip, canonical variant) + profiles/ceilings.json (goldilocks mul)"}
         except Exception:
             pass
-        # whole-proof view: SURVEY 8d algorithmic bytes per cell
+        # whole-proof view: SURVEY 8d algorithmic bytes per cell, E = constraint-evaluation blowup = composition columns (2 for the degree-1
+        # FibAir, 2 / 4 / 8 by the auxiliary constraint's degree, the program's own for a constraint program; until round 6 this said E = 2
+        # for every workload, which priced the degree-8 shapes at 206 instead of 269 B per cell)
         E = 2
+        if over.get("aux"):
+            E = 2 if over["aux"][2] <= 2 else (4 if over["aux"][2] <= 4 else 8)
+        if program:
+            E = int(over["_air"].info().get("ce_blowup", E)) or E
         bpc = 168 + 8 * E + (1259 + 176 * E) / width
         if opt.field_extension == 2:
             bpc += (162 + 176 * E) / width

@@ -44,7 +44,9 @@ for sh in shapes:
         out[sh] = {"launches_per_commit": n_l, "us_all_layers": round(us, 1), "Gcomp_per_s": round(comp / us / 1e3, 2), "of_ceiling": round(comp / us / 1e3 / CEIL, 3)}
         m.free()
         continue
-    log_rows, cols = (int(v) for v in sh.split("x"))
+    leaf = sh.startswith("leaf")          # "leaf27x2": the fused leaf + 3 levels kernel of narrow matrices (<= 4 columns)
+    kname = "merkle_leaf8_kernel" if leaf else "hash_rows_kernel"
+    log_rows, cols = (int(v) for v in sh[4 if leaf else 0:].split("x"))
     rows = 1 << log_rows
     base = aero_amd.fib_trace(2, min(log_rows, 20))
     col = np.tile(base[0], rows // base.shape[1])
@@ -57,14 +59,14 @@ for sh in shapes:
     reps = 5
     for _ in range(2):
         ctx.merkle_commit_rows(m).free()          # wide matrices: hash_rows_kernel + the tree build (only the former is timed)
-    ctx.set_kernel_timing(True, "hash_rows_kernel")
+    ctx.set_kernel_timing(True, kname)
     for _ in range(reps):
         ctx.merkle_commit_rows(m).free()
     rep = ctx.kernel_timing_report()
     ctx.set_kernel_timing(False)
-    calls, ms, _ = rep["hash_rows_kernel"]
+    calls, ms, _ = rep[kname]
     us = 1e3 * ms / calls
-    comp = rows * ((cols + 1) // 2)
+    comp = rows * ((cols + 1) // 2) + (rows * 7 // 8 if leaf else 0)      # the fused kernel also builds the 3 levels above its 8 leaves
     out[sh] = {"us": round(us, 1), "Gcomp_per_s": round(comp / us / 1e3, 2), "of_ceiling": round(comp / us / 1e3 / CEIL, 3),
                "GBps_algorithmic": round(rows * (cols * 8 + 32) / us / 1e3, 1)}
     m.free()
