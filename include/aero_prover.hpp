@@ -143,6 +143,14 @@ public:
     Context& operator=(const Context&) = delete;
     Context(Context&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
     aero_ctx* raw() const { return h_; }
+    // prove-then-verify inside `prove`, as the reference's worker does (proving_worker.rs:196-203; the CLI verifies right behind `prove`,
+    // main.rs:47): with the check on, a proof the library's own verifier rejects surfaces as ProverError{AERO_E_SELF_VERIFY} instead of
+    // a StarkProof. Default: on for proofs made by more than one rank, off on one GPU (aero_ctx_set_self_verify).
+    enum class SelfVerify : int32_t { Auto = AERO_SELF_VERIFY_AUTO, Off = AERO_SELF_VERIFY_OFF, On = AERO_SELF_VERIFY_ON };
+    void set_self_verify(SelfVerify mode) {
+        const int32_t rc = aero_ctx_set_self_verify(h_, (int32_t)mode);
+        if (rc != AERO_OK) throw ProverError(rc, "Context: bad self-verify mode");
+    }
 
 private:
     aero_ctx* h_ = nullptr;

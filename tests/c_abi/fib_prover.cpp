@@ -22,6 +22,11 @@ int main(int argc, char** argv) {
         // execute-and-prove, then what main.rs:46 does with miden_verifier::verify(..).unwrap()
         const StarkProof proof = prover.prove(trace);
         verify(proof, pub_inputs, prover.air());
+        // the same with the verification INSIDE prove (proving_worker.rs:196-203): identical bytes, a rejection would be a ProverError
+        ctx.set_self_verify(Context::SelfVerify::On);
+        const StarkProof checked = prover.prove(trace);
+        ctx.set_self_verify(Context::SelfVerify::Auto);
+        if (checked.to_bytes() != proof.to_bytes()) { fprintf(stderr, "proof bytes change with the self check on\n"); return 1; }
         const uint32_t security = proof.security_level();
 
         // a wrong statement and an unacceptable parameter set are Err(VerifierError), not a panic
