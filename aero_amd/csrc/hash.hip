@@ -706,8 +706,15 @@ template <class Src> void Context::merkle_commit(const Src& src, size_t n, Diges
     bool done = false;
     if constexpr (std::is_same<Src, RowSrc>::value) {
         done = true;
-        if (src.ncols == 1) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<1>), grid, block, 0, src, nodes, n, skip);
-        else if (src.ncols == 2 && getenv("AERO_HASH_XCD") && getenv("AERO_HASH_XCD")[0] == '1') AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<2, 1>), grid, block, 0, src, nodes, n, skip);
+        static const bool xcd = getenv("AERO_HASH_XCD") && getenv("AERO_HASH_XCD")[0] == '1';
+        if (xcd) {
+            if (src.ncols == 1) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<1, 1>), grid, block, 0, src, nodes, n, skip);
+            else if (src.ncols == 2) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<2, 1>), grid, block, 0, src, nodes, n, skip);
+            else if (src.ncols == 3) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<3, 1>), grid, block, 0, src, nodes, n, skip);
+            else if (src.ncols == 4) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<4, 1>), grid, block, 0, src, nodes, n, skip);
+            else done = false;
+        }
+        else if (src.ncols == 1) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<1>), grid, block, 0, src, nodes, n, skip);
         else if (src.ncols == 2) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<2>), grid, block, 0, src, nodes, n, skip);
         else if (src.ncols == 3) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<3>), grid, block, 0, src, nodes, n, skip);
         else if (src.ncols == 4) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<4>), grid, block, 0, src, nodes, n, skip);
