@@ -50,8 +50,7 @@ __device__ __forceinline__ Digest state_digest(const b2s::State& s) {
 }
 
 // Workgroups are dispatched round-robin over the 8 XCDs. XCD = 1 hands XCD x the x-th contiguous eighth of a launch's blocks (as the NTT
-// passes do, ntt.hip: xcd_tile), so that the rows one XCD has in flight are neighbours in memory; 0 = the dispatch order (measurement
-// switch AERO_HASH_XCD, profiles/r6_hash_forms.md).
+// passes do, ntt.hip: xcd_tile), so that the rows one XCD has in flight are neighbours in memory; 0 = the dispatch order.
 template <int XCD> __device__ __forceinline__ size_t hash_block(uint32_t bid, uint32_t nblocks) {
     if (XCD && !(nblocks & 7u)) return (size_t)(bid & 7u) * (nblocks >> 3) + (bid >> 3);
     return bid;
@@ -226,8 +225,8 @@ __global__ __launch_bounds__(256) void merkle_up3_parts_kernel(Digest* nodes, si
 }
 
 // one plain row-hash pass (wide matrices, and the C-ABI hashing seam): lane <-> row, coalesced column reads
-template <class Src, int XCD = 0> __global__ __launch_bounds__(256) void hash_rows_kernel(Src src, size_t rows, Digest* leaves) {
-    size_t j = hash_block<XCD>(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+template <class Src> __global__ __launch_bounds__(256) void hash_rows_kernel(Src src, size_t rows, Digest* leaves) {
+    size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= rows) return;
     store_digest(&leaves[j], leaf_digest(src, j));
 }
@@ -613,9 +612,6 @@ void Context::hash_rows(const uint64_t* cols, size_t col_stride, int ncols, size
     // Round 6 measured three other forms of this kernel on 2^23-row matrices (profiles/r6_hash_forms.md): column loads software-pipelined one
     // chunk of 8 / 16 / 24 columns ahead, two rows per lane, R rows per thread in a loop - none faster at any width (72 columns: 0.93 of the
     // in-register BLAKE2s rate in every form, 24 columns per chunk 0.92; 8 columns 0.80 - 0.81 in every form): the plain form stays.
-    static const bool xcd = getenv("AERO_HASH_XCD") && getenv("AERO_HASH_XCD")[0] == '1';
-    if (xcd && rows % 2048 == 0) AERO_LAUNCH(this, "hash_rows_kernel", rows * ((size_t)ncols * 8 + 32), (hash_rows_kernel<RowSrc, 1>), dim3((unsigned)(rows / 256)), dim3(256), 0, src, rows, leaves);
-    else
     AERO_LAUNCH(this, "hash_rows_kernel", rows * ((size_t)ncols * 8 + 32), (hash_rows_kernel<RowSrc>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
                 src, rows, leaves);
     check_launch("hash_rows");
@@ -706,8 +702,10 @@ template <class Src> void Context::merkle_commit(const Src& src, size_t n, Diges
     bool done = false;
     if constexpr (std::is_same<Src, RowSrc>::value) {
         done = true;
-        static const bool xcd = getenv("AERO_HASH_XCD") && getenv("AERO_HASH_XCD")[0] == '1';
-        if (xcd) {
+        // Stored leaf level (skip = 0: the stage entry points, trees that keep every level): the blocks of one XCD take a contiguous eighth of
+        // the rows - 6 - 8 % faster on 2^23 and 2^27 rows (516 -> 480 us, 6.76 -> 6.39 ms; the launch is write-heavy: 32 B per row + 3 levels).
+        // With skip = 3 (whole proofs: 4 B stored per row) the order makes no difference (398 us either way, profiles/r6_hash_forms.md).
+        if (skip == 0) {
             if (src.ncols == 1) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<1, 1>), grid, block, 0, src, nodes, n, skip);
             else if (src.ncols == 2) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<2, 1>), grid, block, 0, src, nodes, n, skip);
             else if (src.ncols == 3) AERO_LAUNCH(this, "merkle_leaf8_kernel", abytes, (merkle_leaf8_rows_kernel<3, 1>), grid, block, 0, src, nodes, n, skip);
