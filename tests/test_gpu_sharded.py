@@ -1,6 +1,8 @@
 """ONE proof sharded over several ranks (aero_prove_fib_sharded) must be byte-identical to the single-GPU proof and to
-the CPU oracle's. On a 1-GPU box the ranks share the GPU and exchange over gloo; the exchange code path (device
-pointers -> torch.distributed collectives) is the one a multi-GPU node runs with backend "nccl"."""
+the CPU oracle's. On a 1-GPU box the ranks are processes sharing the GPU and exchange over gloo (aero_amd/shard.py: TorchComm, on host
+copies by default, on the device tensors with AERO_TORCHCOMM_GLOO=device); a multi-GPU node takes the library's native RCCL communicator
+(tests/test_gpu_rccl.py). Every rank leaves per-exchange fingerprints of what it sent and received; `diagnose` lines them up across ranks
+when bytes differ (profiles/r6_sharded_anomaly.md). Sharded proofs run with prove-then-verify on (aero_ctx_set_self_verify, AUTO)."""
 import json
 import os
 import socket
