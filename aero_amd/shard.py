@@ -315,6 +315,7 @@ class LocalGroup:
     class _Comm:
         def __init__(self, struct):
             self.struct = struct
+            self.rank, self.world = struct.rank, struct.world
             self.last_error = None
 
     def __init__(self, world, devices=None, min_peer_digests=0):

@@ -166,3 +166,36 @@ def test_program_air_sharded_over_thread_ranks_gives_the_single_gpu_bytes(world,
         g.close()
     for r, p in enumerate(proofs):
         assert p == want, f"host hand-over, rank {r} of {world}"
+
+
+def test_trace_commitment_alone_is_the_proofs_first_commitment(oracle):
+    """aero_commit_trace_sharded (the first half of the fork's commit_to_trace_and_validate, proving_worker.rs:323-332; what the exchange
+    stress loop calls): on one GPU and over thread ranks of world 2 / 4 / 8 the root is bytes 24..55 of the oracle's proof, the subtree
+    roots are the nodes world .. 2 world - 1 of the single-GPU tree, narrow rows (exchanged as rows) and wide ones (exchanged as digests)."""
+    import numpy as np
+    from aero_amd.shard import LocalGroup
+    DEFAULT = [27, 8, 16, 4, 1, 8, 8]
+    opt = aero_amd.ProofOptions(*DEFAULT)
+    ctx = aero_amd.Context(0)
+    for width, log_n in ((2, 12), (8, 10)):
+        trace = aero_amd.fib_trace(width, log_n)
+        want = oracle.prove_fib(width, log_n, DEFAULT)[0][24:56]
+        dev = ctx.trace_upload(trace)
+        root, subs = ctx.commit_trace(dev, opt)
+        assert root == want and subs == [want]
+        # the single-GPU tree over the same LDE: node 1 = root, nodes [world, 2 world) = the subtree roots
+        lde = ctx.evaluate_columns_over(ctx.interpolate_columns(dev), 3)
+        tree = ctx.merkle_commit_rows(lde)
+        nodes = tree.nodes()
+        assert nodes[1].tobytes() == want
+        for world in (2, 4, 8):
+            g = LocalGroup(world)
+            try:
+                res = g.run(lambda r, c, comm: c.commit_trace(c.trace_upload(trace), opt, comm=comm))
+            finally:
+                g.close()
+            for r, (rt, sb) in enumerate(res):
+                assert rt == want, (width, world, r)
+                assert sb == [nodes[world + k].tobytes() for k in range(world)], (width, world, r)
+        tree.free(); lde.free(); dev.free()
+    ctx.close()
