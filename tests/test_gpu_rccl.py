@@ -40,6 +40,8 @@ def test_exchanges_run_on_the_context_stream(env):
     ctx, comm = env
     cs = comm.struct
     assert cs.rank == 0 and cs.world == 1 and cs.flags == 1          # AERO_COMM_STREAM_ORDERED
+    info = comm.info()                                                  # aero_rccl_info: what RCCL itself says (-1 = this librccl lacks the query)
+    assert info["world_asked_for"] == 1 and info["ranks_counted_by_rccl"] in (1, -1) and info["rank_as_rccl_numbers_it"] in (0, -1) and info["device_rccl_bound"] in (0, -1)
     rng = np.random.default_rng(5)
     n = 1 << 17
     data = rng.integers(0, P, size=(1, n), dtype=np.uint64)

@@ -300,3 +300,14 @@ def test_self_verify_modes_on_one_gpu(oracle):
     assert got == ctx.prove_air(air, t, pub, opts)
     trace.free()
     ctx.close()
+    # a pool's slots under the check (aero_pool_set_self_verify): same bytes from every slot; a bad mode is refused
+    pool = aero_amd.Pool(0, 2)
+    pool.set_self_verify(1)
+    hosts = [aero_amd.PinnedTrace(aero_amd.fib_trace(4, 10)) for _ in range(2)]
+    for p, _ in pool.prove_fib_host(hosts, opts, rounds=2):
+        assert p == want
+    pool.set_self_verify("auto")
+    assert aero_amd.lib().aero_pool_set_self_verify(pool.h, C.c_int32(7)) == -1
+    for h in hosts:
+        h.release()
+    pool.close()
