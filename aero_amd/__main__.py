@@ -60,6 +60,8 @@ def main():
     p.add_argument("--trace", default=None, help="AEROTRC file holding the trace (and its AIR parameters) instead of the synthetic one")
     p.add_argument("--air", default=None, help="AEROAIR constraint program (include/aero_air.h) the trace satisfies: proves through aero_prove_air")
     p.add_argument("--pub", default="", help="--air: the program's public-input elements, comma separated")
+    p.add_argument("--no-verify", action="store_true", help="skip the verification miden-proof-generator runs on every proof before it writes it "
+                   "(main.rs:47); by default the library verifies the proof inside the call (aero_ctx_set_self_verify) and nothing is written on a rejection")
     g = sub.add_parser("program", help="write the VM-shaped synthetic constraint program, a trace that satisfies it and its public inputs (no GPU)")
     g.add_argument("--log-n", type=int, default=10)
     g.add_argument("--pairs", type=int, default=26)
@@ -124,6 +126,7 @@ def main():
         if args.quadratic:
             opt.field_extension = 2
         ctx = aero_amd.Context(args.device)
+        ctx.set_self_verify(not args.no_verify)
         if args.trace:
             dev, _, aux = ctx.trace_file_load(args.trace)
             args.width, rows = dev.shape
