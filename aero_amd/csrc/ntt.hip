@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8(PassArg
 // and F8_WAVES * K columns of it (wave w: columns w, w + F8_WAVES, ...): each wave's first column runs the progression and leaves a quarter
 // of the 32 x 64 factors in LDS (16 KiB per workgroup, next to the four 8 KiB exchange buffers: three workgroups per CU as before), one
 // workgroup barrier, and the remaining K - 1 columns of every wave spend ONE multiplication per element on the boundary instead of two
-// (193 -> about 167 VALU instructions per element at K = 9). a.chains = columns of the launch here; grid = (tiles, columns / (F8_WAVES K)).
+// (190 -> 157 VALU instructions per element at K = 9 by SQ_INSTS_VALU, profiles/r6_ntt_f8w_counters.txt). a.chains = columns of the launch here; grid = (tiles, columns / (F8_WAVES K)).
 __global__ __launch_bounds__(64 * F8_WAVES, 3) void ntt_fwd_first_pass_8w(PassArgs a, int K) {
     __shared__ __attribute__((aligned(16))) uint64_t f8_lds[F8_WAVES * F8_TILE_LDS / 2];
     __shared__ __attribute__((aligned(16))) uint64_t f8_tab[F8_TILE_LDS];
